@@ -1,0 +1,72 @@
+/* nemar_hip.h — C ABI of libnemar_hip.so: the gfx950 (MI355X / CDNA4) operator library behind the NeMAR
+ * training step, NEMARModel.optimize_parameters() (reference models/nemar_model.py:266-288).
+ *
+ * The reference has no FFI of its own: its operator boundary is the set of torch call sites listed in
+ * SURVEY.md §2.2 (K1..K15).  Each entry point below replaces one of those call sites and cites it.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  Every pointer is DEVICE memory owned by the caller;
+ *     tensors are contiguous NCHW float32.  The library never allocates, frees or synchronises.
+ *   - every launch goes on `stream` (a hipStream_t passed as void*; NULL = the null stream), so the caller's
+ *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream; no global state.
+ *   - return value: 0 on success, negative on error (NEMAR_EINVAL bad shape/pointer/unsupported,
+ *     NEMAR_ELAUNCH HIP launch error, NEMAR_EWORKSPACE workspace too small); nemar_last_error() returns the
+ *     message of the calling thread's last failure.  Python glue raises on non-zero.
+ *   - gradients are WRITTEN unless the matching `accumulate` flag is non-zero (then added in place).
+ *   - scratch: ops that need it take (workspace, ws_bytes) and export nemar_<op>_workspace(...) -> bytes.
+ */
+#ifndef NEMAR_HIP_H
+#define NEMAR_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEMAR_OK 0
+#define NEMAR_EINVAL (-1)
+#define NEMAR_ELAUNCH (-2)
+#define NEMAR_EWORKSPACE (-3)
+
+/* library */
+int nemar_version(void);              /* major*10000 + minor*100 + patch */
+const char* nemar_last_error(void);   /* thread-local message of the last failing call */
+
+/* ---- K9/K10/K11: sampling-grid generation fused into bilinear grid_sample ------------------------------
+ * F.grid_sample(img, grid, 'bilinear', 'zeros', align_corners=False)
+ *     reference models/stn/unet_stn.py:173-174, models/stn/affine_stn.py:129-130
+ * grid_mode selects how the (never materialised) grid is synthesised from grid_src:
+ *   NEMAR_GRID_EXPLICIT  grid_src = grid [N,Ho,Wo,2] (x,y), normalised coordinates
+ *   NEMAR_GRID_UNET      grid_src = offsets [N,2,Ho,Wo] planar; grid = linspace(-1,1) identity + offsets
+ *                        (reference models/stn/unet_stn.py:121-129,167; channel 0 = x)
+ *   NEMAR_GRID_AFFINE    grid_src = dtheta [N,6]; theta = dtheta + [1,0,0,0,1,0];
+ *                        grid = F.affine_grid(theta, align_corners=False) (models/stn/affine_stn.py:122,128)
+ * in [N,C,H,W] -> out [N,C,Ho,Wo]. */
+#define NEMAR_GRID_EXPLICIT 0
+#define NEMAR_GRID_UNET 1
+#define NEMAR_GRID_AFFINE 2
+int nemar_grid_sample_fwd(const float* in, const float* grid_src, int grid_mode, float* out,
+                          int N, int C, int H, int W, int Ho, int Wo, void* stream);
+/* gin [N,C,H,W] may be NULL (source is data, e.g. real_A).  ggrid has the layout of grid_src
+ * (EXPLICIT [N,Ho,Wo,2]; UNET [N,2,Ho,Wo]; AFFINE [N,6]). */
+int nemar_grid_sample_bwd(const float* in, const float* grid_src, int grid_mode, const float* gout,
+                          float* gin, int accum_gin, float* ggrid, int accum_ggrid,
+                          int N, int C, int H, int W, int Ho, int Wo, void* stream);
+
+/* ---- K12: deformation smoothness / bilateral regulariser -------------------------------------------------
+ * smoothness_loss(deformation, img, alpha)   reference models/stn/stn_losses.py:4-30,
+ * called from UnetSTN._calculate_regularization_term, models/stn/unet_stn.py:179-201.
+ * d [N,2,H,W]; img [N,Ci,H,W] or NULL (alpha<=0 or NULL => unweighted).
+ * fwd: loss[0] = (accumulate ? loss[0] : 0) + factor * smoothness(d, img, alpha)
+ * bwd: gd (+)= gscale[0] * factor * d smoothness / d d     (gscale: device scalar, the upstream gradient) */
+size_t nemar_smoothness_workspace(int N, int H, int W);
+int nemar_smoothness_fwd(const float* d, const float* img, int Ci, float alpha, float factor,
+                         float* loss, int accumulate, void* workspace, size_t ws_bytes,
+                         int N, int H, int W, void* stream);
+int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, const float* gscale,
+                         float factor, float* gd, int accumulate, int N, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMAR_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of the C-ABI library (include/nemar_hip.h -> nemar_amd/lib/libnemar_hip.so).
+
+There is NO fallback: if the gfx950 library is missing or fails to load, importing the operator layer
+raises.  `load(path)` with an explicit path exists only so the CPU test tier can bind the same signatures to
+the host-emulated build of the same kernel sources (tests/emu) — the product never passes a path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "lib", "libnemar_hip.so")
+
+_f = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_i = C.c_int
+_fl = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nemar_hip.h one to one (tests/test_abi.py checks it)
+SIGNATURES = {
+    "nemar_version": (_i, []),
+    "nemar_last_error": (C.c_char_p, []),
+    "nemar_grid_sample_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "nemar_grid_sample_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "nemar_smoothness_workspace": (_sz, [_i, _i, _i]),
+    "nemar_smoothness_fwd": (_i, [_vp, _vp, _i, _fl, _fl, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
+    "nemar_smoothness_bwd": (_i, [_vp, _vp, _i, _fl, _vp, _fl, _vp, _i, _i, _i, _i, _vp]),
+}
+
+
+class NemarHipError(RuntimeError):
+    pass
+
+
+class Library:
+    """Thin wrapper: attribute access returns a checked callable for int-returning entry points."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise NemarHipError(
+                "gfx950 operator library not found at %s — build it with `python -m nemar_amd.csrc.build` "
+                "(there is no CPU/PyTorch fallback for the NeMAR hot path)" % path)
+        self.path = path
+        self._dll = C.CDLL(path)
+        self._fns = {}
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise NemarHipError("%s does not export %s" % (path, name)) from e
+            fn.restype = res
+            fn.argtypes = args
+            self._fns[name] = fn
+
+    def raw(self, name):
+        return self._fns[name]
+
+    def last_error(self):
+        return self._fns["nemar_last_error"]().decode("utf-8", "replace")
+
+    def __getattr__(self, name):
+        fns = self.__dict__.get("_fns", {})
+        full = name if name.startswith("nemar_") else "nemar_" + name
+        if full not in fns:
+            raise AttributeError(name)
+        fn = fns[full]
+        if SIGNATURES[full][0] is not _i or full == "nemar_version":
+            return fn
+
+        def checked(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise NemarHipError("%s failed (%d): %s" % (full, rc, self.last_error()))
+            return rc
+
+        checked.__name__ = full
+        self.__dict__[name] = checked
+        return checked
+
+
+_default = None
+
+
+def load(path=None):
+    """Load (once) and return the library.  `path` is for the emulated test build only."""
+    global _default
+    if path is not None:
+        return Library(path)
+    if _default is None:
+        _default = Library(DEFAULT_PATH)
+    return _default

@@ -1,0 +1,80 @@
+"""Build the gfx950 C-ABI library (nemar_amd/lib/libnemar_hip.so) with hipcc.
+
+In-tree build (the .so travels to the GPU box with the repo snapshot).  hipcc cross-compiles for
+gfx950 without a GPU.  Usage:  python -m nemar_amd.csrc.build [--force] [--jobs N]
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB_PATH = os.path.join(LIB_DIR, "libnemar_hip.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+    "-munsafe-fp-atomics",      # fp32 atomicAdd -> global_atomic_add_f32, not a CAS loop
+    "-ffp-contract=off",        # keep a*b+c un-fused unless the source says fmaf (parity with the oracle)
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build the gfx950 extension")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+    if force or _stale(obj, deps):
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sources()
+    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    if force or _stale(LIB_PATH, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built %s (%d sources)" % (LIB_PATH, len(srcs)))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.jobs)

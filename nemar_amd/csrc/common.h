@@ -1,0 +1,96 @@
+// nemar_amd — shared host/device helpers for the gfx950 kernels behind include/nemar_hip.h.
+//
+// Conventions: the caller owns every buffer, kernels never allocate or
+// synchronise, every launch goes on the stream handed in, tensors are contiguous NCHW fp32.
+// Entry points return 0 or a negative NEMAR_E* code and leave a message for nemar_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define NEMAR_OK 0
+#define NEMAR_EINVAL (-1)   // bad shape / null pointer / unsupported combination
+#define NEMAR_ELAUNCH (-2)  // HIP reported a launch error
+#define NEMAR_EWORKSPACE (-3)  // workspace too small
+
+#define NEMAR_API extern "C" __attribute__((visibility("default")))
+
+// thread-local so the message survives being raised on autograd's backward thread
+void nemar_set_error(const char* fmt, ...);
+
+#define NEMAR_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            nemar_set_error(__VA_ARGS__);        \
+            return NEMAR_EINVAL;                 \
+        }                                        \
+    } while (0)
+
+#define NEMAR_CHECK_LAUNCH(what)                                              \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            nemar_set_error("%s: %s", what, hipGetErrorString(e__));          \
+            return NEMAR_ELAUNCH;                                             \
+        }                                                                     \
+    } while (0)
+
+#define NEMAR_HIP_CALL(expr)                                                 \
+    do {                                                                      \
+        hipError_t e__ = (expr);                                              \
+        if (e__ != hipSuccess) {                                              \
+            nemar_set_error("%s: %s", #expr, hipGetErrorString(e__));         \
+            return NEMAR_ELAUNCH;                                             \
+        }                                                                     \
+    } while (0)
+
+static inline int nemar_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Memory-bound kernels: cap the grid at 256 CUs x 8 workgroups and grid-stride the rest.
+static inline int nemar_stream_grid(long long work_items, int per_block) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 256 * 8) b = 256 * 8;
+    return (int)b;
+}
+
+// Exact unsigned division by a launch-constant divisor d (n*d < 2^40), without a VALU divide:
+// q = (n * M) >> 40 with M = ceil(2^40 / d).  Host builds it, device applies it.
+struct FastDiv {
+    unsigned d;
+    unsigned long long m;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d ? d : 1;
+    f.m = ((1ull << 40) + f.d - 1) / f.d;
+    return f;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
+    return (unsigned)(((unsigned long long)n * f.m) >> 40);
+}
+
+// 64-lane wavefront reductions (gfx950 wave = 64; never 32)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x a multiple of 64 (<=1024).  `red` is >=16 floats of LDS.
+// Result valid in every thread.  Deterministic (fixed tree).
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}

@@ -1,0 +1,76 @@
+"""Kernel-level micro-benchmarks (HIP events on the launch stream) for the HBM-bound ops.
+Prints one JSON object per case: algorithmic bytes / kernel time -> GB/s.  GPU only."""
+import argparse
+import ctypes
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from nemar_amd import _lib
+
+
+def timeit(fn, iters=50, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    a = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    out = []
+    for (N, C, H, W) in ((8, 3, 256, 256), (16, 3, 512, 512), (8, 3, 1024, 1024)):
+        torch.manual_seed(0)
+        img = torch.rand(N, C, H, W, device=dev) * 2 - 1
+        go = torch.randn(N, C, H, W, device=dev)
+        res = torch.empty_like(img)
+        gin = torch.empty_like(img)
+        for sigma in (0.0, 2.0 / W, 0.1):
+            off = torch.randn(N, 2, H, W, device=dev) * sigma
+            gd = torch.empty_like(off)
+            px = N * H * W
+            t = timeit(lambda: lib.grid_sample_fwd(P(img), P(off), 1, P(res), N, C, H, W, H, W, st()), a.iters)
+            out.append(dict(op="grid_sample_fwd", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
+                            GBps=px * 4 * (2 * C + 2) / t / 1e9))
+            t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), P(gin), 0, P(gd), 0, N, C, H, W, H, W, st()), a.iters)
+            out.append(dict(op="grid_sample_bwd+gin", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
+                            GBps=px * 4 * (3 * C + 4) / t / 1e9))
+            t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), None, 0, P(gd), 0, N, C, H, W, H, W, st()), a.iters)
+            out.append(dict(op="grid_sample_bwd", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
+                            GBps=px * 4 * (2 * C + 4) / t / 1e9))
+        off = torch.randn(N, 2, H, W, device=dev) * 0.01
+        gd = torch.empty_like(off)
+        loss = torch.zeros(1, device=dev)
+        gs = torch.ones(1, device=dev)
+        wsb = lib.smoothness_workspace(N, H, W)
+        ws = torch.empty(wsb // 4 + 1, device=dev)
+        for alpha, Ci in ((0.0, 0), (2.0, 3)):
+            im = img if Ci else None
+            t = timeit(lambda: lib.smoothness_fwd(P(off), P(im), Ci, alpha, 1.0, P(loss), 0, P(ws), wsb, N, H, W, st()), a.iters)
+            out.append(dict(op="smoothness_fwd", shape=[N, 2, H, W], alpha=alpha, us=t * 1e6,
+                            GBps=N * H * W * (8 + 4 * Ci) / t / 1e9))
+            t = timeit(lambda: lib.smoothness_bwd(P(off), P(im), Ci, alpha, P(gs), 1.0, P(gd), 0, N, H, W, st()), a.iters)
+            out.append(dict(op="smoothness_bwd", shape=[N, 2, H, W], alpha=alpha, us=t * 1e6,
+                            GBps=N * H * W * (16 + 4 * Ci) / t / 1e9))
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
