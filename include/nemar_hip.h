@@ -66,6 +66,44 @@ int nemar_smoothness_fwd(const float* d, const float* img, int Ci, float alpha, 
 int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, const float* gscale,
                          float factor, float* gd, int accumulate, int N, int H, int W, void* stream);
 
+/* ---- K1/K2/K4/K8: convolution family on fp32 MFMA (exact fp32) ---------------------------------------------
+ * nn.Conv2d / nn.ConvTranspose2d with the ReflectionPad2d and torch.cat feeding them folded in —
+ *     reference models/networks.py:349-377 (ResnetGenerator), :418-439 (ResnetBlock), :576-597
+ *     (NLayerDiscriminator); models/stn/layers.py:85 (Conv); models/stn/unet_stn.py:80,97 (cat);
+ *     models/stn/affine_stn.py:69-72 (nn.Linear == 1x1 conv on a 1x1 image).
+ * x = channel concat of x0 [N,C0,H,W] and x1 [N,C1,H,W] (x1 NULL/C1=0 for a single source), never materialised.
+ * w [K,C0+C1,R,S] (torch layout), bias [K] or NULL.  pad_mode: NEMAR_PAD_ZERO | NEMAR_PAD_REFLECT
+ * (reflect == nn.ReflectionPad2d(pad) followed by an unpadded conv).  act is applied in the epilogue:
+ * NEMAR_ACT_NONE | RELU | LRELU(slope) | TANH.  y [N,K,OH,OW], OH = (H + 2 pad - R) / stride + 1.
+ * workspace: packed weights (nemar_conv2d_fwd_workspace bytes). */
+#define NEMAR_PAD_ZERO 0
+#define NEMAR_PAD_REFLECT 1
+#define NEMAR_ACT_NONE 0
+#define NEMAR_ACT_RELU 1
+#define NEMAR_ACT_LRELU 2
+#define NEMAR_ACT_TANH 3
+size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S);
+int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
+                     float* y, int N, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode,
+                     int act, float slope, void* workspace, size_t ws_bytes, void* stream);
+/* Data gradient: gy [N,K,OH,OW] -> gx0 [N,C0,H,W] | gx1 [N,C1,H,W] (gx0 NULL: its channels are skipped, e.g. the
+ * real_A half of the discriminator input).  With bias/act it is ALSO the forward of
+ * nn.ConvTranspose2d(K -> C, k, stride, pad, output_padding) whose weight is w [K,C,R,S]
+ * (reference models/networks.py:369-372): pass gy := input, (H,W) := the transposed conv's output size. */
+size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                                       int pad_mode);
+int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, int act, float slope,
+                          float* gx0, int C0, float* gx1, int C1, int N, int H, int W, int K, int OH, int OW,
+                          int R, int S, int stride, int pad, int pad_mode, void* workspace, size_t ws_bytes,
+                          void* stream);
+/* Weight gradient, ACCUMULATED into gw [K,C0+C1,R,S] (the caller zero-fills once per optimizer step; the
+ * translation net receives two passes per step).  Pixel reduction is split across workgroups, fp32 atomics. */
+int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw,
+                            int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
+                            int pad_mode, void* stream);
+/* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */
+int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,687 @@
+// K1 + K2 + K4 + K8: the convolution family on the gfx950 matrix cores, exact fp32.
+//
+// Replaces nn.Conv2d / nn.ConvTranspose2d (+ the ReflectionPad2d in front of them and the torch.cat that
+// feeds them) at reference models/networks.py:349-377,418-439,576-597 and models/stn/layers.py:85,
+// models/stn/unet_stn.py:80,97, models/stn/affine_stn.py:69-72,79 — forward, data gradient and weight
+// gradient.  nn.Linear of the affine head is the 1x1 case on a 1x1 image.
+//
+// One tap-table implicit GEMM serves forward AND data-gradient (and therefore ConvTranspose2d, which is
+// the data-gradient of a strided conv):
+//     out[n, m, oy, ox] = act(bias[m] + sum_{t < ntaps} sum_{ch < Cs} A[(t*Cs+ch), m] *
+//                              src[n, ch, oy*sy + dy[t], ox*sx + dx[t]])
+//   - A is the weight tensor re-laid-out ("packed") as [Kred][M] so that tile loads are 16 B/lane coalesced;
+//   - src is the logical channel concat of two tensors (never materialised);
+//   - out-of-range taps read 0 (zero padding / strided data-gradient) or the mirrored texel (reflect);
+//   - a stride-2 data-gradient is four launches, one per output-pixel parity class, each with the subset of
+//     taps that lands on integer source positions.
+// GEMM view: M = output channels, N = output pixels, K = taps x source channels.  MFMA tile
+// v_mfma_f32_32x32x2_f32 with A = weights (rows = channels) and B = gathered pixels (cols = pixels), so the
+// accumulator's col = lane&31 runs along pixels and NCHW stores are coalesced.  f32-in MFMA is an fmaf chain
+// (bit-exact fp32, 157 TF peak): no reduced precision anywhere.
+//
+// The weight gradient is a second implicit GEMM, dW[k][c,r,s] = sum_pixels gy[k,p] * src[c, p (+) tap], with
+// the (huge) pixel reduction split across workgroups and fp32 atomics into the caller's gradient buffer.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;        // reduction depth per LDS stage (fwd/dgrad)
+constexpr int MAX_TAPS = 64;  // 7x7 = 49
+constexpr int BORDER_ZERO = 0, BORDER_REFLECT = 1;
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ int reflect(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+struct TapTable {
+    int n;
+    short dy[MAX_TAPS], dx[MAX_TAPS];
+    int wofs[MAX_TAPS];  // offset of the tap inside one [R][S] filter (pack kernel only)
+};
+
+// ---- weight packing: W[m*wsm + ch*wsc + wofs[t]] -> A[(t*Cs + ch)*Mpad + m], zero padded --------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M,
+                                                           int Mpad, int Cs, int Kred, int KredPad, int wsm, int wsc,
+                                                           TapTable taps) {
+    __shared__ int s_wofs[MAX_TAPS];
+    for (int i = threadIdx.x; i < MAX_TAPS; i += blockDim.x) s_wofs[i] = i < taps.n ? taps.wofs[i] : 0;
+    __syncthreads();
+    const int total = KredPad * Mpad;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int kk = idx / Mpad, m = idx - kk * Mpad;
+        float v = 0.f;
+        if (m < M && kk < Kred) {
+            const int t = kk / Cs, ch = kk - t * Cs;
+            v = w[(size_t)m * wsm + (size_t)ch * wsc + s_wofs[t]];
+        }
+        wp[idx] = v;
+    }
+}
+
+struct IgemmParams {
+    const float* src0; const float* src1; int C0, C1, Hs, Ws;
+    const float* wp; int Mpad, M, Kred;
+    const float* bias;
+    float* dst0; float* dst1; int M0;
+    int OH, OW, OHf, OWf, osy, ooy, osx, oox;
+    int N, P;
+    int sy, sx, border, act;
+    float slope;
+    FastDiv fd_ohw, fd_ow, fd_cs;
+    TapTable taps;
+};
+
+// WM x WN waves (WM*WN == 4), each TM x TN MFMA tiles of 32x32.  FAST: Cs % BK == 0 && C0 % BK == 0, so a whole
+// BK-deep stage shares one tap and one source tensor (address math once per stage instead of per element).
+template <int WM, int WN, int TM, int TN, bool FAST>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int TPC = 256 / BN == 0 ? 1 : 256 / BN;  // threads per pixel column of the B tile
+    constexpr int BROWS = BK / TPC;                    // B rows (reduction indices) per thread per stage
+    constexpr int A_F4 = BK * BM / 4;                  // float4s in an A stage
+    constexpr int A_PER = (A_F4 + 255) / 256;
+    static_assert(BN >= 128 && 256 % TPC == 0, "tile");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    __shared__ int s_tap[MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MAX_TAPS; i += 256)
+        s_tap[i] = i < p.taps.n ? (((int)p.taps.dy[i] << 16) | ((int)p.taps.dx[i] & 0xffff)) : 0;
+
+    const int m0 = blockIdx.y * BM;
+    const int p0 = blockIdx.x * BN;
+    const int Cs = p.C0 + p.C1;
+    const int HW = p.Hs * p.Ws;
+
+    // ---- this thread's pixel column of the B tile (fixed for the whole reduction) -------------------------
+    const int pc = tid % BN;
+    const int prow0 = tid / BN;
+    const int pix = p0 + pc;
+    const bool pvalid = pix < p.P;
+    int by = 0, bx = 0;
+    const float* s0n = p.src0;
+    const float* s1n = p.src1;
+    {
+        const unsigned upix = pvalid ? (unsigned)pix : 0u;
+        const unsigned n = fd_div(upix, p.fd_ohw);
+        const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
+        const unsigned oy = fd_div(rem, p.fd_ow);
+        const unsigned ox = rem - oy * (unsigned)p.OW;
+        by = (int)oy * p.sy;
+        bx = (int)ox * p.sx;
+        s0n = p.src0 + (size_t)n * p.C0 * HW;
+        if (p.C1) s1n = p.src1 + (size_t)n * p.C1 * HW;
+    }
+    __syncthreads();  // s_tap visible
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_PER];
+    float rb[BROWS];
+
+    auto load_stage = [&](int k0) {
+        // A: packed weights, rows k0..k0+BK-1 (zero padded on both axes => no bounds checks)
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            const int i = tid + q * 256;
+            if (A_F4 % 256 == 0 || i < A_F4) {
+                const int row = i / (BM / 4), c4 = i - row * (BM / 4);
+                ra[q] = *reinterpret_cast<const float4*>(p.wp + (size_t)(k0 + row) * p.Mpad + m0 + c4 * 4);
+            }
+        }
+        // B: gathered source pixels
+        if (FAST) {
+            const unsigned t = fd_div((unsigned)k0, p.fd_cs);
+            const int ch0 = k0 - (int)t * Cs;
+            const int tp = s_tap[t];
+            int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
+            bool inb = pvalid && k0 < p.Kred;
+            if (p.border == BORDER_REFLECT) {
+                y = reflect(y, p.Hs);
+                x = reflect(x, p.Ws);
+            } else {
+                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+            }
+            const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;
+            const int off = y * p.Ws + x;
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                const int r = prow0 + TPC * i;
+                rb[i] = inb ? base[(size_t)r * HW + off] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                const int kk = k0 + prow0 + TPC * i;
+                float v = 0.f;
+                if (pvalid && kk < p.Kred) {
+                    const unsigned t = fd_div((unsigned)kk, p.fd_cs);
+                    const int ch = kk - (int)t * Cs;
+                    const int tp = s_tap[t];
+                    int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
+                    bool inb = true;
+                    if (p.border == BORDER_REFLECT) {
+                        y = reflect(y, p.Hs);
+                        x = reflect(x, p.Ws);
+                    } else {
+                        inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+                    }
+                    if (inb) {
+                        const float* base = (ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW;
+                        v = base[y * p.Ws + x];
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            const int i = tid + q * 256;
+            if (A_F4 % 256 == 0 || i < A_F4) {
+                const int row = i / (BM / 4), c4 = i - row * (BM / 4);
+                *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = ra[q];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) Bs[buf][prow0 + TPC * i][pc] = rb[i];
+    };
+
+    const int wid = tid >> 6, lane = tid & 63;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int nk = (p.Kred + BK - 1) / BK;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_stage((ks + 1) * BK);
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            const int kr = 2 * k2 + lhi;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][kr][(wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kr][(wn * TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
+    const size_t oplane = (size_t)p.OHf * p.OWf;
+    const int M1 = p.M - p.M0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int opix = p0 + (wn * TN + j) * 32 + l31;
+        if (opix >= p.P) continue;
+        const unsigned n = fd_div((unsigned)opix, p.fd_ohw);
+        const unsigned rem = (unsigned)opix - n * (unsigned)(p.OH * p.OW);
+        const unsigned oy = fd_div(rem, p.fd_ow);
+        const unsigned ox = rem - oy * (unsigned)p.OW;
+        const size_t sp = (size_t)((int)oy * p.osy + p.ooy) * p.OWf + ((int)ox * p.osx + p.oox);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.M) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[m];
+                    v = apply_act(v, p.act, p.slope);
+                    if (m < p.M0) {
+                        if (p.dst0) p.dst0[((size_t)n * p.M0 + m) * oplane + sp] = v;
+                    } else {
+                        p.dst1[((size_t)n * M1 + (m - p.M0)) * oplane + sp] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM)), block(256);
+    if (fast)
+        hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, p);
+}
+
+int igemm_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+
+void launch_igemm(const IgemmParams& p, hipStream_t st) {
+    const int Cs = p.C0 + p.C1;
+    const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
+    const int bm = igemm_bm(p.M);
+    if (bm == 128)
+        launch_igemm_cfg<2, 2, 2, 2>(p, fast, st);  // 128 channels x 128 pixels
+    else if (bm == 64)
+        launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);  // 64 x 128
+    else
+        launch_igemm_cfg<1, 4, 1, 2>(p, fast, st);  // 32 x 256
+}
+
+size_t packed_floats(int M, int Kred) {
+    const int bm = igemm_bm(M);
+    return (size_t)nemar_cdiv(Kred, BK) * BK * ((size_t)nemar_cdiv(M, bm) * bm);
+}
+
+void launch_pack(const float* w, float* wp, int M, int Cs, int wsm, int wsc, const TapTable& taps, hipStream_t st) {
+    const int Kred = taps.n * Cs;
+    const int KredPad = nemar_cdiv(Kred, BK) * BK;
+    const int bm = igemm_bm(M);
+    const int Mpad = nemar_cdiv(M, bm) * bm;
+    const int total = KredPad * Mpad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, wp, M, Mpad, Cs,
+                       Kred, KredPad, wsm, wsc, taps);
+}
+
+// ---- weight gradient ----------------------------------------------------------------------------------------
+constexpr int WBK = 32;  // pixels per LDS stage
+
+struct WgradParams {
+    const float* src0; const float* src1; int C0, C1, Hs, Ws;
+    const float* gy; int K, OH, OW;
+    float* gw; int J;  // J = Cs * R * S columns, j = c*R*S + r*S + s (the tensor's own memory order)
+    int N, P, sy, sx, R, S, pad, border;
+    int pix_per_split;
+    FastDiv fd_ohw, fd_ow;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDA = BM + 1, LDB = BN + 1;  // odd stride: conflict-free transposing stores
+    constexpr int ACOLS = BM / 8, BCOLS = BN / 8;
+    __shared__ float As[2][WBK][LDA];
+    __shared__ float Bs[2][WBK][LDB];
+    __shared__ int s_jc[BN];   // source channel of column j (or -1: out of range)
+    __shared__ int s_jt[BN];   // packed (dy << 16) | (dx & 0xffff)
+
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * BM;
+    const int j0 = blockIdx.y * BN;
+    const int RS = p.R * p.S;
+    const int HW = p.Hs * p.Ws, OHW = p.OH * p.OW;
+    for (int i = tid; i < BN; i += 256) {
+        const int j = j0 + i;
+        int c = -1, tp = 0;
+        if (j < p.J) {
+            c = j / RS;
+            const int t = j - c * RS;
+            const int r = t / p.S, s = t - r * p.S;
+            tp = ((r - p.pad) << 16) | ((s - p.pad) & 0xffff);
+        }
+        s_jc[i] = c;
+        s_jt[i] = tp;
+    }
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.P, pbeg + p.pix_per_split);
+    const int prow = tid & 31, cgrp = tid >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();
+
+    float ra[ACOLS], rb[BCOLS];
+    auto load_stage = [&](int pb) {
+        const int pix = pb + prow;
+        const bool pv = pix < pend;
+        const unsigned upix = pv ? (unsigned)pix : 0u;
+        const unsigned n = fd_div(upix, p.fd_ohw);
+        const unsigned rem = upix - n * (unsigned)OHW;
+        const unsigned oy = fd_div(rem, p.fd_ow);
+        const unsigned ox = rem - oy * (unsigned)p.OW;
+        const float* g = p.gy + (size_t)n * p.K * OHW + rem;
+#pragma unroll
+        for (int i = 0; i < ACOLS; ++i) {
+            const int m = m0 + cgrp + 8 * i;
+            ra[i] = (pv && m < p.K) ? g[(size_t)m * OHW] : 0.f;
+        }
+        const int by = (int)oy * p.sy, bx = (int)ox * p.sx;
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
+        const float* s1n = p.C1 ? p.src1 + (size_t)n * p.C1 * HW : p.src0;
+#pragma unroll
+        for (int i = 0; i < BCOLS; ++i) {
+            const int col = cgrp + 8 * i;
+            const int c = s_jc[col];
+            const int tp = s_jt[col];
+            float v = 0.f;
+            if (pv && c >= 0) {
+                int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
+                bool inb = true;
+                if (p.border == BORDER_REFLECT) {
+                    y = reflect(y, p.Hs);
+                    x = reflect(x, p.Ws);
+                } else {
+                    inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+                }
+                if (inb) {
+                    const float* base = (c < p.C0) ? s0n + (size_t)c * HW : s1n + (size_t)(c - p.C0) * HW;
+                    v = base[y * p.Ws + x];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ACOLS; ++i) As[buf][prow][cgrp + 8 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < BCOLS; ++i) Bs[buf][prow][cgrp + 8 * i] = rb[i];
+    };
+
+    const int wid = tid >> 6, lane = tid & 63;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int nk = (pend - pbeg + WBK - 1) / WBK;
+    if (nk > 0) {
+        load_stage(pbeg);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_stage(pbeg + (ks + 1) * WBK);
+#pragma unroll
+        for (int k2 = 0; k2 < WBK / 2; ++k2) {
+            const int kr = 2 * k2 + lhi;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][kr][(wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kr][(wn * TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    if (nk <= 0) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int jj = j0 + (wn * TN + j) * 32 + l31;
+        if (jj >= p.J) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.K) atomicAdd(p.gw + (size_t)m * p.J + jj, acc[i][j][r]);
+            }
+    }
+}
+
+// gb[c] += sum_{n,hw} g[n,c,hw]; one workgroup per channel, deterministic tree + one atomic
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, float* __restrict__ gb, int N, int C,
+                                                        int HW) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* q = g + ((size_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) acc += q[i];
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(gb + c, t);
+}
+
+// gx[n,c,h,w] = sum of the padded-domain gradient gp over every padded position that mirrors onto (h,w)
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ gp, float* __restrict__ gx, int H,
+                                                           int W, int pad, long long total) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(idx % W);
+        const long long t = idx / W;
+        const int h = (int)(t % H);
+        const long long nc = t / H;
+        const float* q = gp + nc * (long long)Hp * Wp;
+        // padded rows that map to h: h+pad always; pad-h if 1<=h<=pad; 2(H-1)-h+pad if H-1-pad<=h<=H-2
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = h + pad;
+        if (h >= 1 && h <= pad) ys[ny++] = pad - h;
+        if (h <= H - 2 && h >= H - 1 - pad) ys[ny++] = 2 * (H - 1) - h + pad;
+        xs[nx++] = w + pad;
+        if (w >= 1 && w <= pad) xs[nx++] = pad - w;
+        if (w <= W - 2 && w >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - w + pad;
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) s += q[ys[a] * Wp + xs[b]];
+        gx[idx] = s;
+    }
+}
+
+void fwd_taps(TapTable& t, int R, int S, int pad) {
+    t.n = R * S;
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            t.dy[r * S + s] = (short)(r - pad);
+            t.dx[r * S + s] = (short)(s - pad);
+            t.wofs[r * S + s] = r * S + s;
+        }
+}
+
+// taps of output-pixel parity class (ph, pw) of a stride-`stride` data gradient: r with (ph + pad - r) % stride == 0
+void dgrad_taps(TapTable& t, int R, int S, int pad, int stride, int ph, int pw) {
+    t.n = 0;
+    for (int r = 0; r < R; ++r) {
+        if ((ph + pad - r) % stride != 0) continue;
+        for (int s = 0; s < S; ++s) {
+            if ((pw + pad - s) % stride != 0) continue;
+            t.dy[t.n] = (short)((ph + pad - r) / stride);
+            t.dx[t.n] = (short)((pw + pad - s) / stride);
+            t.wofs[t.n] = r * S + s;
+            t.n++;
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+NEMAR_API size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S) {
+    if (K <= 0 || C <= 0 || R <= 0 || S <= 0) return 0;
+    return sizeof(float) * packed_floats(K, C * R * S);
+}
+
+NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
+                               float* y, int N, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode,
+                               int act, float slope, void* workspace, size_t ws_bytes, void* stream) {
+    NEMAR_REQUIRE(x0 && w && y && workspace, "conv2d_fwd: null pointer");
+    NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_fwd: bad channel split %d+%d", C0, C1);
+    NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && R > 0 && S > 0 && R * S <= MAX_TAPS, "conv2d_fwd: bad shape");
+    NEMAR_REQUIRE(stride >= 1 && pad >= 0 && pad < 32768, "conv2d_fwd: bad stride/pad");
+    NEMAR_REQUIRE(pad_mode == BORDER_ZERO || (pad_mode == BORDER_REFLECT && pad < H && pad < W),
+                  "conv2d_fwd: reflect pad %d needs pad < H,W (%d,%d)", pad, H, W);
+    const int C = C0 + C1;
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    NEMAR_REQUIRE(OH > 0 && OW > 0, "conv2d_fwd: empty output");
+    NEMAR_REQUIRE((long long)N * OH * OW < (1ll << 31) && (long long)C * H * W < (1ll << 31) &&
+                      (long long)C * R * S < (1 << 20),
+                  "conv2d_fwd: problem too large for 32-bit tile indexing");
+    const size_t need = nemar_conv2d_fwd_workspace(K, C, R, S);
+    if (ws_bytes < need) {
+        nemar_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+        return NEMAR_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    IgemmParams p;
+    fwd_taps(p.taps, R, S, pad);
+    launch_pack(w, (float*)workspace, K, C, C * R * S, R * S, p.taps, st);
+    p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
+    p.wp = (const float*)workspace; p.M = K; p.Mpad = nemar_cdiv(K, igemm_bm(K)) * igemm_bm(K); p.Kred = C * R * S;
+    p.bias = bias;
+    p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
+    p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
+    p.N = N; p.P = N * OH * OW;
+    p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope;
+    p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
+    launch_igemm(p, st);
+    NEMAR_CHECK_LAUNCH("conv2d_fwd");
+    return NEMAR_OK;
+}
+
+// Data gradient of the conv above: gy [N,K,OH,OW] -> gx [N,C,H,W] (split over gx0[C0] | gx1[C1]; gx0 may be NULL to
+// skip its channels).  With bias/act it is also the FORWARD of nn.ConvTranspose2d(K -> C) whose weight is w[K][C][R][S].
+NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                                                 int pad_mode) {
+    if (N <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
+    size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
+    if (pad_mode == BORDER_REFLECT && pad > 0) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    return sizeof(float) * fl;
+}
+
+NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, int act, float slope,
+                                    float* gx0, int C0, float* gx1, int C1, int N, int H, int W, int K, int OH, int OW,
+                                    int R, int S, int stride, int pad, int pad_mode, void* workspace, size_t ws_bytes,
+                                    void* stream) {
+    NEMAR_REQUIRE(gy && w && workspace && (gx0 || gx1), "conv2d_bwd_data: null pointer");
+    NEMAR_REQUIRE(C0 >= 0 && C1 >= 0 && C0 + C1 > 0 && (C1 == 0 || gx1), "conv2d_bwd_data: bad channel split");
+    NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && OH > 0 && OW > 0 && R * S <= MAX_TAPS && R > 0 && S > 0,
+                  "conv2d_bwd_data: bad shape");
+    NEMAR_REQUIRE(stride >= 1 && stride <= 4 && pad >= 0, "conv2d_bwd_data: bad stride/pad");
+    NEMAR_REQUIRE((H + 2 * pad - R) / stride + 1 == OH && (W + 2 * pad - S) / stride + 1 == OW,
+                  "conv2d_bwd_data: gy %dx%d inconsistent with x %dx%d k%d s%d p%d", OH, OW, H, W, R, stride, pad);
+    const int C = C0 + C1;
+    const bool refl = pad_mode == BORDER_REFLECT && pad > 0;
+    NEMAR_REQUIRE(!refl || (pad < H && pad < W && !bias && act == ACT_NONE && gx1 == nullptr),
+                  "conv2d_bwd_data: reflect mode supports a single destination without bias/activation");
+    const size_t need = nemar_conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode);
+    if (ws_bytes < need) {
+        nemar_set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+        return NEMAR_EWORKSPACE;
+    }
+    NEMAR_REQUIRE((long long)N * (H + 2 * pad) * (W + 2 * pad) < (1ll << 31) && (long long)K * OH * OW < (1ll << 31) &&
+                      (long long)K * R * S < (1 << 20),
+                  "conv2d_bwd_data: problem too large for 32-bit tile indexing");
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)workspace;
+    const size_t pack_stride = packed_floats(C, K * R * S);
+    // reflect: differentiate w.r.t. the PADDED input (a zero-pad-free problem on the padded domain), then fold
+    const int Hd = refl ? H + 2 * pad : H, Wd = refl ? W + 2 * pad : W;
+    const int padd = refl ? 0 : pad;
+    float* padded = refl ? wsf + pack_stride * (size_t)(stride * stride) : nullptr;
+    // skipping the first C0 channels when gx0 == NULL: start the M range at C0
+    const int mskip = (gx0 == nullptr) ? C0 : 0;
+    int cls = 0;
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw, ++cls) {
+            IgemmParams p;
+            dgrad_taps(p.taps, R, S, padd, stride, ph, pw);
+            const int OHc = (Hd - ph + stride - 1) / stride, OWc = (Wd - pw + stride - 1) / stride;
+            if (OHc <= 0 || OWc <= 0) continue;
+            const int Mc = C - mskip;
+            p.src0 = gy; p.src1 = nullptr; p.C0 = K; p.C1 = 0; p.Hs = OH; p.Ws = OW;
+            p.M = Mc; p.Mpad = nemar_cdiv(Mc, igemm_bm(Mc)) * igemm_bm(Mc); p.Kred = p.taps.n * K;
+            p.bias = bias ? bias + mskip : nullptr;
+            if (refl) { p.dst0 = padded; p.dst1 = nullptr; p.M0 = Mc; }
+            else if (mskip) { p.dst0 = gx1; p.dst1 = nullptr; p.M0 = Mc; }
+            else { p.dst0 = gx0; p.dst1 = gx1; p.M0 = C0; }
+            p.OH = OHc; p.OW = OWc; p.OHf = Hd; p.OWf = Wd; p.osy = stride; p.ooy = ph; p.osx = stride; p.oox = pw;
+            p.N = N; p.P = N * OHc * OWc;
+            p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
+            p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
+            float* wp = wsf + pack_stride * (size_t)cls;
+            p.wp = wp;
+            if (p.taps.n == 0) {
+                // no tap reaches this class (e.g. k1 s2): gradient is bias-only / zero; run with one zero tap
+                p.taps.n = 1; p.taps.dy[0] = -32000; p.taps.dx[0] = -32000; p.taps.wofs[0] = 0; p.Kred = K;
+            }
+            // A[(t*K + k)][c] = w[k][c + mskip][r][s]
+            launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
+            launch_igemm(p, st);
+        }
+    if (refl) {
+        const long long total = (long long)N * C * H * W;
+        hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st,
+                           (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total);
+    }
+    NEMAR_CHECK_LAUNCH("conv2d_bwd_data");
+    return NEMAR_OK;
+}
+
+// gw[K][C][R][S] += d loss / d w   (always accumulates: the caller zero-fills once per optimizer step)
+NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw,
+                                      int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
+                                      int pad_mode, void* stream) {
+    NEMAR_REQUIRE(x0 && gy && gw, "conv2d_bwd_weight: null pointer");
+    NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_bwd_weight: bad channel split");
+    NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && OH > 0 && OW > 0 && R > 0 && S > 0, "conv2d_bwd_weight: bad shape");
+    NEMAR_REQUIRE(pad_mode == BORDER_ZERO || (pad < H && pad < W), "conv2d_bwd_weight: reflect pad too large");
+    NEMAR_REQUIRE((long long)N * OH * OW < (1ll << 31) && (long long)(C0 + C1) * H * W < (1ll << 31),
+                  "conv2d_bwd_weight: problem too large for 32-bit tile indexing");
+    hipStream_t st = (hipStream_t)stream;
+    WgradParams p;
+    p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
+    p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
+    p.gw = gw; p.J = (C0 + C1) * R * S;
+    p.N = N; p.P = N * OH * OW; p.sy = stride; p.sx = stride; p.R = R; p.S = S; p.pad = pad; p.border = pad_mode;
+    p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW);
+    const bool wide = K > 32;
+    const int BM = wide ? 128 : 32, BN = wide ? 128 : 256;
+    const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(p.J, BN);
+    // split the pixel reduction so that ~4 workgroups per CU exist, but keep >= 8 stages per split
+    int splits = nemar_cdiv(1024, mt * jt);
+    const int max_splits = nemar_cdiv(p.P, WBK * 8);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    p.pix_per_split = nemar_cdiv(nemar_cdiv(p.P, splits), WBK) * WBK;
+    splits = nemar_cdiv(p.P, p.pix_per_split);
+    dim3 grid(mt, jt, splits), block(256);
+    if (wide)
+        hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 2>), grid, block, 0, st, p);
+    NEMAR_CHECK_LAUNCH("conv2d_bwd_weight");
+    return NEMAR_OK;
+}
+
+// gb[C] += sum over N and the plane of g [N,C,HW]   (bias gradient; also ConvTranspose2d's)
+NEMAR_API int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream) {
+    NEMAR_REQUIRE(g && gb && N > 0 && C > 0 && HW > 0, "bias_grad: bad arguments");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, gb, N, C, HW);
+    NEMAR_CHECK_LAUNCH("bias_grad");
+    return NEMAR_OK;
+}

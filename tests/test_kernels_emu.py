@@ -38,3 +38,49 @@ def test_smoothness(be, Ci, alpha):
 def test_smoothness_accumulate_factor(be):
     K.case_smoothness(be, N=1, H=2, W=2, Ci=3, alpha=0.9, factor=0.5, accumulate=True)
     K.case_smoothness(be, N=3, H=17, W=5, Ci=0, alpha=0.0, factor=0.25)
+
+
+# conv family: (C0, C1, K, R, stride, pad, pad_mode) chosen to hit every tile config (K<=32, <=64, >64), the FAST
+# (channels % 16 == 0) and general loaders, concat, reflect, stride-2 parity classes, k=4/7/1
+CONV_CASES = [
+    (3, 0, 8, 7, 1, 3, K.PAD_REFLECT),     # T stem-like (general loader, 49 taps)
+    (16, 0, 40, 3, 1, 1, K.PAD_REFLECT),   # resblock-like, FAST loader, BM=64
+    (32, 0, 70, 3, 2, 1, K.PAD_ZERO),      # downsample, FAST, BM=128 (ragged M)
+    (16, 16, 24, 3, 1, 1, K.PAD_ZERO),     # decoder concat, FAST across two sources
+    (3, 3, 12, 4, 2, 1, K.PAD_ZERO),       # D first layer: concat, k4 s2, general
+    (5, 0, 33, 4, 1, 1, K.PAD_ZERO),       # D k4 s1 (output shrinks by 1)
+    (20, 0, 2, 3, 1, 1, K.PAD_ZERO),       # STN output conv (K=2)
+    (16, 0, 130, 1, 1, 0, K.PAD_ZERO),     # 1x1
+]
+
+
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm", CONV_CASES)
+def test_conv_fwd(be, C0, C1, Kc, R, stride, pad, pm):
+    K.case_conv_fwd(be, 2, C0, C1, 9, 10, Kc, R, stride, pad, pm, act=K.O.ACT_LRELU)
+
+
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm", CONV_CASES)
+def test_conv_bwd_data(be, C0, C1, Kc, R, stride, pad, pm):
+    if pm == K.PAD_REFLECT and C1:
+        pytest.skip("reflect dgrad is single-destination")
+    K.case_conv_bwd_data(be, 2, C0, C1, 9, 10, Kc, R, stride, pad, pm)
+
+
+def test_conv_bwd_data_skip_first_source(be):
+    K.case_conv_bwd_data(be, 2, 3, 3, 10, 8, 12, 4, 2, 1, K.PAD_ZERO, skip0=True)
+
+
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm", CONV_CASES)
+def test_conv_bwd_weight(be, C0, C1, Kc, R, stride, pad, pm):
+    K.case_conv_bwd_weight(be, 2, C0, C1, 9, 10, Kc, R, stride, pad, pm)
+
+
+def test_conv_fwd_acts_and_linear(be):
+    K.case_conv_fwd(be, 2, 16, 0, 6, 6, 3, 7, 1, 3, K.PAD_REFLECT, act=K.O.ACT_TANH)      # T head
+    K.case_conv_fwd(be, 3, 64, 0, 1, 1, 20, 1, 1, 0, K.PAD_ZERO, act=K.O.ACT_RELU)        # nn.Linear
+    K.case_conv_fwd(be, 1, 8, 0, 2, 2, 8, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE, bias=False)  # 2x2 bottleneck
+
+
+@pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
+def test_conv_transpose_fwd(be, R, op):
+    K.case_conv_transpose_fwd(be, 2, 16, 12, 5, 6, R, op)
