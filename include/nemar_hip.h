@@ -104,6 +104,60 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */
 int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream);
 
+/* ---- K3 (+K5): InstanceNorm2d(affine=False, track_running_stats=False) with fused activation / residual -------
+ * nn.InstanceNorm2d — reference models/networks.py:24 (used :351,358,373,426,439,584,592), models/stn/layers.py:16;
+ * the ReLU/LeakyReLU(0.2) after it, and the ResnetBlock skip `x + conv_block(x)` (models/networks.py:445).
+ * x,y,residual: [planes = N*C, HW]; stats [planes,2] = (mean, rstd) saved for the backward.
+ * fwd: y = (residual ? residual : 0) + act((x - mean) * rstd), biased variance, eps inside the sqrt.
+ * bwd: gx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = gy * act'(xhat).  act: NONE | RELU | LRELU. */
+int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
+                       float eps, int act, float slope, void* stream);
+int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
+                       int act, float slope, void* stream);
+
+/* ---- K5/K6/K7: pointwise, pooling, resize, dropout -----------------------------------------------------------------
+ * act_bwd: gx = gy * f'(.) expressed with the activation OUTPUT y (f fused into a conv epilogue):
+ *     nn.LeakyReLU / nn.ReLU / nn.Tanh — reference models/networks.py:377,576 ; models/stn/layers.py:61-64. */
+int nemar_act_bwd(const float* gy, const float* y, float* gx, long long n, int act, float slope, void* stream);
+/* nn.MaxPool2d(2) — reference models/stn/layers.py:174.  x [planes,H,W] -> y [planes,H/2,W/2].
+ * bwd: gx = (addend ? addend : 0) + unpool(gy); the argmax (first maximum, row-major) is recomputed from x. */
+int nemar_maxpool2_fwd(const float* x, float* y, int planes, int H, int W, void* stream);
+int nemar_maxpool2_bwd(const float* x, const float* gy, const float* addend, float* gx, int planes, int H, int W,
+                       void* stream);
+/* F.interpolate(x, (Ho,Wo), mode='bilinear', align_corners=False) — reference models/stn/unet_stn.py:96,188-195,
+ * models/nemar_model.py:187-188,204-205,226-227,240-241,254-255.  bwd WRITES gx [planes,H,W]. */
+int nemar_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int Ho, int Wo, void* stream);
+int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, int W, int Ho, int Wo, void* stream);
+/* nn.Dropout(p) in training mode — reference models/networks.py:427-428.  y = x * mask / (1-p), mask drawn from
+ * Philox4x32-10(seed, offset); the backward is the same call on the upstream gradient (mask regenerated). */
+int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned offset,
+                  void* stream);
+
+/* ---- K13: losses (already multiplied by their lambda `weight`; optionally accumulated into a device scalar) ------
+ * l1:  torch.nn.L1Loss — reference models/nemar_model.py:68,179,195; b == NULL gives mean|a|
+ *      (affine STN regulariser, reference models/stn/affine_stn.py:136-138).
+ * gan: GANLoss.__call__ against a constant target — reference models/networks.py:263-281.
+ *      mode NEMAR_GAN_VANILLA (BCEWithLogits) | NEMAR_GAN_LSGAN (MSE) | NEMAR_GAN_WGANGP (+-mean).
+ * fwd: loss[0] = (accumulate ? loss[0] : 0) + weight * L ;  bwd: grad = gscale[0] * weight * dL/dx. */
+#define NEMAR_GAN_VANILLA 0
+#define NEMAR_GAN_LSGAN 1
+#define NEMAR_GAN_WGANGP 2
+size_t nemar_loss_workspace(void);
+int nemar_l1_loss_fwd(const float* a, const float* b, long long n, float weight, float* loss, int accumulate,
+                      void* workspace, size_t ws_bytes, void* stream);
+int nemar_l1_loss_bwd(const float* a, const float* b, long long n, const float* gscale, float weight, float* ga,
+                      int accumulate, void* stream);
+int nemar_gan_loss_fwd(const float* x, long long n, int mode, int target_is_real, float weight, float* loss,
+                       int accumulate, void* workspace, size_t ws_bytes, void* stream);
+int nemar_gan_loss_bwd(const float* x, long long n, int mode, int target_is_real, const float* gscale,
+                       float weight, float* gx, void* stream);
+
+/* ---- K15: fused Adam over a flat parameter buffer --------------------------------------------------------------------
+ * torch.optim.Adam(lr, betas=(beta1, beta2), eps).step() — reference models/nemar_model.py:128-137 (construction),
+ * :274,282-283 (step).  p,g,m,v: length n; step is 1-based.  Hyper-parameters are doubles, as in torch. */
+int nemar_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
+                    double beta2, double eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,10 @@ _vp = C.c_void_p
 _i = C.c_int
 _fl = C.c_float
 _sz = C.c_size_t
+_ll = C.c_longlong
+_db = C.c_double
+_u64 = C.c_ulonglong
+_u32 = C.c_uint
 
 # name -> (restype, argtypes); mirrors include/nemar_hip.h one to one (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -32,6 +36,20 @@ SIGNATURES = {
                                    _i, _vp, _sz, _vp]),
     "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
+    "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
+    "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
+    "nemar_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "nemar_maxpool2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "nemar_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nemar_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nemar_dropout": (_i, [_vp, _vp, _ll, _fl, _u64, _u32, _vp]),
+    "nemar_loss_workspace": (_sz, []),
+    "nemar_l1_loss_fwd": (_i, [_vp, _vp, _ll, _fl, _vp, _i, _vp, _sz, _vp]),
+    "nemar_l1_loss_bwd": (_i, [_vp, _vp, _ll, _vp, _fl, _vp, _i, _vp]),
+    "nemar_gan_loss_fwd": (_i, [_vp, _ll, _i, _i, _fl, _vp, _i, _vp, _sz, _vp]),
+    "nemar_gan_loss_bwd": (_i, [_vp, _ll, _i, _i, _vp, _fl, _vp, _vp]),
+    "nemar_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _db, _db, _db, _db, _i, _vp]),
 }
 
 

@@ -1,0 +1,189 @@
+// K3 (+K5 fused): InstanceNorm2d(affine=False, track_running_stats=False), forward and backward, with the
+// following ReLU / LeakyReLU and the ResnetBlock residual add fused in.
+//
+// Replaces nn.InstanceNorm2d at reference models/networks.py:24 (norm_layer of ResnetGenerator :351,358,373,
+// ResnetBlock :426,439, NLayerDiscriminator :584,592) and models/stn/layers.py:16 (STN ResnetBlocks, affine STN
+// convs), the nn.ReLU(True)/nn.LeakyReLU(0.2, True) that follow them, and `x + self.conv_block(x)`
+// (models/networks.py:445).
+//   fwd:  y = [residual +] act((x - mean_hw) * rsqrt(var_hw(biased) + eps)),   stats[plane] = (mean, rstd)
+//   bwd:  g = gy * act'(xhat);  gx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+// HBM-bound.  One workgroup per (n,c) plane; planes up to THREADS*PER elements are held in registers so x (and gy)
+// are read from memory exactly once and the variance is the exact two-pass form.
+#include "common.h"
+
+namespace {
+
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2;
+
+__device__ __forceinline__ float act_f(float v, int act, float slope) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    return v;
+}
+__device__ __forceinline__ float act_df(float xhat, int act, float slope) {
+    if (act == ACT_RELU) return xhat > 0.f ? 1.f : 0.f;
+    if (act == ACT_LRELU) return xhat > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+// PER > 0: register-cached plane (HW <= THREADS*PER).  PER == 0: streaming (shifted one-pass statistics).
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ residual,
+                                                               float* __restrict__ y, float* __restrict__ stats, int HW,
+                                                               float eps, int act, float slope) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float* xp = x + base;
+    float* yp = y + base;
+    const float* rp = residual ? residual + base : nullptr;
+    const float inv = 1.f / (float)HW;
+    float mean, rstd;
+    if (PER > 0) {
+        float v[PER > 0 ? PER : 1];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * THREADS;
+            v[k] = i < HW ? xp[i] : 0.f;
+            s += v[k];
+        }
+        mean = block_sum(s, red) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * THREADS;
+            const float d = i < HW ? v[k] - mean : 0.f;
+            q += d * d;
+        }
+        rstd = 1.f / sqrtf(block_sum(q, red) * inv + eps);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * THREADS;
+            if (i < HW) {
+                float o = act_f((v[k] - mean) * rstd, act, slope);
+                if (rp) o += rp[i];
+                yp[i] = o;
+            }
+        }
+    } else {
+        const float shift = xp[0];
+        float s = 0.f, q = 0.f;
+        for (int i = threadIdx.x; i < HW; i += THREADS) {
+            const float d = xp[i] - shift;
+            s += d;
+            q += d * d;
+        }
+        const float ms = block_sum(s, red) * inv;
+        const float var = fmaxf(block_sum(q, red) * inv - ms * ms, 0.f);
+        mean = shift + ms;
+        rstd = 1.f / sqrtf(var + eps);
+        for (int i = threadIdx.x; i < HW; i += THREADS) {
+            float o = act_f((xp[i] - mean) * rstd, act, slope);
+            if (rp) o += rp[i];
+            yp[i] = o;
+        }
+    }
+    if (threadIdx.x == 0) {
+        stats[2 * (size_t)blockIdx.x] = mean;
+        stats[2 * (size_t)blockIdx.x + 1] = rstd;
+    }
+}
+
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ gy, float* __restrict__ gx,
+                                                               int HW, int act, float slope) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float* xp = x + base;
+    const float* gp = gy + base;
+    float* op = gx + base;
+    const float mean = stats[2 * (size_t)blockIdx.x], rstd = stats[2 * (size_t)blockIdx.x + 1];
+    const float inv = 1.f / (float)HW;
+    if (PER > 0) {
+        float xh[PER > 0 ? PER : 1], g[PER > 0 ? PER : 1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * THREADS;
+            if (i < HW) {
+                xh[k] = (xp[i] - mean) * rstd;
+                g[k] = gp[i] * act_df(xh[k], act, slope);
+            } else {
+                xh[k] = 0.f;
+                g[k] = 0.f;
+            }
+            s1 += g[k];
+            s2 += g[k] * xh[k];
+        }
+        const float m1 = block_sum(s1, red) * inv;
+        const float m2 = block_sum(s2, red) * inv;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * THREADS;
+            if (i < HW) op[i] = rstd * (g[k] - m1 - xh[k] * m2);
+        }
+    } else {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += THREADS) {
+            const float xh = (xp[i] - mean) * rstd;
+            const float g = gp[i] * act_df(xh, act, slope);
+            s1 += g;
+            s2 += g * xh;
+        }
+        const float m1 = block_sum(s1, red) * inv;
+        const float m2 = block_sum(s2, red) * inv;
+        for (int i = threadIdx.x; i < HW; i += THREADS) {
+            const float xh = (xp[i] - mean) * rstd;
+            const float g = gp[i] * act_df(xh, act, slope);
+            op[i] = rstd * (g - m1 - xh * m2);
+        }
+    }
+}
+
+}  // namespace
+
+// x, y, residual (nullable): [planes, HW] with planes = N*C;  stats: [planes, 2] = (mean, rstd)
+NEMAR_API int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
+                                 float eps, int act, float slope, void* stream) {
+    NEMAR_REQUIRE(x && y && stats, "instnorm_fwd: null pointer");
+    NEMAR_REQUIRE(planes > 0 && HW > 0, "instnorm_fwd: bad shape planes=%d HW=%d", planes, HW);
+    NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_fwd: unsupported act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(planes);
+    if (HW <= 64 * 8)
+        hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope);
+    else if (HW <= 256 * 16)
+        hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope);
+    else if (HW <= 1024 * 16)
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope);
+    else if (HW <= 1024 * 64)
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 64>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope);
+    else
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope);
+    NEMAR_CHECK_LAUNCH("instnorm_fwd");
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
+                                 int act, float slope, void* stream) {
+    NEMAR_REQUIRE(x && stats && gy && gx, "instnorm_bwd: null pointer");
+    NEMAR_REQUIRE(planes > 0 && HW > 0, "instnorm_bwd: bad shape planes=%d HW=%d", planes, HW);
+    NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_bwd: unsupported act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(planes);
+    if (HW <= 64 * 8)
+        hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope);
+    else if (HW <= 256 * 16)
+        hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope);
+    else if (HW <= 1024 * 16)
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope);
+    else if (HW <= 1024 * 32)
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 32>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope);
+    else
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope);
+    NEMAR_CHECK_LAUNCH("instnorm_bwd");
+    return NEMAR_OK;
+}

@@ -182,3 +182,142 @@ def case_conv_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, seed=
     d_gb = be.full((K,), -0.25)
     be.lib.bias_grad(be.ptr(d_gy), be.ptr(d_gb), N, K, OH * OW, be.stream)
     _assert_close(be.np(d_gb), want_gb - 0.25, atol=2e-5, rtol=2e-5, what="bias_grad")
+
+
+# ------------------------------------------------------------------------------------------------
+def case_instnorm(be, N, C, H, W, act, residual=False, seed=0):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((N, C, H, W)) * 2 + rng.standard_normal((N, C, 1, 1)) * 3).astype(np.float32)
+    res = rng.standard_normal((N, C, H, W)).astype(np.float32) if residual else None
+    gy = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    x64 = x.astype(np.float64)
+    xhat, m, rstd = O.instance_norm_fwd(x64)
+    want = O.act_fwd(xhat, act) + (res.astype(np.float64) if residual else 0.0)
+    g = gy.astype(np.float64) * (O.act_bwd(np.ones_like(xhat), O.act_fwd(xhat, act), act))
+    want_gx = O.instance_norm_bwd(x64, g)
+    d_x, d_gy = be.dev(x), be.dev(gy)
+    d_res = be.dev(res) if residual else None
+    d_y = be.full((N, C, H, W), np.nan)
+    d_st = be.full((N * C, 2), np.nan)
+    be.lib.instnorm_fwd(be.ptr(d_x), be.ptr(d_res), be.ptr(d_y), be.ptr(d_st), N * C, H * W, 1e-5, act, 0.2, be.stream)
+    _assert_close(be.np(d_y), want, atol=3e-5, rtol=1e-5, what="instnorm_fwd")
+    st = be.np(d_st)
+    _assert_close(st[:, 0], m.reshape(-1), atol=1e-5, rtol=1e-5, what="instnorm mean")
+    _assert_close(st[:, 1], rstd.reshape(-1), atol=0, rtol=3e-5, what="instnorm rstd")
+    d_gx = be.full((N, C, H, W), np.nan)
+    be.lib.instnorm_bwd(be.ptr(d_x), be.ptr(d_st), be.ptr(d_gy), be.ptr(d_gx), N * C, H * W, act, 0.2, be.stream)
+    _assert_close(be.np(d_gx), want_gx, atol=3e-5 * np.abs(want_gx).max(), rtol=1e-4, what="instnorm_bwd")
+
+
+def case_pointwise(be, seed=0):
+    rng = np.random.default_rng(seed)
+    # act_bwd
+    for act in (O.ACT_RELU, O.ACT_LRELU, O.ACT_TANH):
+        n = 1027
+        pre = rng.standard_normal(n).astype(np.float32)
+        y = O.act_fwd(pre.astype(np.float64), act).astype(np.float32)
+        gy = rng.standard_normal(n).astype(np.float32)
+        want = O.act_bwd(gy.astype(np.float64), y.astype(np.float64), act)
+        d_g = be.full((n,), np.nan)
+        be.lib.act_bwd(be.ptr(be.dev(gy)), be.ptr(be.dev(y)), be.ptr(d_g), n, act, 0.2, be.stream)
+        _assert_close(be.np(d_g), want, atol=1e-6, rtol=1e-6, what="act_bwd")
+    # maxpool (even, odd sizes; ties)
+    for (H, W) in ((8, 10), (7, 9), (2, 2)):
+        x = rng.integers(-3, 4, (2, 3, H, W)).astype(np.float32)     # many exact ties
+        want, _ = O.maxpool2_fwd(x.astype(np.float64))
+        Ho, Wo = H // 2, W // 2
+        d_x = be.dev(x)
+        d_y = be.full((2, 3, Ho, Wo), np.nan)
+        be.lib.maxpool2_fwd(be.ptr(d_x), be.ptr(d_y), 6, H, W, be.stream)
+        _assert_close(be.np(d_y), want, atol=0, what="maxpool2_fwd")
+        gy = rng.standard_normal((2, 3, Ho, Wo)).astype(np.float32)
+        add = rng.standard_normal((2, 3, H, W)).astype(np.float32)
+        want_g = O.maxpool2_bwd(x.astype(np.float64), gy.astype(np.float64))
+        d_gx = be.full((2, 3, H, W), np.nan)
+        be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(be.dev(gy)), None, be.ptr(d_gx), 6, H, W, be.stream)
+        _assert_close(be.np(d_gx), want_g, atol=0, what="maxpool2_bwd")
+        be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(be.dev(gy)), be.ptr(be.dev(add)), be.ptr(d_gx), 6, H, W, be.stream)
+        _assert_close(be.np(d_gx), want_g + add, atol=1e-6, what="maxpool2_bwd+addend")
+    # bilinear: 2x up (gather backward), /2 and /4 down, arbitrary
+    for (H, W, Ho, Wo) in ((4, 5, 8, 10), (2, 2, 4, 4), (1, 3, 2, 6), (8, 12, 4, 6), (8, 12, 2, 3), (5, 7, 9, 4)):
+        x = rng.standard_normal((2, 2, H, W)).astype(np.float32)
+        want = O.bilinear_resize_fwd(x.astype(np.float64), Ho, Wo)
+        d_y = be.full((2, 2, Ho, Wo), np.nan)
+        be.lib.bilinear_fwd(be.ptr(be.dev(x)), be.ptr(d_y), 4, H, W, Ho, Wo, be.stream)
+        _assert_close(be.np(d_y), want, atol=2e-6, what="bilinear_fwd %s" % ((H, W, Ho, Wo),))
+        gy = rng.standard_normal((2, 2, Ho, Wo)).astype(np.float32)
+        want_g = O.bilinear_resize_bwd(gy.astype(np.float64), H, W)
+        d_gx = be.full((2, 2, H, W), np.nan)
+        be.lib.bilinear_bwd(be.ptr(be.dev(gy)), be.ptr(d_gx), 4, H, W, Ho, Wo, be.stream)
+        _assert_close(be.np(d_gx), want_g, atol=5e-6, what="bilinear_bwd %s" % ((H, W, Ho, Wo),))
+
+
+def case_dropout(be, n=40003, p=0.5):
+    x = np.ones(n, dtype=np.float32) * 3
+    d_x = be.dev(x)
+    d_y = be.full((n,), np.nan)
+    be.lib.dropout(be.ptr(d_x), be.ptr(d_y), n, p, 1234567, 7, be.stream)
+    y = be.np(d_y)
+    keep = y != 0
+    assert np.allclose(y[keep], 3 / (1 - p))
+    frac = keep.mean()
+    assert abs(frac - (1 - p)) < 5 * np.sqrt(p * (1 - p) / n), frac
+    d_y2 = be.full((n,), np.nan)
+    be.lib.dropout(be.ptr(d_x), be.ptr(d_y2), n, p, 1234567, 7, be.stream)
+    assert np.array_equal(be.np(d_y2), y)                 # same (seed, offset) -> same mask (backward relies on it)
+    be.lib.dropout(be.ptr(d_x), be.ptr(d_y2), n, p, 1234567, 8, be.stream)
+    assert not np.array_equal(be.np(d_y2), y)             # different offset -> different mask
+    # lag-1 independence of neighbouring elements
+    k = keep.astype(np.float64)
+    assert abs(np.corrcoef(k[:-1], k[1:])[0, 1]) < 0.03
+
+
+def case_losses(be, seed=0):
+    rng = np.random.default_rng(seed)
+    wsb = be.lib.loss_workspace()
+    ws = be.bytes_buf(wsb)
+    gs = be.dev(np.array([0.5], dtype=np.float32))
+    for n in (7, 5000):
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        b[:3] = a[:3]                                  # sign(0) = 0
+        for bb in (b, None):
+            b64 = bb.astype(np.float64) if bb is not None else np.zeros(n)
+            loss = be.full((1,), 2.0)
+            be.lib.l1_loss_fwd(be.ptr(be.dev(a)), be.ptr(be.dev(bb)) if bb is not None else None, n, 100.0, be.ptr(loss), 1,
+                               be.ptr(ws), wsb, be.stream)
+            _assert_close(be.np(loss), [2.0 + 100.0 * O.l1_loss_fwd(a.astype(np.float64), b64)], atol=1e-5, rtol=1e-5,
+                          what="l1_loss_fwd")
+            ga = be.full((n,), np.nan)
+            be.lib.l1_loss_bwd(be.ptr(be.dev(a)), be.ptr(be.dev(bb)) if bb is not None else None, n, be.ptr(gs), 100.0,
+                               be.ptr(ga), 0, be.stream)
+            _assert_close(be.np(ga), 50.0 * O.l1_loss_bwd(a.astype(np.float64), b64), atol=1e-9, rtol=1e-6, what="l1_loss_bwd")
+        x = (rng.standard_normal(n) * 4).astype(np.float32)
+        for mode, name in ((0, 'vanilla'), (1, 'lsgan'), (2, 'wgangp')):
+            for real in (1, 0):
+                loss = be.full((1,), np.nan)
+                be.lib.gan_loss_fwd(be.ptr(be.dev(x)), n, mode, real, 0.5, be.ptr(loss), 0, be.ptr(ws), wsb, be.stream)
+                _assert_close(be.np(loss), [0.5 * O.gan_loss_fwd(x.astype(np.float64), bool(real), name)], atol=1e-6,
+                              rtol=1e-5, what="gan_loss_fwd " + name)
+                gx = be.full((n,), np.nan)
+                be.lib.gan_loss_bwd(be.ptr(be.dev(x)), n, mode, real, be.ptr(gs), 0.5, be.ptr(gx), be.stream)
+                _assert_close(be.np(gx), 0.25 * O.gan_loss_bwd(x.astype(np.float64), bool(real), name), atol=1e-9,
+                              rtol=2e-5, what="gan_loss_bwd " + name)
+
+
+def case_adam(be, n=3001, steps=3, seed=0):
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, dtype=np.float32)
+    v = np.zeros(n, dtype=np.float32)
+    d_p, d_m, d_v = be.dev(p), be.dev(m), be.dev(v)
+    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in range(1, steps + 1):
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 1, n)).astype(np.float32)
+        be.lib.adam_step(be.ptr(d_p), be.ptr(be.dev(g)), be.ptr(d_m), be.ptr(d_v), n, 2e-4, 0.5, 0.999, 1e-8, step,
+                         be.stream)
+        p64, m64, v64 = O.adam_step(p64, g.astype(np.float64), m64, v64, step)
+    _assert_close(be.np(d_p), p64, atol=2e-7, rtol=2e-7, what="adam p")
+    # g spans six decades, so m = lerp(m, g) cancels: fp32 rounding is relative to the larger operand
+    _assert_close(be.np(d_m), m64, atol=1e-7 * np.abs(m64).max(), rtol=1e-6, what="adam m")
+    _assert_close(be.np(d_v), v64, atol=1e-7 * np.abs(v64).max(), rtol=1e-6, what="adam v")

@@ -84,3 +84,25 @@ def test_conv_fwd_acts_and_linear(be):
 @pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
 def test_conv_transpose_fwd(be, R, op):
     K.case_conv_transpose_fwd(be, 2, 16, 12, 5, 6, R, op)
+
+
+@pytest.mark.parametrize("H,W", [(2, 2), (4, 4), (9, 7), (31, 31), (40, 30), (70, 66)])
+@pytest.mark.parametrize("act", [K.O.ACT_NONE, K.O.ACT_RELU, K.O.ACT_LRELU])
+def test_instnorm(be, H, W, act):
+    K.case_instnorm(be, 2, 3, H, W, act, residual=(act == K.O.ACT_NONE))
+
+
+def test_pointwise(be):
+    K.case_pointwise(be)
+
+
+def test_dropout(be):
+    K.case_dropout(be)
+
+
+def test_losses(be):
+    K.case_losses(be)
+
+
+def test_adam(be):
+    K.case_adam(be)

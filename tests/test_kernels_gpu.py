@@ -47,3 +47,76 @@ def test_smoothness_accumulate_factor(be):
 @pytest.mark.parametrize("alpha", [0.0, 2.0])
 def test_smoothness_hot_path_size(be, alpha):
     K.case_smoothness(be, N=8, H=256, W=256, Ci=3, alpha=alpha)
+
+
+from test_kernels_emu import CONV_CASES  # noqa: E402  (same shapes as the emulator tier)
+
+
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm", CONV_CASES)
+def test_conv_fwd(be, C0, C1, Kc, R, stride, pad, pm):
+    K.case_conv_fwd(be, 2, C0, C1, 9, 10, Kc, R, stride, pad, pm, act=K.O.ACT_LRELU)
+
+
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm", CONV_CASES)
+def test_conv_bwd_data(be, C0, C1, Kc, R, stride, pad, pm):
+    if pm == K.PAD_REFLECT and C1:
+        pytest.skip("reflect dgrad is single-destination")
+    K.case_conv_bwd_data(be, 2, C0, C1, 9, 10, Kc, R, stride, pad, pm)
+
+
+def test_conv_bwd_data_skip_first_source(be):
+    K.case_conv_bwd_data(be, 2, 3, 3, 10, 8, 12, 4, 2, 1, K.PAD_ZERO, skip0=True)
+
+
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm", CONV_CASES)
+def test_conv_bwd_weight(be, C0, C1, Kc, R, stride, pad, pm):
+    K.case_conv_bwd_weight(be, 2, C0, C1, 9, 10, Kc, R, stride, pad, pm)
+
+
+def test_conv_fwd_acts_and_linear(be):
+    K.case_conv_fwd(be, 2, 16, 0, 6, 6, 3, 7, 1, 3, K.PAD_REFLECT, act=K.O.ACT_TANH)
+    K.case_conv_fwd(be, 3, 64, 0, 1, 1, 20, 1, 1, 0, K.PAD_ZERO, act=K.O.ACT_RELU)
+    K.case_conv_fwd(be, 1, 8, 0, 2, 2, 8, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE, bias=False)
+
+
+@pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
+def test_conv_transpose_fwd(be, R, op):
+    K.case_conv_transpose_fwd(be, 2, 16, 12, 5, 6, R, op)
+
+
+# hot-path layer shapes at batch 1-2: multi-tile grids, many reduction stages
+@pytest.mark.parametrize("C0,C1,Kc,R,stride,pad,pm,HW", [
+    (256, 0, 256, 3, 1, 1, K.PAD_REFLECT, 32),   # T resblock conv (spatial reduced so the fp64 oracle stays fast)
+    (32, 0, 32, 3, 1, 1, K.PAD_REFLECT, 64),     # STN full-res resblock conv
+    (64, 32, 32, 3, 1, 1, K.PAD_ZERO, 48),       # STN up_1 (concat 64+32)
+    (3, 3, 64, 4, 2, 1, K.PAD_ZERO, 64),         # D layer 1
+    (128, 0, 256, 4, 2, 1, K.PAD_ZERO, 32),      # D layer 3
+    (64, 0, 3, 7, 1, 3, K.PAD_REFLECT, 40),      # T head
+])
+def test_conv_hot_shapes(be, C0, C1, Kc, R, stride, pad, pm, HW):
+    K.case_conv_fwd(be, 2, C0, C1, HW, HW, Kc, R, stride, pad, pm, act=K.O.ACT_RELU)
+    if not (pm == K.PAD_REFLECT and C1):
+        K.case_conv_bwd_data(be, 2, C0, C1, HW, HW, Kc, R, stride, pad, pm)
+    K.case_conv_bwd_weight(be, 2, C0, C1, HW, HW, Kc, R, stride, pad, pm)
+
+
+@pytest.mark.parametrize("H,W", [(2, 2), (4, 4), (9, 7), (31, 31), (64, 64), (128, 128), (256, 256), (300, 300)])
+@pytest.mark.parametrize("act", [K.O.ACT_NONE, K.O.ACT_RELU, K.O.ACT_LRELU])
+def test_instnorm(be, H, W, act):
+    K.case_instnorm(be, 2, 3, H, W, act, residual=(act == K.O.ACT_NONE))
+
+
+def test_pointwise(be):
+    K.case_pointwise(be)
+
+
+def test_dropout(be):
+    K.case_dropout(be, n=1 << 20)
+
+
+def test_losses(be):
+    K.case_losses(be)
+
+
+def test_adam(be):
+    K.case_adam(be, n=100003)

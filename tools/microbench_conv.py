@@ -1,0 +1,70 @@
+"""Conv-family micro-benchmark: achieved fp32 TFLOP/s per layer shape of BASELINE config 2 (B=8, 256x256)."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from nemar_amd import _lib
+from tools.microbench import timeit
+
+SHAPES = [  # name, C0, C1, K, R, stride, pad, pad_mode, H
+    ("T.resblock 256->256 k3 refl @64", 256, 0, 256, 3, 1, 1, 1, 64),
+    ("T.stem 3->64 k7 refl @256", 3, 0, 64, 7, 1, 3, 1, 256),
+    ("T.down1 64->128 k3s2 @256", 64, 0, 128, 3, 2, 1, 0, 256),
+    ("T.down2 128->256 k3s2 @128", 128, 0, 256, 3, 2, 1, 0, 128),
+    ("T.head 64->3 k7 refl @256", 64, 0, 3, 7, 1, 3, 1, 256),
+    ("R.res 32->32 k3 refl @256", 32, 0, 32, 3, 1, 1, 1, 256),
+    ("R.up1 96->32 k3 @256", 64, 32, 32, 3, 1, 1, 0, 256),
+    ("R.res 64->64 k3 refl @128", 64, 0, 64, 3, 1, 1, 1, 128),
+    ("R.up2 128->64 k3 @128", 64, 64, 64, 3, 1, 1, 0, 128),
+    ("D.l1 6->64 k4s2 @256", 3, 3, 64, 4, 2, 1, 0, 256),
+    ("D.l2 64->128 k4s2 @128", 64, 0, 128, 4, 2, 1, 0, 128),
+    ("D.l4 256->512 k4s1 @32", 256, 0, 512, 4, 1, 1, 0, 32),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    N = a.batch
+    for (name, C0, C1, K, R, s, p, pm, H) in SHAPES:
+        C = C0 + C1
+        OH = (H + 2 * p - R) // s + 1
+        x0 = torch.randn(N, C0, H, H, device=dev)
+        x1 = torch.randn(N, C1, H, H, device=dev) if C1 else None
+        w = torch.randn(K, C, R, R, device=dev) * 0.05
+        b = torch.randn(K, device=dev)
+        y = torch.empty(N, K, OH, OH, device=dev)
+        gy = torch.randn(N, K, OH, OH, device=dev)
+        gx0 = torch.empty(N, C0, H, H, device=dev) if not C1 else torch.empty(N, C0, H, H, device=dev)
+        gx1 = torch.empty(N, C1, H, H, device=dev) if C1 else None
+        gw = torch.zeros_like(w)
+        wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm))
+        ws = torch.empty(wsb // 4 + 16, device=dev)
+        flop = 2.0 * N * K * OH * OH * C * R * R
+        t_f = timeit(lambda: lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, 1, 0.2,
+                                            P(ws), wsb, st()), a.iters, 2)
+        if pm == 1 and C1:
+            t_d = float('nan')
+        else:
+            t_d = timeit(lambda: lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx0), C0, P(gx1), C1, N, H, H, K, OH,
+                                                     OH, R, R, s, p, pm, P(ws), wsb, st()), a.iters, 2)
+        t_w = timeit(lambda: lib.conv2d_bwd_weight(P(x0), C0, P(x1), C1, P(gy), P(gw), N, H, H, K, OH, OH, R, R, s, p,
+                                                   pm, st()), a.iters, 2)
+        print(json.dumps(dict(layer=name, gflop=flop / 1e9, fwd_us=t_f * 1e6, fwd_TF=flop / t_f / 1e12,
+                              dgrad_us=t_d * 1e6, dgrad_TF=flop / t_d / 1e12, wgrad_us=t_w * 1e6,
+                              wgrad_TF=flop / t_w / 1e12)))
+
+
+if __name__ == "__main__":
+    main()
