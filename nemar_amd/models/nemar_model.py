@@ -1,0 +1,227 @@
+"""NeMAR training step on MI355X — drop-in for reference models/nemar_model.py (NEMARModel :12-288).
+
+Same flags (:30-45), same attributes (`netT`, `netR`, `netD`, `netD_multiresolution`, `loss_*`, `visual_names`,
+`model_names`, `optimizers`), same call order inside optimize_parameters (:266-288): forward, discriminator step,
+then translation+registration step against the freshly updated discriminator.  What differs is how the step
+executes:
+  * every operator is a gfx950 kernel (nemar_amd.ops); concatenations (real_A, X) are two-pointer conv inputs;
+  * each loss term leaves its kernel already multiplied by its lambda, and the step back-propagates from the list
+    of terms at once (`torch.autograd.backward(terms)` == backward of their sum), so no scalar arithmetic kernels
+    run; the reference's `loss_*` scalars are formed lazily, only when somebody reads them;
+  * the three Adam optimizers are single fused launches over flat buffers (ops.FlatAdam), whose gradient buffers are
+    also the data-parallel all-reduce buckets (nemar_amd.distributed): one bucket after backward_D, two after
+    backward_T_and_R.
+"""
+import itertools
+
+import torch
+
+from .. import distributed as dist
+from .. import ops
+from . import networks
+from . import stn
+from .base_model import BaseModel
+
+
+class _LazyLoss:
+    """sum_i scale_i * term_i, evaluated on first use (float(), .item(), arithmetic via .value())."""
+
+    def __init__(self, parts):
+        self.parts = parts            # list of (0-dim tensor, python scale)
+        self._v = None
+
+    def value(self):
+        if self._v is None:
+            with torch.no_grad():
+                v = None
+                for t, s in self.parts:
+                    x = t.detach() * s if s != 1.0 else t.detach()
+                    v = x if v is None else v + x
+                self._v = v if v is not None else torch.zeros((), device='cuda')
+        return self._v
+
+    def __float__(self):
+        return float(self.value())
+
+    def item(self):
+        return float(self)
+
+    def detach(self):
+        return self.value()
+
+    def __repr__(self):
+        return 'LazyLoss(%g)' % float(self)
+
+
+class NEMARModel(BaseModel):
+    """netT: translation A->B; netR: registration (STN) A~>B; netD: PatchGAN on (A, B) pairs."""
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train=True):
+        parser = stn.modify_commandline_options(parser, is_train)
+        if is_train:
+            parser.add_argument('--lambda_GAN', type=float, default=1.0, help='Weight for the GAN loss.')
+            parser.add_argument('--lambda_recon', type=float, default=100.0,
+                                help='Weight for the L1 reconstruction loss.')
+            parser.add_argument('--lambda_smooth', type=float, default=0.0, help='Regularization term used by the STN')
+            parser.add_argument('--enable_tbvis', action='store_true',
+                                help='Enable tensorboard visualizer (default : False)')
+            parser.add_argument('--multi_resolution', type=int, default=1,
+                                help='Use of multi-resolution discriminator.'
+                                     '(if equals to 1 then no multi-resolution training is applied)')
+            # flags of the reference's TensorboardVisualizer (util/tb_visualizer.py:6-15), accepted for CLI parity
+            parser.add_argument('--tbvis_iteration_update_rate', type=int, default=1000)
+            parser.add_argument('--tbvis_disable_report_weights', action='store_true')
+            parser.add_argument('--tbvis_disable_report_offsets', action='store_true')
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        self.train_stn = True
+        self.setup_visualizers()
+        if self.isTrain and getattr(opt, 'enable_tbvis', False):
+            print('TensorBoard visualisation is outside the MI355X hot path (SURVEY.md §2): --enable_tbvis ignored')
+        self.tb_visualizer = None
+        self.define_networks()
+        if self.isTrain:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode)
+            self.criterionL1 = ops.l1_loss
+            self.setup_optimizers()
+            self._one = torch.ones((), dtype=torch.float32, device=self.device)
+            self._lam_smooth = torch.full((), float(opt.lambda_smooth), dtype=torch.float32, device=self.device)
+
+    def setup_visualizers(self):
+        # <loss>_TR: registration-first branch T(R(a)); <loss>_RT: translation-first branch R(T(a))
+        self.loss_names = ['L1_TR', 'GAN_TR', 'L1_RT', 'GAN_RT', 'smoothness', 'D_fake_TR', 'D_fake_RT', 'D']
+        self.visual_names = ['real_A', 'real_B', 'fake_TR_B', 'fake_RT_B', 'registered_real_A', 'fake_B']
+        self.model_names = ['T', 'R'] + (['D'] if self.isTrain else [])
+
+    def define_networks(self):
+        opt = self.opt
+        AtoB = opt.direction == 'AtoB'
+        in_c = opt.input_nc if AtoB else opt.output_nc
+        out_c = opt.output_nc if AtoB else opt.input_nc
+        self.netT = networks.define_G(in_c, out_c, opt.ngf, opt.netG, opt.norm, not opt.no_dropout, opt.init_type,
+                                      opt.init_gain, self.gpu_ids)
+        self.netR = stn.define_stn(self.opt, self.opt.stn_type)
+        if self.isTrain:
+            self.netD = networks.define_D(opt.output_nc + opt.input_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm,
+                                          opt.init_type, opt.init_gain, self.gpu_ids)
+            # extra discriminators on 1/2, 1/4, ... resolution inputs (reference :106-113)
+            self.netD_multiresolution = []
+            for _ in range(max(0, opt.multi_resolution - 1)):
+                self.netD_multiresolution.append(
+                    networks.define_D(opt.output_nc + opt.input_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm,
+                                      opt.init_type, opt.init_gain, self.gpu_ids))
+
+    def reset_weights(self):
+        opt = self.opt
+        networks.init_weights(self.netT, opt.init_type, opt.init_gain)
+        networks.init_weights(self.netD, opt.init_type, opt.init_gain)
+        for netD_S in self.netD_multiresolution:
+            networks.init_weights(netD_S, opt.init_type, opt.init_gain)
+
+    def setup_optimizers(self):
+        opt = self.opt
+        betas = (opt.beta1, 0.999)
+        self.optimizer_R = ops.FlatAdam(self.netR.parameters(), lr=opt.lr, betas=betas)
+        self.optimizer_T = ops.FlatAdam(self.netT.parameters(), lr=opt.lr, betas=betas)
+        d_params = itertools.chain(self.netD.parameters(), *[x.parameters() for x in self.netD_multiresolution])
+        self.optimizer_D = ops.FlatAdam(d_params, lr=opt.lr, betas=betas)
+        self.optimizers += [self.optimizer_T, self.optimizer_D, self.optimizer_R]
+        # identical replicas on every rank before the first step
+        dist.broadcast_parameters(self.optimizers)
+
+    def set_input(self, input):
+        AtoB = self.opt.direction == 'AtoB'
+        a, b = ('A', 'B') if AtoB else ('B', 'A')
+        self.real_A = input[a].to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        self.real_B = input[b].to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        self.image_paths = input[a + '_paths']
+        self._resized = {}
+
+    # ---- forward -------------------------------------------------------------------------------------------
+    def forward(self):
+        self.fake_B = self.netT(self.real_A)
+        warped, reg_term = self.netR(self.real_A, self.real_B, apply_on=[self.real_A, self.fake_B])
+        self.stn_reg_term = reg_term
+        self.registered_real_A = warped[0]
+        self.fake_TR_B = self.netT(self.registered_real_A)     # registration first, then translation
+        self.fake_RT_B = warped[1]                             # translation first, then registration
+        self._resized = {}
+
+    def _half(self, name, tensor, level):
+        """tensor bilinearly resized to 1/2^level resolution (reference :185-188 etc.); constants are cached per
+        step instead of being recomputed for every discriminator pass."""
+        sh, sw = self.real_A.size(2) // (2 ** level), self.real_A.size(3) // (2 ** level)
+        if name is None:
+            return ops.resize_bilinear(tensor, sh, sw)
+        key = (name, level)
+        if key not in self._resized:
+            self._resized[key] = ops.resize_bilinear(tensor, sh, sw)
+        return self._resized[key]
+
+    def _d_terms(self, image, image_name, target_is_real, weight, detach):
+        """[weight * GANLoss(D_i(real_A_i, image_i), target)] over the full-resolution discriminator and every
+        reduced-resolution one."""
+        img = image.detach() if detach else image
+        terms = [self.criterionGAN(self.netD(self.real_A, img), target_is_real, weight)]
+        for i, netD_S in enumerate(self.netD_multiresolution):
+            a_r = self._half('real_A', self.real_A, i + 1)
+            img_r = self._half(image_name if detach else None, img, i + 1)
+            terms.append(self.criterionGAN(netD_S(a_r, img_r), target_is_real, weight))
+        return terms
+
+    # ---- discriminator step ---------------------------------------------------------------------------------
+    def backward_D(self):
+        w = 0.5 * self.opt.lambda_GAN
+        real = self._d_terms(self.real_B, 'real_B', True, w, detach=True)
+        fake_tr = self._d_terms(self.fake_TR_B, 'fake_TR_B', False, w, detach=True)
+        fake_rt = self._d_terms(self.fake_RT_B, 'fake_RT_B', False, w, detach=True)
+        inv = 1.0 / w if w != 0 else 0.0
+        self.loss_D_fake_TR = _LazyLoss([(t, inv) for t in fake_tr])
+        self.loss_D_fake_RT = _LazyLoss([(t, inv) for t in fake_rt])
+        terms = real + fake_tr + fake_rt
+        self.loss_D = _LazyLoss([(t, 1.0) for t in terms])
+        torch.autograd.backward(terms, [self._one] * len(terms))
+        return self.loss_D
+
+    # ---- translation + registration step ----------------------------------------------------------------------
+    def backward_T_and_R(self):
+        opt = self.opt
+        l1_tr = self.criterionL1(self.fake_TR_B, self.real_B, opt.lambda_recon)
+        gan_tr = self._d_terms(self.fake_TR_B, None, True, opt.lambda_GAN, detach=False)
+        l1_rt = self.criterionL1(self.fake_RT_B, self.real_B, opt.lambda_recon)
+        gan_rt = self._d_terms(self.fake_RT_B, None, True, opt.lambda_GAN, detach=False)
+        self.loss_L1_TR = _LazyLoss([(l1_tr, 1.0)])
+        self.loss_GAN_TR = _LazyLoss([(t, 1.0) for t in gan_tr])
+        self.loss_L1_RT = _LazyLoss([(l1_rt, 1.0)])
+        self.loss_GAN_RT = _LazyLoss([(t, 1.0) for t in gan_rt])
+        self.loss_smoothness = _LazyLoss([(self.stn_reg_term, float(opt.lambda_smooth))])
+        roots = [l1_tr, l1_rt] + gan_tr + gan_rt
+        grads = [self._one] * len(roots)
+        if opt.lambda_smooth != 0.0:
+            roots.append(self.stn_reg_term)         # d(lambda * reg) = lambda * d(reg): the weight is the seed
+            grads.append(self._lam_smooth)
+        torch.autograd.backward(roots, grads)
+        return _LazyLoss([(r, 1.0) for r in roots[:len(roots) - (1 if opt.lambda_smooth != 0.0 else 0)]] +
+                         [(self.stn_reg_term, float(opt.lambda_smooth))])
+
+    def optimize_parameters(self):
+        self.forward()
+        # D step
+        self.set_requires_grad([self.netT, self.netR], False)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        dist.all_reduce_gradients([self.optimizer_D])
+        self.optimizer_D.step()
+        self.set_requires_grad([self.netT, self.netR], True)
+        # T + R step (sees the updated D)
+        self.set_requires_grad([self.netD, *self.netD_multiresolution], False)
+        self.optimizer_R.zero_grad()
+        self.optimizer_T.zero_grad()
+        self.backward_T_and_R()
+        dist.all_reduce_gradients([self.optimizer_R, self.optimizer_T])
+        self.optimizer_R.step()
+        self.optimizer_T.step()
+        self.set_requires_grad([self.netD, *self.netD_multiresolution], True)

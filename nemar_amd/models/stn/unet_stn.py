@@ -1,0 +1,152 @@
+"""Dense-deformation registration network — mirror of reference models/stn/unet_stn.py (ResUnet :28-102, UnetSTN
+:105-201, cfg dicts :11-25) on the gfx950 kernels.
+
+MI355X-first differences from the reference, none of which change results:
+  * the identity grid (torch.linspace, :121-129) and the permute to NHWC (:167) are never materialised: the warp
+    kernel synthesises `linspace(-1,1) + offsets` in registers from the planar offset field;
+  * both `apply_on` images are warped by one autograd node, so d loss / d offsets is accumulated inside the
+    backward kernels;
+  * torch.cat([img_a, img_b]) and torch.cat([x, skip]) (:80,97) are two-pointer conv inputs;
+  * the multi-resolution weights 1, 1/2, 1/4... of the regulariser (:186-200) are folded into the stencil kernel.
+The reference's quirks are reproduced deliberately: the linspace identity under
+align_corners=False is a slight zoom (B1); decoder convs ignore --init_type and use kaiming (B4: the `init_fun`
+typo); the low-res upsample branch fires only if BOTH dims differ (B3).
+"""
+import torch.nn as nn
+
+from ... import ops
+from .layers import Conv, DownBlock, ResnetTransformer
+from .stn_losses import smoothness_loss
+
+sampling_align_corners = False
+sampling_mode = 'bilinear'
+
+# encoder widths / decoder widths / options per configuration (reference :11-25).  'A' is the reference's only
+# configuration; further entries can be added through the same dicts (BASELINE.json config 5 asks for a deeper one).
+ndf = {'A': [32, 64, 64, 64, 64, 64, 64], }
+nuf = {'A': [64, 64, 64, 64, 64, 64, 32], }
+use_down_resblocks = {'A': True, }
+resnet_nblocks = {'A': 3, }
+refine_output = {'A': True, }
+down_activation = {'A': 'leaky_relu', }
+up_activation = {'A': 'leaky_relu', }
+
+
+class ResUnet(nn.Module):
+    """(img_a, img_b) -> 2-channel offset field (reference :28-102)."""
+
+    def __init__(self, nc_a, nc_b, cfg, init_func, init_to_identity):
+        super().__init__()
+        act = down_activation[cfg]
+        self.ndown_blocks = len(ndf[cfg])
+        self.nup_blocks = len(nuf[cfg])
+        assert self.ndown_blocks >= self.nup_blocks
+        in_nf = nc_a + nc_b
+        skip_nf = {}
+        for i, out_nf in enumerate(ndf[cfg], start=1):
+            setattr(self, 'down_%d' % i, DownBlock(in_nf, out_nf, 3, 1, 1, activation=act, init_func=init_func,
+                                                   bias=True, use_resnet=use_down_resblocks[cfg], use_norm=False))
+            skip_nf[i] = out_nf
+            in_nf = out_nf
+        self.has_bottleneck = use_down_resblocks[cfg]
+        if self.has_bottleneck:
+            self.c1 = Conv(in_nf, 2 * in_nf, 1, 1, 0, activation=act, init_func=init_func, bias=True)
+            self.t = ResnetTransformer(2 * in_nf, resnet_nblocks[cfg], init_func) if resnet_nblocks[cfg] else None
+            self.c2 = Conv(2 * in_nf, in_nf, 1, 1, 0, activation=act, init_func=init_func, bias=True)
+        act = up_activation[cfg]
+        level = self.ndown_blocks
+        for out_nf in nuf[cfg]:
+            # the reference passes `init_fun=` (sic) here, which Conv swallows: decoder convs are always kaiming
+            setattr(self, 'up_%d' % level, Conv(in_nf + skip_nf[level], out_nf, 3, 1, 1, bias=True, activation=act,
+                                                init_func='kaiming'))
+            in_nf = out_nf
+            level -= 1
+        if refine_output[cfg]:
+            self.refine = nn.Sequential(ResnetTransformer(in_nf, 1, init_func),
+                                        Conv(in_nf, in_nf, 1, 1, 0, init_func=init_func, activation=act))
+        else:
+            self.refine = None
+        self.output = Conv(in_nf, 2, 3, 1, 1, bias=True, activation=None,
+                           init_func=('zeros' if init_to_identity else init_func))
+
+    def forward(self, img_a, img_b):
+        skips = {}
+        x, x2 = img_a, img_b                      # cat([img_a, img_b], 1) as two conv sources
+        for i in range(1, self.ndown_blocks + 1):
+            x, skips[i] = getattr(self, 'down_%d' % i)(x, x2)
+            x2 = None
+        if self.has_bottleneck:
+            x = self.c1(x)
+            if self.t is not None:
+                x = self.t(x)
+            x = self.c2(x)
+        level = self.ndown_blocks
+        while level > self.ndown_blocks - self.nup_blocks:
+            s = skips[level]
+            x = ops.resize_bilinear(x, s.size(2), s.size(3))
+            x = getattr(self, 'up_%d' % level)(x, s)   # cat([x, s], 1) as two conv sources
+            level -= 1
+        if self.refine is not None:
+            x = self.refine(x)
+        return self.output(x)
+
+
+class UnetSTN(nn.Module):
+    """Predicts the deformation and applies it (reference :105-201)."""
+
+    def __init__(self, in_channels_a, in_channels_b, height, width, cfg, init_func, stn_bilateral_alpha,
+                 init_to_identity, multi_resolution_regularization):
+        super().__init__()
+        self.oh, self.ow = height, width
+        self.in_channels_a, self.in_channels_b = in_channels_a, in_channels_b
+        self.offset_map = ResUnet(in_channels_a, in_channels_b, cfg, init_func, init_to_identity)
+        self.alpha = stn_bilateral_alpha
+        self.multi_resolution_regularization = multi_resolution_regularization
+
+    def _deformation(self, img_a, img_b):
+        d = self.offset_map(img_a, img_b)
+        if d.size(2) != self.oh and d.size(3) != self.ow:       # `and`, as in the reference (:139,165)
+            d_up = ops.resize_bilinear(d, self.oh, self.ow)
+        else:
+            d_up = d
+        return d, d_up
+
+    def get_grid(self, img_a, img_b, return_offsets_only=False):
+        """The sampling grid [N,H,W,2] aligning img_a with img_b (reference :131-146).  Built with torch ops: this is
+        the inspection API, not the training path (the kernels never materialise the grid)."""
+        import torch
+        _, d = self._deformation(img_a, img_b)
+        if return_offsets_only:
+            return d.permute(0, 2, 3, 1)
+        x = torch.linspace(-1.0, 1.0, self.ow, device=d.device)
+        y = torch.linspace(-1.0, 1.0, self.oh, device=d.device)
+        ident = torch.stack([x[None, :].expand(self.oh, self.ow), y[:, None].expand(self.oh, self.ow)], 0)
+        return (ident[None] + d).permute(0, 2, 3, 1)
+
+    def forward(self, img_a, img_b, apply_on=None):
+        """-> (list of warped tensors in `apply_on` order (default [img_a]), regularisation term)."""
+        deformation, d_up = self._deformation(img_a, img_b)
+        if apply_on is None:
+            apply_on = [img_a]
+        warped = ops.warp_unet(d_up, list(apply_on))
+        reg = self._calculate_regularization_term(deformation, warped[0])
+        return warped, reg
+
+    def _calculate_regularization_term(self, deformation, img):
+        """sum_i 2^-i * smoothness(resize(d, /2^i), resize(img.detach(), /2^i), alpha) — reference :179-201."""
+        dh, dw = deformation.size(2), deformation.size(3)
+        img = None if img is None else img.detach()
+        reg = None
+        factor = 1.0
+        for i in range(self.multi_resolution_regularization):
+            if i != 0:
+                d_r = ops.resize_bilinear(deformation, dh // (2 ** i), dw // (2 ** i))
+                img_r = ops.resize_bilinear(img, dh // (2 ** i), dw // (2 ** i))
+            elif img is not None and tuple(deformation.shape[2:]) != tuple(img.shape[2:]):
+                d_r, img_r = deformation, ops.resize_bilinear(img, dh, dw)
+            else:
+                d_r, img_r = deformation, img
+            term = smoothness_loss(d_r, img_r, alpha=self.alpha, factor=factor)
+            reg = term if reg is None else reg + term
+            factor /= 2.0
+        return reg

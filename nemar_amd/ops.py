@@ -1,0 +1,523 @@
+"""Autograd glue: one torch.autograd.Function per fused operator, each a thin call into the gfx950 C-ABI library
+(include/nemar_hip.h) on torch's current HIP stream.  PyTorch is used here for device memory, stream ordering and
+the autograd graph only — every number is produced by the hand-written kernels.  There is no fallback path: the
+library is loaded at import and a missing/failed build raises.
+
+Conventions
+  * tensors are made contiguous NCHW fp32 before their pointer is taken;
+  * weight/bias gradients are ACCUMULATED by the kernels straight into `param.grad` (a view of the owning
+    optimizer's flat gradient buffer, see FlatAdam) and the Function returns None for them — no per-parameter
+    autograd accumulation kernels, and the flat buffer is what a data-parallel all-reduce consumes;
+  * loss Functions return 0-dim tensors already multiplied by their lambda.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+L = _lib.load()          # raises NemarHipError when the extension is missing: no CPU / eager fallback
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+GRID_EXPLICIT, GRID_UNET, GRID_AFFINE = 0, 1, 2
+GAN_MODES = {"vanilla": 0, "lsgan": 1, "wgangp": 2}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError("nemar_amd ops are fp32 only, got %s" % t.dtype)
+    if not t.is_cuda:
+        raise RuntimeError("nemar_amd ops need a GPU tensor (there is no CPU path in the product)")
+    return t.contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch buffer per device.  Kernels are stream-ordered, so one buffer serves consecutive ops."""
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty(max(int(nbytes) // 4 + 64, 1 << 20), dtype=torch.float32, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def _grad_buffer(param):
+    """param.grad as an accumulation target (allocated zero-filled on first use)."""
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+    return param.grad
+
+
+# ------------------------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape):
+        x, x2, w, b = _c(x), _c(x2), _c(weight), _c(bias)
+        if wshape is not None:
+            w = w.view(wshape)          # e.g. nn.Linear's [out,in] seen as a 1x1 conv; gradients keep the param's shape
+        N, C0, H, W = x.shape
+        C1 = 0 if x2 is None else x2.shape[1]
+        K, C, R, S = w.shape
+        if C != C0 + C1:
+            raise ValueError("conv2d: weight expects %d input channels, got %d+%d" % (C, C0, C1))
+        OH = (H + 2 * pad - R) // stride + 1
+        OW = (W + 2 * pad - S) // stride + 1
+        y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
+        wsb = L.conv2d_fwd_workspace(K, C, R, S)
+        ws = _workspace(wsb, x.device)
+        L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act, slope,
+                     _p(ws), wsb, _stream())
+        ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.cfg = (stride, pad, pad_mode, act, slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, x2, w, y = ctx.saved_tensors
+        stride, pad, pad_mode, act, slope = ctx.cfg
+        gy = _c(gy)
+        N, C0, H, W = x.shape
+        C1 = 0 if x2 is None else x2.shape[1]
+        K, C, R, S = w.shape
+        OH, OW = gy.shape[2:]
+        st = _stream()
+        if act != ACT_NONE:
+            g = torch.empty_like(gy)
+            L.act_bwd(_p(gy), _p(y), _p(g), gy.numel(), act, slope, st)
+        else:
+            g = gy
+        need_x, need_x2, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
+            ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gx = gx2 = None
+        if need_x or need_x2:
+            gx = torch.empty_like(x) if need_x else None
+            gx2 = torch.empty_like(x2) if (need_x2 and x2 is not None) else None
+            if x2 is not None and gx2 is None:
+                # kernel splits channels [0,C0) | [C0,C); a missing second half still needs a destination
+                gx2 = torch.empty_like(x2)
+            wsb = L.conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode)
+            ws = _workspace(wsb, x.device)
+            if pad_mode == PAD_REFLECT and pad > 0 and x2 is not None:
+                raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
+            L.conv2d_bwd_data(_p(g), _p(w), None, ACT_NONE, 0.0, _p(gx), C0, _p(gx2), C1, N, H, W, K, OH, OW, R, S,
+                              stride, pad, pad_mode, _p(ws), wsb, st)
+            if not need_x2:
+                gx2 = None
+        if need_w:
+            L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), N, H, W, K, OH, OW, R, S,
+                                stride, pad, pad_mode, st)
+        if need_b and ctx.bias is not None:
+            L.bias_grad(_p(g), _p(_grad_buffer(ctx.bias)), N, K, OH * OW, st)
+        return gx, gx2, None, None, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2, x2=None, wshape=None):
+    """act(conv2d(pad(cat(x, x2)), weight) + bias).  pad_mode PAD_REFLECT == nn.ReflectionPad2d(pad) + conv.
+    `weight` must be the leaf Parameter (its .grad is the accumulation target); `wshape` reinterprets it as 4-D."""
+    return _Conv2d.apply(x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape)
+
+
+class _ConvTranspose2d(Function):
+    """nn.ConvTranspose2d(Ci -> Co, k, stride, pad, output_padding): forward is the data-gradient kernel of the
+    conv whose weight tensor is weight[Ci][Co][R][S]; backward-data is that conv's forward; backward-weight is its
+    weight gradient with the roles of input and output-gradient swapped."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, act, slope):
+        x, w, b = _c(x), _c(weight), _c(bias)
+        N, Ci, H, W = x.shape
+        _, Co, R, S = w.shape
+        Ho = (H - 1) * stride - 2 * pad + R + out_pad
+        Wo = (W - 1) * stride - 2 * pad + S + out_pad
+        y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        wsb = L.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO)
+        ws = _workspace(wsb, x.device)
+        L.conv2d_bwd_data(_p(x), _p(w), _p(b), act, slope, _p(y), Co, None, 0, N, Ho, Wo, Ci, H, W, R, S, stride, pad,
+                          PAD_ZERO, _p(ws), wsb, _stream())
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.cfg = (stride, pad, act, slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, slope = ctx.cfg
+        gy = _c(gy)
+        N, Ci, H, W = x.shape
+        _, Co, R, S = w.shape
+        Ho, Wo = gy.shape[2:]
+        st = _stream()
+        if act != ACT_NONE:
+            g = torch.empty_like(gy)
+            L.act_bwd(_p(gy), _p(y), _p(g), gy.numel(), act, slope, st)
+        else:
+            g = gy
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            wsb = L.conv2d_fwd_workspace(Ci, Co, R, S)
+            ws = _workspace(wsb, x.device)
+            L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
+                         0.0, _p(ws), wsb, st)
+        if ctx.needs_input_grad[1]:
+            L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), N, Ho, Wo, Ci, H, W, R, S,
+                                stride, pad, PAD_ZERO, st)
+        if ctx.needs_input_grad[2] and ctx.bias is not None:
+            L.bias_grad(_p(g), _p(_grad_buffer(ctx.bias)), N, Co, Ho * Wo, st)
+        return gx, None, None, None, None, None, None, None
+
+
+def conv_transpose2d(x, weight, bias=None, stride=2, pad=1, out_pad=1, act=ACT_NONE, slope=0.2):
+    return _ConvTranspose2d.apply(x, weight, bias, stride, pad, out_pad, act, slope)
+
+
+# ------------------------------------------------------------------------------------------------------
+class _InstanceNorm(Function):
+    @staticmethod
+    def forward(ctx, x, residual, act, slope, eps):
+        x, residual = _c(x), _c(residual)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((N * C, 2), dtype=torch.float32, device=x.device)
+        L.instnorm_fwd(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _stream())
+        ctx.save_for_backward(x, stats)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, stats = ctx.saved_tensors
+        act, slope = ctx.cfg
+        gy = _c(gy)
+        N, C, H, W = x.shape
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            L.instnorm_bwd(_p(x), _p(stats), _p(gy), _p(gx), N * C, H * W, act, slope, _stream())
+        gres = gy if ctx.needs_input_grad[1] else None
+        return gx, gres, None, None, None
+
+
+def instance_norm(x, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
+    """(residual +) act(InstanceNorm2d(x)) with affine=False, track_running_stats=False."""
+    return _InstanceNorm.apply(x, residual, act, slope, eps)
+
+
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        L.maxpool2_fwd(_p(x), _p(y), N * C, H, W, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = _c(gy)
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        L.maxpool2_bwd(_p(x), _p(gy), None, _p(gx), N * C, H, W, _stream())
+        return gx
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _Bilinear(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = _c(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        L.bilinear_fwd(_p(x), _p(y), N * C, H, W, Ho, Wo, _stream())
+        ctx.shape = (N, C, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        N, C, H, W, Ho, Wo = ctx.shape
+        gy = _c(gy)
+        gx = torch.empty((N, C, H, W), dtype=torch.float32, device=gy.device)
+        L.bilinear_bwd(_p(gy), _p(gx), N * C, H, W, Ho, Wo, _stream())
+        return gx, None, None
+
+
+def resize_bilinear(x, Ho, Wo):
+    """F.interpolate(x, (Ho, Wo), mode='bilinear', align_corners=False)."""
+    if x.shape[2] == Ho and x.shape[3] == Wo:
+        return x
+    return _Bilinear.apply(x, int(Ho), int(Wo))
+
+
+_dropout_state = {"seed": 0x5EED5EED, "offset": 0}
+
+
+def manual_seed(seed):
+    """Seed of the counter-based dropout generator (per process; ranks should pass different seeds)."""
+    _dropout_state["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _dropout_state["offset"] = 0
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
+        ctx.key = (p, _dropout_state["seed"], _dropout_state["offset"])
+        L.dropout(_p(x), _p(y), x.numel(), p, ctx.key[1], ctx.key[2], _stream())
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = _c(gy)
+        gx = torch.empty_like(gy)
+        p, seed, off = ctx.key
+        L.dropout(_p(gy), _p(gx), gy.numel(), p, seed, off, _stream())
+        return gx, None
+
+
+def dropout(x, p=0.5, training=True):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p))
+
+
+# ------------------------------------------------------------------------------------------------------
+class _Warp(Function):
+    """grid_sample(img, grid(grid_src)) for every image in `imgs` with ONE shared grid source; the gradient w.r.t.
+    the grid source is accumulated across the images inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, grid_src, mode, Ho, Wo, *imgs):
+        gs = _c(grid_src)
+        imgs = [_c(i) for i in imgs]
+        outs = []
+        st = _stream()
+        for img in imgs:
+            N, C, H, W = img.shape
+            out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=img.device)
+            L.grid_sample_fwd(_p(img), _p(gs), mode, _p(out), N, C, H, W, Ho, Wo, st)
+            outs.append(out)
+        ctx.save_for_backward(gs, *imgs)
+        ctx.cfg = (mode, Ho, Wo)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        gs, *imgs = ctx.saved_tensors
+        mode, Ho, Wo = ctx.cfg
+        st = _stream()
+        need_gs = ctx.needs_input_grad[0]
+        ggs = torch.empty_like(gs)
+        first = True
+        gimgs = []
+        for k, (img, go) in enumerate(zip(imgs, gouts)):
+            need_img = ctx.needs_input_grad[4 + k]
+            if go is None or (not need_img and not need_gs):
+                gimgs.append(None)
+                continue
+            go = _c(go)
+            N, C, H, W = img.shape
+            gin = torch.empty_like(img) if need_img else None
+            L.grid_sample_bwd(_p(img), _p(gs), mode, _p(go), _p(gin), 0, _p(ggs), 0 if first else 1, N, C, H, W, Ho, Wo,
+                              st)
+            first = False
+            gimgs.append(gin)
+        if first:
+            ggs.zero_()
+        return (ggs if need_gs else None, None, None, None, *gimgs)
+
+
+def warp_unet(offsets, imgs):
+    """UnetSTN sampling: grid = linspace identity + offsets [N,2,H,W]; returns the list of warped images."""
+    Ho, Wo = offsets.shape[2:]
+    return list(_Warp.apply(offsets, GRID_UNET, int(Ho), int(Wo), *imgs))
+
+
+def warp_affine(dtheta, imgs):
+    """AffineSTN sampling: theta = dtheta + I, F.affine_grid(align_corners=False) at each image's own size."""
+    outs = []
+    # one grid source, possibly different image sizes -> group by size (normally a single group)
+    by_size = {}
+    for i, img in enumerate(imgs):
+        by_size.setdefault(tuple(img.shape[2:]), []).append(i)
+    res = [None] * len(imgs)
+    for (H, W), idxs in by_size.items():
+        o = _Warp.apply(dtheta, GRID_AFFINE, int(H), int(W), *[imgs[i] for i in idxs])
+        for i, t in zip(idxs, o):
+            res[i] = t
+    outs.extend(res)
+    return outs
+
+
+def grid_sample(img, grid):
+    """F.grid_sample(img, grid, 'bilinear', 'zeros', align_corners=False) with an explicit [N,Ho,Wo,2] grid."""
+    return _Warp.apply(grid, GRID_EXPLICIT, int(grid.shape[1]), int(grid.shape[2]), img)[0]
+
+
+class _Smoothness(Function):
+    @staticmethod
+    def forward(ctx, d, img, alpha, factor):
+        d, img = _c(d), _c(img)
+        N, _, H, W = d.shape
+        Ci = 0 if img is None else img.shape[1]
+        loss = torch.empty((1,), dtype=torch.float32, device=d.device)
+        wsb = L.smoothness_workspace(N, H, W)
+        ws = _workspace(wsb, d.device)
+        L.smoothness_fwd(_p(d), _p(img), Ci, alpha, factor, _p(loss), 0, _p(ws), wsb, N, H, W, _stream())
+        ctx.save_for_backward(d, img)
+        ctx.cfg = (alpha, factor, Ci)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        d, img = ctx.saved_tensors
+        alpha, factor, Ci = ctx.cfg
+        N, _, H, W = d.shape
+        gd = torch.empty_like(d)
+        L.smoothness_bwd(_p(d), _p(img), Ci, alpha, _p(_c(g)), factor, _p(gd), 0, N, H, W, _stream())
+        return gd, None, None, None
+
+
+def smoothness(d, img=None, alpha=0.0, factor=1.0):
+    """factor * smoothness_loss(d, img, alpha); img carries no gradient."""
+    if img is not None:
+        img = img.detach()
+    return _Smoothness.apply(d, img, float(alpha), float(factor))
+
+
+class _L1(Function):
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        a, b = _c(a), _c(b)
+        loss = torch.empty((1,), dtype=torch.float32, device=a.device)
+        wsb = L.loss_workspace()
+        ws = _workspace(wsb, a.device)
+        L.l1_loss_fwd(_p(a), _p(b), a.numel(), weight, _p(loss), 0, _p(ws), wsb, _stream())
+        ctx.save_for_backward(a, b)
+        ctx.weight = weight
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        L.l1_loss_bwd(_p(a), _p(b), a.numel(), _p(_c(g)), ctx.weight, _p(ga), 0, _stream())
+        return ga, None, None
+
+
+def l1_loss(a, b=None, weight=1.0):
+    """weight * mean|a - b| (b None: weight * mean|a|); b is treated as a constant."""
+    if b is not None:
+        b = b.detach()
+    return _L1.apply(a, b, float(weight))
+
+
+class _GanLoss(Function):
+    @staticmethod
+    def forward(ctx, x, mode, real, weight):
+        x = _c(x)
+        loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+        wsb = L.loss_workspace()
+        ws = _workspace(wsb, x.device)
+        L.gan_loss_fwd(_p(x), x.numel(), mode, real, weight, _p(loss), 0, _p(ws), wsb, _stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (mode, real, weight)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        mode, real, weight = ctx.cfg
+        gx = torch.empty_like(x)
+        L.gan_loss_bwd(_p(x), x.numel(), mode, real, _p(_c(g)), weight, _p(gx), _stream())
+        return gx, None, None, None
+
+
+def gan_loss(x, target_is_real, mode="vanilla", weight=1.0):
+    if mode not in GAN_MODES:
+        raise NotImplementedError('gan mode %s not implemented' % mode)
+    return _GanLoss.apply(x, GAN_MODES[mode], 1 if target_is_real else 0, float(weight))
+
+
+# ------------------------------------------------------------------------------------------------------
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas) semantics over ONE flat fp32 buffer per optimizer: parameters and their
+    gradients are re-seated as views of flat buffers, so a step is a single fused kernel launch, zero_grad is one
+    memset, and the gradient buffer is a single all-reduce bucket for data parallelism."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam: empty parameter list")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.param_groups = [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        # 16-byte align every parameter inside the flat buffers (float4 kernels)
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.numel, self.flat_numel = n, total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                view = self.flat_p[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.offsets = offs
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+
+    def step(self):
+        self.step_count += 1
+        g = self.param_groups[0]
+        L.adam_step(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, float(g["lr"]),
+                    self.betas[0], self.betas[1], self.eps, self.step_count, _stream())
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone()}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])

@@ -1,0 +1,128 @@
+"""Generate the golden fixtures in tests/golden/*.npz by IMPORTING THE REFERENCE (/root/reference) in the build
+container and running its own code on seeded inputs/weights (tests/seeded.py).  The reference cannot travel to the
+GPU box; only these small data files do.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures are DATA (inputs are regenerated from seeds; expected outputs are stored): losses, regularisation terms,
+image crops/means, offsets, per-parameter gradient norms and post-Adam parameter checksums of
+NEMARModel.optimize_parameters() (reference models/nemar_model.py:266-288), plus op-level values of the reference's
+own functions (smoothness_loss, UnetSTN identity warp, GANLoss).
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, '/root/reference')
+tb = types.ModuleType('torch.utils.tensorboard')
+tb.SummaryWriter = object
+sys.modules['torch.utils.tensorboard'] = tb          # the only missing import on the model's import path
+
+import torch  # noqa: E402
+
+import seeded  # noqa: E402
+from step_configs import STEP_CONFIGS, make_opt  # noqa: E402
+
+
+KEYS = {}
+
+
+def load_seeded(net, seed, overrides):
+    sd = net.state_dict()
+    new = seeded.seeded_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed, overrides)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+
+
+def crop(t):
+    return t[:, :, :16, :16].detach().numpy().copy()
+
+
+def run_step_config(name, cfg):
+    from models.nemar_model import NEMARModel
+    opt = make_opt(cfg)
+    torch.manual_seed(0)
+    m = NEMARModel(opt)
+    m.setup(opt)
+    load_seeded(m.netT, cfg['seed'] + 1, cfg.get('overrides_T'))
+    load_seeded(m.netR, cfg['seed'] + 2, cfg.get('overrides_R'))
+    load_seeded(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
+    for i, d in enumerate(m.netD_multiresolution):
+        load_seeded(d, cfg['seed'] + 10 + i, cfg.get('overrides_D'))
+    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    out = {}
+    KEYS[name] = {nm: [[k, list(v.shape)] for k, v in net.state_dict().items()]
+                  for nm, net in (('T', m.netT), ('R', m.netR), ('D', m.netD))}
+    for step in range(cfg.get('steps', 1)):
+        m.set_input({'A': torch.from_numpy(A), 'B': torch.from_numpy(B), 'A_paths': ['a'], 'B_paths': ['b']})
+        # gradients are captured by hooks-free inspection: run the pieces exactly as optimize_parameters does
+        m.optimize_parameters()
+        losses = m.get_current_losses()
+        for k, v in losses.items():
+            out['s%d/loss/%s' % (step, k)] = np.float64(v)
+        out['s%d/reg' % step] = np.float64(float(m.stn_reg_term))
+        for nm in ('fake_B', 'registered_real_A', 'fake_TR_B', 'fake_RT_B'):
+            t = getattr(m, nm)
+            out['s%d/crop/%s' % (step, nm)] = crop(t)
+            out['s%d/mean/%s' % (step, nm)] = np.float64(t.double().mean().item())
+            out['s%d/absmean/%s' % (step, nm)] = np.float64(t.double().abs().mean().item())
+        for nm, net in (('T', m.netT), ('R', m.netR), ('D', m.netD)):
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    out['s%d/gradnorm/%s/%s' % (step, nm, k)] = np.float64(p.grad.double().norm().item())
+                out['s%d/psum/%s/%s' % (step, nm, k)] = np.float64(p.detach().double().sum().item())
+                out['s%d/pabs/%s/%s' % (step, nm, k)] = np.float64(p.detach().double().abs().sum().item())
+    np.savez_compressed(os.path.join(HERE, 'step_%s.npz' % name), **out)
+    print(name, {k: float(v) for k, v in out.items() if '/loss/' in k and k.startswith('s0')})
+
+
+def run_op_fixtures():
+    from models.stn.stn_losses import smoothness_loss
+    from models.stn.unet_stn import UnetSTN
+    from models.networks import GANLoss
+    out = {}
+    d = torch.from_numpy(seeded.uniform((2, 2, 9, 13), 5, 0) * 0.1)
+    img = torch.from_numpy(seeded.uniform((2, 3, 9, 13), 5, 1))
+    for al in (0.0, 1.7):
+        dd = d.clone().requires_grad_(True)
+        l = smoothness_loss(dd, img, alpha=al)
+        l.backward()
+        out['smooth/a%g/loss' % al] = np.float64(l.item())
+        out['smooth/a%g/grad' % al] = dd.grad.numpy().copy()
+    # UnetSTN identity-grid warp: the reference's "identity" is a slight zoom
+    stn = UnetSTN(1, 1, 8, 12, 'A', 'normal', 0.0, True, 1)
+    ident = stn.get_identity_grid()
+    out['unet/identity_grid'] = ident.numpy().copy()
+    row = torch.arange(12, dtype=torch.float32).view(1, 1, 1, 12).repeat(1, 1, 8, 1)
+    warped = torch.nn.functional.grid_sample(row, ident.permute(0, 2, 3, 1), mode='bilinear', padding_mode='zeros',
+                                             align_corners=False)
+    out['unet/identity_warp_of_arange'] = warped.numpy().copy()
+    lg = torch.from_numpy(seeded.uniform((2, 1, 6, 6), 9, 0) * 4)
+    for mode in ('vanilla', 'lsgan', 'wgangp'):
+        for real in (True, False):
+            x = lg.clone().requires_grad_(True)
+            l = GANLoss(mode)(x, real)
+            l.backward()
+            out['gan/%s/%d/loss' % (mode, real)] = np.float64(l.item())
+            out['gan/%s/%d/grad' % (mode, real)] = x.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'ops_reference.npz'), **out)
+    print('ops fixtures:', len(out))
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    if a.only in (None, 'ops'):
+        run_op_fixtures()
+    for name, cfg in STEP_CONFIGS.items():
+        if a.only in (None, name):
+            run_step_config(name, cfg)
+    if a.only is None:
+        import json
+        with open(os.path.join(HERE, 'state_dict_keys.json'), 'w') as f:
+            json.dump(KEYS, f, indent=0)

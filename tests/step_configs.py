@@ -1,0 +1,33 @@
+"""Scaled-down step configurations shared by the golden generator (reference), the oracle tests and the GPU
+parity tests.  UnetSTN cfg 'A' cannot go below 256x256 (7 poolings + ReflectionPad at the 2x2 bottleneck,
+SURVEY.md Appendix B5), so the small cases shrink widths and batch instead."""
+import argparse
+
+STEP_CONFIGS = {
+    # BASELINE config 1 shape (affine, 128x128) at reduced width
+    'affine128': dict(stn_type='affine', netG='resnet_3blocks', ngf=8, ndf=8, size=128, batch=2, seed=11,
+                      lambda_smooth=0.5, steps=2,
+                      overrides_R={'net.local.2.weight': 0.02, 'net.local.2.bias': 0.05}),
+    # BASELINE config 2/3/4 features: dense deformation + bilateral smoothness + multi-resolution D and regulariser
+    'unet256': dict(stn_type='unet', netG='resnet_3blocks', ngf=8, ndf=8, size=256, batch=1, seed=23,
+                    lambda_smooth=10.0, stn_bilateral_alpha=1.5, multi_resolution=2, stn_multires_reg=2, steps=2,
+                    overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+    # plain unet path, lsgan objective
+    'unet256_lsgan': dict(stn_type='unet', netG='resnet_3blocks', ngf=8, ndf=8, size=256, batch=1, seed=31,
+                          lambda_smooth=1.0, gan_mode='lsgan', steps=1,
+                          overrides_R={'offset_map.output.conv2d.weight': 0.05}),
+}
+
+
+def make_opt(cfg, gpu_ids=()):
+    return argparse.Namespace(
+        gpu_ids=list(gpu_ids), isTrain=True, checkpoints_dir='/tmp/nemar_ck', name='golden', preprocess='none',
+        input_nc=3, output_nc=3, ngf=cfg['ngf'], ndf=cfg['ndf'], netG=cfg['netG'], netD='basic', n_layers_D=3,
+        norm='instance', init_type='normal', init_gain=0.02, no_dropout=True, direction='AtoB',
+        img_height=cfg['size'], img_width=cfg['size'], lr=2e-4, beta1=0.5, gan_mode=cfg.get('gan_mode', 'vanilla'),
+        lambda_GAN=1.0, lambda_recon=100.0, lambda_smooth=cfg.get('lambda_smooth', 0.0), enable_tbvis=False,
+        multi_resolution=cfg.get('multi_resolution', 1), stn_cfg='A', stn_type=cfg['stn_type'],
+        stn_bilateral_alpha=cfg.get('stn_bilateral_alpha', 0.0), stn_no_identity_init=False,
+        stn_multires_reg=cfg.get('stn_multires_reg', 1), lr_policy='linear', epoch_count=1, niter=100,
+        niter_decay=100, continue_train=False, verbose=False, batch_size=cfg['batch'], load_iter=0, epoch='latest',
+        lr_decay_iters=50, model='nemar')
