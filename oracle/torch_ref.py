@@ -121,8 +121,8 @@ def unet_stn(P, a, b, apply_on, alpha=0.0, multires=1, cfg='A'):
     """UnetSTN.forward — reference models/stn/unet_stn.py:148-201.  Returns (warped list, reg, offsets)."""
     d = res_unet(P, a, b, cfg)
     N, _, H, W = d.shape
-    xs = torch.linspace(-1.0, 1.0, W)
-    ys = torch.linspace(-1.0, 1.0, H)
+    xs = torch.linspace(-1.0, 1.0, W, dtype=d.dtype)
+    ys = torch.linspace(-1.0, 1.0, H, dtype=d.dtype)
     ident = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W)], 0)[None]
     grid = (ident + d).permute(0, 2, 3, 1)
     warped = [F.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False) for img in apply_on]
@@ -148,7 +148,7 @@ def affine_stn(P, a, b, apply_on):
     x = x.reshape(x.size(0), -1)
     x = F.relu(F.linear(x, P['net.local.0.weight'], P['net.local.0.bias']))
     dtheta = F.linear(x, P['net.local.2.weight'], P['net.local.2.bias'])
-    theta = dtheta + torch.tensor([1.0, 0, 0, 0, 1, 0])[None]
+    theta = dtheta + torch.tensor([1.0, 0, 0, 0, 1, 0], dtype=dtheta.dtype)[None]
     warped = []
     for img in apply_on:
         grid = F.affine_grid(theta.view(-1, 2, 3), img.size(), align_corners=False)
@@ -173,8 +173,11 @@ class RefModel:
     the reference's optimize_parameters() with them."""
 
     def __init__(self, sd_T, sd_R, sd_D, sd_D_mr=(), *, n_blocks, stn_type='unet', gan_mode='vanilla', lr=2e-4,
-                 beta1=0.5, lambda_GAN=1.0, lambda_recon=100.0, lambda_smooth=0.0, alpha=0.0, multires_reg=1):
-        leaf = lambda sd: OrderedDict((k, v.detach().clone().float().requires_grad_(True)) for k, v in sd.items())
+                 beta1=0.5, lambda_GAN=1.0, lambda_recon=100.0, lambda_smooth=0.0, alpha=0.0, multires_reg=1,
+                 dtype=torch.float32):
+        """dtype=torch.float64 gives the 'true value' run used to calibrate fp32 tolerances (conditioning)."""
+        self.dtype = dtype
+        leaf = lambda sd: OrderedDict((k, v.detach().clone().to(dtype).requires_grad_(True)) for k, v in sd.items())
         self.T, self.R, self.D = leaf(sd_T), leaf(sd_R), leaf(sd_D)
         self.D_mr = [leaf(s) for s in sd_D_mr]
         self.cfg = dict(n_blocks=n_blocks, stn_type=stn_type, gan_mode=gan_mode, lambda_GAN=lambda_GAN,
@@ -183,6 +186,25 @@ class RefModel:
         self.opt_T = mk(list(self.T.values()))
         self.opt_R = mk(list(self.R.values()))
         self.opt_D = mk(list(self.D.values()) + [p for s in self.D_mr for p in s.values()])
+
+    def load_from(self, params_T, params_R, params_D, params_D_mr, adam_T, adam_R, adam_D):
+        """Teacher forcing for multi-step parity: take parameters (dict name -> tensor) and Adam state
+        (step, dict name -> exp_avg, dict name -> exp_avg_sq) from another implementation."""
+        def put(dst, src, opt, adam):
+            step, m, v = adam
+            with torch.no_grad():
+                for k, p in dst.items():
+                    p.copy_(src[k].to(self.dtype))
+                    if step > 0:
+                        st = opt.state[p]
+                        st['step'] = torch.tensor(float(step))
+                        st['exp_avg'] = m[k].to(self.dtype).clone()
+                        st['exp_avg_sq'] = v[k].to(self.dtype).clone()
+        put(self.T, params_T, self.opt_T, adam_T)
+        put(self.R, params_R, self.opt_R, adam_R)
+        put(self.D, params_D, self.opt_D, adam_D[0])
+        for d, s, a in zip(self.D_mr, params_D_mr, adam_D[1:]):
+            put(d, s, self.opt_D, a)
 
     def _netT(self, x):
         return resnet_generator(self.T, x, self.cfg['n_blocks'])
@@ -204,6 +226,7 @@ class RefModel:
         return loss
 
     def forward(self, A, B):
+        A, B = A.to(self.dtype), B.to(self.dtype)
         self.real_A, self.real_B = A, B
         self.fake_B = self._netT(A)
         warped, self.reg, self.offsets = self._netR(A, B, [A, self.fake_B])
@@ -219,6 +242,7 @@ class RefModel:
 
     def optimize_parameters(self, A, B):
         c = self.cfg
+        A, B = A.to(self.dtype), B.to(self.dtype)
         self.forward(A, B)
         losses = OrderedDict()
         # discriminator step (reference :217-264, 271-275)

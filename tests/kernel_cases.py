@@ -219,7 +219,8 @@ def case_pointwise(be, seed=0):
         gy = rng.standard_normal(n).astype(np.float32)
         want = O.act_bwd(gy.astype(np.float64), y.astype(np.float64), act)
         d_g = be.full((n,), np.nan)
-        be.lib.act_bwd(be.ptr(be.dev(gy)), be.ptr(be.dev(y)), be.ptr(d_g), n, act, 0.2, be.stream)
+        d_gy, d_y = be.dev(gy), be.dev(y)          # keep the device buffers alive across the call
+        be.lib.act_bwd(be.ptr(d_gy), be.ptr(d_y), be.ptr(d_g), n, act, 0.2, be.stream)
         _assert_close(be.np(d_g), want, atol=1e-6, rtol=1e-6, what="act_bwd")
     # maxpool (even, odd sizes; ties)
     for (H, W) in ((8, 10), (7, 9), (2, 2)):
@@ -234,21 +235,24 @@ def case_pointwise(be, seed=0):
         add = rng.standard_normal((2, 3, H, W)).astype(np.float32)
         want_g = O.maxpool2_bwd(x.astype(np.float64), gy.astype(np.float64))
         d_gx = be.full((2, 3, H, W), np.nan)
-        be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(be.dev(gy)), None, be.ptr(d_gx), 6, H, W, be.stream)
+        d_gy, d_add = be.dev(gy), be.dev(add)
+        be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(d_gy), None, be.ptr(d_gx), 6, H, W, be.stream)
         _assert_close(be.np(d_gx), want_g, atol=0, what="maxpool2_bwd")
-        be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(be.dev(gy)), be.ptr(be.dev(add)), be.ptr(d_gx), 6, H, W, be.stream)
+        be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(d_gy), be.ptr(d_add), be.ptr(d_gx), 6, H, W, be.stream)
         _assert_close(be.np(d_gx), want_g + add, atol=1e-6, what="maxpool2_bwd+addend")
     # bilinear: 2x up (gather backward), /2 and /4 down, arbitrary
     for (H, W, Ho, Wo) in ((4, 5, 8, 10), (2, 2, 4, 4), (1, 3, 2, 6), (8, 12, 4, 6), (8, 12, 2, 3), (5, 7, 9, 4)):
         x = rng.standard_normal((2, 2, H, W)).astype(np.float32)
         want = O.bilinear_resize_fwd(x.astype(np.float64), Ho, Wo)
         d_y = be.full((2, 2, Ho, Wo), np.nan)
-        be.lib.bilinear_fwd(be.ptr(be.dev(x)), be.ptr(d_y), 4, H, W, Ho, Wo, be.stream)
+        d_x = be.dev(x)
+        be.lib.bilinear_fwd(be.ptr(d_x), be.ptr(d_y), 4, H, W, Ho, Wo, be.stream)
         _assert_close(be.np(d_y), want, atol=2e-6, what="bilinear_fwd %s" % ((H, W, Ho, Wo),))
         gy = rng.standard_normal((2, 2, Ho, Wo)).astype(np.float32)
         want_g = O.bilinear_resize_bwd(gy.astype(np.float64), H, W)
         d_gx = be.full((2, 2, H, W), np.nan)
-        be.lib.bilinear_bwd(be.ptr(be.dev(gy)), be.ptr(d_gx), 4, H, W, Ho, Wo, be.stream)
+        d_gy = be.dev(gy)
+        be.lib.bilinear_bwd(be.ptr(d_gy), be.ptr(d_gx), 4, H, W, Ho, Wo, be.stream)
         _assert_close(be.np(d_gx), want_g, atol=5e-6, what="bilinear_bwd %s" % ((H, W, Ho, Wo),))
 
 
@@ -284,23 +288,23 @@ def case_losses(be, seed=0):
         for bb in (b, None):
             b64 = bb.astype(np.float64) if bb is not None else np.zeros(n)
             loss = be.full((1,), 2.0)
-            be.lib.l1_loss_fwd(be.ptr(be.dev(a)), be.ptr(be.dev(bb)) if bb is not None else None, n, 100.0, be.ptr(loss), 1,
-                               be.ptr(ws), wsb, be.stream)
+            d_a, d_b = be.dev(a), (be.dev(bb) if bb is not None else None)
+            be.lib.l1_loss_fwd(be.ptr(d_a), be.ptr(d_b), n, 100.0, be.ptr(loss), 1, be.ptr(ws), wsb, be.stream)
             _assert_close(be.np(loss), [2.0 + 100.0 * O.l1_loss_fwd(a.astype(np.float64), b64)], atol=1e-5, rtol=1e-5,
                           what="l1_loss_fwd")
             ga = be.full((n,), np.nan)
-            be.lib.l1_loss_bwd(be.ptr(be.dev(a)), be.ptr(be.dev(bb)) if bb is not None else None, n, be.ptr(gs), 100.0,
-                               be.ptr(ga), 0, be.stream)
+            be.lib.l1_loss_bwd(be.ptr(d_a), be.ptr(d_b), n, be.ptr(gs), 100.0, be.ptr(ga), 0, be.stream)
             _assert_close(be.np(ga), 50.0 * O.l1_loss_bwd(a.astype(np.float64), b64), atol=1e-9, rtol=1e-6, what="l1_loss_bwd")
         x = (rng.standard_normal(n) * 4).astype(np.float32)
+        d_x = be.dev(x)
         for mode, name in ((0, 'vanilla'), (1, 'lsgan'), (2, 'wgangp')):
             for real in (1, 0):
                 loss = be.full((1,), np.nan)
-                be.lib.gan_loss_fwd(be.ptr(be.dev(x)), n, mode, real, 0.5, be.ptr(loss), 0, be.ptr(ws), wsb, be.stream)
+                be.lib.gan_loss_fwd(be.ptr(d_x), n, mode, real, 0.5, be.ptr(loss), 0, be.ptr(ws), wsb, be.stream)
                 _assert_close(be.np(loss), [0.5 * O.gan_loss_fwd(x.astype(np.float64), bool(real), name)], atol=1e-6,
                               rtol=1e-5, what="gan_loss_fwd " + name)
                 gx = be.full((n,), np.nan)
-                be.lib.gan_loss_bwd(be.ptr(be.dev(x)), n, mode, real, be.ptr(gs), 0.5, be.ptr(gx), be.stream)
+                be.lib.gan_loss_bwd(be.ptr(d_x), n, mode, real, be.ptr(gs), 0.5, be.ptr(gx), be.stream)
                 _assert_close(be.np(gx), 0.25 * O.gan_loss_bwd(x.astype(np.float64), bool(real), name), atol=1e-9,
                               rtol=2e-5, what="gan_loss_bwd " + name)
 
@@ -314,8 +318,8 @@ def case_adam(be, n=3001, steps=3, seed=0):
     p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
     for step in range(1, steps + 1):
         g = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 1, n)).astype(np.float32)
-        be.lib.adam_step(be.ptr(d_p), be.ptr(be.dev(g)), be.ptr(d_m), be.ptr(d_v), n, 2e-4, 0.5, 0.999, 1e-8, step,
-                         be.stream)
+        d_g = be.dev(g)
+        be.lib.adam_step(be.ptr(d_p), be.ptr(d_g), be.ptr(d_m), be.ptr(d_v), n, 2e-4, 0.5, 0.999, 1e-8, step, be.stream)
         p64, m64, v64 = O.adam_step(p64, g.astype(np.float64), m64, v64, step)
     _assert_close(be.np(d_p), p64, atol=2e-7, rtol=2e-7, what="adam p")
     # g spans six decades, so m = lerp(m, g) cancels: fp32 rounding is relative to the larger operand

@@ -43,5 +43,28 @@ def seeded_state_dict(shapes, seed, overrides=None):
     return out
 
 
-def seeded_images(N, C, H, W, seed):
-    return uniform((N, C, H, W), seed, 1000), uniform((N, C, H, W), seed, 1001)
+def _upsample_linear(x, f):
+    """separable linear upsampling by integer factor f along the last two axes (align_corners=True style)."""
+    def up(a, axis):
+        n = a.shape[axis]
+        pos = np.linspace(0, n - 1, n * f)
+        i0 = np.floor(pos).astype(int)
+        i1 = np.minimum(i0 + 1, n - 1)
+        t = (pos - i0).astype(np.float32)
+        shp = [1] * a.ndim
+        shp[axis] = -1
+        return np.take(a, i0, axis) * (1 - t).reshape(shp) + np.take(a, i1, axis) * t.reshape(shp)
+    return up(up(x, -1), -2)
+
+
+def seeded_images(N, C, H, W, seed, smooth=8):
+    """A/B pairs in [-1,1]: low-frequency structure (1/`smooth`-resolution noise, linearly upsampled) plus 10% white
+    noise.  Smooth content keeps d(warp)/d(offset) well conditioned, so gradient parity is a test of the kernels and
+    not of floor() decisions on white noise; B is a slightly shifted remix of A so registration has signal."""
+    def one(stream):
+        base = uniform((N, C, H // smooth, W // smooth), seed, stream)
+        img = 0.9 * _upsample_linear(base, smooth) + 0.1 * uniform((N, C, H, W), seed, stream + 50)
+        return np.ascontiguousarray(img.astype(np.float32))
+    a = one(1000)
+    b = 0.7 * np.roll(a, (2, -3), axis=(2, 3)) + 0.3 * one(1001)
+    return a, np.ascontiguousarray(b.astype(np.float32))

@@ -1,6 +1,10 @@
 """Step-level parity harness: the MI355X build's NEMARModel vs the CPU oracle (oracle/torch_ref.py) and vs the
 golden fixtures recorded from the reference, on identical seeded weights and inputs."""
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import numpy as np
 import torch
@@ -32,29 +36,63 @@ def build_hip_model(name):
     return m
 
 
-def _rel(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+def _adam_state(opt, nets):
+    out, idx = [], 0
+    for net in nets:
+        m, v = {}, {}
+        for k, p in net.named_parameters():
+            o, n = opt.offsets[idx], p.numel()
+            m[k] = opt.m[o:o + n].view(p.shape).detach().cpu().clone()
+            v[k] = opt.v[o:o + n].view(p.shape).detach().cpu().clone()
+            idx += 1
+        out.append((opt.step_count, m, v))
+    return out
+
+
+def _params(net):
+    return {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
+
+
+def _force(ref, hip):
+    """teacher forcing: the oracle takes the build's parameters and Adam moments before every step, so each step
+    is compared from an identical state (Adam's sign-like early updates make free-running trajectories chaotic)."""
+    ref.load_from(_params(hip.netT), _params(hip.netR), _params(hip.netD), [_params(d) for d in hip.netD_multiresolution],
+                  _adam_state(hip.optimizer_T, [hip.netT])[0], _adam_state(hip.optimizer_R, [hip.netR])[0],
+                  _adam_state(hip.optimizer_D, [hip.netD, *hip.netD_multiresolution]))
+
+
+def _maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
 
 
 def run(name, report=None, check=True):
-    """Returns a list of (what, error, tolerance, ok)."""
+    """One row per compared quantity: (what, error, tolerance, ok).
+
+    err(build, fp64 oracle) must stay within  base + 4 * err(fp32 oracle, fp64 oracle):  the fp64 run is the true
+    value of the reference's algorithm and the fp32-vs-fp64 gap measures how ill-conditioned each quantity is
+    (sign() in the L1 gradient, ReLU/max-pool masks, floor() in the sampler).  Step 0 is additionally compared with
+    the golden fixtures recorded from the reference itself."""
     cfg = STEP_CONFIGS[name]
     g = np.load(os.path.join(GOLD, 'step_%s.npz' % name))
     ref = build_ref_model(name)
+    ref64 = build_ref_model(name, dtype=torch.float64)
     hip = build_hip_model(name)
     A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
     tA, tB = torch.from_numpy(A), torch.from_numpy(B)
     rows = []
 
     def add(what, err, tol):
-        rows.append((what, err, tol, bool(err <= tol)))
+        rows.append((what, float(err), float(tol), bool(err <= tol)))
 
     for step in range(cfg.get('steps', 1)):
         pre = 's%d/' % step
+        if step > 0:
+            _force(ref, hip)
+            _force(ref64, hip)
         ref_losses = ref.optimize_parameters(tA, tB)
+        ref64_losses = ref64.optimize_parameters(tA, tB)
         hip.set_input({'A': tA, 'B': tB, 'A_paths': ['a'], 'B_paths': ['b']})
-        # capture gradients before Adam consumes them: run the step pieces in the reference's order
+        # the reference's optimize_parameters() order, with the gradients captured before Adam consumes them
         hip.forward()
         hip.set_requires_grad([hip.netT, hip.netR], False)
         hip.optimizer_D.zero_grad()
@@ -74,42 +112,54 @@ def run(name, report=None, check=True):
         torch.cuda.synchronize()
         losses = hip.get_current_losses()
         for k in ref_losses:
-            tol = 2e-4 * max(1.0, abs(ref_losses[k])) * (step + 1)
-            add(pre + 'loss/%s vs oracle' % k, abs(losses[k] - ref_losses[k]), tol)
-            add(pre + 'loss/%s vs reference' % k, abs(losses[k] - float(g[pre + 'loss/' + k])), tol)
-        add(pre + 'reg vs reference', abs(float(hip.stn_reg_term) - float(g[pre + 'reg'])), 1e-4 * max(1, abs(float(g[pre + 'reg']))))
+            cond = abs(ref_losses[k] - ref64_losses[k])
+            tol = 1e-4 * max(1.0, abs(ref64_losses[k])) + 4 * cond
+            add(pre + 'loss/%s' % k, abs(losses[k] - ref64_losses[k]), tol)
+            if step == 0:
+                add(pre + 'loss/%s vs reference' % k, abs(losses[k] - float(g[pre + 'loss/' + k])), tol)
+        if step == 0:
+            add(pre + 'reg vs reference', abs(float(hip.stn_reg_term) - float(g[pre + 'reg'])),
+                1e-4 * max(1, abs(float(g[pre + 'reg']))) + 4 * abs(float(ref.reg) - float(ref64.reg)))
         for nm in ('fake_B', 'registered_real_A', 'fake_TR_B', 'fake_RT_B'):
-            t = getattr(hip, nm).detach().cpu()
-            add(pre + 'image/%s vs oracle (max abs)' % nm, float((t - getattr(ref, nm).detach()).abs().max()), 2e-3 * (step + 1))
-            add(pre + 'image/%s crop vs reference' % nm, float(np.abs(t[:, :, :16, :16].numpy() - g[pre + 'crop/' + nm]).max()), 2e-3 * (step + 1))
-            add(pre + 'image/%s mean vs reference' % nm, abs(t.double().mean().item() - float(g[pre + 'mean/' + nm])), 2e-5 * (step + 1))
-        # gradients: relative max-abs error per tensor, for tensors whose oracle gradient is not numerically null
-        for nm, mine, theirs in (('T', gT, ref.grads_T), ('R', gR, ref.grads_R), ('D', gD, ref.grads_D)):
-            gmax = max(float(v.abs().max()) for v in theirs.values())
-            worst, worst_k = 0.0, None
-            for k, v in theirs.items():
+            t = getattr(hip, nm).detach().cpu().numpy()
+            r64 = getattr(ref64, nm).detach().numpy()
+            cond = _maxabs(getattr(ref, nm).detach().numpy(), r64)
+            add(pre + 'image/%s (max abs)' % nm, _maxabs(t, r64), 2e-5 + 4 * cond)
+            if step == 0:
+                add(pre + 'image/%s crop vs reference' % nm, _maxabs(t[:, :, :16, :16], g[pre + 'crop/' + nm]), 2e-5 + 4 * cond)
+        off = ref64.offsets.detach().numpy()
+        add(pre + 'offsets/deformation or dtheta cond (fp32 oracle vs fp64)', _maxabs(ref.offsets.detach().numpy(), off), 1.0)
+        # gradients: per tensor, max-abs error relative to the tensor's max, vs the fp64 value
+        for nm, mine, g32, g64 in (('T', gT, ref.grads_T, ref64.grads_T), ('R', gR, ref.grads_R, ref64.grads_R),
+                                   ('D', gD, ref.grads_D, ref64.grads_D)):
+            gmax = max(float(v.abs().max()) for v in g64.values())
+            worst = (0.0, 0.0, None)
+            for k, v in g64.items():
                 vmax = float(v.abs().max())
                 if vmax < 1e-5 * gmax:
-                    continue                      # e.g. conv biases in front of InstanceNorm: exactly-zero gradient + noise
-                e = _rel(mine[k], v.numpy())
-                if e > worst:
-                    worst, worst_k = e, k
-            add(pre + 'grad/%s worst tensor rel err (%s)' % (nm, worst_k), worst, 5e-3 * (step + 1))
-        # post-Adam weights: fraction of elements whose update differs by more than half a step
-        for nm, net, theirs in (('T', hip.netT, ref.T), ('R', hip.netR, ref.R), ('D', hip.netD, ref.D)):
-            bad = tot = 0
+                    continue              # e.g. conv biases in front of InstanceNorm: exactly-zero gradient + noise
+                e = _maxabs(mine[k], v.numpy()) / vmax
+                c = _maxabs(g32[k].numpy(), v.numpy()) / vmax
+                if e - 4 * c > worst[0] - 4 * worst[1]:
+                    worst = (e, c, k)
+            add(pre + 'grad/%s worst tensor (%s)' % (nm, worst[2]), worst[0], 2e-4 + 4 * worst[1])
+        # post-Adam weights vs the fp64 oracle: elements whose update differs by more than half a step
+        for nm, net, p32, p64 in (('T', hip.netT, ref.T, ref64.T), ('R', hip.netR, ref.R, ref64.R),
+                                  ('D', hip.netD, ref.D, ref64.D)):
+            bad = bad32 = tot = 0
             for k, p in net.named_parameters():
                 if not k.endswith('weight'):
                     continue
-                d = (p.detach().cpu() - theirs[k].detach()).abs()
-                bad += int((d > 0.5 * LR * (step + 1)).sum())
-                tot += d.numel()
-            add(pre + 'adam/%s fraction of weights off by > lr/2' % nm, bad / max(tot, 1), 0.02 * (step + 1))
+                q = p64[k].detach()
+                bad += int(((p.detach().cpu().double() - q).abs() > 0.5 * LR).sum())
+                bad32 += int(((p32[k].detach().double() - q).abs() > 0.5 * LR).sum())
+                tot += q.numel()
+            add(pre + 'adam/%s fraction of weights off by > lr/2' % nm, bad / max(tot, 1), 1e-4 + 4 * bad32 / max(tot, 1))
     if report:
         with open(report, 'a') as f:
             f.write('== %s\n' % name)
             for r in rows:
-                f.write('%-70s err=%.3e tol=%.1e %s\n' % (r[0], r[1], r[2], 'ok' if r[3] else 'FAIL'))
+                f.write('%-78s err=%.3e tol=%.1e %s\n' % (r[0], r[1], r[2], 'ok' if r[3] else 'FAIL'))
     if check:
         bad = [r for r in rows if not r[3]]
         assert not bad, bad[:5]
@@ -117,12 +167,11 @@ def run(name, report=None, check=True):
 
 
 if __name__ == '__main__':
-    import sys
     out = sys.argv[1] if len(sys.argv) > 1 else '/dev/stdout'
     for name in STEP_CONFIGS:
         try:
             run(name, report=out, check=False)
-        except Exception as e:  # noqa
+        except Exception:  # noqa
             import traceback
             with open(out, 'a') as f:
                 f.write('== %s EXCEPTION\n%s\n' % (name, traceback.format_exc()))

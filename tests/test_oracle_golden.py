@@ -51,7 +51,7 @@ def _seeded_sd(keyshapes, seed, overrides):
     return {k: torch.from_numpy(v) for k, v in seeded.seeded_state_dict(shapes, seed, overrides).items()}
 
 
-def build_ref_model(name):
+def build_ref_model(name, dtype=torch.float32):
     cfg = STEP_CONFIGS[name]
     ks = _keys(name)
     sd_T = _seeded_sd(ks['T'], cfg['seed'] + 1, cfg.get('overrides_T'))
@@ -62,7 +62,8 @@ def build_ref_model(name):
     n_blocks = int(cfg['netG'].split('_')[1][0])
     return R.RefModel(sd_T, sd_R, sd_D, sd_mr, n_blocks=n_blocks, stn_type=cfg['stn_type'],
                       gan_mode=cfg.get('gan_mode', 'vanilla'), lambda_smooth=cfg.get('lambda_smooth', 0.0),
-                      alpha=cfg.get('stn_bilateral_alpha', 0.0), multires_reg=cfg.get('stn_multires_reg', 1))
+                      alpha=cfg.get('stn_bilateral_alpha', 0.0), multires_reg=cfg.get('stn_multires_reg', 1),
+                      dtype=dtype)
 
 
 @pytest.mark.parametrize("name", list(STEP_CONFIGS))
