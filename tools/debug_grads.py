@@ -51,3 +51,24 @@ print('T fwd err', float((out.detach().cpu() - ref.detach()).abs().max()))
 torch.autograd.backward([out], [w]); (ref * w.cpu()).sum().backward()
 report('T', netT, PT)
 print('T dx rel', float((x.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max()))
+
+# ---- D step structure: three passes, BCE, multi-root backward
+print('--- D step structure')
+netD2 = networks.define_D(6, 8, 'basic', 3, 'instance', 'normal', 0.02, [0])
+PD2 = seeded_load(netD2, 3)
+optD2 = ops.FlatAdam(netD2.parameters())
+f1, f2 = seeded.seeded_images(N, 3, S, S, 9)
+tf1, tf2 = torch.from_numpy(f1), torch.from_numpy(f2)
+crit = networks.GANLoss('vanilla')
+one = torch.ones((), device=dev)
+dA, dB, d1, d2 = tA.to(dev), tB.to(dev), tf1.to(dev), tf2.to(dev)
+for npass in (1, 2, 3):
+    optD2.zero_grad()
+    for p in PD2.values(): p.grad = None
+    imgs = [(dB, tB, True), (d1, tf1, False), (d2, tf2, False)][:npass]
+    terms = [crit(netD2(dA, di.detach()), real, 0.5) for di, _, real in imgs]
+    torch.autograd.backward(terms, [one] * len(terms))
+    loss = sum(0.5 * R.gan_loss(R.nlayer_discriminator(PD2, torch.cat([tA, ti], 1)), real) for _, ti, real in imgs)
+    loss.backward()
+    print('npass', npass, 'loss err', abs(float(sum(float(t) for t in terms)) - float(loss)))
+    report('D%d' % npass, netD2, PD2)
