@@ -96,9 +96,10 @@ int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, in
                           float* gx0, int C0, float* gx1, int C1, int N, int H, int W, int K, int OH, int OW,
                           int R, int S, int stride, int pad, int pad_mode, void* workspace, size_t ws_bytes,
                           void* stream);
-/* Weight gradient, ACCUMULATED into gw [K,C0+C1,R,S] (the caller zero-fills once per optimizer step; the
- * translation net receives two passes per step).  Pixel reduction is split across workgroups, fp32 atomics. */
-int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw,
+/* Weight gradient, ACCUMULATED into gw [K,C0+C1,R,S] and, when gb != NULL, the bias gradient ACCUMULATED into
+ * gb [K] in the same pass (the caller zero-fills once per optimizer step; the translation net receives two passes
+ * per step).  Pixel reduction is split across workgroups, fp32 atomics. */
+int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
                             int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
                             int pad_mode, void* stream);
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */

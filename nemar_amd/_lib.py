@@ -34,7 +34,7 @@ SIGNATURES = {
     "nemar_conv2d_bwd_data_workspace": (_sz, [_i] * 10),
     "nemar_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _fl, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _i, _vp, _sz, _vp]),
-    "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),

@@ -30,6 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;        // reduction depth per LDS stage (fwd/dgrad)
 constexpr int MAX_TAPS = 64;  // 7x7 = 49
 constexpr int BORDER_ZERO = 0, BORDER_REFLECT = 1;
+// data-gradient of a reflect-padded stride-1 conv, evaluated on the UNPADDED domain: besides the regular source row
+// h+dy, rows 1..pad also collect from the mirrored padded row (source row dy-h) and rows H-1-pad..H-2 from
+// 2(H-1)-h+dy; the same filter tap multiplies all of them, so the loader simply sums the candidates.
+constexpr int BORDER_REFLECT_ADJOINT = 2;
 constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -42,6 +46,23 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 __device__ __forceinline__ int reflect(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// candidate source indices along one axis for BORDER_REFLECT_ADJOINT (h: output index, d: tap offset, n_out: output
+// extent, n_src: source extent); returns the count (0..3)
+__device__ __forceinline__ int adjoint_candidates(int h, int d, int pad, int n_out, int n_src, int* c) {
+    int n = 0;
+    const int y0 = h + d;
+    if ((unsigned)y0 < (unsigned)n_src) c[n++] = y0;
+    if (h >= 1 && h <= pad) {
+        const int y1 = d - h;
+        if ((unsigned)y1 < (unsigned)n_src) c[n++] = y1;
+    }
+    if (h <= n_out - 2 && h >= n_out - 1 - pad) {
+        const int y2 = 2 * (n_out - 1) - h + d;
+        if ((unsigned)y2 < (unsigned)n_src) c[n++] = y2;
+    }
+    return n;
 }
 
 struct TapTable {
@@ -76,7 +97,7 @@ struct IgemmParams {
     float* dst0; float* dst1; int M0;
     int OH, OW, OHf, OWf, osy, ooy, osx, oox;
     int N, P;
-    int sy, sx, border, act;
+    int sy, sx, border, act, pad;
     float slope;
     FastDiv fd_ohw, fd_ow, fd_cs;
     TapTable taps;
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     constexpr int BROWS = BK / TPC;                    // B rows (reduction indices) per thread per stage
     constexpr int A_F4 = BK * BM / 4;                  // float4s in an A stage
     constexpr int A_PER = (A_F4 + 255) / 256;
-    static_assert(BN >= 128 && 256 % TPC == 0, "tile");
+    static_assert(BN >= 64 && 256 % TPC == 0 && BK % TPC == 0, "tile");
 
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
@@ -156,18 +177,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             const int tp = s_tap[t];
             int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
             bool inb = pvalid && k0 < p.Kred;
-            if (p.border == BORDER_REFLECT) {
-                y = reflect(y, p.Hs);
-                x = reflect(x, p.Ws);
-            } else {
-                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-            }
             const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;
-            const int off = y * p.Ws + x;
+            if (p.border == BORDER_REFLECT_ADJOINT) {
+                int ys[3], xs[3];
+                const int ny = inb ? adjoint_candidates(by, tp >> 16, p.pad, p.OH, p.Hs, ys) : 0;
+                const int nx = inb ? adjoint_candidates(bx, (int)(short)(tp & 0xffff), p.pad, p.OW, p.Ws, xs) : 0;
+                if (ny == 1 && nx == 1) {           // interior: exactly the zero-border gather
+                    const int off = ys[0] * p.Ws + xs[0];
 #pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
-                const int r = prow0 + TPC * i;
-                rb[i] = inb ? base[(size_t)r * HW + off] : 0.f;
+                    for (int i = 0; i < BROWS; ++i) rb[i] = base[(size_t)(prow0 + TPC * i) * HW + off];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BROWS; ++i) {
+                        const float* q = base + (size_t)(prow0 + TPC * i) * HW;
+                        float v = 0.f;
+                        for (int a = 0; a < ny; ++a)
+                            for (int b = 0; b < nx; ++b) v += q[ys[a] * p.Ws + xs[b]];
+                        rb[i] = v;
+                    }
+                }
+            } else {
+                if (p.border == BORDER_REFLECT) {
+                    y = reflect(y, p.Hs);
+                    x = reflect(x, p.Ws);
+                } else {
+                    inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+                }
+                const int off = y * p.Ws + x;
+#pragma unroll
+                for (int i = 0; i < BROWS; ++i) {
+                    const int r = prow0 + TPC * i;
+                    rb[i] = inb ? base[(size_t)r * HW + off] : 0.f;
+                }
             }
         } else {
 #pragma unroll
@@ -179,16 +220,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                     const int ch = kk - (int)t * Cs;
                     const int tp = s_tap[t];
                     int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
-                    bool inb = true;
-                    if (p.border == BORDER_REFLECT) {
-                        y = reflect(y, p.Hs);
-                        x = reflect(x, p.Ws);
+                    const float* base = (ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW;
+                    if (p.border == BORDER_REFLECT_ADJOINT) {
+                        int ys[3], xs[3];
+                        const int ny = adjoint_candidates(by, tp >> 16, p.pad, p.OH, p.Hs, ys);
+                        const int nx = adjoint_candidates(bx, (int)(short)(tp & 0xffff), p.pad, p.OW, p.Ws, xs);
+                        for (int a = 0; a < ny; ++a)
+                            for (int b = 0; b < nx; ++b) v += base[ys[a] * p.Ws + xs[b]];
                     } else {
-                        inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-                    }
-                    if (inb) {
-                        const float* base = (ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW;
-                        v = base[y * p.Ws + x];
+                        bool inb = true;
+                        if (p.border == BORDER_REFLECT) {
+                            y = reflect(y, p.Hs);
+                            x = reflect(x, p.Ws);
+                        } else {
+                            inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+                        }
+                        if (inb) v = base[y * p.Ws + x];
                     }
                 }
                 rb[i] = v;
@@ -279,30 +326,46 @@ void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, p);
 }
 
-int igemm_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+// Tile selection.  The channel tile follows M; the pixel tile shrinks when the grid would leave most of the 256 CUs
+// idle (the small-spatial discriminator / bottleneck layers): ~2 workgroups per CU is the target.
+struct TileChoice { int bm, bn; };
+TileChoice igemm_tile(int M, int P) {
+    const int kMinBlocks = 384;
+    TileChoice t;
+    if (M > 64) {
+        t.bm = 128; t.bn = 128;
+        if ((long long)nemar_cdiv(M, 128) * nemar_cdiv(P, 128) < kMinBlocks) { t.bm = 64; t.bn = 64; }
+    } else if (M > 32) {
+        t.bm = 64; t.bn = 128;
+        if ((long long)nemar_cdiv(P, 128) < kMinBlocks) t.bn = 64;
+    } else {
+        t.bm = 32; t.bn = 256;
+        if ((long long)nemar_cdiv(P, 256) < kMinBlocks) t.bn = 128;
+    }
+    return t;
+}
+int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 128) * 128 : 32; }
 
 void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
-    const int bm = igemm_bm(p.M);
-    if (bm == 128)
-        launch_igemm_cfg<2, 2, 2, 2>(p, fast, st);  // 128 channels x 128 pixels
-    else if (bm == 64)
-        launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);  // 64 x 128
-    else
-        launch_igemm_cfg<1, 4, 1, 2>(p, fast, st);  // 32 x 256
+    const TileChoice t = igemm_tile(p.M, p.P);
+    if (t.bm == 128) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st);                       // 128 channels x 128 pixels
+    else if (t.bm == 64 && t.bn == 128) launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);    // 64 x 128
+    else if (t.bm == 64) launch_igemm_cfg<2, 2, 1, 1>(p, fast, st);                   // 64 x 64
+    else if (t.bn == 256) launch_igemm_cfg<1, 4, 1, 2>(p, fast, st);                  // 32 x 256
+    else launch_igemm_cfg<1, 4, 1, 1>(p, fast, st);                                   // 32 x 128
 }
 
+// packed weights are padded to a multiple of 128 channels (32 when M <= 32) so every tile config can read them
 size_t packed_floats(int M, int Kred) {
-    const int bm = igemm_bm(M);
-    return (size_t)nemar_cdiv(Kred, BK) * BK * ((size_t)nemar_cdiv(M, bm) * bm);
+    return (size_t)nemar_cdiv(Kred, BK) * BK * (size_t)igemm_mpad(M);
 }
 
 void launch_pack(const float* w, float* wp, int M, int Cs, int wsm, int wsc, const TapTable& taps, hipStream_t st) {
     const int Kred = taps.n * Cs;
     const int KredPad = nemar_cdiv(Kred, BK) * BK;
-    const int bm = igemm_bm(M);
-    const int Mpad = nemar_cdiv(M, bm) * bm;
+    const int Mpad = igemm_mpad(M);
     const int total = KredPad * Mpad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, wp, M, Mpad, Cs,
                        Kred, KredPad, wsm, wsc, taps);
@@ -315,6 +378,7 @@ struct WgradParams {
     const float* src0; const float* src1; int C0, C1, Hs, Ws;
     const float* gy; int K, OH, OW;
     float* gw; int J;  // J = Cs * R * S columns, j = c*R*S + r*S + s (the tensor's own memory order)
+    float* gb;         // optional [K]: += sum_pixels gy (bias gradient), folded into the A-tile loads of column-tile 0
     int N, P, sy, sx, R, S, pad, border;
     int pix_per_split;
     FastDiv fd_ohw, fd_ow;
@@ -361,6 +425,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __syncthreads();
 
     float ra[ACOLS], rb[BCOLS];
+    float bsum[ACOLS];
+#pragma unroll
+    for (int i = 0; i < ACOLS; ++i) bsum[i] = 0.f;
+    const bool do_bias = p.gb != nullptr && blockIdx.y == 0;
     auto load_stage = [&](int pb) {
         const int pix = pb + prow;
         const bool pv = pix < pend;
@@ -374,6 +442,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         for (int i = 0; i < ACOLS; ++i) {
             const int m = m0 + cgrp + 8 * i;
             ra[i] = (pv && m < p.K) ? g[(size_t)m * OHW] : 0.f;
+            bsum[i] += ra[i];
         }
         const int by = (int)oy * p.sy, bx = (int)ox * p.sx;
         const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
@@ -438,6 +507,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         __syncthreads();
     }
     if (nk <= 0) return;
+    if (do_bias) {
+        // this thread summed gy over its pixel rows for channels cgrp + 8i; fold the 32 pixel lanes of each half-wave
+#pragma unroll
+        for (int i = 0; i < ACOLS; ++i) {
+            float v = bsum[i];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int m = m0 + cgrp + 8 * i;
+            if (prow == 0 && m < p.K) atomicAdd(p.gb + m, v);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int jj = j0 + (wn * TN + j) * 32 + l31;
@@ -452,16 +532,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
-// gb[c] += sum_{n,hw} g[n,c,hw]; one workgroup per channel, deterministic tree + one atomic
+// gb[c] += sum_{n,hw} g[n,c,hw]; grid (C, N, chunks of the plane): tree per workgroup + one atomic
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, float* __restrict__ gb, int N, int C,
-                                                        int HW) {
+                                                        int HW, int chunk) {
     __shared__ float red[16];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, n = blockIdx.y;
+    const int beg = blockIdx.z * chunk, end = min(HW, beg + chunk);
+    const float* q = g + ((size_t)n * C + c) * HW;
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* q = g + ((size_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) acc += q[i];
-    }
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) acc += q[i];
     const float t = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(gb + c, t);
 }
@@ -550,12 +629,12 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     fwd_taps(p.taps, R, S, pad);
     launch_pack(w, (float*)workspace, K, C, C * R * S, R * S, p.taps, st);
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
-    p.wp = (const float*)workspace; p.M = K; p.Mpad = nemar_cdiv(K, igemm_bm(K)) * igemm_bm(K); p.Kred = C * R * S;
+    p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
     p.N = N; p.P = N * OH * OW;
-    p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope;
+    p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope; p.pad = pad;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
     launch_igemm(p, st);
     NEMAR_CHECK_LAUNCH("conv2d_fwd");
@@ -568,7 +647,7 @@ NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int
                                                  int pad_mode) {
     if (N <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
     size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
-    if (pad_mode == BORDER_REFLECT && pad > 0) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    if (pad_mode == BORDER_REFLECT && pad > 0 && stride != 1) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
     return sizeof(float) * fl;
 }
 
@@ -584,9 +663,13 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     NEMAR_REQUIRE((H + 2 * pad - R) / stride + 1 == OH && (W + 2 * pad - S) / stride + 1 == OW,
                   "conv2d_bwd_data: gy %dx%d inconsistent with x %dx%d k%d s%d p%d", OH, OW, H, W, R, stride, pad);
     const int C = C0 + C1;
-    const bool refl = pad_mode == BORDER_REFLECT && pad > 0;
-    NEMAR_REQUIRE(!refl || (pad < H && pad < W && !bias && act == ACT_NONE && gx1 == nullptr),
-                  "conv2d_bwd_data: reflect mode supports a single destination without bias/activation");
+    // stride-1 reflect: adjoint-reflect gather on the unpadded domain (no scratch image, no fold pass);
+    // strided reflect (not used by NeMAR): differentiate w.r.t. the padded input, then fold
+    const bool refl_adj = pad_mode == BORDER_REFLECT && pad > 0 && stride == 1;
+    const bool refl = pad_mode == BORDER_REFLECT && pad > 0 && !refl_adj;
+    NEMAR_REQUIRE(pad_mode != BORDER_REFLECT || (pad < H && pad < W), "conv2d_bwd_data: reflect pad too large");
+    NEMAR_REQUIRE(!refl || (!bias && act == ACT_NONE && gx1 == nullptr),
+                  "conv2d_bwd_data: strided reflect mode supports a single destination without bias/activation");
     const size_t need = nemar_conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode);
     if (ws_bytes < need) {
         nemar_set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
@@ -613,14 +696,15 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             if (OHc <= 0 || OWc <= 0) continue;
             const int Mc = C - mskip;
             p.src0 = gy; p.src1 = nullptr; p.C0 = K; p.C1 = 0; p.Hs = OH; p.Ws = OW;
-            p.M = Mc; p.Mpad = nemar_cdiv(Mc, igemm_bm(Mc)) * igemm_bm(Mc); p.Kred = p.taps.n * K;
+            p.M = Mc; p.Mpad = igemm_mpad(Mc); p.Kred = p.taps.n * K;
             p.bias = bias ? bias + mskip : nullptr;
             if (refl) { p.dst0 = padded; p.dst1 = nullptr; p.M0 = Mc; }
             else if (mskip) { p.dst0 = gx1; p.dst1 = nullptr; p.M0 = Mc; }
             else { p.dst0 = gx0; p.dst1 = gx1; p.M0 = C0; }
             p.OH = OHc; p.OW = OWc; p.OHf = Hd; p.OWf = Wd; p.osy = stride; p.ooy = ph; p.osx = stride; p.oox = pw;
             p.N = N; p.P = N * OHc * OWc;
-            p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
+            p.sy = 1; p.sx = 1; p.border = refl_adj ? BORDER_REFLECT_ADJOINT : BORDER_ZERO; p.act = act; p.slope = slope;
+            p.pad = pad;
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
@@ -641,10 +725,11 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     return NEMAR_OK;
 }
 
-// gw[K][C][R][S] += d loss / d w   (always accumulates: the caller zero-fills once per optimizer step)
+// gw[K][C][R][S] += d loss / d w, and (gb != NULL) gb[K] += sum_pixels gy   (always accumulate: the caller
+// zero-fills once per optimizer step)
 NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw,
-                                      int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
-                                      int pad_mode, void* stream) {
+                                      float* gb, int N, int H, int W, int K, int OH, int OW, int R, int S, int stride,
+                                      int pad, int pad_mode, void* stream) {
     NEMAR_REQUIRE(x0 && gy && gw, "conv2d_bwd_weight: null pointer");
     NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_bwd_weight: bad channel split");
     NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && OH > 0 && OW > 0 && R > 0 && S > 0, "conv2d_bwd_weight: bad shape");
@@ -655,7 +740,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     WgradParams p;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
-    p.gw = gw; p.J = (C0 + C1) * R * S;
+    p.gw = gw; p.gb = gb; p.J = (C0 + C1) * R * S;
     p.N = N; p.P = N * OH * OW; p.sy = stride; p.sx = stride; p.R = R; p.S = S; p.pad = pad; p.border = pad_mode;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW);
     const bool wide = K > 32;
@@ -681,7 +766,9 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
 // gb[C] += sum over N and the plane of g [N,C,HW]   (bias gradient; also ConvTranspose2d's)
 NEMAR_API int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream) {
     NEMAR_REQUIRE(g && gb && N > 0 && C > 0 && HW > 0, "bias_grad: bad arguments");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, gb, N, C, HW);
+    const int chunk = 4096;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C, N, nemar_cdiv(HW, chunk)), dim3(256), 0, (hipStream_t)stream, g, gb, N, C,
+                       HW, chunk);
     NEMAR_CHECK_LAUNCH("bias_grad");
     return NEMAR_OK;
 }

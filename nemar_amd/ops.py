@@ -132,16 +132,16 @@ class _Conv2d(Function):
                 gx2 = torch.empty_like(x2)
             wsb = L.conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode)
             ws = _workspace(wsb, x.device)
-            if pad_mode == PAD_REFLECT and pad > 0 and x2 is not None:
-                raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
             L.conv2d_bwd_data(_p(g), _p(w), None, ACT_NONE, 0.0, _p(gx), C0, _p(gx2), C1, N, H, W, K, OH, OW, R, S,
                               stride, pad, pad_mode, _p(ws), wsb, st)
             if not need_x2:
                 gx2 = None
+        want_b = need_b and ctx.bias is not None
         if need_w:
-            L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), N, H, W, K, OH, OW, R, S,
-                                stride, pad, pad_mode, st)
-        if need_b and ctx.bias is not None:
+            gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
+            L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
+                                R, S, stride, pad, pad_mode, st)
+        elif want_b:
             L.bias_grad(_p(g), _p(_grad_buffer(ctx.bias)), N, K, OH * OW, st)
         return gx, gx2, None, None, None, None, None, None, None, None
 
@@ -197,8 +197,8 @@ class _ConvTranspose2d(Function):
             L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
                          0.0, _p(ws), wsb, st)
         if ctx.needs_input_grad[1]:
-            L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), N, Ho, Wo, Ci, H, W, R, S,
-                                stride, pad, PAD_ZERO, st)
+            L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
+                                S, stride, pad, PAD_ZERO, st)
         if ctx.needs_input_grad[2] and ctx.bias is not None:
             L.bias_grad(_p(g), _p(_grad_buffer(ctx.bias)), N, Co, Ho * Wo, st)
         return gx, None, None, None, None, None, None, None

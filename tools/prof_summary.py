@@ -3,6 +3,7 @@
 import glob
 import os
 import sqlite3
+import re
 import sys
 
 
@@ -15,6 +16,7 @@ def summarise(db_path):
     tot = sum(r[2] for r in rows) or 1
     out = ["name,calls,total_us,avg_us,min_us,max_us,pct,vgpr,agpr,lds_bytes"]
     for r in rows:
+        r = (re.sub(r"\s+", " ", r[0])[:150],) + tuple(r[1:])
         out.append('"%s",%d,%.2f,%.3f,%.3f,%.3f,%.2f,%s,%s,%s' % (
             r[0], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot, r[6], r[7], r[8]))
     return "\n".join(out) + "\n"
