@@ -102,6 +102,8 @@ int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, in
 int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
                             int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
                             int pad_mode, void* stream);
+/* Tuning switches for A/B measurements (tools/): key 0 = workgroup shape of the 128x128 conv tile (0: 8 waves, 1: 4). */
+int nemar_tune(int key, int value);
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */
 int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream);
 

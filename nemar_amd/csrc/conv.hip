@@ -30,10 +30,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;        // reduction depth per LDS stage (fwd/dgrad)
 constexpr int MAX_TAPS = 64;  // 7x7 = 49
 constexpr int BORDER_ZERO = 0, BORDER_REFLECT = 1;
-// data-gradient of a reflect-padded stride-1 conv, evaluated on the UNPADDED domain: besides the regular source row
-// h+dy, rows 1..pad also collect from the mirrored padded row (source row dy-h) and rows H-1-pad..H-2 from
-// 2(H-1)-h+dy; the same filter tap multiplies all of them, so the loader simply sums the candidates.
-constexpr int BORDER_REFLECT_ADJOINT = 2;
 constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -46,23 +42,6 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 __device__ __forceinline__ int reflect(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * (n - 1) - i : i;
-}
-
-// candidate source indices along one axis for BORDER_REFLECT_ADJOINT (h: output index, d: tap offset, n_out: output
-// extent, n_src: source extent); returns the count (0..3)
-__device__ __forceinline__ int adjoint_candidates(int h, int d, int pad, int n_out, int n_src, int* c) {
-    int n = 0;
-    const int y0 = h + d;
-    if ((unsigned)y0 < (unsigned)n_src) c[n++] = y0;
-    if (h >= 1 && h <= pad) {
-        const int y1 = d - h;
-        if ((unsigned)y1 < (unsigned)n_src) c[n++] = y1;
-    }
-    if (h <= n_out - 2 && h >= n_out - 1 - pad) {
-        const int y2 = 2 * (n_out - 1) - h + d;
-        if ((unsigned)y2 < (unsigned)n_src) c[n++] = y2;
-    }
-    return n;
 }
 
 struct TapTable {
@@ -103,24 +82,25 @@ struct IgemmParams {
     TapTable taps;
 };
 
-// WM x WN waves (WM*WN == 4), each TM x TN MFMA tiles of 32x32.  FAST: Cs % BK == 0 && C0 % BK == 0, so a whole
-// BK-deep stage shares one tap and one source tensor (address math once per stage instead of per element).
+// WM x WN waves, each TM x TN MFMA tiles of 32x32 (workgroup = WM*WN*64 threads).  FAST: Cs % BK == 0 && C0 % BK == 0,
+// so a whole BK-deep stage shares one tap and one source tensor (address math once per stage instead of per element).
 template <int WM, int WN, int TM, int TN, bool FAST>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
+    constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int TPC = 256 / BN == 0 ? 1 : 256 / BN;  // threads per pixel column of the B tile
-    constexpr int BROWS = BK / TPC;                    // B rows (reduction indices) per thread per stage
-    constexpr int A_F4 = BK * BM / 4;                  // float4s in an A stage
-    constexpr int A_PER = (A_F4 + 255) / 256;
-    static_assert(BN >= 64 && 256 % TPC == 0 && BK % TPC == 0, "tile");
+    constexpr int TPC = NT / BN;        // threads per pixel column of the B tile
+    constexpr int BROWS = BK / TPC;     // B rows (reduction indices) per thread per stage
+    constexpr int A_F4 = BK * BM / 4;   // float4s in an A stage
+    constexpr int A_PER = (A_F4 + NT - 1) / NT;
+    static_assert(TPC >= 1 && NT % BN == 0 && BK % TPC == 0 && A_PER <= 2, "tile");
 
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     __shared__ int s_tap[MAX_TAPS];
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < MAX_TAPS; i += 256)
+    for (int i = tid; i < MAX_TAPS; i += NT)
         s_tap[i] = i < p.taps.n ? (((int)p.taps.dy[i] << 16) | ((int)p.taps.dx[i] & 0xffff)) : 0;
 
     const int m0 = blockIdx.y * BM;
@@ -147,6 +127,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         s0n = p.src0 + (size_t)n * p.C0 * HW;
         if (p.C1) s1n = p.src1 + (size_t)n * p.C1 * HW;
     }
+    // A tile: this thread's float4 slots (row, 4 channels) of a stage
+    const int a_row0 = tid / (BM / 4), a_c0 = (tid - a_row0 * (BM / 4)) * 4;
+    const int a_row1 = (tid + NT) / (BM / 4), a_c1 = ((tid + NT) - a_row1 * (BM / 4)) * 4;
+    const bool a_on0 = tid < A_F4, a_on1 = A_PER > 1 && (tid + NT) < A_F4;
+    const float* wp0 = p.wp + (size_t)a_row0 * p.Mpad + m0 + a_c0;
+    const float* wp1 = p.wp + (size_t)a_row1 * p.Mpad + m0 + a_c1;
     __syncthreads();  // s_tap visible
 
     f32x16 acc[TM][TN];
@@ -157,115 +143,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_PER];
+    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0;
     float rb[BROWS];
 
-    auto load_stage = [&](int k0) {
-        // A: packed weights, rows k0..k0+BK-1 (zero padded on both axes => no bounds checks)
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            const int i = tid + q * 256;
-            if (A_F4 % 256 == 0 || i < A_F4) {
-                const int row = i / (BM / 4), c4 = i - row * (BM / 4);
-                ra[q] = *reinterpret_cast<const float4*>(p.wp + (size_t)(k0 + row) * p.Mpad + m0 + c4 * 4);
-            }
-        }
-        // B: gathered source pixels
-        if (FAST) {
-            const unsigned t = fd_div((unsigned)k0, p.fd_cs);
-            const int ch0 = k0 - (int)t * Cs;
-            const int tp = s_tap[t];
-            int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
-            bool inb = pvalid && k0 < p.Kred;
-            const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;
-            if (p.border == BORDER_REFLECT_ADJOINT) {
-                int ys[3], xs[3];
-                const int ny = inb ? adjoint_candidates(by, tp >> 16, p.pad, p.OH, p.Hs, ys) : 0;
-                const int nx = inb ? adjoint_candidates(bx, (int)(short)(tp & 0xffff), p.pad, p.OW, p.Ws, xs) : 0;
-                if (ny == 1 && nx == 1) {           // interior: exactly the zero-border gather
-                    const int off = ys[0] * p.Ws + xs[0];
-#pragma unroll
-                    for (int i = 0; i < BROWS; ++i) rb[i] = base[(size_t)(prow0 + TPC * i) * HW + off];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < BROWS; ++i) {
-                        const float* q = base + (size_t)(prow0 + TPC * i) * HW;
-                        float v = 0.f;
-                        for (int a = 0; a < ny; ++a)
-                            for (int b = 0; b < nx; ++b) v += q[ys[a] * p.Ws + xs[b]];
-                        rb[i] = v;
-                    }
-                }
-            } else {
-                if (p.border == BORDER_REFLECT) {
-                    y = reflect(y, p.Hs);
-                    x = reflect(x, p.Ws);
-                } else {
-                    inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-                }
-                const int off = y * p.Ws + x;
-#pragma unroll
-                for (int i = 0; i < BROWS; ++i) {
-                    const int r = prow0 + TPC * i;
-                    rb[i] = inb ? base[(size_t)r * HW + off] : 0.f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
-                const int kk = k0 + prow0 + TPC * i;
-                float v = 0.f;
-                if (pvalid && kk < p.Kred) {
-                    const unsigned t = fd_div((unsigned)kk, p.fd_cs);
-                    const int ch = kk - (int)t * Cs;
-                    const int tp = s_tap[t];
-                    int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
-                    const float* base = (ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW;
-                    if (p.border == BORDER_REFLECT_ADJOINT) {
-                        int ys[3], xs[3];
-                        const int ny = adjoint_candidates(by, tp >> 16, p.pad, p.OH, p.Hs, ys);
-                        const int nx = adjoint_candidates(bx, (int)(short)(tp & 0xffff), p.pad, p.OW, p.Ws, xs);
-                        for (int a = 0; a < ny; ++a)
-                            for (int b = 0; b < nx; ++b) v += base[ys[a] * p.Ws + xs[b]];
-                    } else {
-                        bool inb = true;
-                        if (p.border == BORDER_REFLECT) {
-                            y = reflect(y, p.Hs);
-                            x = reflect(x, p.Ws);
-                        } else {
-                            inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-                        }
-                        if (inb) v = base[y * p.Ws + x];
-                    }
-                }
-                rb[i] = v;
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            const int i = tid + q * 256;
-            if (A_F4 % 256 == 0 || i < A_F4) {
-                const int row = i / (BM / 4), c4 = i - row * (BM / 4);
-                *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = ra[q];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) Bs[buf][prow0 + TPC * i][pc] = rb[i];
-    };
+    // global -> registers for the stage starting at reduction index k0 (packed weights are zero padded on both axes)
+#define IGEMM_LOAD_STAGE(k0_)                                                                                        \
+    {                                                                                                                \
+        const int k0 = (k0_);                                                                                        \
+        if (a_on0) ra0 = *reinterpret_cast<const float4*>(wp0 + (size_t)k0 * p.Mpad);                                \
+        if (A_PER > 1 && a_on1) ra1 = *reinterpret_cast<const float4*>(wp1 + (size_t)k0 * p.Mpad);                   \
+        if (FAST) {                                                                                                  \
+            const unsigned t = fd_div((unsigned)k0, p.fd_cs);                                                        \
+            const int ch0 = k0 - (int)t * Cs;                                                                        \
+            const int tp = s_tap[t];                                                                                 \
+            int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);                                             \
+            bool inb = pvalid && k0 < p.Kred;                                                                        \
+            if (p.border == BORDER_REFLECT) {                                                                        \
+                y = reflect(y, p.Hs);                                                                                \
+                x = reflect(x, p.Ws);                                                                                \
+            } else {                                                                                                 \
+                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                           \
+            }                                                                                                        \
+            const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;           \
+            base += (size_t)prow0 * HW + (inb ? y * p.Ws + x : 0);                                                   \
+            _Pragma("unroll") for (int i = 0; i < BROWS; ++i) rb[i] = inb ? base[(size_t)(TPC * i) * HW] : 0.f;      \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < BROWS; ++i) {                                                      \
+                const int kk = k0 + prow0 + TPC * i;                                                                 \
+                float v = 0.f;                                                                                       \
+                if (pvalid && kk < p.Kred) {                                                                         \
+                    const unsigned t = fd_div((unsigned)kk, p.fd_cs);                                                \
+                    const int ch = kk - (int)t * Cs;                                                                 \
+                    const int tp = s_tap[t];                                                                         \
+                    int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);                                     \
+                    bool inb = true;                                                                                 \
+                    if (p.border == BORDER_REFLECT) {                                                                \
+                        y = reflect(y, p.Hs);                                                                        \
+                        x = reflect(x, p.Ws);                                                                        \
+                    } else {                                                                                         \
+                        inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                          \
+                    }                                                                                                \
+                    if (inb) {                                                                                       \
+                        const float* base = (ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW;   \
+                        v = base[y * p.Ws + x];                                                                      \
+                    }                                                                                                \
+                }                                                                                                    \
+                rb[i] = v;                                                                                           \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define IGEMM_STORE_STAGE(buf_)                                                                                      \
+    {                                                                                                                \
+        if (a_on0) *reinterpret_cast<float4*>(&As[buf_][a_row0][a_c0]) = ra0;                                        \
+        if (A_PER > 1 && a_on1) *reinterpret_cast<float4*>(&As[buf_][a_row1][a_c1]) = ra1;                           \
+        _Pragma("unroll") for (int i = 0; i < BROWS; ++i) Bs[buf_][prow0 + TPC * i][pc] = rb[i];                     \
+    }
 
     const int wid = tid >> 6, lane = tid & 63;
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     const int nk = (p.Kred + BK - 1) / BK;
-    load_stage(0);
-    store_stage(0);
+    IGEMM_LOAD_STAGE(0);
+    IGEMM_STORE_STAGE(0);
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) load_stage((ks + 1) * BK);
+        if (ks + 1 < nk) IGEMM_LOAD_STAGE((ks + 1) * BK);
 #pragma unroll
         for (int k2 = 0; k2 < BK / 2; ++k2) {
             const int kr = 2 * k2 + lhi;
@@ -280,9 +224,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (ks + 1 < nk) store_stage(buf ^ 1);
+        if (ks + 1 < nk) IGEMM_STORE_STAGE(buf ^ 1);
         __syncthreads();
     }
+#undef IGEMM_LOAD_STAGE
+#undef IGEMM_STORE_STAGE
 
     // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
@@ -319,12 +265,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 template <int WM, int WN, int TM, int TN>
 void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM)), block(256);
+    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM)), block(WM * WN * 64);
     if (fast)
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, p);
     else
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, p);
 }
+
+static int g_cfg128 = 0;   // tuning switch (nemar_tune): 0 = 8-wave 128x128 workgroup, 1 = 4-wave
 
 // Tile selection.  The channel tile follows M; the pixel tile shrinks when the grid would leave most of the 256 CUs
 // idle (the small-spatial discriminator / bottleneck layers): ~2 workgroups per CU is the target.
@@ -350,7 +298,8 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
     const TileChoice t = igemm_tile(p.M, p.P);
-    if (t.bm == 128) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st);                       // 128 channels x 128 pixels
+    if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st);      // 128 x 128, 4 waves of 64x64
+    else if (t.bm == 128) launch_igemm_cfg<2, 4, 2, 1>(p, fast, st);                  // 128 x 128, 8 waves of 64x32
     else if (t.bm == 64 && t.bn == 128) launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);    // 64 x 128
     else if (t.bm == 64) launch_igemm_cfg<2, 2, 1, 1>(p, fast, st);                   // 64 x 64
     else if (t.bn == 256) launch_igemm_cfg<1, 4, 1, 2>(p, fast, st);                  // 32 x 256
@@ -647,7 +596,7 @@ NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int
                                                  int pad_mode) {
     if (N <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
     size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
-    if (pad_mode == BORDER_REFLECT && pad > 0 && stride != 1) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    if (pad_mode == BORDER_REFLECT && pad > 0) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
     return sizeof(float) * fl;
 }
 
@@ -663,13 +612,10 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     NEMAR_REQUIRE((H + 2 * pad - R) / stride + 1 == OH && (W + 2 * pad - S) / stride + 1 == OW,
                   "conv2d_bwd_data: gy %dx%d inconsistent with x %dx%d k%d s%d p%d", OH, OW, H, W, R, stride, pad);
     const int C = C0 + C1;
-    // stride-1 reflect: adjoint-reflect gather on the unpadded domain (no scratch image, no fold pass);
-    // strided reflect (not used by NeMAR): differentiate w.r.t. the padded input, then fold
-    const bool refl_adj = pad_mode == BORDER_REFLECT && pad > 0 && stride == 1;
-    const bool refl = pad_mode == BORDER_REFLECT && pad > 0 && !refl_adj;
+    const bool refl = pad_mode == BORDER_REFLECT && pad > 0;
     NEMAR_REQUIRE(pad_mode != BORDER_REFLECT || (pad < H && pad < W), "conv2d_bwd_data: reflect pad too large");
     NEMAR_REQUIRE(!refl || (!bias && act == ACT_NONE && gx1 == nullptr),
-                  "conv2d_bwd_data: strided reflect mode supports a single destination without bias/activation");
+                  "conv2d_bwd_data: reflect mode supports a single destination without bias/activation");
     const size_t need = nemar_conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode);
     if (ws_bytes < need) {
         nemar_set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
@@ -703,7 +649,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             else { p.dst0 = gx0; p.dst1 = gx1; p.M0 = C0; }
             p.OH = OHc; p.OW = OWc; p.OHf = Hd; p.OWf = Wd; p.osy = stride; p.ooy = ph; p.osx = stride; p.oox = pw;
             p.N = N; p.P = N * OHc * OWc;
-            p.sy = 1; p.sx = 1; p.border = refl_adj ? BORDER_REFLECT_ADJOINT : BORDER_ZERO; p.act = act; p.slope = slope;
+            p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
             p.pad = pad;
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
@@ -761,6 +707,13 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 2>), grid, block, 0, st, p);
     NEMAR_CHECK_LAUNCH("conv2d_bwd_weight");
     return NEMAR_OK;
+}
+
+// Tuning switches for A/B measurements (not part of the operator contract): key 0 = 128x128 workgroup shape.
+NEMAR_API int nemar_tune(int key, int value) {
+    if (key == 0) { g_cfg128 = value; return NEMAR_OK; }
+    nemar_set_error("nemar_tune: unknown key %d", key);
+    return NEMAR_EINVAL;
 }
 
 // gb[C] += sum over N and the plane of g [N,C,HW]   (bias gradient; also ConvTranspose2d's)

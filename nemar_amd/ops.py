@@ -132,6 +132,8 @@ class _Conv2d(Function):
                 gx2 = torch.empty_like(x2)
             wsb = L.conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode)
             ws = _workspace(wsb, x.device)
+            if pad_mode == PAD_REFLECT and pad > 0 and x2 is not None:
+                raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
             L.conv2d_bwd_data(_p(g), _p(w), None, ACT_NONE, 0.0, _p(gx), C0, _p(gx2), C1, N, H, W, K, OH, OW, R, S,
                               stride, pad, pad_mode, _p(ws), wsb, st)
             if not need_x2:

@@ -31,13 +31,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--tune", type=int, nargs=2, action='append', default=[], help="nemar_tune key value")
+    ap.add_argument("--only", type=str, default=None)
     a = ap.parse_args()
     lib = _lib.load()
+    for k, v in a.tune:
+        lib.tune(k, v)
     dev = torch.device("cuda:0")
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     N = a.batch
     for (name, C0, C1, K, R, s, p, pm, H) in SHAPES:
+        if a.only and a.only not in name:
+            continue
         C = C0 + C1
         OH = (H + 2 * p - R) // s + 1
         x0 = torch.randn(N, C0, H, H, device=dev)

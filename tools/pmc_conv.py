@@ -1,0 +1,22 @@
+"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: pmc_conv.py [fwd|dgrad|wgrad] [iters]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nemar_amd import _lib
+which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+lib = _lib.load(); dev = torch.device('cuda:0')
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+N, C, K, H, R, s, p, pm = 8, 256, 256, 64, 3, 1, 1, 1
+x = torch.randn(N, C, H, H, device=dev); w = torch.randn(K, C, R, R, device=dev) * 0.05; b = torch.randn(K, device=dev)
+y = torch.empty(N, K, H, H, device=dev); gy = torch.randn(N, K, H, H, device=dev); gx = torch.empty_like(x); gw = torch.zeros_like(w)
+wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm)); ws = torch.empty(wsb // 4 + 16, device=dev)
+for _ in range(iters):
+    if which == 'fwd':
+        lib.conv2d_fwd(P(x), C, None, 0, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, 1, 0.2, P(ws), wsb, st())
+    elif which == 'dgrad':
+        lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx), C, None, 0, N, H, H, K, H, H, R, R, s, p, pm, P(ws), wsb, st())
+    else:
+        lib.conv2d_bwd_weight(P(x), C, None, 0, P(gy), P(gw), P(b), N, H, H, K, H, H, R, R, s, p, pm, st())
+torch.cuda.synchronize()
