@@ -70,6 +70,18 @@ __device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
     return (unsigned)(((unsigned long long)n * f.m) >> 40);
 }
 
+// Direct global -> LDS copies (no VGPR staging): each lane supplies its own global address, the LDS destination is the
+// wave-uniform `lds` base + lane * size.  Asynchronous: complete after s_waitcnt vmcnt(0) (+ a barrier for other waves).
+__device__ __forceinline__ void glds_b128(const float* g, float* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ void glds_b32(const float* g, float* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 4, 0, 0);
+}
+__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // s_waitcnt vmcnt(0)
+
 // 64-lane wavefront reductions (gfx950 wave = 64; never 32)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

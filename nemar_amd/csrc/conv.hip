@@ -53,15 +53,15 @@ struct TapTable {
 // ---- weight packing: W[m*wsm + ch*wsc + wofs[t]] -> A[(t*Cs + ch)*Mpad + m], zero padded --------------------
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M,
                                                            int Mpad, int Cs, int Kred, int KredPad, int wsm, int wsc,
-                                                           TapTable taps) {
+                                                           int zero_tail, TapTable taps) {
     __shared__ int s_wofs[MAX_TAPS];
     for (int i = threadIdx.x; i < MAX_TAPS; i += blockDim.x) s_wofs[i] = i < taps.n ? taps.wofs[i] : 0;
     __syncthreads();
-    const int total = KredPad * Mpad;
+    const int core = KredPad * Mpad, total = core + zero_tail;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int kk = idx / Mpad, m = idx - kk * Mpad;
         float v = 0.f;
-        if (m < M && kk < Kred) {
+        if (idx < core && m < M && kk < Kred) {
             const int t = kk / Cs, ch = kk - t * Cs;
             v = w[(size_t)m * wsm + (size_t)ch * wsc + s_wofs[t]];
         }
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 struct IgemmParams {
     const float* src0; const float* src1; int C0, C1, Hs, Ws;
     const float* wp; int Mpad, M, Kred;
+    const float* zero;   // >= 16 readable bytes of zeros (tail of the packed-weight buffer)
     const float* bias;
     float* dst0; float* dst1; int M0;
     int OH, OW, OHf, OWf, osy, ooy, osx, oox;
@@ -84,22 +85,34 @@ struct IgemmParams {
 
 // WM x WN waves, each TM x TN MFMA tiles of 32x32 (workgroup = WM*WN*64 threads).  FAST: Cs % BK == 0 && C0 % BK == 0,
 // so a whole BK-deep stage shares one tap and one source tensor (address math once per stage instead of per element).
+//
+// Staging is direct global -> LDS (global_load_lds_*): no VGPR round trip, no ds_write pass, and no register hazards for
+// the compiler to guard with early waits.  The stage for step k+1 is issued before the MFMAs of step k and drained
+// (s_waitcnt vmcnt(0) + barrier) after them.  A tile: packed weights, 16 B per lane, dense LDS rows (one wave
+// instruction = 1 KiB).  B tile: one 4-byte gather per lane, 64 consecutive pixels of one reduction row per wave
+// instruction; taps that fall outside a zero-padded source (and tile tails) are pointed at a zero page.
 template <int WM, int WN, int TM, int TN, bool FAST>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
-    constexpr int NT = WM * WN * 64;
+    constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int TPC = NT / BN;        // threads per pixel column of the B tile
-    constexpr int BROWS = BK / TPC;     // B rows (reduction indices) per thread per stage
-    constexpr int A_F4 = BK * BM / 4;   // float4s in an A stage
-    constexpr int A_PER = (A_F4 + NT - 1) / NT;
-    static_assert(TPC >= 1 && NT % BN == 0 && BK % TPC == 0 && A_PER <= 2, "tile");
+    constexpr int LDA = BM, LDB = BN + 4;
+    constexpr int SEGS = BN / 64;               // 64-pixel segments per B row
+    constexpr int RGRP = NW / SEGS;             // waves working on the same segment (each takes every RGRP-th row)
+    constexpr int BROWS = BK / RGRP;            // B rows per wave per stage
+    constexpr int A_INSTR = BK * BM / 256;      // 1 KiB wave-instructions per A stage
+    constexpr int A_PER = (A_INSTR + NW - 1) / NW;
+    static_assert(BN % 64 == 0 && NW % SEGS == 0 && BK % RGRP == 0, "tile");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
-    __shared__ int s_tap[MAX_TAPS];
+    // ONE __shared__ object: with several, hipcc guards every ds_read of a stage with s_waitcnt vmcnt(0) while a
+    // global_load_lds is in flight (it cannot tell which object the DMA writes), which would serialise the pipeline
+    constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_FLOATS + 2 * B_FLOATS + MAX_TAPS];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * A_FLOATS;
+    int* const s_tap = reinterpret_cast<int*>(smem + 2 * A_FLOATS + 2 * B_FLOATS);
 
     const int tid = threadIdx.x;
+    const int wid = tid >> 6, lane = tid & 63;
     for (int i = tid; i < MAX_TAPS; i += NT)
         s_tap[i] = i < p.taps.n ? (((int)p.taps.dy[i] << 16) | ((int)p.taps.dx[i] & 0xffff)) : 0;
 
@@ -108,9 +121,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int Cs = p.C0 + p.C1;
     const int HW = p.Hs * p.Ws;
 
-    // ---- this thread's pixel column of the B tile (fixed for the whole reduction) -------------------------
-    const int pc = tid % BN;
-    const int prow0 = tid / BN;
+    // ---- this lane's pixel column of the B tile (fixed for the whole reduction) ----------------------------------
+    const int seg = wid % SEGS, rgrp = wid / SEGS;
+    const int pc = seg * 64 + lane;
     const int pix = p0 + pc;
     const bool pvalid = pix < p.P;
     int by = 0, bx = 0;
@@ -127,12 +140,16 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         s0n = p.src0 + (size_t)n * p.C0 * HW;
         if (p.C1) s1n = p.src1 + (size_t)n * p.C1 * HW;
     }
-    // A tile: this thread's float4 slots (row, 4 channels) of a stage
-    const int a_row0 = tid / (BM / 4), a_c0 = (tid - a_row0 * (BM / 4)) * 4;
-    const int a_row1 = (tid + NT) / (BM / 4), a_c1 = ((tid + NT) - a_row1 * (BM / 4)) * 4;
-    const bool a_on0 = tid < A_F4, a_on1 = A_PER > 1 && (tid + NT) < A_F4;
-    const float* wp0 = p.wp + (size_t)a_row0 * p.Mpad + m0 + a_c0;
-    const float* wp1 = p.wp + (size_t)a_row1 * p.Mpad + m0 + a_c1;
+    // ---- this lane's 16-byte slots of the A tile -----------------------------------------------------------------------
+    const float* wsrc[A_PER];
+    int a_lds[A_PER];
+#pragma unroll
+    for (int q = 0; q < A_PER; ++q) {
+        const int e = (wid + q * NW) * 256 + lane * 4;      // float index inside the dense [BK][BM] stage
+        const int row = e / BM, col = e - row * BM;
+        wsrc[q] = p.wp + (size_t)row * p.Mpad + m0 + col;
+        a_lds[q] = (wid + q * NW) * 256;                    // wave-uniform LDS base (floats)
+    }
     __syncthreads();  // s_tap visible
 
     f32x16 acc[TM][TN];
@@ -143,15 +160,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0;
-    float rb[BROWS];
-
-    // global -> registers for the stage starting at reduction index k0 (packed weights are zero padded on both axes)
-#define IGEMM_LOAD_STAGE(k0_)                                                                                        \
+#define IGEMM_ISSUE_STAGE(k0_, buf_)                                                                                 \
     {                                                                                                                \
         const int k0 = (k0_);                                                                                        \
-        if (a_on0) ra0 = *reinterpret_cast<const float4*>(wp0 + (size_t)k0 * p.Mpad);                                \
-        if (A_PER > 1 && a_on1) ra1 = *reinterpret_cast<const float4*>(wp1 + (size_t)k0 * p.Mpad);                   \
+        _Pragma("unroll") for (int q = 0; q < A_PER; ++q) {                                                          \
+            if (A_INSTR % NW == 0 || wid + q * NW < A_INSTR)                                                         \
+                glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + (buf_) * A_FLOATS + a_lds[q]);                                       \
+        }                                                                                                            \
         if (FAST) {                                                                                                  \
             const unsigned t = fd_div((unsigned)k0, p.fd_cs);                                                        \
             const int ch0 = k0 - (int)t * Cs;                                                                        \
@@ -165,12 +180,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                           \
             }                                                                                                        \
             const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;           \
-            base += (size_t)prow0 * HW + (inb ? y * p.Ws + x : 0);                                                   \
-            _Pragma("unroll") for (int i = 0; i < BROWS; ++i) rb[i] = inb ? base[(size_t)(TPC * i) * HW] : 0.f;      \
+            base += (size_t)rgrp * HW + (inb ? y * p.Ws + x : 0);                                                    \
+            _Pragma("unroll") for (int i = 0; i < BROWS; ++i)                                                        \
+                glds_b32(inb ? base + (size_t)(RGRP * i) * HW : p.zero,                                              \
+                         Bs0 + (buf_) * B_FLOATS + (rgrp + RGRP * i) * LDB + seg * 64);       \
         } else {                                                                                                     \
             _Pragma("unroll") for (int i = 0; i < BROWS; ++i) {                                                      \
-                const int kk = k0 + prow0 + TPC * i;                                                                 \
-                float v = 0.f;                                                                                       \
+                const int kk = k0 + rgrp + RGRP * i;                                                                 \
+                const float* src = p.zero;                                                                           \
                 if (pvalid && kk < p.Kred) {                                                                         \
                     const unsigned t = fd_div((unsigned)kk, p.fd_cs);                                                \
                     const int ch = kk - (int)t * Cs;                                                                 \
@@ -183,52 +200,41 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                     } else {                                                                                         \
                         inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                          \
                     }                                                                                                \
-                    if (inb) {                                                                                       \
-                        const float* base = (ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW;   \
-                        v = base[y * p.Ws + x];                                                                      \
-                    }                                                                                                \
+                    if (inb) src = ((ch < p.C0) ? s0n + (size_t)ch * HW : s1n + (size_t)(ch - p.C0) * HW) + y * p.Ws + x; \
                 }                                                                                                    \
-                rb[i] = v;                                                                                           \
+                glds_b32(src, Bs0 + (buf_) * B_FLOATS + (rgrp + RGRP * i) * LDB + seg * 64);                                                 \
             }                                                                                                        \
         }                                                                                                            \
     }
-#define IGEMM_STORE_STAGE(buf_)                                                                                      \
-    {                                                                                                                \
-        if (a_on0) *reinterpret_cast<float4*>(&As[buf_][a_row0][a_c0]) = ra0;                                        \
-        if (A_PER > 1 && a_on1) *reinterpret_cast<float4*>(&As[buf_][a_row1][a_c1]) = ra1;                           \
-        _Pragma("unroll") for (int i = 0; i < BROWS; ++i) Bs[buf_][prow0 + TPC * i][pc] = rb[i];                     \
-    }
 
-    const int wid = tid >> 6, lane = tid & 63;
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     const int nk = (p.Kred + BK - 1) / BK;
-    IGEMM_LOAD_STAGE(0);
-    IGEMM_STORE_STAGE(0);
+    IGEMM_ISSUE_STAGE(0, 0);
+    wait_vmem();
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) IGEMM_LOAD_STAGE((ks + 1) * BK);
+        if (ks + 1 < nk) IGEMM_ISSUE_STAGE((ks + 1) * BK, buf ^ 1);
 #pragma unroll
         for (int k2 = 0; k2 < BK / 2; ++k2) {
             const int kr = 2 * k2 + lhi;
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][kr][(wm * TM + i) * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = As0[buf * A_FLOATS + kr * LDA + (wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kr][(wn * TN + j) * 32 + l31];
+            for (int j = 0; j < TN; ++j) b[j] = Bs0[buf * B_FLOATS + kr * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (ks + 1 < nk) IGEMM_STORE_STAGE(buf ^ 1);
+        wait_vmem();       // the next stage has landed in LDS (it had the whole MFMA phase to do so)
         __syncthreads();
     }
-#undef IGEMM_LOAD_STAGE
-#undef IGEMM_STORE_STAGE
+#undef IGEMM_ISSUE_STAGE
 
     // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
@@ -307,17 +313,17 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
 }
 
 // packed weights are padded to a multiple of 128 channels (32 when M <= 32) so every tile config can read them
-size_t packed_floats(int M, int Kred) {
-    return (size_t)nemar_cdiv(Kred, BK) * BK * (size_t)igemm_mpad(M);
-}
+constexpr int ZERO_PAGE = 64;   // floats of zeros appended to every packed-weight buffer (target of masked gathers)
+size_t packed_core_floats(int M, int Kred) { return (size_t)nemar_cdiv(Kred, BK) * BK * (size_t)igemm_mpad(M); }
+size_t packed_floats(int M, int Kred) { return packed_core_floats(M, Kred) + ZERO_PAGE; }
 
 void launch_pack(const float* w, float* wp, int M, int Cs, int wsm, int wsc, const TapTable& taps, hipStream_t st) {
     const int Kred = taps.n * Cs;
     const int KredPad = nemar_cdiv(Kred, BK) * BK;
     const int Mpad = igemm_mpad(M);
-    const int total = KredPad * Mpad;
+    const int total = KredPad * Mpad + ZERO_PAGE;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, wp, M, Mpad, Cs,
-                       Kred, KredPad, wsm, wsc, taps);
+                       Kred, KredPad, wsm, wsc, ZERO_PAGE, taps);
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------
@@ -579,6 +585,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     launch_pack(w, (float*)workspace, K, C, C * R * S, R * S, p.taps, st);
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
+    p.zero = p.wp + packed_core_floats(K, C * R * S);
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
@@ -654,6 +661,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
+            p.zero = wp + packed_core_floats(Mc, K * (p.taps.n > 0 ? p.taps.n : 1));
             if (p.taps.n == 0) {
                 // no tap reaches this class (e.g. k1 s2): gradient is bias-only / zero; run with one zero tap
                 p.taps.n = 1; p.taps.dy[0] = -32000; p.taps.dx[0] = -32000; p.taps.wofs[0] = 0; p.Kred = K;

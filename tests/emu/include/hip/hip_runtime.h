@@ -142,6 +142,14 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
     return d;
 }
 
+// ---- direct global->LDS copy (global_load_lds_*): LDS destination = wave-uniform base + lane*size ------------------
+static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* g,
+                                                    __attribute__((address_space(3))) void* l, unsigned size,
+                                                    int offset, unsigned /*aux*/) {
+    memcpy((char*)(void*)l + (size_t)emu_lane_id() * size + offset, (const void*)g, size);
+}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+
 // ---- scalar/uniform builtins ------------------------------------------------------------------
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
