@@ -26,6 +26,10 @@ void nemar_set_error(const char* fmt, ...);
         }                                        \
     } while (0)
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process (torch, rocBLAS...):
+// discard whatever is pending before our launches so that NEMAR_CHECK_LAUNCH reports only our own failures.
+#define NEMAR_CLEAR_HIP_ERROR() ((void)hipGetLastError())
+
 #define NEMAR_CHECK_LAUNCH(what)                                              \
     do {                                                                      \
         hipError_t e__ = hipGetLastError();                                   \

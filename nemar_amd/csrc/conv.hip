@@ -268,17 +268,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     }
 }
 
+static int g_cfg128 = 0;   // tuning switch (nemar_tune): 0 = 8-wave 128x128 workgroup, 1 = 4-wave
+static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgroup (limits workgroups per CU)
+
 template <int WM, int WN, int TM, int TN>
 void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM)), block(WM * WN * 64);
     if (fast)
-        hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, g_lds_pad, st, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, g_lds_pad, st, p);
 }
-
-static int g_cfg128 = 0;   // tuning switch (nemar_tune): 0 = 8-wave 128x128 workgroup, 1 = 4-wave
 
 // Tile selection.  The channel tile follows M; the pixel tile shrinks when the grid would leave most of the 256 CUs
 // idle (the small-spatial discriminator / bottleneck layers): ~2 workgroups per CU is the target.
@@ -562,6 +563,7 @@ NEMAR_API size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S) {
 NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
                                float* y, int N, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode,
                                int act, float slope, void* workspace, size_t ws_bytes, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x0 && w && y && workspace, "conv2d_fwd: null pointer");
     NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_fwd: bad channel split %d+%d", C0, C1);
     NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && R > 0 && S > 0 && R * S <= MAX_TAPS, "conv2d_fwd: bad shape");
@@ -611,6 +613,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                                     float* gx0, int C0, float* gx1, int C1, int N, int H, int W, int K, int OH, int OW,
                                     int R, int S, int stride, int pad, int pad_mode, void* workspace, size_t ws_bytes,
                                     void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(gy && w && workspace && (gx0 || gx1), "conv2d_bwd_data: null pointer");
     NEMAR_REQUIRE(C0 >= 0 && C1 >= 0 && C0 + C1 > 0 && (C1 == 0 || gx1), "conv2d_bwd_data: bad channel split");
     NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && OH > 0 && OW > 0 && R * S <= MAX_TAPS && R > 0 && S > 0,
@@ -684,6 +687,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
 NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw,
                                       float* gb, int N, int H, int W, int K, int OH, int OW, int R, int S, int stride,
                                       int pad, int pad_mode, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x0 && gy && gw, "conv2d_bwd_weight: null pointer");
     NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_bwd_weight: bad channel split");
     NEMAR_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && OH > 0 && OW > 0 && R > 0 && S > 0, "conv2d_bwd_weight: bad shape");
@@ -720,12 +724,14 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
 // Tuning switches for A/B measurements (not part of the operator contract): key 0 = 128x128 workgroup shape.
 NEMAR_API int nemar_tune(int key, int value) {
     if (key == 0) { g_cfg128 = value; return NEMAR_OK; }
+    if (key == 1) { g_lds_pad = value; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
 }
 
 // gb[C] += sum over N and the plane of g [N,C,HW]   (bias gradient; also ConvTranspose2d's)
 NEMAR_API int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(g && gb && N > 0 && C > 0 && HW > 0, "bias_grad: bad arguments");
     const int chunk = 4096;
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C, N, nemar_cdiv(HW, chunk)), dim3(256), 0, (hipStream_t)stream, g, gb, N, C,

@@ -112,6 +112,7 @@ NEMAR_API size_t nemar_loss_workspace(void) { return sizeof(float) * RED_BLOCKS;
 // loss[0] = (accumulate ? loss[0] : 0) + weight * mean|a - b|      (b NULL => mean|a|)
 NEMAR_API int nemar_l1_loss_fwd(const float* a, const float* b, long long n, float weight, float* loss, int accumulate,
                                 void* workspace, size_t ws_bytes, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(a && loss && workspace && n > 0, "l1_loss_fwd: bad arguments");
     if (ws_bytes < nemar_loss_workspace()) { nemar_set_error("l1_loss_fwd: workspace too small"); return NEMAR_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
@@ -126,6 +127,7 @@ NEMAR_API int nemar_l1_loss_fwd(const float* a, const float* b, long long n, flo
 // ga (+)= gscale[0] * weight * sign(a - b) / n
 NEMAR_API int nemar_l1_loss_bwd(const float* a, const float* b, long long n, const float* gscale, float weight, float* ga,
                                 int accumulate, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(a && gscale && ga && n > 0, "l1_loss_bwd: bad arguments");
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(nemar_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, gscale,
                        (float)(weight / (double)n), ga, n, accumulate);
@@ -136,6 +138,7 @@ NEMAR_API int nemar_l1_loss_bwd(const float* a, const float* b, long long n, con
 // loss[0] = (accumulate ? loss[0] : 0) + weight * GANLoss(mode)(x, target_is_real)
 NEMAR_API int nemar_gan_loss_fwd(const float* x, long long n, int mode, int target_is_real, float weight, float* loss,
                                  int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && loss && workspace && n > 0, "gan_loss_fwd: bad arguments");
     NEMAR_REQUIRE(mode >= 0 && mode <= 2, "gan_loss_fwd: unknown gan mode %d", mode);
     if (ws_bytes < nemar_loss_workspace()) { nemar_set_error("gan_loss_fwd: workspace too small"); return NEMAR_EWORKSPACE; }
@@ -150,6 +153,7 @@ NEMAR_API int nemar_gan_loss_fwd(const float* x, long long n, int mode, int targ
 
 NEMAR_API int nemar_gan_loss_bwd(const float* x, long long n, int mode, int target_is_real, const float* gscale,
                                  float weight, float* gx, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && gscale && gx && n > 0, "gan_loss_bwd: bad arguments");
     NEMAR_REQUIRE(mode >= 0 && mode <= 2, "gan_loss_bwd: unknown gan mode %d", mode);
     hipLaunchKernelGGL(gan_bwd_kernel, dim3(nemar_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, gscale,
@@ -161,6 +165,7 @@ NEMAR_API int nemar_gan_loss_bwd(const float* x, long long n, int mode, int targ
 // One Adam step over a flat parameter buffer (p, g, m, v all length n); `step` is 1-based.
 NEMAR_API int nemar_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
                               double beta2, double eps, int step, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
     // hyper-parameters arrive as doubles (python floats) and are rounded to fp32 exactly where torch rounds them
     const double bc1 = 1.0 - pow(beta1, (double)step);

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __re
 // x, y, residual (nullable): [planes, HW] with planes = N*C;  stats: [planes, 2] = (mean, rstd)
 NEMAR_API int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
                                  float eps, int act, float slope, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && y && stats, "instnorm_fwd: null pointer");
     NEMAR_REQUIRE(planes > 0 && HW > 0, "instnorm_fwd: bad shape planes=%d HW=%d", planes, HW);
     NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_fwd: unsupported act %d", act);
@@ -169,6 +170,7 @@ NEMAR_API int nemar_instnorm_fwd(const float* x, const float* residual, float* y
 
 NEMAR_API int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                                  int act, float slope, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && stats && gy && gx, "instnorm_bwd: null pointer");
     NEMAR_REQUIRE(planes > 0 && HW > 0, "instnorm_bwd: bad shape planes=%d HW=%d", planes, HW);
     NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_bwd: unsupported act %d", act);

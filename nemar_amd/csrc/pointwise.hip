@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 }  // namespace
 
 NEMAR_API int nemar_act_bwd(const float* gy, const float* y, float* gx, long long n, int act, float slope, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(gy && y && gx && n > 0, "act_bwd: bad arguments");
     NEMAR_REQUIRE((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gx) & 15) == 0, "act_bwd: pointers must be 16-byte aligned");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nemar_stream_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, gy, y,
@@ -226,6 +227,7 @@ NEMAR_API int nemar_act_bwd(const float* gy, const float* y, float* gx, long lon
 }
 
 NEMAR_API int nemar_maxpool2_fwd(const float* x, float* y, int planes, int H, int W, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && y && planes > 0 && H >= 2 && W >= 2, "maxpool2_fwd: bad arguments");
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)planes * Ho * Wo;
@@ -241,6 +243,7 @@ NEMAR_API int nemar_maxpool2_fwd(const float* x, float* y, int planes, int H, in
 // gx [planes,H,W] = (addend ? addend : 0) + unpool(gy [planes,H/2,W/2]) using x to recompute the argmax
 NEMAR_API int nemar_maxpool2_bwd(const float* x, const float* gy, const float* addend, float* gx, int planes, int H, int W,
                                  void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && gy && gx && planes > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad arguments");
     const long long total = (long long)planes * H * W;
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gy,
@@ -250,6 +253,7 @@ NEMAR_API int nemar_maxpool2_bwd(const float* x, const float* gy, const float* a
 }
 
 NEMAR_API int nemar_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int Ho, int Wo, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "bilinear_fwd: bad arguments");
     const long long total = (long long)planes * Ho * Wo;
     hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H,
@@ -260,6 +264,7 @@ NEMAR_API int nemar_bilinear_fwd(const float* x, float* y, int planes, int H, in
 
 // gx [planes,H,W] <- gy [planes,Ho,Wo]   (written, not accumulated)
 NEMAR_API int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, int W, int Ho, int Wo, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(gy && gx && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "bilinear_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (Ho == 2 * H && Wo == 2 * W) {
@@ -280,6 +285,7 @@ NEMAR_API int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, 
 // (seed, offset) on the upstream gradient for the backward pass.
 NEMAR_API int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned offset,
                             void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
     NEMAR_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "dropout: pointers must be 16-byte aligned");
     const double t = (double)p * 4294967296.0;

@@ -170,6 +170,7 @@ NEMAR_API size_t nemar_smoothness_workspace(int N, int H, int W) {
 NEMAR_API int nemar_smoothness_fwd(const float* d, const float* img, int Ci, float alpha, float factor,
                                    float* loss, int accumulate, void* workspace, size_t ws_bytes, int N, int H, int W,
                                    void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(d && loss && workspace, "smoothness_fwd: null pointer");
     NEMAR_REQUIRE(N > 0 && N <= 65535 && H > 1 && W > 1, "smoothness_fwd: bad shape N=%d H=%d W=%d", N, H, W);
     const bool bil = img != nullptr && alpha > 0.f;
@@ -196,6 +197,7 @@ NEMAR_API int nemar_smoothness_fwd(const float* d, const float* img, int Ci, flo
 
 NEMAR_API int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, const float* gscale,
                                    float factor, float* gd, int accumulate, int N, int H, int W, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(d && gscale && gd, "smoothness_bwd: null pointer");
     NEMAR_REQUIRE(N > 0 && N <= 65535 && H > 1 && W > 1, "smoothness_bwd: bad shape N=%d H=%d W=%d", N, H, W);
     const bool bil = img != nullptr && alpha > 0.f;

@@ -254,6 +254,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 
 NEMAR_API int nemar_grid_sample_fwd(const float* in, const float* grid_src, int grid_mode, float* out, int N, int C,
                                     int H, int W, int Ho, int Wo, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(in && grid_src && out, "grid_sample_fwd: null pointer");
     NEMAR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "grid_sample_fwd: bad shape");
     NEMAR_REQUIRE((long long)H * W < (1ll << 31) && (long long)Ho * Wo < (1ll << 31) && N <= 65535,
@@ -272,6 +273,7 @@ NEMAR_API int nemar_grid_sample_fwd(const float* in, const float* grid_src, int 
 NEMAR_API int nemar_grid_sample_bwd(const float* in, const float* grid_src, int grid_mode, const float* gout,
                                     float* gin, int accum_gin, float* ggrid, int accum_ggrid, int N, int C, int H,
                                     int W, int Ho, int Wo, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(in && grid_src && gout && ggrid, "grid_sample_bwd: null pointer");
     NEMAR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "grid_sample_bwd: bad shape");
     NEMAR_REQUIRE((long long)H * W < (1ll << 31) && (long long)Ho * Wo < (1ll << 31) && N <= 65535,
