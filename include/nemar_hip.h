@@ -104,6 +104,7 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
                             int pad_mode, void* stream);
 /* Tuning switches for A/B measurements (tools/): key 0 = workgroup shape of the 128x128 conv tile (0: 8 waves, 1: 4). */
 int nemar_tune(int key, int value);
+int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */
 int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream);
 

@@ -73,6 +73,8 @@ struct IgemmParams {
     const float* src0; const float* src1; int C0, C1, Hs, Ws;
     const float* wp; int Mpad, M, Kred;
     const float* zero;   // >= 16 readable bytes of zeros (tail of the packed-weight buffer)
+    long long* tl;       // optional timeline buffer (nemar_tune_ptr): per-stage s_memtime stamps of workgroup 0
+    int dbg;             // ablation switches (nemar_tune key 2): 1 = skip staging, 2 = skip MFMAs, 4 = skip barriers
     const float* bias;
     float* dst0; float* dst1; int M0;
     int OH, OW, OHf, OWf, osy, ooy, osx, oox;
@@ -210,31 +212,59 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
+    long long tA[5] = {0, 0, 0, 0, 0}, tB[5] = {0, 0, 0, 0, 0}, tC[5] = {0, 0, 0, 0, 0}, tD[5] = {0, 0, 0, 0, 0};
     const int nk = (p.Kred + BK - 1) / BK;
     IGEMM_ISSUE_STAGE(0, 0);
     wait_vmem();
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) IGEMM_ISSUE_STAGE((ks + 1) * BK, buf ^ 1);
-#pragma unroll
-        for (int k2 = 0; k2 < BK / 2; ++k2) {
-            const int kr = 2 * k2 + lhi;
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As0[buf * A_FLOATS + kr * LDA + (wm * TM + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs0[buf * B_FLOATS + kr * LDB + (wn * TN + j) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        // timeline probe (nemar_tune_ptr): s_memtime stamps of 4 consecutive stages, kept in scalar registers so the
+        // probe adds no memory traffic; written out once at the end by workgroup 0
+#define IGEMM_STAMP(i)                                                                   \
+        if (p.tl) {                                                                          \
+            const long long c_ = clock64();                                                  \
+            if (ks == 40) tA[i] = c_; else if (ks == 41) tB[i] = c_;                         \
+            else if (ks == 42) tC[i] = c_; else if (ks == 43) tD[i] = c_;                    \
         }
+        IGEMM_STAMP(0)
+        if (ks + 1 < nk && !(p.dbg & 1)) IGEMM_ISSUE_STAGE((ks + 1) * BK, buf ^ 1);
+        IGEMM_STAMP(1)
+        if (!(p.dbg & 2)) {
+            // all MFMA operands of the stage into registers first (one LDS round trip per stage), then the MFMAs
+            // back to back: reading fragments just-in-time makes hipcc reuse the operand registers, and the
+            // write-after-read wait on them puts an LDS latency between every pair of MFMAs
+            float a[BK / 2][TM], b[BK / 2][TN];
+#pragma unroll
+            for (int k2 = 0; k2 < BK / 2; ++k2) {
+                const int kr = 2 * k2 + lhi;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[k2][i] = As0[buf * A_FLOATS + kr * LDA + (wm * TM + i) * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[k2][j] = Bs0[buf * B_FLOATS + kr * LDB + (wn * TN + j) * 32 + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads above, in their own registers
+            if (p.tl) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): stamp 2 = operands have arrived
+            IGEMM_STAMP(2)
+#pragma unroll
+            for (int k2 = 0; k2 < BK / 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2][i], b[k2][j], acc[i][j], 0, 0, 0);
+        }
+        IGEMM_STAMP(3)
         wait_vmem();       // the next stage has landed in LDS (it had the whole MFMA phase to do so)
-        __syncthreads();
+        IGEMM_STAMP(4)
+        if (!(p.dbg & 4)) __syncthreads();
     }
 #undef IGEMM_ISSUE_STAGE
+#undef IGEMM_STAMP
+    if (p.tl && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+        long long* o = p.tl + wid * 20;
+        for (int i = 0; i < 5; ++i) { o[i] = tA[i]; o[5 + i] = tB[i]; o[10 + i] = tC[i]; o[15 + i] = tD[i]; }
+    }
 
     // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
@@ -269,6 +299,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 }
 
 static int g_cfg128 = 0;   // tuning switch (nemar_tune): 0 = 8-wave 128x128 workgroup, 1 = 4-wave
+static int g_dbg = 0;
+static long long* g_tl = nullptr;
 static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgroup (limits workgroups per CU)
 
 template <int WM, int WN, int TM, int TN>
@@ -588,6 +620,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
     p.zero = p.wp + packed_core_floats(K, C * R * S);
+    p.dbg = g_dbg; p.tl = g_tl;
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
@@ -665,6 +698,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
             p.zero = wp + packed_core_floats(Mc, K * (p.taps.n > 0 ? p.taps.n : 1));
+            p.dbg = g_dbg; p.tl = nullptr;
             if (p.taps.n == 0) {
                 // no tap reaches this class (e.g. k1 s2): gradient is bias-only / zero; run with one zero tap
                 p.taps.n = 1; p.taps.dy[0] = -32000; p.taps.dx[0] = -32000; p.taps.wofs[0] = 0; p.Kred = K;
@@ -721,10 +755,13 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     return NEMAR_OK;
 }
 
+NEMAR_API int nemar_tune_ptr(void* p) { g_tl = (long long*)p; return NEMAR_OK; }
+
 // Tuning switches for A/B measurements (not part of the operator contract): key 0 = 128x128 workgroup shape.
 NEMAR_API int nemar_tune(int key, int value) {
     if (key == 0) { g_cfg128 = value; return NEMAR_OK; }
     if (key == 1) { g_lds_pad = value; return NEMAR_OK; }
+    if (key == 2) { g_dbg = value; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
 }

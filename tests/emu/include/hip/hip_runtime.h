@@ -177,6 +177,7 @@ static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); re
 using std::min;
 using std::max;
 static inline void __threadfence() {}
+static inline long long clock64() { return 0; }
 
 // ---- launch ---------------------------------------------------------------------------------------
 template <typename K, typename Tup, size_t... I>
