@@ -23,6 +23,13 @@
 // the (huge) pixel reduction split across workgroups and fp32 atomics into the caller's gradient buffer.
 #include "common.h"
 
+// conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
+bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW);
+int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int K, int R,
+                     int pad, int border, int act, float slope, hipStream_t st);
+int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int R, int pad,
+                       int border, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 }
 
 static int g_cfg128 = 0;   // tuning switch (nemar_tune): 0 = 8-wave 128x128 workgroup, 1 = 4-wave
+static int g_narrow = 1;   // tuning switch (key 3): route <=4-channel layers to the VALU kernels
 static int g_dbg = 0;
 static long long* g_tl = nullptr;
 static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgroup (limits workgroups per CU)
@@ -369,6 +377,7 @@ struct WgradParams {
     float* gb;         // optional [K]: += sum_pixels gy (bias gradient), folded into the A-tile loads of column-tile 0
     int N, P, sy, sx, R, S, pad, border;
     int pix_per_split;
+    int dbg;   // ablation (nemar_tune key 2): 1 = skip staging loads, 2 = skip MFMAs, 8 = skip the atomic epilogue
     FastDiv fd_ohw, fd_ow;
 };
 
@@ -476,7 +485,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) load_stage(pbeg + (ks + 1) * WBK);
+        if (ks + 1 < nk && !(p.dbg & 1)) load_stage(pbeg + (ks + 1) * WBK);
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int k2 = 0; k2 < WBK / 2; ++k2) {
             const int kr = 2 * k2 + lhi;
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         if (ks + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
     }
-    if (nk <= 0) return;
+    if (nk <= 0 || (p.dbg & 8)) return;
     if (do_bias) {
         // this thread summed gy over its pixel rows for channels cgrp + 8i; fold the 32 pixel lanes of each half-wave
 #pragma unroll
@@ -614,6 +624,11 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         return NEMAR_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (nemar_narrow_eligible(K, C1, R, S, stride, N, OH, OW) && g_narrow) {
+        nemar_narrow_fwd(x0, w, bias, y, N, C, H, W, K, R, pad, pad_mode, act, slope, st);
+        NEMAR_CHECK_LAUNCH("conv2d_fwd (narrow)");
+        return NEMAR_OK;
+    }
     IgemmParams p;
     fwd_taps(p.taps, R, S, pad);
     launch_pack(w, (float*)workspace, K, C, C * R * S, R * S, p.taps, st);
@@ -729,12 +744,23 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     NEMAR_REQUIRE((long long)N * OH * OW < (1ll << 31) && (long long)(C0 + C1) * H * W < (1ll << 31),
                   "conv2d_bwd_weight: problem too large for 32-bit tile indexing");
     hipStream_t st = (hipStream_t)stream;
+    if (nemar_narrow_eligible(K, C1, R, S, stride, N, OH, OW) && g_narrow) {
+        nemar_narrow_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad, pad_mode, st);
+        if (gb) {
+            const int chunk = 4096;
+            hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, nemar_cdiv(OH * OW, chunk)), dim3(256), 0, st, gy, gb, N, K,
+                               OH * OW, chunk);
+        }
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
+        return NEMAR_OK;
+    }
     WgradParams p;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
     p.gw = gw; p.gb = gb; p.J = (C0 + C1) * R * S;
     p.N = N; p.P = N * OH * OW; p.sy = stride; p.sx = stride; p.R = R; p.S = S; p.pad = pad; p.border = pad_mode;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW);
+    p.dbg = g_dbg;
     const bool wide = K > 32;
     const int BM = wide ? 128 : 32, BN = wide ? 128 : 256;
     const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(p.J, BN);
@@ -762,6 +788,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 0) { g_cfg128 = value; return NEMAR_OK; }
     if (key == 1) { g_lds_pad = value; return NEMAR_OK; }
     if (key == 2) { g_dbg = value; return NEMAR_OK; }
+    if (key == 3) { g_narrow = value; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
 }

@@ -1,0 +1,219 @@
+// K1 for "narrow" layers: convolutions with at most 4 output channels — the translation net's 7x7
+// RGB head (reference models/networks.py:376), the STN's 2-channel offset head (models/stn/unet_stn.py:75-77) and the
+// discriminator's 1-channel logit conv (models/networks.py:597) — forward and weight gradient.
+//
+// On the matrix cores these layers waste 29..31 of 32 MFMA rows, so they run on the vector ALUs instead: one output
+// pixel per lane, <= 4 accumulators, the source staged through LDS as a halo tile (16 channels x (8+R-1) x (32+R-1)),
+// so every source texel is fetched from memory once per workgroup and re-read R*R times from LDS (128 B/clk), not R*R
+// times through the texture path.  Weights are wave-uniform (scalar loads).  Border handling (zero / reflect) happens
+// once, while the tile is filled.  fp32 fmaf-free multiply-add in (channel, r, s) order.
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 32, TH = 8, CH = 16;
+constexpr int BORDER_REFLECT = 1;
+constexpr int ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+struct NarrowParams {
+    const float* x; const float* w; const float* bias; float* y;
+    const float* gy; float* gw;
+    int N, C, H, W, OH, OW, pad, border, act;
+    float slope;
+    int tiles_x, tiles_y, tiles_total;
+};
+
+// fill the LDS halo tile of channels [c0, c0+CH) for the output tile whose origin is (oy0, ox0)
+template <int R>
+__device__ __forceinline__ void fill_tile(float* tile, const NarrowParams& p, const float* xn, int c0, int oy0, int ox0) {
+    constexpr int LH = TH + R - 1, LW = TW + R - 1;
+    const int HW = p.H * p.W;
+    for (int idx = threadIdx.x; idx < CH * LH * LW; idx += 256) {
+        const int ch = idx / (LH * LW);
+        const int rem = idx - ch * (LH * LW);
+        const int ly = rem / LW, lx = rem - ly * LW;
+        int iy = oy0 - p.pad + ly, ix = ox0 - p.pad + lx;
+        float v = 0.f;
+        if (c0 + ch < p.C) {
+            if (p.border == BORDER_REFLECT) {
+                // tile tails may reach beyond the mirrored range: clamp after reflecting (those lanes are never stored)
+                iy = min(max(reflect_idx(iy, p.H), 0), p.H - 1);
+                ix = min(max(reflect_idx(ix, p.W), 0), p.W - 1);
+                v = xn[(size_t)(c0 + ch) * HW + iy * p.W + ix];
+            } else if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                v = xn[(size_t)(c0 + ch) * HW + iy * p.W + ix];
+            }
+        }
+        tile[idx] = v;
+    }
+}
+
+template <int M, int R>
+__global__ __launch_bounds__(256) void narrow_fwd_kernel(NarrowParams p) {
+    constexpr int LH = TH + R - 1, LW = TW + R - 1;
+    __shared__ float tile[CH * LH * LW];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const float* xn = p.x + (size_t)n * p.C * p.H * p.W;
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = p.bias ? p.bias[m] : 0.f;
+    const int CRS = p.C * R * R;
+    for (int c0 = 0; c0 < p.C; c0 += CH) {
+        __syncthreads();
+        fill_tile<R>(tile, p, xn, c0, oy0, ox0);
+        __syncthreads();
+        const int nch = min(CH, p.C - c0);
+        for (int ch = 0; ch < nch; ++ch) {
+            const float* t0 = tile + ch * (LH * LW) + ty * LW + tx;
+            const float* wc = p.w + (size_t)(c0 + ch) * R * R;     // wave-uniform => scalar loads
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const float v = t0[r * LW + s];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) acc[m] += wc[(size_t)m * CRS + r * R + s] * v;
+                }
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < p.OH && ox < p.OW) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            p.y[(((size_t)n * M + m) * p.OH + oy) * p.OW + ox] = act_apply(acc[m], p.act, p.slope);
+    }
+}
+
+// gw[k][c][r][s] += sum_pixels gy[k][p] * x[c][p + (r,s) - pad].  blockIdx.y = channel chunk; blockIdx.x strides over
+// output tiles, accumulating in registers; each thread owns up to PAIRS (channel, tap) columns x K rows.
+template <int K, int R>
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowParams p) {
+    constexpr int LH = TH + R - 1, LW = TW + R - 1;
+    constexpr int NPAIR = CH * R * R;
+    constexpr int PAIRS = (NPAIR + 255) / 256;
+    __shared__ float tile[CH * LH * LW];
+    __shared__ float gyt[K * TH * TW];
+    const int c0 = blockIdx.y * CH;
+    float acc[PAIRS][K];
+    int toff[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int pr = threadIdx.x + q * 256;
+        const int ch = pr / (R * R), t = pr - ch * (R * R);
+        const int r = t / R, s = t - r * R;
+        toff[q] = (pr < NPAIR) ? ch * (LH * LW) + r * LW + s : -1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[q][k] = 0.f;
+    }
+    for (int tl = blockIdx.x; tl < p.tiles_total; tl += gridDim.x) {
+        const int n = tl / (p.tiles_x * p.tiles_y);
+        const int rem = tl - n * (p.tiles_x * p.tiles_y);
+        const int tyi = rem / p.tiles_x, txi = rem - tyi * p.tiles_x;
+        const int oy0 = tyi * TH, ox0 = txi * TW;
+        __syncthreads();
+        fill_tile<R>(tile, p, p.x + (size_t)n * p.C * p.H * p.W, c0, oy0, ox0);
+        for (int idx = threadIdx.x; idx < K * TH * TW; idx += 256) {
+            const int k = idx / (TH * TW), r2 = idx - k * (TH * TW);
+            const int oy = oy0 + r2 / TW, ox = ox0 + (r2 - (r2 / TW) * TW);
+            gyt[idx] = (oy < p.OH && ox < p.OW) ? p.gy[(((size_t)n * K + k) * p.OH + oy) * p.OW + ox] : 0.f;
+        }
+        __syncthreads();
+        for (int py = 0; py < TH; ++py)
+#pragma unroll 4
+            for (int px = 0; px < TW; ++px) {
+                float g[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) g[k] = gyt[k * (TH * TW) + py * TW + px];   // broadcast reads
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q) {
+                    if (toff[q] >= 0) {
+                        const float v = tile[toff[q] + py * LW + px];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[q][k] += g[k] * v;
+                    }
+                }
+            }
+    }
+    const int CRS = p.C * R * R;
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int pr = threadIdx.x + q * 256;
+        const int ch = pr / (R * R), t = pr - ch * (R * R);
+        if (pr < NPAIR && c0 + ch < p.C) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) atomicAdd(p.gw + (size_t)k * CRS + (size_t)(c0 + ch) * R * R + t, acc[q][k]);
+        }
+    }
+}
+
+template <int R>
+void launch_fwd_r(const NarrowParams& p, int M, dim3 grid, hipStream_t st) {
+    switch (M) {
+        case 1: hipLaunchKernelGGL((narrow_fwd_kernel<1, R>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((narrow_fwd_kernel<2, R>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((narrow_fwd_kernel<3, R>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((narrow_fwd_kernel<4, R>), grid, dim3(256), 0, st, p); break;
+    }
+}
+template <int R>
+void launch_wgrad_r(const NarrowParams& p, int K, dim3 grid, hipStream_t st) {
+    switch (K) {
+        case 1: hipLaunchKernelGGL((narrow_wgrad_kernel<1, R>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((narrow_wgrad_kernel<2, R>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((narrow_wgrad_kernel<3, R>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((narrow_wgrad_kernel<4, R>), grid, dim3(256), 0, st, p); break;
+    }
+}
+
+}  // namespace
+
+// Eligibility shared with conv.hip's entry points (declared there as extern).
+bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW) {
+    return K >= 1 && K <= 4 && C1 == 0 && R == S && (R == 3 || R == 4 || R == 7) && stride == 1 && N <= 65535 &&
+           nemar_cdiv(OH, TH) <= 65535;
+}
+
+int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int K, int R,
+                     int pad, int border, int act, float slope, hipStream_t st) {
+    NarrowParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.gy = nullptr; p.gw = nullptr;
+    p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
+    p.pad = pad; p.border = border; p.act = act; p.slope = slope;
+    p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
+    dim3 grid(p.tiles_x, p.tiles_y, N);
+    if (R == 3) launch_fwd_r<3>(p, K, grid, st);
+    else if (R == 4) launch_fwd_r<4>(p, K, grid, st);
+    else launch_fwd_r<7>(p, K, grid, st);
+    return 0;
+}
+
+int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int R, int pad,
+                       int border, hipStream_t st) {
+    NarrowParams p;
+    p.x = x; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.gy = gy; p.gw = gw;
+    p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
+    p.pad = pad; p.border = border; p.act = 0; p.slope = 0.f;
+    p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
+    const int chunks = nemar_cdiv(C, CH);
+    int gx = nemar_cdiv(1024, chunks);           // ~4 workgroups per CU in total
+    if (gx > p.tiles_total) gx = p.tiles_total;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, chunks);
+    if (R == 3) launch_wgrad_r<3>(p, K, grid, st);
+    else if (R == 4) launch_wgrad_r<4>(p, K, grid, st);
+    else launch_wgrad_r<7>(p, K, grid, st);
+    return 0;
+}

@@ -51,6 +51,9 @@ CONV_CASES = [
     (5, 0, 33, 4, 1, 1, K.PAD_ZERO),       # D k4 s1 (output shrinks by 1)
     (20, 0, 2, 3, 1, 1, K.PAD_ZERO),       # STN output conv (K=2)
     (16, 0, 130, 1, 1, 0, K.PAD_ZERO),     # 1x1
+    (18, 0, 3, 7, 1, 3, K.PAD_REFLECT),    # T head: narrow (VALU + LDS halo) path, 2 channel chunks
+    (24, 0, 1, 4, 1, 1, K.PAD_ZERO),       # D logit conv: narrow path, k4
+    (5, 0, 4, 3, 1, 1, K.PAD_REFLECT),     # narrow path, M=4, reflect k3
 ]
 
 
