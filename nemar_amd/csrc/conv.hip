@@ -305,7 +305,146 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     }
 }
 
-static int g_cfg128 = 0;   // tuning switch (nemar_tune): 0 = 8-wave 128x128 workgroup, 1 = 4-wave
+// ---- wave-specialised 128x128 tile (FAST shapes): 8 MFMA waves + 2 loader waves ---------------------------------------
+// Measured on the 4-/8-wave kernels above (tools/timeline_conv.py, ablation switches): the MFMA phase of a stage and the
+// global->LDS staging of the next one do not overlap — every wave first spends ~1-3k cycles getting its
+// global_load_lds accepted by the memory pipeline and only then starts its MFMAs, and all waves of a workgroup do so
+// together after each barrier.  Here the MFMA waves issue no vector-memory instructions at all: two extra waves own
+// the staging (each: one 64-pixel segment of every B row + half of the A rows), run TWO stages ahead through a 3-deep
+// LDS ring, and keep one stage in flight across the barrier with a counted s_waitcnt vmcnt(N).
+constexpr int WS_NC = 8, WS_NL = 2, WS_NT = (WS_NC + WS_NL) * 64, WS_NBUF = 3;
+__global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
+    constexpr int BM = 128, BN = 128, LDA = BM, LDB = BN + 4, TM = 2, WN = 4;
+    constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    constexpr int A_PER_LOADER = BK * BM / 256 / WS_NL;      // 1 KiB wave-instructions of A per loader per stage (4)
+    constexpr int LOADS_PER_STAGE = A_PER_LOADER + BK;       // + one 64-pixel segment of each of the BK rows (16)
+    __shared__ __attribute__((aligned(16))) float smem[WS_NBUF * (A_FLOATS + B_FLOATS)];
+    float* const As0 = smem;
+    float* const Bs0 = smem + WS_NBUF * A_FLOATS;
+
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * BM, p0 = blockIdx.x * BN;
+    const int Cs = p.C0 + p.C1, HW = p.Hs * p.Ws;
+    const int nk = (p.Kred + BK - 1) / BK;
+
+    if (wid >= WS_NC) {
+        // ================================ loader waves ================================
+        const int seg = wid - WS_NC;                       // 64-pixel segment of the B tile owned by this wave
+        const int pix = p0 + seg * 64 + lane;
+        const bool pvalid = pix < p.P;
+        const unsigned upix = pvalid ? (unsigned)pix : 0u;
+        const unsigned n = fd_div(upix, p.fd_ohw);
+        const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
+        const unsigned oy = fd_div(rem, p.fd_ow);
+        const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
+        const float* s1n = p.C1 ? p.src1 + (size_t)n * p.C1 * HW : p.src0;
+        const float* wsrc[A_PER_LOADER];
+        int a_lds[A_PER_LOADER];
+#pragma unroll
+        for (int q = 0; q < A_PER_LOADER; ++q) {
+            const int inst = seg * A_PER_LOADER + q;
+            const int e = inst * 256 + lane * 4;
+            const int row = e / BM, col = e - row * BM;
+            wsrc[q] = p.wp + (size_t)row * p.Mpad + m0 + col;
+            a_lds[q] = inst * 256;
+        }
+        auto issue = [&](int ks) {
+            const int k0 = ks * BK, buf = ks % WS_NBUF;
+#pragma unroll
+            for (int q = 0; q < A_PER_LOADER; ++q) glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + buf * A_FLOATS + a_lds[q]);
+            const unsigned t = fd_div((unsigned)k0, p.fd_cs);
+            const int ch0 = k0 - (int)t * Cs;
+            int y = by + p.taps.dy[t], x = bx + p.taps.dx[t];
+            bool inb = pvalid;
+            if (p.border == BORDER_REFLECT) {
+                y = reflect(y, p.Hs);
+                x = reflect(x, p.Ws);
+            } else {
+                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+            }
+            const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;
+            base += inb ? y * p.Ws + x : 0;
+#pragma unroll
+            for (int r = 0; r < BK; ++r)
+                glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + seg * 64);
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        // stage 0 must have landed before the first barrier; stage 1 may stay in flight
+        if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS_PER_STAGE & 15) | ((LOADS_PER_STAGE >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        for (int ks = 0; ks < nk; ++ks) {
+            // buffer (ks+2)%3 == (ks-1)%3 was released by the barrier that ended stage ks-1
+            if (ks + 2 < nk) {
+                issue(ks + 2);
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS_PER_STAGE & 15) | ((LOADS_PER_STAGE >> 4) << 14));  // ks+1 landed
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ================================ MFMA waves ================================
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    __builtin_amdgcn_s_barrier();      // stage 0 is in LDS
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks % WS_NBUF;
+        float a[BK / 2][TM], b[BK / 2];
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            const int kr = 2 * k2 + lhi;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[k2][i] = As0[buf * A_FLOATS + kr * LDA + (wm * TM + i) * 32 + l31];
+            b[k2] = Bs0[buf * B_FLOATS + kr * LDB + wn * 32 + l31];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2][i], b[k2], acc[i], 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): all LDS reads of this buffer returned before releasing it
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const size_t oplane = (size_t)p.OHf * p.OWf;
+    const int M1 = p.M - p.M0;
+    const int opix = p0 + wn * 32 + l31;
+    if (opix >= p.P) return;
+    const unsigned n = fd_div((unsigned)opix, p.fd_ohw);
+    const unsigned rem = (unsigned)opix - n * (unsigned)(p.OH * p.OW);
+    const unsigned oy = fd_div(rem, p.fd_ow);
+    const unsigned ox = rem - oy * (unsigned)p.OW;
+    const size_t sp = (size_t)((int)oy * p.osy + p.ooy) * p.OWf + ((int)ox * p.osx + p.oox);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < p.M) {
+                float v = acc[i][r];
+                if (p.bias) v += p.bias[m];
+                v = apply_act(v, p.act, p.slope);
+                if (m < p.M0) {
+                    if (p.dst0) p.dst0[((size_t)n * p.M0 + m) * oplane + sp] = v;
+                } else {
+                    p.dst1[((size_t)n * M1 + (m - p.M0)) * oplane + sp] = v;
+                }
+            }
+        }
+    }
+}
+
+static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = wave-specialised 128x128, 1 = 4-wave, 2 = 8-wave
 static int g_narrow = 1;   // tuning switch (key 3): route <=4-channel layers to the VALU kernels
 static int g_dbg = 0;
 static long long* g_tl = nullptr;
@@ -345,7 +484,9 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
     const TileChoice t = igemm_tile(p.M, p.P);
-    if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st);      // 128 x 128, 4 waves of 64x64
+    if (t.bm == 128 && fast && g_cfg128 == 0)                                          // 128 x 128, 8 MFMA + 2 loader waves
+        hipLaunchKernelGGL(igemm_ws_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(WS_NT), g_lds_pad, st, p);
+    else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
     else if (t.bm == 128) launch_igemm_cfg<2, 4, 2, 1>(p, fast, st);                  // 128 x 128, 8 waves of 64x32
     else if (t.bm == 64 && t.bn == 128) launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);    // 64 x 128
     else if (t.bm == 64) launch_igemm_cfg<2, 2, 1, 1>(p, fast, st);                   // 64 x 64
