@@ -7,6 +7,11 @@ the host-emulated build of the same kernel sources (tests/emu) — the product n
 import ctypes as C
 import os
 
+# torch must be imported BEFORE the library is dlopen'ed: PyTorch-ROCm bundles its own libamdhip64, and whichever
+# copy is mapped first serves the whole process.  Loading ours first would bring in the system runtime instead of the
+# one torch was built against ("no ROCm-capable device is detected" on the first launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "lib", "libnemar_hip.so")
 

@@ -19,10 +19,10 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, int iters)
 int main() {
     float *in, *out; float h[512];
     hipMalloc(&in, 2048); hipMalloc(&out, 4096 * 256 * 4);
-    for (int mode = 0; mode < 2; ++mode) {
-        for (int i = 0; i < 512; ++i) h[i] = mode ? (rand() / (float)RAND_MAX - 0.5f) * 1e-3f : 0.f;
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int i = 0; i < 512; ++i) h[i] = mode == 0 ? 0.f : mode == 1 ? (rand() / (float)RAND_MAX - 0.5f) * 1e-3f : (rand() / (float)RAND_MAX - 0.5f) * 4.f * (1.0f + (rand() % 7));
         hipMemcpy(in, h, 2048, hipMemcpyHostToDevice);
-        for (int blocks = 256; blocks <= 2048; blocks *= 2) {
+        for (int blocks = 512; blocks <= 1024; blocks *= 2) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             int iters = 20000;
             hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, in, out, 1000);
@@ -31,7 +31,7 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double fl = (double)blocks * 4 * iters * 4 * 32 * 32 * 2 * 2;
-            printf("%s operands, %d blocks (%d waves/SIMD): %.1f TFLOP/s  (%.3f ms)\n", mode ? "random" : "zero", blocks, blocks / 256, fl / ms / 1e9, ms);
+            printf("%s operands, %d blocks (%d waves/SIMD): %.1f TFLOP/s  (%.3f ms)\n", mode == 0 ? "zero" : mode == 1 ? "random 1e-3" : "random O(1) wide", blocks, blocks / 256, fl / ms / 1e9, ms);
         }
     }
     return 0;
