@@ -75,7 +75,9 @@ int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, 
  * w [K,C0+C1,R,S] (torch layout), bias [K] or NULL.  pad_mode: NEMAR_PAD_ZERO | NEMAR_PAD_REFLECT
  * (reflect == nn.ReflectionPad2d(pad) followed by an unpadded conv).  act is applied in the epilogue:
  * NEMAR_ACT_NONE | RELU | LRELU(slope) | TANH.  y [N,K,OH,OW], OH = (H + 2 pad - R) / stride + 1.
- * workspace: packed weights (nemar_conv2d_fwd_workspace bytes). */
+ * workspace: packed weights (nemar_conv2d_fwd_workspace bytes).  prepacked != 0: the workspace already holds this
+ * weight tensor's packed image from an earlier call with the same (w values, shape, stride, pad): the pack launch is
+ * skipped (the caller caches one workspace per weight tensor and invalidates it when the optimizer steps). */
 #define NEMAR_PAD_ZERO 0
 #define NEMAR_PAD_REFLECT 1
 #define NEMAR_ACT_NONE 0
@@ -85,7 +87,7 @@ int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, 
 size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S);
 int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
                      float* y, int N, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode,
-                     int act, float slope, void* workspace, size_t ws_bytes, void* stream);
+                     int act, float slope, void* workspace, size_t ws_bytes, int prepacked, void* stream);
 /* Data gradient: gy [N,K,OH,OW] -> gx0 [N,C0,H,W] | gx1 [N,C1,H,W] (gx0 NULL: its channels are skipped, e.g. the
  * real_A half of the discriminator input).  With bias/act it is ALSO the forward of
  * nn.ConvTranspose2d(K -> C, k, stride, pad, output_padding) whose weight is w [K,C,R,S]
@@ -95,7 +97,7 @@ size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int K, int R,
 int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, int act, float slope,
                           float* gx0, int C0, float* gx1, int C1, int N, int H, int W, int K, int OH, int OW,
                           int R, int S, int stride, int pad, int pad_mode, void* workspace, size_t ws_bytes,
-                          void* stream);
+                          int prepacked, void* stream);
 /* Weight gradient, ACCUMULATED into gw [K,C0+C1,R,S] and, when gb != NULL, the bias gradient ACCUMULATED into
  * gb [K] in the same pass (the caller zero-fills once per optimizer step; the translation net receives two passes
  * per step).  Pixel reduction is split across workgroups, fp32 atomics. */

@@ -478,13 +478,14 @@ TileChoice igemm_tile(int M, int P) {
     }
     return t;
 }
-int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 128) * 128 : 32; }
+int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 256) * 256 : 32; }
 
 void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
     const TileChoice t = igemm_tile(p.M, p.P);
-    if (t.bm == 128 && fast && g_cfg128 == 0)                                          // 128 x 128, 8 MFMA + 2 loader waves
+    if (t.bm == 128 && g_cfg128 == 3 && p.M >= 256) launch_igemm_cfg<4, 2, 2, 2>(p, fast, st);   // 256 x 128, 8 waves of 64x64
+    else if (t.bm == 128 && fast && g_cfg128 == 0)                                     // 128 x 128, 8 MFMA + 2 loader waves
         hipLaunchKernelGGL(igemm_ws_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(WS_NT), g_lds_pad, st, p);
     else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
     else if (t.bm == 128) launch_igemm_cfg<2, 4, 2, 1>(p, fast, st);                  // 128 x 128, 8 waves of 64x32
@@ -745,7 +746,7 @@ NEMAR_API size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S) {
 
 NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
                                float* y, int N, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode,
-                               int act, float slope, void* workspace, size_t ws_bytes, void* stream) {
+                               int act, float slope, void* workspace, size_t ws_bytes, int prepacked, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x0 && w && y && workspace, "conv2d_fwd: null pointer");
     NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_fwd: bad channel split %d+%d", C0, C1);
@@ -772,7 +773,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     }
     IgemmParams p;
     fwd_taps(p.taps, R, S, pad);
-    launch_pack(w, (float*)workspace, K, C, C * R * S, R * S, p.taps, st);
+    if (!prepacked) launch_pack(w, (float*)workspace, K, C, C * R * S, R * S, p.taps, st);
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
     p.zero = p.wp + packed_core_floats(K, C * R * S);
@@ -801,7 +802,7 @@ NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int
 NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, int act, float slope,
                                     float* gx0, int C0, float* gx1, int C1, int N, int H, int W, int K, int OH, int OW,
                                     int R, int S, int stride, int pad, int pad_mode, void* workspace, size_t ws_bytes,
-                                    void* stream) {
+                                    int prepacked, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(gy && w && workspace && (gx0 || gx1), "conv2d_bwd_data: null pointer");
     NEMAR_REQUIRE(C0 >= 0 && C1 >= 0 && C0 + C1 > 0 && (C1 == 0 || gx1), "conv2d_bwd_data: bad channel split");
@@ -860,7 +861,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 p.taps.n = 1; p.taps.dy[0] = -32000; p.taps.dx[0] = -32000; p.taps.wofs[0] = 0; p.Kred = K;
             }
             // A[(t*K + k)][c] = w[k][c + mskip][r][s]
-            launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
+            if (!prepacked) launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
             launch_igemm(p, st);
         }
     if (refl) {

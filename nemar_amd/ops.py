@@ -72,6 +72,32 @@ def _workspace(nbytes, device):
     return buf
 
 
+# ---- packed-weight cache ---------------------------------------------------------------------------------------------
+# The MFMA kernels read weights in a packed [reduction][channel] layout.  Packing is a tiny kernel, but a step applies
+# every weight tensor several times (T: 2 forward + 2 backward passes, D: 5), so each (weight, direction) keeps its own
+# packed workspace until the values change: FlatAdam.step() / load_state_dict bump the epoch, in-place torch ops bump
+# tensor._version.
+_param_epoch = [0]
+_pack_cache = {}
+
+
+def invalidate_packed_weights():
+    _param_epoch[0] += 1
+
+
+def _packed(weight, kind, nbytes):
+    """-> (workspace tensor, prepacked flag) for `weight` used in direction `kind`."""
+    key = (weight.data_ptr(), kind)
+    token = (_param_epoch[0], weight._version, tuple(weight.shape))
+    ent = _pack_cache.get(key)
+    if ent is not None and ent[1] == token and ent[0].numel() * 4 >= nbytes:
+        return ent[0], 1
+    buf = ent[0] if (ent is not None and ent[0].numel() * 4 >= nbytes) else \
+        torch.empty(int(nbytes) // 4 + 64, dtype=torch.float32, device=weight.device)
+    _pack_cache[key] = (buf, token)
+    return buf, 0
+
+
 def _grad_buffer(param):
     """param.grad as an accumulation target (allocated zero-filled on first use)."""
     if param.grad is None:
@@ -95,11 +121,11 @@ class _Conv2d(Function):
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_fwd_workspace(K, C, R, S)
-        ws = _workspace(wsb, x.device)
+        ws, hit = _packed(weight, ('fwd', stride, pad), wsb)
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
             L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
-                         slope, _p(ws), wsb, _stream())
+                         slope, _p(ws), wsb, hit, _stream())
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
         ctx.cfg = (stride, pad, pad_mode, act, slope)
@@ -131,11 +157,12 @@ class _Conv2d(Function):
                 # kernel splits channels [0,C0) | [C0,C); a missing second half still needs a destination
                 gx2 = torch.empty_like(x2)
             wsb = L.conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode)
-            ws = _workspace(wsb, x.device)
             if pad_mode == PAD_REFLECT and pad > 0 and x2 is not None:
                 raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
+            # the packed image depends on which source halves are differentiated (channel skip) and on the geometry
+            ws, hit = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, N, H, W), wsb)
             L.conv2d_bwd_data(_p(g), _p(w), None, ACT_NONE, 0.0, _p(gx), C0, _p(gx2), C1, N, H, W, K, OH, OW, R, S,
-                              stride, pad, pad_mode, _p(ws), wsb, st)
+                              stride, pad, pad_mode, _p(ws), wsb, hit, st)
             if not need_x2:
                 gx2 = None
         want_b = need_b and ctx.bias is not None
@@ -168,9 +195,9 @@ class _ConvTranspose2d(Function):
         Wo = (W - 1) * stride - 2 * pad + S + out_pad
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO)
-        ws = _workspace(wsb, x.device)
+        ws, hit = _packed(weight, ('convT_fwd', stride, pad, N, Ho, Wo), wsb)
         L.conv2d_bwd_data(_p(x), _p(w), _p(b), act, slope, _p(y), Co, None, 0, N, Ho, Wo, Ci, H, W, R, S, stride, pad,
-                          PAD_ZERO, _p(ws), wsb, _stream())
+                          PAD_ZERO, _p(ws), wsb, hit, _stream())
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
         ctx.cfg = (stride, pad, act, slope)
@@ -195,9 +222,9 @@ class _ConvTranspose2d(Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             wsb = L.conv2d_fwd_workspace(Ci, Co, R, S)
-            ws = _workspace(wsb, x.device)
+            ws, hit = _packed(ctx.weight, ('convT_bwd', stride, pad), wsb)
             L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
-                         0.0, _p(ws), wsb, st)
+                         0.0, _p(ws), wsb, hit, st)
         if ctx.needs_input_grad[1]:
             L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
                                 S, stride, pad, PAD_ZERO, st)
@@ -531,6 +558,7 @@ class FlatAdam:
         self.flat_g.zero_()
 
     def step(self):
+        invalidate_packed_weights()
         self.step_count += 1
         g = self.param_groups[0]
         L.adam_step(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, float(g["lr"]),
@@ -540,6 +568,7 @@ class FlatAdam:
         return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone()}
 
     def load_state_dict(self, sd):
+        invalidate_packed_weights()
         self.step_count = int(sd["step"])
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])

@@ -123,7 +123,7 @@ def case_conv_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NO
     d_y = be.full((N, K, OH, OW), np.nan)
     ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(K, C, R, R))
     be.lib.conv2d_fwd(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_w), be.ptr(d_b), be.ptr(d_y), N, H, W, K, R, R,
-                      stride, pad, pad_mode, act, 0.2, be.ptr(ws), wsb, be.stream)
+                      stride, pad, pad_mode, act, 0.2, be.ptr(ws), wsb, 0, be.stream)
     _assert_close(be.np(d_y), want, atol=2e-5, rtol=2e-5, what="conv2d_fwd")
 
 
@@ -140,7 +140,7 @@ def case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=F
     d_g1 = be.full((N, C1, H, W), np.nan) if C1 else None
     ws, wsb = _ws(be, be.lib.conv2d_bwd_data_workspace(N, C, H, W, K, R, R, stride, pad, pad_mode))
     be.lib.conv2d_bwd_data(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_g0), C0, be.ptr(d_g1), C1, N, H, W, K, OH,
-                           OW, R, R, stride, pad, pad_mode, be.ptr(ws), wsb, be.stream)
+                           OW, R, R, stride, pad, pad_mode, be.ptr(ws), wsb, 0, be.stream)
     if d_g0 is not None:
         _assert_close(be.np(d_g0), want[:, :C0], atol=2e-5, rtol=2e-5, what="conv2d_bwd_data gx0")
     if d_g1 is not None:
@@ -160,7 +160,7 @@ def case_conv_transpose_fwd(be, N, Ci, Co, H, W, R, out_pad, act=O.ACT_RELU, see
     d_y = be.full((N, Co, Ho, Wo), np.nan)
     ws, wsb = _ws(be, be.lib.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, R, 2, 1, PAD_ZERO))
     be.lib.conv2d_bwd_data(be.ptr(d_x), be.ptr(d_w), be.ptr(d_b), act, 0.2, be.ptr(d_y), Co, None, 0, N, Ho, Wo, Ci, H,
-                           W, R, R, 2, 1, PAD_ZERO, be.ptr(ws), wsb, be.stream)
+                           W, R, R, 2, 1, PAD_ZERO, be.ptr(ws), wsb, 0, be.stream)
     _assert_close(be.np(d_y), want, atol=2e-5, rtol=2e-5, what="conv_transpose2d_fwd")
 
 
@@ -291,7 +291,7 @@ def case_losses(be, seed=0):
             b64 = bb.astype(np.float64) if bb is not None else np.zeros(n)
             loss = be.full((1,), 2.0)
             d_a, d_b = be.dev(a), (be.dev(bb) if bb is not None else None)
-            be.lib.l1_loss_fwd(be.ptr(d_a), be.ptr(d_b), n, 100.0, be.ptr(loss), 1, be.ptr(ws), wsb, be.stream)
+            be.lib.l1_loss_fwd(be.ptr(d_a), be.ptr(d_b), n, 100.0, be.ptr(loss), 1, be.ptr(ws), wsb, 0, be.stream)
             _assert_close(be.np(loss), [2.0 + 100.0 * O.l1_loss_fwd(a.astype(np.float64), b64)], atol=1e-5, rtol=1e-5,
                           what="l1_loss_fwd")
             ga = be.full((n,), np.nan)
@@ -302,7 +302,7 @@ def case_losses(be, seed=0):
         for mode, name in ((0, 'vanilla'), (1, 'lsgan'), (2, 'wgangp')):
             for real in (1, 0):
                 loss = be.full((1,), np.nan)
-                be.lib.gan_loss_fwd(be.ptr(d_x), n, mode, real, 0.5, be.ptr(loss), 0, be.ptr(ws), wsb, be.stream)
+                be.lib.gan_loss_fwd(be.ptr(d_x), n, mode, real, 0.5, be.ptr(loss), 0, be.ptr(ws), wsb, 0, be.stream)
                 _assert_close(be.np(loss), [0.5 * O.gan_loss_fwd(x.astype(np.float64), bool(real), name)], atol=1e-6,
                               rtol=1e-5, what="gan_loss_fwd " + name)
                 gx = be.full((n,), np.nan)

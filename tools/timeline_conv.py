@@ -15,7 +15,7 @@ wsb = lib.conv2d_fwd_workspace(K, C, 3, 3); ws = torch.empty(wsb // 4 + 16, devi
 tl = torch.zeros(8 * 64 * 8, dtype=torch.int64, device=dev)
 for it in range(3):
     lib.tune_ptr(P(tl) if it == 2 else None)
-    lib.conv2d_fwd(P(x), C, None, 0, P(w), P(b), P(y), N, H, H, K, 3, 3, 1, 1, 1, 1, 0.2, P(ws), wsb, st())
+    lib.conv2d_fwd(P(x), C, None, 0, P(w), P(b), P(y), N, H, H, K, 3, 3, 1, 1, 1, 1, 0.2, P(ws), wsb, 0, st())
 torch.cuda.synchronize()
 lib.tune_ptr(None)
 t = tl.cpu()[:8 * 20].view(8, 4, 5)
