@@ -11,6 +11,7 @@ Conventions
   * loss Functions return 0-dim tensors already multiplied by their lambda.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -87,14 +88,16 @@ def invalidate_packed_weights():
 
 def _packed(weight, kind, nbytes):
     """-> (workspace tensor, prepacked flag) for `weight` used in direction `kind`."""
-    key = (weight.data_ptr(), kind)
-    token = (_param_epoch[0], weight._version, tuple(weight.shape))
+    key = (id(weight), kind)
+    token = (_param_epoch[0], weight._version, weight.data_ptr(), tuple(weight.shape))
     ent = _pack_cache.get(key)
-    if ent is not None and ent[1] == token and ent[0].numel() * 4 >= nbytes:
+    # id() and device addresses are recycled once a tensor dies: an entry is only valid for the very object it was
+    # made for (weak reference), with unchanged values (epoch, _version) at an unchanged address
+    if ent is not None and ent[2]() is weight and ent[1] == token and ent[0].numel() * 4 >= nbytes:
         return ent[0], 1
-    buf = ent[0] if (ent is not None and ent[0].numel() * 4 >= nbytes) else \
+    buf = ent[0] if (ent is not None and ent[2]() is weight and ent[0].numel() * 4 >= nbytes) else \
         torch.empty(int(nbytes) // 4 + 64, dtype=torch.float32, device=weight.device)
-    _pack_cache[key] = (buf, token)
+    _pack_cache[key] = (buf, token, weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None)))
     return buf, 0
 
 
@@ -546,6 +549,7 @@ class FlatAdam:
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_count = 0
+        invalidate_packed_weights()
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 view = self.flat_p[o:o + p.numel()].view(p.shape)
