@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PMC_FILE = "profiles/r1_pmc_traffic.json"
 
 
 def build_opt(batch, size, extra=()):
@@ -174,13 +175,23 @@ def main():
     }
     C = 256
     hw = (a.size // 4) ** 2
+    # HBM traffic comes from separate rocprofv3 --pmc passes over the same kernels (tools/profile_round.sh); it is
+    # only attached when the bench runs the shape those passes measured.
+    pmc, std = {}, (a.size == 256 and a.batch == 8)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)) as f:
+            pmc = json.load(f)
+    except OSError:
+        pass
     if 'igemm_fwd_resblock' in spans:
         n, sec = spans['igemm_fwd_resblock']
         flop = 2.0 * a.batch * C * hw * C * 9
         out["roofline"] = {"bound": "mfma", "achieved": flop / sec / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": flop / sec / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
-                           "kernel": "igemm_kernel<2,2,2,2,fast> (conv2d_fwd 256->256 k3 reflect @%dx%d, batch %d; "
-                                     "span includes its weight-pack launch)" % (a.size // 4, a.size // 4, a.batch),
+                           "frac": flop / sec / 1e12 / FP32_MFMA_PEAK_TF,
+                           "traffic": pmc.get("igemm_fwd_resblock", {}).get("traffic_bytes") if std else None,
+                           "traffic_source": PMC_FILE if std and pmc else None,
+                           "kernel": "igemm_ws_kernel (conv2d_fwd 256->256 k3 reflect @%dx%d, batch %d)"
+                                     % (a.size // 4, a.size // 4, a.batch),
                            "launches_timed": n, "avg_launch_us": sec * 1e6,
                            "algorithmic_flop_per_launch": flop}
     px = a.batch * a.size * a.size
@@ -194,7 +205,9 @@ def main():
         tot_b = sum(v["bytes_per_px"] * px for v in gs.values())
         tot_t = sum(v["avg_launch_us"] * 1e-6 for v in gs.values())
         out["roofline_grid_sample"] = {"bound": "hbm", "achieved": tot_b / tot_t / 1e9, "peak": HBM_PEAK_GBS,
-                                       "unit": "GB/s", "frac": tot_b / tot_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "unit": "GB/s", "frac": tot_b / tot_t / 1e9 / HBM_PEAK_GBS,
+                                       "traffic": sum(pmc.get(t, {}).get("traffic_bytes", 0) for t in gs)
+                                       if std and pmc else None,
                                        "kernels": gs}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
