@@ -30,9 +30,16 @@ int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y
 int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int R, int pad,
                        int border, hipStream_t st);
 
+// conv_wgrad.hip: wave-specialised weight gradient for wide layers
+bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy);
+void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
+                         int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
+                         int target_blocks, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;        // reduction depth per LDS stage (fwd/dgrad)
 constexpr int MAX_TAPS = 64;  // 7x7 = 49
@@ -57,7 +64,13 @@ struct TapTable {
     int wofs[MAX_TAPS];  // offset of the tap inside one [R][S] filter (pack kernel only)
 };
 
-// ---- weight packing: W[m*wsm + ch*wsc + wofs[t]] -> A[(t*Cs + ch)*Mpad + m], zero padded --------------------
+// ---- weight packing -----------------------------------------------------------------------------------------------
+// W[m*wsm + ch*wsc + wofs[t]] with reduction index k = t*Cs + ch goes to
+//     A[((k/8)*2 + (k&1)) * Mpad*4 + m*4 + ((k%8)>>1)]            (zero padded to KredPad x Mpad)
+// i.e. blocks of 8 reduction rows, split by the MFMA k-slot (k&1), channel-major, with the four MFMA steps of the block
+// adjacent: lane (m, kslot) of v_mfma_f32_32x32x2_f32 fetches its A operand for 4 consecutive steps with ONE
+// ds_read_b128, the rows of a 16-lane read group fall on 16 different bank slots, and a tile stage is still a dense
+// run of 16-byte chunks for global_load_lds.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int M,
                                                            int Mpad, int Cs, int Kred, int KredPad, int wsm, int wsc,
                                                            int zero_tail, TapTable taps) {
@@ -66,7 +79,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     __syncthreads();
     const int core = KredPad * Mpad, total = core + zero_tail;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int kk = idx / Mpad, m = idx - kk * Mpad;
+        const int blk = idx / (Mpad * 4), within = idx - blk * (Mpad * 4);
+        const int m = within >> 2, s = within & 3;
+        const int kk = 8 * (blk >> 1) + 2 * s + (blk & 1);
         float v = 0.f;
         if (idx < core && m < M && kk < Kred) {
             const int t = kk / Cs, ch = kk - t * Cs;
@@ -104,7 +119,7 @@ template <int WM, int WN, int TM, int TN, bool FAST>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDA = BM, LDB = BN + 4;
+    constexpr int LDB = BN + 4;
     constexpr int SEGS = BN / 64;               // 64-pixel segments per B row
     constexpr int RGRP = NW / SEGS;             // waves working on the same segment (each takes every RGRP-th row)
     constexpr int BROWS = BK / RGRP;            // B rows per wave per stage
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 
     // ONE __shared__ object: with several, hipcc guards every ds_read of a stage with s_waitcnt vmcnt(0) while a
     // global_load_lds is in flight (it cannot tell which object the DMA writes), which would serialise the pipeline
-    constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_FLOATS + 2 * B_FLOATS + MAX_TAPS];
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * A_FLOATS;
@@ -154,9 +169,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     int a_lds[A_PER];
 #pragma unroll
     for (int q = 0; q < A_PER; ++q) {
-        const int e = (wid + q * NW) * 256 + lane * 4;      // float index inside the dense [BK][BM] stage
-        const int row = e / BM, col = e - row * BM;
-        wsrc[q] = p.wp + (size_t)row * p.Mpad + m0 + col;
+        const int e = (wid + q * NW) * 256 + lane * 4;      // float index inside the dense [4 blocks][BM][4] stage
+        const int blk = e / (BM * 4), m = (e - blk * (BM * 4)) >> 2;
+        wsrc[q] = p.wp + ((size_t)blk * p.Mpad + m0 + m) * 4;
         a_lds[q] = (wid + q * NW) * 256;                    // wave-uniform LDS base (floats)
     }
     __syncthreads();  // s_tap visible
@@ -241,12 +256,17 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             // all MFMA operands of the stage into registers first (one LDS round trip per stage), then the MFMAs
             // back to back: reading fragments just-in-time makes hipcc reuse the operand registers, and the
             // write-after-read wait on them puts an LDS latency between every pair of MFMAs
-            float a[BK / 2][TM], b[BK / 2][TN];
+            f32x4 a[BK / 8][TM];
+            float b[BK / 2][TN];
+#pragma unroll
+            for (int kg = 0; kg < BK / 8; ++kg)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[kg][i] = *reinterpret_cast<const f32x4*>(
+                        As0 + buf * A_FLOATS + ((kg * 2 + lhi) * BM + (wm * TM + i) * 32 + l31) * 4);
 #pragma unroll
             for (int k2 = 0; k2 < BK / 2; ++k2) {
                 const int kr = 2 * k2 + lhi;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[k2][i] = As0[buf * A_FLOATS + kr * LDA + (wm * TM + i) * 32 + l31];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[k2][j] = Bs0[buf * B_FLOATS + kr * LDB + (wn * TN + j) * 32 + l31];
             }
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2][i], b[k2][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2 >> 2][i][k2 & 3], b[k2][j], acc[i][j], 0, 0, 0);
         }
         IGEMM_STAMP(3)
         wait_vmem();       // the next stage has landed in LDS (it had the whole MFMA phase to do so)
@@ -314,8 +334,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 // LDS ring, and keep one stage in flight across the barrier with a counted s_waitcnt vmcnt(N).
 constexpr int WS_NC = 8, WS_NL = 2, WS_NT = (WS_NC + WS_NL) * 64, WS_NBUF = 3;
 __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
-    constexpr int BM = 128, BN = 128, LDA = BM, LDB = BN + 4, TM = 2, WN = 4;
-    constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    constexpr int BM = 128, BN = 128, LDB = BN + 4, TM = 2, WN = 4;
+    constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
     constexpr int A_PER_LOADER = BK * BM / 256 / WS_NL;      // 1 KiB wave-instructions of A per loader per stage (4)
     constexpr int LOADS_PER_STAGE = A_PER_LOADER + BK;       // + one 64-pixel segment of each of the BK rows (16)
     __shared__ __attribute__((aligned(16))) float smem[WS_NBUF * (A_FLOATS + B_FLOATS)];
@@ -345,8 +365,8 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
         for (int q = 0; q < A_PER_LOADER; ++q) {
             const int inst = seg * A_PER_LOADER + q;
             const int e = inst * 256 + lane * 4;
-            const int row = e / BM, col = e - row * BM;
-            wsrc[q] = p.wp + (size_t)row * p.Mpad + m0 + col;
+            const int blk = e / (BM * 4), m = (e - blk * (BM * 4)) >> 2;
+            wsrc[q] = p.wp + ((size_t)blk * p.Mpad + m0 + m) * 4;
             a_lds[q] = inst * 256;
         }
         auto issue = [&](int ks) {
@@ -399,19 +419,22 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
     __builtin_amdgcn_s_barrier();      // stage 0 is in LDS
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks % WS_NBUF;
-        float a[BK / 2][TM], b[BK / 2];
+        f32x4 a[BK / 8][TM];
+        float b[BK / 2];
 #pragma unroll
-        for (int k2 = 0; k2 < BK / 2; ++k2) {
-            const int kr = 2 * k2 + lhi;
+        for (int kg = 0; kg < BK / 8; ++kg)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[k2][i] = As0[buf * A_FLOATS + kr * LDA + (wm * TM + i) * 32 + l31];
-            b[k2] = Bs0[buf * B_FLOATS + kr * LDB + wn * 32 + l31];
-        }
+            for (int i = 0; i < TM; ++i)
+                a[kg][i] = *reinterpret_cast<const f32x4*>(
+                    As0 + buf * A_FLOATS + ((kg * 2 + lhi) * BM + (wm * TM + i) * 32 + l31) * 4);
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) b[k2] = Bs0[buf * B_FLOATS + (2 * k2 + lhi) * LDB + wn * 32 + l31];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k2 = 0; k2 < BK / 2; ++k2)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2][i], b[k2], acc[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2 >> 2][i][k2 & 3], b[k2], acc[i], 0, 0, 0);
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): all LDS reads of this buffer returned before releasing it
         __builtin_amdgcn_s_barrier();
     }
@@ -444,10 +467,202 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
     }
 }
 
-static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = wave-specialised 128x128, 1 = 4-wave, 2 = 8-wave
+// ---- wave-specialised 128x128 tile, second generation: 4 MFMA waves of 32 channels x 128 pixels + 2 loader waves -------
+// Same staging as igemm_ws_kernel (the loader code is shared in spirit: A dense 16 B/lane, B one gathered texel per lane),
+// different consumer:
+//   * B fragments are read with ds_read_b128: lane (J, kslot) takes pixels 4J..4J+3 of reduction row 2s+kslot and feeds
+//     component t to MFMA tile t, i.e. the four 32-pixel MFMA tiles of a wave interleave the 128 pixels (tile t owns
+//     pixels == t mod 4).  One 16-byte read per MFMA step serves four MFMAs; a 16-lane read group covers one 256-byte run
+//     of a row, so it is conflict-free for any row pitch; and in the epilogue every lane owns 4 consecutive pixels of
+//     each of its channel rows: 16-byte stores.
+//   * A fragments: one ds_read_b128 per 4 MFMA steps (k-interleaved packing, see pack_weights_kernel).
+//   * fragments of the next 8 reduction rows are prefetched into a second register set before the 16 MFMAs of the
+//     current 8 rows are issued; the stage barrier sits between the two halves of a stage, when the reads of the current
+//     buffer have all been issued, so neither LDS latency nor the barrier idles the matrix pipe.
+constexpr int W2_NC = 4, W2_NL = 2, W2_NT = (W2_NC + W2_NL) * 64, W2_NBUF = 3;
+__global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
+    constexpr int BM = 128, BN = 128, LDB = BN + 4;
+    constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
+    constexpr int A_PER_LOADER = BK * BM / 256 / W2_NL;      // 1 KiB wave-instructions of A per loader per stage (4)
+    constexpr int LOADS_PER_STAGE = A_PER_LOADER + BK;       // + one 64-pixel segment of each of the BK rows (16)
+    static_assert(BK == 16, "a stage is two 8-row fragment groups");
+    __shared__ __attribute__((aligned(16))) float smem[W2_NBUF * (A_FLOATS + B_FLOATS)];
+    float* const As0 = smem;
+    float* const Bs0 = smem + W2_NBUF * A_FLOATS;
+
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * BM, p0 = blockIdx.x * BN;
+    const int Cs = p.C0 + p.C1, HW = p.Hs * p.Ws;
+    const int nk = (p.Kred + BK - 1) / BK;
+
+    if (wid >= W2_NC) {
+        // ================================ loader waves ================================
+        const int seg = wid - W2_NC;                       // 64-pixel segment of the B tile owned by this wave
+        const int pix = p0 + seg * 64 + lane;
+        const bool pvalid = pix < p.P;
+        const unsigned upix = pvalid ? (unsigned)pix : 0u;
+        const unsigned n = fd_div(upix, p.fd_ohw);
+        const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
+        const unsigned oy = fd_div(rem, p.fd_ow);
+        const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;
+        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
+        const float* s1n = p.C1 ? p.src1 + (size_t)n * p.C1 * HW : p.src0;
+        const float* wsrc[A_PER_LOADER];
+        int a_lds[A_PER_LOADER];
+#pragma unroll
+        for (int q = 0; q < A_PER_LOADER; ++q) {
+            const int inst = seg * A_PER_LOADER + q;
+            const int e = inst * 256 + lane * 4;
+            const int blk = e / (BM * 4), m = (e - blk * (BM * 4)) >> 2;
+            wsrc[q] = p.wp + ((size_t)blk * p.Mpad + m0 + m) * 4;
+            a_lds[q] = inst * 256;
+        }
+#define WS2_ISSUE(ks_)                                                                                               \
+        {                                                                                                            \
+            const int k0 = (ks_) * BK, buf = (ks_) % W2_NBUF;                                                        \
+            _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q)                                                 \
+                glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + buf * A_FLOATS + a_lds[q]);                           \
+            const unsigned t = fd_div((unsigned)k0, p.fd_cs);                                                        \
+            const int ch0 = k0 - (int)t * Cs;                                                                        \
+            int y = by + p.taps.dy[t], x = bx + p.taps.dx[t];                                                        \
+            bool inb = pvalid;                                                                                       \
+            if (p.border == BORDER_REFLECT) {                                                                        \
+                y = reflect(y, p.Hs);                                                                                \
+                x = reflect(x, p.Ws);                                                                                \
+            } else {                                                                                                 \
+                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                           \
+            }                                                                                                        \
+            const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;             \
+            base += inb ? y * p.Ws + x : 0;                                                                          \
+            _Pragma("unroll") for (int r = 0; r < BK; ++r)                                                           \
+                glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + seg * 64);           \
+        }
+#define WS2_WAIT_ONE_IN_FLIGHT() \
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS_PER_STAGE & 15) | ((LOADS_PER_STAGE >> 4) << 14))
+        WS2_ISSUE(0);
+        if (nk > 1) {
+            WS2_ISSUE(1);
+            WS2_WAIT_ONE_IN_FLIGHT();
+        } else {
+            wait_vmem();
+        }
+        __builtin_amdgcn_s_barrier();                 // stage 0 is in LDS
+        if (nk > 2) WS2_ISSUE(2);
+        for (int ks = 0; ks < nk; ++ks) {
+            // the barrier of iteration ks needs stage ks+1 landed; stage ks+2 (if any) may stay in flight
+            if (ks + 2 < nk) WS2_WAIT_ONE_IN_FLIGHT();
+            else wait_vmem();
+            __builtin_amdgcn_s_barrier();             // also: every MFMA wave has finished reading buffer ks % NBUF
+            if (ks + 3 < nk) WS2_ISSUE(ks + 3);
+        }
+#undef WS2_ISSUE
+#undef WS2_WAIT_ONE_IN_FLIGHT
+        return;
+    }
+
+    // ================================ MFMA waves ================================
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int a_off = (lhi * BM + wid * 32 + l31) * 4;        // + kg * 2*BM*4 floats for the second 8-row group
+    const int b_off = lhi * LDB + 4 * l31;                    // + (8*kg + 2*s) * LDB
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 a0, a1, b0[4], b1[4];
+
+#define WS2_READ(buf_, kg_, A_, B_)                                                                        \
+    {                                                                                                          \
+        const float* sa = As0 + (buf_) * A_FLOATS + (kg_) * (2 * BM * 4) + a_off;                              \
+        const float* sb = Bs0 + (buf_) * B_FLOATS + (kg_) * (8 * LDB) + b_off;                                 \
+        A_ = *reinterpret_cast<const f32x4*>(sa);                                                              \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) B_[s] = *reinterpret_cast<const f32x4*>(sb + 2 * s * LDB); \
+    }
+#define WS2_MFMA(A_, B_)                                                                                   \
+    {                                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[s], B_[s][t], acc[t], 0, 0, 0);               \
+    }
+    __builtin_amdgcn_s_barrier();                     // stage 0 is in LDS
+    WS2_READ(0, 0, a0, b0);
+    int buf = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        WS2_READ(buf, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        WS2_MFMA(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): this wave is done reading buffer `buf`
+        __builtin_amdgcn_s_barrier();                 // stage ks+1 has landed; buffer `buf` goes back to the loaders
+        buf = buf + 1 == W2_NBUF ? 0 : buf + 1;
+        if (ks + 1 < nk) WS2_READ(buf, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        WS2_MFMA(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef WS2_READ
+#undef WS2_MFMA
+
+    // ---- epilogue: lane owns pixels p0 + 4*l31 + {0..3} (tile t -> pixel t) of 16 channel rows ---------------------
+    const size_t oplane = (size_t)p.OHf * p.OWf;
+    const int M1 = p.M - p.M0;
+    const int opix0 = p0 + 4 * l31;
+    if (opix0 >= p.P) return;
+    // 16-byte stores when the 4 pixels are consecutive, in range and aligned in the destination
+    const bool vec = p.osx == 1 && p.osy == 1 && p.oox == 0 && p.ooy == 0 && (p.OW & 3) == 0 && p.OW == p.OWf &&
+                     p.OH == p.OHf && opix0 + 3 < p.P &&
+                     ((reinterpret_cast<uintptr_t>(p.dst0) | reinterpret_cast<uintptr_t>(p.dst1)) & 15) == 0;
+    if (vec) {
+        const unsigned n = fd_div((unsigned)opix0, p.fd_ohw);
+        const unsigned rem = (unsigned)opix0 - n * (unsigned)(p.OH * p.OW);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < p.M) {
+                const float bv = p.bias ? p.bias[m] : 0.f;
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = apply_act(acc[t][r] + bv, p.act, p.slope);
+                float* dst = (m < p.M0) ? (p.dst0 ? p.dst0 + ((size_t)n * p.M0 + m) * oplane + rem : nullptr)
+                                        : p.dst1 + ((size_t)n * M1 + (m - p.M0)) * oplane + rem;
+                if (dst) *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int opix = opix0 + t;
+        if (opix >= p.P) continue;
+        const unsigned n = fd_div((unsigned)opix, p.fd_ohw);
+        const unsigned rem = (unsigned)opix - n * (unsigned)(p.OH * p.OW);
+        const unsigned oy = fd_div(rem, p.fd_ow);
+        const unsigned ox = rem - oy * (unsigned)p.OW;
+        const size_t sp = (size_t)((int)oy * p.osy + p.ooy) * p.OWf + ((int)ox * p.osx + p.oox);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < p.M) {
+                float v = acc[t][r];
+                if (p.bias) v += p.bias[m];
+                v = apply_act(v, p.act, p.slope);
+                if (m < p.M0) {
+                    if (p.dst0) p.dst0[((size_t)n * p.M0 + m) * oplane + sp] = v;
+                } else {
+                    p.dst1[((size_t)n * M1 + (m - p.M0)) * oplane + sp] = v;
+                }
+            }
+        }
+    }
+}
+
+static int g_min_blocks = 384;   // tuning switch (key 6): workgroups below which the pixel/channel tile shrinks
+static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = ws2 128x128, 1 = 4-wave, 2 = 8-wave, 3 = 256x128, 4 = ws (gen 1)
 static int g_narrow = 1;   // tuning switch (key 3): route <=4-channel layers to the VALU kernels
 static int g_dbg = 0;
 static long long* g_tl = nullptr;
+static int g_wgrad = 0;    // tuning switch (key 4): 0 = wave-specialised wide weight gradient, 1 = VGPR-staged kernel
+static int g_wgrad_blocks = 1024;   // tuning switch (key 5): workgroups targeted by the pixel split
 static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgroup (limits workgroups per CU)
 
 template <int WM, int WN, int TM, int TN>
@@ -464,7 +679,7 @@ void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
 // idle (the small-spatial discriminator / bottleneck layers): ~2 workgroups per CU is the target.
 struct TileChoice { int bm, bn; };
 TileChoice igemm_tile(int M, int P) {
-    const int kMinBlocks = 384;
+    const int kMinBlocks = g_min_blocks;
     TileChoice t;
     if (M > 64) {
         t.bm = 128; t.bn = 128;
@@ -485,7 +700,9 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
     const TileChoice t = igemm_tile(p.M, p.P);
     if (t.bm == 128 && g_cfg128 == 3 && p.M >= 256) launch_igemm_cfg<4, 2, 2, 2>(p, fast, st);   // 256 x 128, 8 waves of 64x64
-    else if (t.bm == 128 && fast && g_cfg128 == 0)                                     // 128 x 128, 8 MFMA + 2 loader waves
+    else if (t.bm == 128 && fast && g_cfg128 == 0)                                     // 128 x 128, 4 MFMA + 2 loader waves
+        hipLaunchKernelGGL(igemm_ws2_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(W2_NT), g_lds_pad, st, p);
+    else if (t.bm == 128 && fast && g_cfg128 == 4)                                     // 128 x 128, 8 MFMA + 2 loader waves
         hipLaunchKernelGGL(igemm_ws_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(WS_NT), g_lds_pad, st, p);
     else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
     else if (t.bm == 128) launch_igemm_cfg<2, 4, 2, 1>(p, fast, st);                  // 128 x 128, 8 waves of 64x32
@@ -896,6 +1113,12 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
+    if (g_wgrad == 0 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
+        nemar_wgrad2_launch(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
+                            st);
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide)");
+        return NEMAR_OK;
+    }
     WgradParams p;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
@@ -931,6 +1154,9 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 1) { g_lds_pad = value; return NEMAR_OK; }
     if (key == 2) { g_dbg = value; return NEMAR_OK; }
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
+    if (key == 4) { g_wgrad = value; return NEMAR_OK; }
+    if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
+    if (key == 5) { g_wgrad_blocks = value > 0 ? value : 1024; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
 }

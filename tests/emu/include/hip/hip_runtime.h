@@ -24,6 +24,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define amdgpu_waves_per_eu(...)   /* __attribute__((amdgpu_waves_per_eu(a, b))) -> __attribute__(()) */
 #define __constant__ static
 
 struct dim3 {

@@ -186,6 +186,21 @@ def case_conv_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, seed=
     _assert_close(be.np(d_gb), want_gb - 0.25, atol=2e-5, rtol=2e-5, what="bias_grad")
 
 
+# wave-specialised wide weight gradient (conv_wgrad.hip): K > 32 and OH*OW % 4 == 0
+WGRAD_WIDE_CASES = [
+    # N, C0, C1, H,  W,  K,   R, stride, pad, pad_mode
+    (2, 16, 0, 8, 10, 40, 3, 1, 1, PAD_REFLECT),    # 2 column tiles (J = 144), ragged K, reflect border
+    (3, 8, 0, 6, 6, 150, 3, 1, 1, PAD_ZERO),        # 2 channel tiles, P = 108: 16-pixel stage tail, image straddle
+    (2, 32, 0, 8, 12, 70, 3, 2, 1, PAD_ZERO),       # stride 2 -> 4x6 outputs
+    (2, 16, 16, 8, 8, 48, 3, 1, 1, PAD_ZERO),       # two sources (decoder concat)
+    (2, 3, 3, 10, 10, 64, 4, 2, 1, PAD_ZERO),       # D first layer: k4 s2 -> 5x5?  (25 % 4 != 0: falls back)
+    (2, 6, 0, 17, 17, 64, 4, 2, 1, PAD_ZERO),       # k4 s2 -> 8x8
+    (1, 16, 0, 8, 8, 130, 1, 1, 0, PAD_ZERO),       # 1x1, 3 row tiles... K = 130 -> 2 tiles
+    (9, 4, 0, 12, 12, 33, 3, 1, 1, PAD_REFLECT),    # many splits (P = 1296)
+]
+
+
+
 # ------------------------------------------------------------------------------------------------
 def case_instnorm(be, N, C, H, W, act, residual=False, seed=0):
     rng = np.random.default_rng(seed)

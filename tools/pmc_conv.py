@@ -1,4 +1,4 @@
-"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: pmc_conv.py [fwd|dgrad|wgrad] [iters]"""
+"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: pmc_conv.py [fwd|dgrad|wgrad] [iters] [key=value ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,6 +6,8 @@ from nemar_amd import _lib
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 lib = _lib.load(); dev = torch.device('cuda:0')
+for kv in sys.argv[3:]:          # nemar_tune switches as key=value
+    k, v = kv.split('='); lib.tune(int(k), int(v))
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 N, C, K, H, R, s, p, pm = 8, 256, 256, 64, 3, 1, 1, 1
