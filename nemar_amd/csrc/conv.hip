@@ -479,12 +479,14 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 //   * fragments of the next 8 reduction rows are prefetched into a second register set before the 16 MFMAs of the
 //     current 8 rows are issued; the stage barrier sits between the two halves of a stage, when the reads of the current
 //     buffer have all been issued, so neither LDS latency nor the barrier idles the matrix pipe.
-constexpr int W2_NC = 4, W2_NL = 2, W2_NT = (W2_NC + W2_NL) * 64, W2_NBUF = 3;
-__global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
+constexpr int W2_NC = 4, W2_NBUF = 3;
+template <int W2_NL>   // loader waves: 2 (one 64-pixel segment x 16 rows each) or 4 (x 8 rows each)
+__global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmParams p) {
     constexpr int BM = 128, BN = 128, LDB = BN + 4;
     constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
     constexpr int A_PER_LOADER = BK * BM / 256 / W2_NL;      // 1 KiB wave-instructions of A per loader per stage (4)
-    constexpr int LOADS_PER_STAGE = A_PER_LOADER + BK;       // + one 64-pixel segment of each of the BK rows (16)
+    constexpr int BROWS = BK / (W2_NL / 2);                  // B rows per loader per stage
+    constexpr int LOADS_PER_STAGE = A_PER_LOADER + BROWS;    // + one 64-pixel segment of each of its rows
     static_assert(BK == 16, "a stage is two 8-row fragment groups");
     __shared__ __attribute__((aligned(16))) float smem[W2_NBUF * (A_FLOATS + B_FLOATS)];
     float* const As0 = smem;
@@ -497,7 +499,9 @@ __global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
 
     if (wid >= W2_NC) {
         // ================================ loader waves ================================
-        const int seg = wid - W2_NC;                       // 64-pixel segment of the B tile owned by this wave
+        const int ldr = wid - W2_NC;
+        const int seg = ldr & 1;                           // 64-pixel segment of the B tile owned by this wave
+        const int row0 = (ldr >> 1) * BROWS;               // first of its B rows
         const int pix = p0 + seg * 64 + lane;
         const bool pvalid = pix < p.P;
         const unsigned upix = pvalid ? (unsigned)pix : 0u;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
         int a_lds[A_PER_LOADER];
 #pragma unroll
         for (int q = 0; q < A_PER_LOADER; ++q) {
-            const int inst = seg * A_PER_LOADER + q;
+            const int inst = ldr * A_PER_LOADER + q;
             const int e = inst * 256 + lane * 4;
             const int blk = e / (BM * 4), m = (e - blk * (BM * 4)) >> 2;
             wsrc[q] = p.wp + ((size_t)blk * p.Mpad + m0 + m) * 4;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
         {                                                                                                            \
             const int k0 = (ks_) * BK, buf = (ks_) % W2_NBUF;                                                        \
             _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q)                                                 \
-                glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + buf * A_FLOATS + a_lds[q]);                           \
+                if (!(p.dbg & 32)) glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + buf * A_FLOATS + a_lds[q]);        \
             const unsigned t = fd_div((unsigned)k0, p.fd_cs);                                                        \
             const int ch0 = k0 - (int)t * Cs;                                                                        \
             int y = by + p.taps.dy[t], x = bx + p.taps.dx[t];                                                        \
@@ -534,8 +538,9 @@ __global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
             }                                                                                                        \
             const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;             \
             base += inb ? y * p.Ws + x : 0;                                                                          \
-            _Pragma("unroll") for (int r = 0; r < BK; ++r)                                                           \
-                glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + seg * 64);           \
+            _Pragma("unroll") for (int r = row0; r < row0 + BROWS; ++r)                                              \
+                if (!(p.dbg & 16) || (r & 3) == 0)                                                                   \
+                    glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + seg * 64);       \
         }
 #define WS2_WAIT_ONE_IN_FLIGHT() \
         __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS_PER_STAGE & 15) | ((LOADS_PER_STAGE >> 4) << 14))
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(W2_NT) void igemm_ws2_kernel(IgemmParams p) {
         _Pragma("unroll") for (int s = 0; s < 4; ++s) B_[s] = *reinterpret_cast<const f32x4*>(sb + 2 * s * LDB); \
     }
 #define WS2_MFMA(A_, B_)                                                                                   \
-    {                                                                                                          \
+    if (!(p.dbg & 2)) {                                                                                        \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                          \
             _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[s], B_[s][t], acc[t], 0, 0, 0);               \
@@ -662,7 +667,7 @@ static int g_narrow = 1;   // tuning switch (key 3): route <=4-channel layers to
 static int g_dbg = 0;
 static long long* g_tl = nullptr;
 static int g_wgrad = 0;    // tuning switch (key 4): 0 = wave-specialised wide weight gradient, 1 = VGPR-staged kernel
-static int g_wgrad_blocks = 1024;   // tuning switch (key 5): workgroups targeted by the pixel split
+static int g_wgrad_blocks = 512;   // tuning switch (key 5): workgroups targeted by the pixel split
 static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgroup (limits workgroups per CU)
 
 template <int WM, int WN, int TM, int TN>
@@ -701,7 +706,9 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const TileChoice t = igemm_tile(p.M, p.P);
     if (t.bm == 128 && g_cfg128 == 3 && p.M >= 256) launch_igemm_cfg<4, 2, 2, 2>(p, fast, st);   // 256 x 128, 8 waves of 64x64
     else if (t.bm == 128 && fast && g_cfg128 == 0)                                     // 128 x 128, 4 MFMA + 2 loader waves
-        hipLaunchKernelGGL(igemm_ws2_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(W2_NT), g_lds_pad, st, p);
+        hipLaunchKernelGGL(igemm_ws2_kernel<2>, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(6 * 64), g_lds_pad, st, p);
+    else if (t.bm == 128 && fast && g_cfg128 == 5)                                     // same with 4 loader waves
+        hipLaunchKernelGGL(igemm_ws2_kernel<4>, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64), g_lds_pad, st, p);
     else if (t.bm == 128 && fast && g_cfg128 == 4)                                     // 128 x 128, 8 MFMA + 2 loader waves
         hipLaunchKernelGGL(igemm_ws_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(WS_NT), g_lds_pad, st, p);
     else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
@@ -1156,7 +1163,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
     if (key == 4) { g_wgrad = value; return NEMAR_OK; }
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
-    if (key == 5) { g_wgrad_blocks = value > 0 ? value : 1024; return NEMAR_OK; }
+    if (key == 5) { g_wgrad_blocks = value > 0 ? value : 512; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
 }

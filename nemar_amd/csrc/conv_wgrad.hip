@@ -257,8 +257,10 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW);
     p.fd_rs = make_fastdiv(R * S); p.fd_s = make_fastdiv(S);
     const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(p.J, BN);
-    // split the pixel reduction so that ~target_blocks workgroups exist, but keep >= 8 stages per split
-    int splits = nemar_cdiv(target_blocks, mt * jt);
+    // Split the pixel reduction so that the grid is ONE full round of resident workgroups (2 per CU x 256 CUs): every
+    // workgroup starts and ends together, so a grid of 1.1 or 2.04 rounds pays for 2 or 3.  target_blocks is that
+    // capacity; the split count is rounded DOWN to fit it, with >= 8 stages per split.
+    int splits = target_blocks / (mt * jt);
     const int max_splits = nemar_cdiv(p.P, BKP * 8);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
