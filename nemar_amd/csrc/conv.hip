@@ -103,9 +103,34 @@ struct IgemmParams {
     int N, P;
     int sy, sx, border, act, pad;
     float slope;
+    // ring mode (ring_p > 0): the "pixels" of this launch are the border ring of width ring_p around a ring_H x ring_W
+    // image, in padded coordinates; OH*OW = ring length; results are atomically ADDED at the reflected in-image position
+    int ring_p, ring_H, ring_W;
     FastDiv fd_ohw, fd_ow, fd_cs;
     TapTable taps;
 };
+
+// pixel index inside one image -> (oy, ox).  Ring mode enumerates, in padded coordinates of a (H+2p) x (W+2p) plane:
+// top band (p rows), bottom band (p rows), then for each image row the p left and p right columns.
+__device__ __forceinline__ void decode_pixel(const IgemmParams& p, unsigned rem, unsigned& oy, unsigned& ox) {
+    if (p.ring_p == 0) {
+        oy = fd_div(rem, p.fd_ow);
+        ox = rem - oy * (unsigned)p.OW;
+        return;
+    }
+    const unsigned rp = (unsigned)p.ring_p, Wp = (unsigned)p.ring_W + 2 * rp, band = rp * Wp;
+    if (rem < 2 * band) {
+        const unsigned q = rem < band ? rem : rem - band;
+        const unsigned r = q / Wp;
+        oy = rem < band ? r : (unsigned)p.ring_H + rp + r;
+        ox = q - r * Wp;
+    } else {
+        const unsigned q = rem - 2 * band;
+        const unsigned r = q / (2 * rp), e = q - r * (2 * rp);
+        oy = rp + r;
+        ox = e < rp ? e : (unsigned)p.ring_W + e;
+    }
+}
 
 // WM x WN waves, each TM x TN MFMA tiles of 32x32 (workgroup = WM*WN*64 threads).  FAST: Cs % BK == 0 && C0 % BK == 0,
 // so a whole BK-deep stage shares one tap and one source tensor (address math once per stage instead of per element).
@@ -157,8 +182,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         const unsigned upix = pvalid ? (unsigned)pix : 0u;
         const unsigned n = fd_div(upix, p.fd_ohw);
         const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
-        const unsigned oy = fd_div(rem, p.fd_ow);
-        const unsigned ox = rem - oy * (unsigned)p.OW;
+        unsigned oy, ox;
+        decode_pixel(p, rem, oy, ox);
         by = (int)oy * p.sy;
         bx = (int)ox * p.sx;
         s0n = p.src0 + (size_t)n * p.C0 * HW;
@@ -302,8 +327,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         if (opix >= p.P) continue;
         const unsigned n = fd_div((unsigned)opix, p.fd_ohw);
         const unsigned rem = (unsigned)opix - n * (unsigned)(p.OH * p.OW);
-        const unsigned oy = fd_div(rem, p.fd_ow);
-        const unsigned ox = rem - oy * (unsigned)p.OW;
+        unsigned oy, ox;
+        decode_pixel(p, rem, oy, ox);
+        if (p.ring_p) {
+            // gradient w.r.t. a reflect-padded border texel: add it to the texel it mirrors
+            const size_t tp = (size_t)reflect((int)oy - p.ring_p, p.ring_H) * p.ring_W + reflect((int)ox - p.ring_p, p.ring_W);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (m < p.M) atomicAdd(p.dst0 + ((size_t)n * p.M + m) * oplane + tp, acc[i][j][r]);
+                }
+            continue;
+        }
         const size_t sp = (size_t)((int)oy * p.osy + p.ooy) * p.OWf + ((int)ox * p.osx + p.oox);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -479,14 +516,21 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 //   * fragments of the next 8 reduction rows are prefetched into a second register set before the 16 MFMAs of the
 //     current 8 rows are issued; the stage barrier sits between the two halves of a stage, when the reads of the current
 //     buffer have all been issued, so neither LDS latency nor the barrier idles the matrix pipe.
-constexpr int W2_NC = 4, W2_NBUF = 3;
-template <int W2_NL>   // loader waves: 2 (one 64-pixel segment x 16 rows each) or 4 (x 8 rows each)
-__global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmParams p) {
-    constexpr int BM = 128, BN = 128, LDB = BN + 4;
+constexpr int W2_NBUF = 3;
+// MT = MFMA waves = 32-channel row tiles (BM = 32*MT: 128 / 64 / 32 output channels per workgroup).
+// VEC = the B tile is staged with 16-byte global->LDS loads: lane = 4 consecutive output pixels of one reduction row
+// (stride-1 layers with OW % 4 == 0 and |dx| <= 1: the four source texels are consecutive in memory, at an address that
+// is only 4-byte aligned — global_load_lds_dwordx4 takes that).  A group whose shifted window would stick out of the
+// source row by one texel is loaded from the clamped address instead, and the MFMA wave that consumes it rotates the
+// three good texels into place and inserts the mirrored texel (reflect) or 0 (zero padding) — a handful of
+// v_cndmask per stage on the two border lanes of a row.  8 wave-instructions per stage instead of 32.
+template <int MT, bool VEC>
+__global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p) {
+    constexpr int BM = 32 * MT, BN = 128, LDB = VEC ? BN : BN + 4;
     constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
-    constexpr int A_PER_LOADER = BK * BM / 256 / W2_NL;      // 1 KiB wave-instructions of A per loader per stage (4)
-    constexpr int BROWS = BK / (W2_NL / 2);                  // B rows per loader per stage
-    constexpr int LOADS_PER_STAGE = A_PER_LOADER + BROWS;    // + one 64-pixel segment of each of its rows
+    constexpr int A_PER_LOADER = BK * BM / 256 / 2;          // 1 KiB wave-instructions of A per loader per stage (MT)
+    constexpr int B_PER_LOADER = VEC ? BK / 4 : BK;          // VEC: 2 rows x 128 px per instruction; else 1 row x 64 px
+    constexpr int LOADS_PER_STAGE = A_PER_LOADER + B_PER_LOADER;
     static_assert(BK == 16, "a stage is two 8-row fragment groups");
     __shared__ __attribute__((aligned(16))) float smem[W2_NBUF * (A_FLOATS + B_FLOATS)];
     float* const As0 = smem;
@@ -497,20 +541,21 @@ __global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmPa
     const int Cs = p.C0 + p.C1, HW = p.Hs * p.Ws;
     const int nk = (p.Kred + BK - 1) / BK;
 
-    if (wid >= W2_NC) {
+    if (wid >= MT) {
         // ================================ loader waves ================================
-        const int ldr = wid - W2_NC;
-        const int seg = ldr & 1;                           // 64-pixel segment of the B tile owned by this wave
-        const int row0 = (ldr >> 1) * BROWS;               // first of its B rows
-        const int pix = p0 + seg * 64 + lane;
+        const int ldr = wid - MT;
+        // VEC: lane = (pixel group lane&31, row parity lane>>5), this loader's rows are ldr*8 .. ldr*8+7
+        // else: lane = pixel of 64-pixel segment `ldr`, rows 0..15
+        const int pix = VEC ? p0 + 4 * (lane & 31) : p0 + ldr * 64 + lane;
         const bool pvalid = pix < p.P;
         const unsigned upix = pvalid ? (unsigned)pix : 0u;
         const unsigned n = fd_div(upix, p.fd_ohw);
         const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
         const unsigned oy = fd_div(rem, p.fd_ow);
         const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;
-        const float* s0n = p.src0 + (size_t)n * p.C0 * HW;
-        const float* s1n = p.C1 ? p.src1 + (size_t)n * p.C1 * HW : p.src0;
+        const int rofs = VEC ? ldr * 8 + (lane >> 5) : 0;  // first reduction row (channel offset inside the stage) of this lane
+        const float* s0n = p.src0 + ((size_t)n * p.C0 + rofs) * HW;
+        const float* s1n = p.C1 ? p.src1 + ((size_t)n * p.C1 + rofs) * HW : s0n;
         const float* wsrc[A_PER_LOADER];
         int a_lds[A_PER_LOADER];
 #pragma unroll
@@ -530,17 +575,23 @@ __global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmPa
             const int ch0 = k0 - (int)t * Cs;                                                                        \
             int y = by + p.taps.dy[t], x = bx + p.taps.dx[t];                                                        \
             bool inb = pvalid;                                                                                       \
-            if (p.border == BORDER_REFLECT) {                                                                        \
-                y = reflect(y, p.Hs);                                                                                \
-                x = reflect(x, p.Ws);                                                                                \
-            } else {                                                                                                 \
-                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                           \
-            }                                                                                                        \
+            if (p.border == BORDER_REFLECT) y = reflect(y, p.Hs);                                                    \
+            else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                          \
+            if (VEC) x = min(max(x, 0), p.Ws - 4);                                                                   \
+            else if (p.border == BORDER_REFLECT) x = reflect(x, p.Ws);                                               \
+            else inb = inb && (unsigned)x < (unsigned)p.Ws;                                                          \
             const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;             \
             base += inb ? y * p.Ws + x : 0;                                                                          \
-            _Pragma("unroll") for (int r = row0; r < row0 + BROWS; ++r)                                              \
-                if (!(p.dbg & 16) || (r & 3) == 0)                                                                   \
-                    glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + seg * 64);       \
+            if (VEC) {                                                                                               \
+                _Pragma("unroll") for (int i = 0; i < B_PER_LOADER; ++i)                                             \
+                    if (!(p.dbg & 16) || i == 0)                                                                     \
+                        glds_b128(inb ? base + (size_t)(2 * i) * HW : p.zero,                                        \
+                                  Bs0 + buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256);                            \
+            } else {                                                                                                 \
+                _Pragma("unroll") for (int r = 0; r < BK; ++r)                                                       \
+                    if (!(p.dbg & 16) || (r & 3) == 0)                                                               \
+                        glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + ldr * 64);   \
+            }                                                                                                        \
         }
 #define WS2_WAIT_ONE_IN_FLIGHT() \
         __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS_PER_STAGE & 15) | ((LOADS_PER_STAGE >> 4) << 14))
@@ -569,6 +620,17 @@ __global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmPa
     const int l31 = lane & 31, lhi = lane >> 5;
     const int a_off = (lhi * BM + wid * 32 + l31) * 4;        // + kg * 2*BM*4 floats for the second 8-row group
     const int b_off = lhi * LDB + 4 * l31;                    // + (8*kg + 2*s) * LDB
+    // VEC: is this lane's 4-pixel group the first / last of a source row?  (those are the groups the loaders clamp)
+    bool first_grp = false, last_grp = false;
+    if (VEC) {
+        const unsigned gp = (unsigned)min(p0 + 4 * l31, p.P - 1);
+        const unsigned gn = fd_div(gp, p.fd_ohw);
+        const unsigned grem = gp - gn * (unsigned)(p.OH * p.OW);
+        const unsigned gox = grem - fd_div(grem, p.fd_ow) * (unsigned)p.OW;
+        first_grp = gox == 0;
+        last_grp = (int)gox == p.OW - 4;
+    }
+    const bool refl = p.border == BORDER_REFLECT;
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -585,6 +647,24 @@ __global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmPa
     }
 #define WS2_MFMA(A_, B_)                                                                                   \
     if (!(p.dbg & 2)) {                                                                                        \
+        if (VEC && fix_l) {                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
+                const f32x4 v = B_[s];                                                                         \
+                B_[s][0] = first_grp ? (refl ? v[1] : 0.f) : v[0];                                             \
+                B_[s][1] = first_grp ? v[0] : v[1];                                                            \
+                B_[s][2] = first_grp ? v[1] : v[2];                                                            \
+                B_[s][3] = first_grp ? v[2] : v[3];                                                            \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (VEC && fix_r) {                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
+                const f32x4 v = B_[s];                                                                         \
+                B_[s][0] = last_grp ? v[1] : v[0];                                                             \
+                B_[s][1] = last_grp ? v[2] : v[1];                                                             \
+                B_[s][2] = last_grp ? v[3] : v[2];                                                             \
+                B_[s][3] = last_grp ? (refl ? v[2] : 0.f) : v[3];                                              \
+            }                                                                                                  \
+        }                                                                                                      \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                          \
             _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[s], B_[s][t], acc[t], 0, 0, 0);               \
@@ -593,6 +673,9 @@ __global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmPa
     WS2_READ(0, 0, a0, b0);
     int buf = 0;
     for (int ks = 0; ks < nk; ++ks) {
+        // the tap of this stage decides which border groups need patching (wave-uniform)
+        const int dxs = VEC ? (int)p.taps.dx[fd_div((unsigned)(ks * BK), p.fd_cs)] : 0;
+        const bool fix_l = dxs < 0, fix_r = dxs > 0;
         WS2_READ(buf, 1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         WS2_MFMA(a0, b0);
@@ -661,8 +744,9 @@ __global__ __launch_bounds__((W2_NC + W2_NL) * 64) void igemm_ws2_kernel(IgemmPa
     }
 }
 
+static int g_ws2_mt = 0;         // tuning switch (key 7): force the wave-specialised kernel's channel tile (1, 2, 4 x 32)
 static int g_min_blocks = 384;   // tuning switch (key 6): workgroups below which the pixel/channel tile shrinks
-static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = ws2 128x128, 1 = 4-wave, 2 = 8-wave, 3 = 256x128, 4 = ws (gen 1)
+static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = ws2 (all FAST shapes), 5 = ws2 without 16-byte B loads; 128x128 only: 1 = 4-wave, 2 = 8-wave, 3 = 256x128, 4 = ws gen 1
 static int g_narrow = 1;   // tuning switch (key 3): route <=4-channel layers to the VALU kernels
 static int g_dbg = 0;
 static long long* g_tl = nullptr;
@@ -678,6 +762,13 @@ void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, g_lds_pad, st, p);
     else
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, g_lds_pad, st, p);
+}
+
+template <int MT>
+void launch_ws2(const IgemmParams& p, bool vec, hipStream_t st) {
+    dim3 grid(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 32 * MT)), block((MT + 2) * 64);
+    if (vec) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true>), grid, block, g_lds_pad, st, p);
+    else hipLaunchKernelGGL((igemm_ws2_kernel<MT, false>), grid, block, g_lds_pad, st, p);
 }
 
 // Tile selection.  The channel tile follows M; the pixel tile shrinks when the grid would leave most of the 256 CUs
@@ -703,12 +794,24 @@ int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 256) * 256 : 32; }
 void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
-    const TileChoice t = igemm_tile(p.M, p.P);
+    TileChoice t = igemm_tile(p.M, p.P);
+    if (p.ring_p) {   // few pixels, full reduction depth: small tiles so the launch spreads over the CUs (generic kernel only)
+        t.bm = p.M > 32 ? 64 : 32;
+        t.bn = p.M > 32 ? 64 : 128;
+    }
+    if (fast && !p.ring_p && (g_cfg128 == 0 || g_cfg128 == 5) && (t.bm == 128 || g_ws2_mt)) {
+        // wave-specialised kernel: 128 pixels x 32*MT channels.  Measured: MT = 4 beats every generic configuration on
+        // layers big enough for 128x128 tiles; MT = 1, 2 (fewer MFMAs per staged B tile) lose to the generic 64x64 /
+        // 32x256 kernels and are only reachable through the tuning switch.
+        int mt = g_ws2_mt ? g_ws2_mt : 4;
+        bool vec = g_cfg128 == 0 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4;
+        for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
+        if (mt == 4) launch_ws2<4>(p, vec, st);
+        else if (mt == 2) launch_ws2<2>(p, vec, st);
+        else launch_ws2<1>(p, vec, st);
+        return;
+    }
     if (t.bm == 128 && g_cfg128 == 3 && p.M >= 256) launch_igemm_cfg<4, 2, 2, 2>(p, fast, st);   // 256 x 128, 8 waves of 64x64
-    else if (t.bm == 128 && fast && g_cfg128 == 0)                                     // 128 x 128, 4 MFMA + 2 loader waves
-        hipLaunchKernelGGL(igemm_ws2_kernel<2>, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(6 * 64), g_lds_pad, st, p);
-    else if (t.bm == 128 && fast && g_cfg128 == 5)                                     // same with 4 loader waves
-        hipLaunchKernelGGL(igemm_ws2_kernel<4>, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64), g_lds_pad, st, p);
     else if (t.bm == 128 && fast && g_cfg128 == 4)                                     // 128 x 128, 8 MFMA + 2 loader waves
         hipLaunchKernelGGL(igemm_ws_kernel, dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(WS_NT), g_lds_pad, st, p);
     else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
@@ -1002,6 +1105,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
     p.zero = p.wp + packed_core_floats(K, C * R * S);
     p.dbg = g_dbg; p.tl = g_tl;
+    p.ring_p = 0; p.ring_H = 0; p.ring_W = 0;
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
@@ -1019,7 +1123,7 @@ NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int
                                                  int pad_mode) {
     if (N <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
     size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
-    if (pad_mode == BORDER_REFLECT && pad > 0) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    if (pad_mode == BORDER_REFLECT && pad > 0 && stride > 1) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
     return sizeof(float) * fl;
 }
 
@@ -1051,10 +1155,16 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)workspace;
     const size_t pack_stride = packed_floats(C, K * R * S);
-    // reflect: differentiate w.r.t. the PADDED input (a zero-pad-free problem on the padded domain), then fold
-    const int Hd = refl ? H + 2 * pad : H, Wd = refl ? W + 2 * pad : W;
-    const int padd = refl ? 0 : pad;
-    float* padded = refl ? wsf + pack_stride * (size_t)(stride * stride) : nullptr;
+    // Reflect padding.  The gradient w.r.t. the PADDED input splits into the image interior — exactly the zero-padded
+    // data gradient, computed on the unpadded domain — and the border ring, whose texels are mirrors of in-image
+    // texels: a second, small launch evaluates the same implicit GEMM at the ring positions only and atomically adds each
+    // result to the texel it mirrors (stride 1).  Strided reflect convolutions (not on the hot path) keep the simple
+    // form: differentiate on the padded domain into scratch, then fold.
+    const bool ring = refl && stride == 1;
+    const bool fold = refl && !ring;
+    const int Hd = fold ? H + 2 * pad : H, Wd = fold ? W + 2 * pad : W;
+    const int padd = fold ? 0 : pad;
+    float* padded = fold ? wsf + pack_stride * (size_t)(stride * stride) : nullptr;
     // skipping the first C0 channels when gx0 == NULL: start the M range at C0
     const int mskip = (gx0 == nullptr) ? C0 : 0;
     int cls = 0;
@@ -1068,13 +1178,14 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             p.src0 = gy; p.src1 = nullptr; p.C0 = K; p.C1 = 0; p.Hs = OH; p.Ws = OW;
             p.M = Mc; p.Mpad = igemm_mpad(Mc); p.Kred = p.taps.n * K;
             p.bias = bias ? bias + mskip : nullptr;
-            if (refl) { p.dst0 = padded; p.dst1 = nullptr; p.M0 = Mc; }
+            if (fold) { p.dst0 = padded; p.dst1 = nullptr; p.M0 = Mc; }
             else if (mskip) { p.dst0 = gx1; p.dst1 = nullptr; p.M0 = Mc; }
             else { p.dst0 = gx0; p.dst1 = gx1; p.M0 = C0; }
             p.OH = OHc; p.OW = OWc; p.OHf = Hd; p.OWf = Wd; p.osy = stride; p.ooy = ph; p.osx = stride; p.oox = pw;
             p.N = N; p.P = N * OHc * OWc;
             p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
             p.pad = pad;
+            p.ring_p = 0; p.ring_H = 0; p.ring_W = 0;
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
@@ -1087,8 +1198,18 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             // A[(t*K + k)][c] = w[k][c + mskip][r][s]
             if (!prepacked) launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
             launch_igemm(p, st);
+            if (ring) {
+                // same weights (stride 1: every tap, same order), taps re-based to padded coordinates
+                dgrad_taps(p.taps, R, S, 0, 1, 0, 0);
+                const int ring_len = 2 * pad * (W + 2 * pad) + 2 * pad * H;
+                p.ring_p = pad; p.ring_H = H; p.ring_W = W;
+                p.OH = 1; p.OW = ring_len; p.P = N * ring_len;
+                p.fd_ohw = make_fastdiv(ring_len); p.fd_ow = make_fastdiv(ring_len);
+                p.dst0 = gx0 ? gx0 : gx1; p.dst1 = nullptr; p.M0 = Mc;
+                launch_igemm(p, st);
+            }
         }
-    if (refl) {
+    if (fold) {
         const long long total = (long long)N * C * H * W;
         hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st,
                            (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total);
@@ -1163,6 +1284,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
     if (key == 4) { g_wgrad = value; return NEMAR_OK; }
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
+    if (key == 7) { g_ws2_mt = (value == 1 || value == 2 || value == 4) ? value : 0; return NEMAR_OK; }
     if (key == 5) { g_wgrad_blocks = value > 0 ? value : 512; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;

@@ -32,6 +32,7 @@ struct NarrowParams {
     int N, C, H, W, OH, OW, pad, border, act;
     float slope;
     int tiles_x, tiles_y, tiles_total;
+    int csplit;   // forward: channel ranges per image (grid.z = N * csplit); > 1 => partial sums are atomically added to y
 };
 
 // fill the LDS halo tile of channels [c0, c0+CH) for the output tile whose origin is (oy0, ox0)
@@ -64,18 +65,23 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(NarrowParams p) {
     constexpr int LH = TH + R - 1, LW = TW + R - 1;
     __shared__ float tile[CH * LH * LW];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int n = blockIdx.z;
+    // grid.z = image x channel range.  With csplit > 1 (deep, spatially small layers: the discriminator's logit conv has
+    // 32 output tiles for 512 channels) each workgroup reduces its own channel range and the partial sums meet in y by
+    // fp32 atomics; y was zero-filled by the launcher and range 0 carries the bias (no activation in this mode).
+    const int n = blockIdx.z / p.csplit, cs = blockIdx.z - n * p.csplit;
+    const int cper = ((p.C + p.csplit - 1) / p.csplit + CH - 1) / CH * CH;
+    const int cbeg = cs * cper, cend = min(p.C, cbeg + cper);
     const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const float* xn = p.x + (size_t)n * p.C * p.H * p.W;
     float acc[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = p.bias ? p.bias[m] : 0.f;
+    for (int m = 0; m < M; ++m) acc[m] = (p.bias && cs == 0) ? p.bias[m] : 0.f;
     const int CRS = p.C * R * R;
-    for (int c0 = 0; c0 < p.C; c0 += CH) {
+    for (int c0 = cbeg; c0 < cend; c0 += CH) {
         __syncthreads();
         fill_tile<R>(tile, p, xn, c0, oy0, ox0);
         __syncthreads();
-        const int nch = min(CH, p.C - c0);
+        const int nch = min(CH, cend - c0);
         for (int ch = 0; ch < nch; ++ch) {
             const float* t0 = tile + ch * (LH * LW) + ty * LW + tx;
             const float* wc = p.w + (size_t)(c0 + ch) * R * R;     // wave-uniform => scalar loads
@@ -92,8 +98,11 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(NarrowParams p) {
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy < p.OH && ox < p.OW) {
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-            p.y[(((size_t)n * M + m) * p.OH + oy) * p.OW + ox] = act_apply(acc[m], p.act, p.slope);
+        for (int m = 0; m < M; ++m) {
+            float* dst = p.y + (((size_t)n * M + m) * p.OH + oy) * p.OW + ox;
+            if (p.csplit > 1) atomicAdd(dst, acc[m]);
+            else *dst = act_apply(acc[m], p.act, p.slope);
+        }
     }
 }
 
@@ -193,7 +202,18 @@ int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y
     p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
     p.pad = pad; p.border = border; p.act = act; p.slope = slope;
     p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
-    dim3 grid(p.tiles_x, p.tiles_y, N);
+    // few output tiles and many channels: split the channel reduction so the launch fills the chip
+    p.csplit = 1;
+    const int chunks = nemar_cdiv(C, CH);
+    if (act == 0 && p.tiles_total < 512 && chunks > 1) {
+        p.csplit = nemar_cdiv(1024, p.tiles_total);
+        if (p.csplit > chunks) p.csplit = chunks;
+        // ranges are whole CH-channel chunks: drop ranges that would be empty
+        const int cper = nemar_cdiv(nemar_cdiv(C, p.csplit), CH) * CH;
+        p.csplit = nemar_cdiv(C, cper);
+    }
+    if (p.csplit > 1) (void)hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * K * p.OH * p.OW, st);
+    dim3 grid(p.tiles_x, p.tiles_y, N * p.csplit);
     if (R == 3) launch_fwd_r<3>(p, K, grid, st);
     else if (R == 4) launch_fwd_r<4>(p, K, grid, st);
     else launch_fwd_r<7>(p, K, grid, st);
@@ -205,7 +225,7 @@ int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C,
     NarrowParams p;
     p.x = x; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.gy = gy; p.gw = gw;
     p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
-    p.pad = pad; p.border = border; p.act = 0; p.slope = 0.f;
+    p.pad = pad; p.border = border; p.act = 0; p.slope = 0.f; p.csplit = 1;
     p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
     const int chunks = nemar_cdiv(C, CH);
     int gx = nemar_cdiv(1024, chunks);           // ~4 workgroups per CU in total

@@ -107,6 +107,29 @@ def test_conv_forced_128_tiles(be, cfg):
         be.lib.tune(6, 384)
 
 
+@pytest.mark.parametrize("mt", [1, 2, 4])
+def test_conv_ws2_vector_loads(be, mt):
+    """Wave-specialised igemm with 16-byte B loads (stride 1, OW % 4 == 0, |dx| <= 1): clamped border groups are patched
+    by the MFMA waves — reflect and zero borders, 4-wide rows (one group is both first and last), tile tails."""
+    be.lib.tune(7, mt)
+    try:
+        K.case_conv_fwd(be, 2, 16, 0, 6, 8, 40, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_RELU)
+        K.case_conv_fwd(be, 3, 32, 0, 5, 4, 33, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)      # OW = 4
+        K.case_conv_fwd(be, 1, 16, 16, 9, 12, 70, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)   # concat, P = 108 (tail)
+        K.case_conv_fwd(be, 2, 16, 0, 3, 16, 20, 1, 1, 0, K.PAD_ZERO)                       # 1x1
+        K.case_conv_bwd_data(be, 2, 24, 0, 7, 8, 32, 3, 1, 1, K.PAD_REFLECT)                # ring + vector main pass
+        K.case_conv_bwd_data(be, 2, 24, 0, 7, 8, 16, 3, 1, 1, K.PAD_ZERO)
+        K.case_conv_transpose_fwd(be, 2, 16, 40, 5, 8, 3, 1)                                # parity classes, dx in {0, 1}
+    finally:
+        be.lib.tune(7, 0)
+
+
+def test_conv_narrow_channel_split(be):
+    """Narrow forward with few output tiles and no activation: channel ranges meet in y through atomics."""
+    K.case_conv_fwd(be, 2, 40, 0, 9, 10, 1, 4, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)              # D logit conv, 3 ranges
+    K.case_conv_fwd(be, 1, 70, 0, 6, 6, 2, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE, bias=False)  # ragged last range
+
+
 def test_conv_fwd_acts_and_linear(be):
     K.case_conv_fwd(be, 2, 16, 0, 6, 6, 3, 7, 1, 3, K.PAD_REFLECT, act=K.O.ACT_TANH)      # T head
     K.case_conv_fwd(be, 3, 64, 0, 1, 1, 20, 1, 1, 0, K.PAD_ZERO, act=K.O.ACT_RELU)        # nn.Linear
