@@ -34,7 +34,7 @@ int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C,
 bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy);
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
-                         int target_blocks, hipStream_t st);
+                         int target_blocks, bool vec_ok, hipStream_t st);
 
 namespace {
 
@@ -105,7 +105,7 @@ struct IgemmParams {
     float slope;
     // ring mode (ring_p > 0): the "pixels" of this launch are the border ring of width ring_p around a ring_H x ring_W
     // image, in padded coordinates; OH*OW = ring length; results are atomically ADDED at the reflected in-image position
-    int ring_p, ring_H, ring_W;
+    int ring_p, ring_H, ring_W, ksplit;
     FastDiv fd_ohw, fd_ow, fd_cs;
     TapTable taps;
 };
@@ -260,11 +260,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int l31 = lane & 31, lhi = lane >> 5;
 
     long long tA[5] = {0, 0, 0, 0, 0}, tB[5] = {0, 0, 0, 0, 0}, tC[5] = {0, 0, 0, 0, 0}, tD[5] = {0, 0, 0, 0, 0};
-    const int nk = (p.Kred + BK - 1) / BK;
-    IGEMM_ISSUE_STAGE(0, 0);
+    // ring mode splits the reduction over blockIdx.z (the atomic epilogue sums the partial results)
+    const int nk_all = (p.Kred + BK - 1) / BK;
+    const int nk_per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int ks0 = blockIdx.z * nk_per, nk = min(nk_all, ks0 + nk_per);
+    if (ks0 >= nk) return;
+    IGEMM_ISSUE_STAGE(ks0 * BK, ks0 & 1);
     wait_vmem();
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
+    for (int ks = ks0; ks < nk; ++ks) {
         const int buf = ks & 1;
         // timeline probe (nemar_tune_ptr): s_memtime stamps of 4 consecutive stages, kept in scalar registers so the
         // probe adds no memory traffic; written out once at the end by workgroup 0
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         unsigned oy, ox;
         decode_pixel(p, rem, oy, ox);
         if (p.ring_p) {
+            if (p.dbg & 64) continue;
             // gradient w.r.t. a reflect-padded border texel: add it to the texel it mirrors
             const size_t tp = (size_t)reflect((int)oy - p.ring_p, p.ring_H) * p.ring_W + reflect((int)ox - p.ring_p, p.ring_W);
 #pragma unroll
@@ -744,20 +749,21 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
     }
 }
 
+static int g_ring_split = 0;     // tuning switch (key 8): reduction splits of the reflect-border ring launch (0 = auto)
 static int g_ws2_mt = 0;         // tuning switch (key 7): force the wave-specialised kernel's channel tile (1, 2, 4 x 32)
 static int g_min_blocks = 384;   // tuning switch (key 6): workgroups below which the pixel/channel tile shrinks
 static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = ws2 (all FAST shapes), 5 = ws2 without 16-byte B loads; 128x128 only: 1 = 4-wave, 2 = 8-wave, 3 = 256x128, 4 = ws gen 1
 static int g_narrow = 1;   // tuning switch (key 3): route <=4-channel layers to the VALU kernels
 static int g_dbg = 0;
 static long long* g_tl = nullptr;
-static int g_wgrad = 0;    // tuning switch (key 4): 0 = wave-specialised wide weight gradient, 1 = VGPR-staged kernel
+static int g_wgrad = 0;    // tuning switch (key 4): 0 = wave-specialised wide weight gradient, 1 = VGPR-staged kernel, 2 = wave-specialised without 16-byte source loads
 static int g_wgrad_blocks = 512;   // tuning switch (key 5): workgroups targeted by the pixel split
 static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgroup (limits workgroups per CU)
 
 template <int WM, int WN, int TM, int TN>
 void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM)), block(WM * WN * 64);
+    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM), p.ring_p ? p.ksplit : 1), block(WM * WN * 64);
     if (fast)
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, g_lds_pad, st, p);
     else
@@ -1105,7 +1111,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
     p.zero = p.wp + packed_core_floats(K, C * R * S);
     p.dbg = g_dbg; p.tl = g_tl;
-    p.ring_p = 0; p.ring_H = 0; p.ring_W = 0;
+    p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1;
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
@@ -1185,7 +1191,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             p.N = N; p.P = N * OHc * OWc;
             p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
             p.pad = pad;
-            p.ring_p = 0; p.ring_H = 0; p.ring_W = 0;
+            p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1;
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
@@ -1203,6 +1209,16 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 dgrad_taps(p.taps, R, S, 0, 1, 0, 0);
                 const int ring_len = 2 * pad * (W + 2 * pad) + 2 * pad * H;
                 p.ring_p = pad; p.ring_H = H; p.ring_W = W;
+                // A ring tile is a few pixels deep in a full-length reduction, and a lone workgroup per CU runs it at
+                // memory latency (one stage of prefetch), so the reduction is split over grid.z — but every split repeats
+                // the scattered atomic epilogue (measured on the resblock shape: 8 splits = 155 us, of which ~90 atomics),
+                // so only until ~1.5 workgroups per CU exist (3 splits there: 97 us).
+                {
+                    const int tiles = nemar_cdiv(N * ring_len, 64) * nemar_cdiv(Mc, 64), stages = nemar_cdiv(p.Kred, BK);
+                    p.ksplit = g_ring_split ? g_ring_split : nemar_cdiv(384, tiles);
+                    if (p.ksplit > nemar_cdiv(stages, 8)) p.ksplit = nemar_cdiv(stages, 8);
+                    if (p.ksplit < 1) p.ksplit = 1;
+                }
                 p.OH = 1; p.OW = ring_len; p.P = N * ring_len;
                 p.fd_ohw = make_fastdiv(ring_len); p.fd_ow = make_fastdiv(ring_len);
                 p.dst0 = gx0 ? gx0 : gx1; p.dst1 = nullptr; p.M0 = Mc;
@@ -1241,9 +1257,9 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
-    if (g_wgrad == 0 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
+    if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
         nemar_wgrad2_launch(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
-                            st);
+                            g_wgrad != 2, st);
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide)");
         return NEMAR_OK;
     }
@@ -1284,6 +1300,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
     if (key == 4) { g_wgrad = value; return NEMAR_OK; }
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
+    if (key == 8) { g_ring_split = value > 0 ? value : 0; return NEMAR_OK; }
     if (key == 7) { g_ws2_mt = (value == 1 || value == 2 || value == 4) ? value : 0; return NEMAR_OK; }
     if (key == 5) { g_wgrad_blocks = value > 0 ? value : 512; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);

@@ -36,8 +36,8 @@ constexpr int NC = 4, NL = 4, NT = (NC + NL) * 64;
 constexpr int TILE = BM * BKP;          // floats per operand per stage (BM == BN)
 constexpr int STAGE = 2 * TILE;
 constexpr int A_PER = (BM / 16) / NL;   // 16-row gy wave-instructions per loader per stage (2)
-constexpr int B_PER = (BN / 4) / NL;    // 4-row source wave-instructions per loader per stage (8)
-constexpr int LOADS = A_PER + B_PER;
+constexpr int B_PER = (BN / 4) / NL;    // scalar path: 4-row source wave-instructions per loader per stage (8)
+constexpr int BV_PER = (BN / 16) / NL;  // vector path: 16-row (16 B per lane) source wave-instructions per loader (2)
 static_assert(NL == 4, "loader l owns the source rows whose swizzle key (row>>2)&3 == l");
 
 __device__ __attribute__((aligned(16))) float wg_zero_page[64];
@@ -57,7 +57,16 @@ struct Wgrad2Params {
     FastDiv fd_ohw, fd_ow, fd_rs, fd_s;
 };
 
+// VEC: the source tile is staged like the gy tile — 16 bytes per lane = 4 consecutive pixels of one (channel, tap)
+// row, whose texels are consecutive in memory for a stride-1 layer (the address is only 4-byte aligned:
+// global_load_lds_dwordx4 takes that).  A chunk whose shifted window would stick out of the source row by one texel
+// (first chunk of an image row for dx = -1, last for dx = +1) is loaded from the clamped address; the MFMA wave that
+// consumes it rotates the three good texels into place and inserts the mirrored texel (reflect) or 0 (zero padding).
+// 4 wave-instructions per loader per stage instead of 10.
+template <bool VEC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad2_kernel(Wgrad2Params p) {
+    constexpr int LOADS = A_PER + (VEC ? BV_PER : B_PER);
+    constexpr int NROW = VEC ? BV_PER : B_PER;
     __shared__ __attribute__((aligned(16))) float smem[NBUF * STAGE];
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
@@ -76,11 +85,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const int a_m = m0 + (l * A_PER) * 16 + a_row;          // first instruction's channel; the next is +16
         // source: instruction q = l + 4i covers rows 4q..4q+3 x 16 pixels; swizzle key of all its rows = l
         const int b_pix = 4 * (((lane & 15) >> 2) ^ l) + (lane & 3);
-        const float* rowp[B_PER];
-        int rowns[B_PER], rowt[B_PER];
+        const float* rowp[NROW];
+        int rowns[NROW], rowt[NROW];
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int j = j0 + 4 * (l + 4 * i) + (lane >> 4);
+        for (int i = 0; i < NROW; ++i) {
+            // vector path: instruction l*BV_PER + i covers rows 16*(l*BV_PER + i) .. +15, lane -> (row, stored chunk) as for gy
+            const int j = VEC ? j0 + 16 * (l * BV_PER + i) + a_row : j0 + 4 * (l + 4 * i) + (lane >> 4);
             rowp[i] = nullptr;
             rowns[i] = 0;
             rowt[i] = 0;
@@ -112,7 +122,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     glds_b128((pix < pend && a_m + 16 * q < p.K) ? g + (size_t)(16 * q) * OHW : wg_zero_page,        \
                               sb + (l * A_PER + q) * 256);                                                           \
             }                                                                                                        \
-            {                                                                                                        \
+            if (VEC) {                                                                                               \
+                const int pix = pb + a_pix;                                                                          \
+                const bool pv = pix < pend;                                                                          \
+                const unsigned upix = pv ? (unsigned)pix : 0u;                                                       \
+                const unsigned n = fd_div(upix, p.fd_ohw);                                                           \
+                const unsigned rem = upix - n * (unsigned)OHW;                                                       \
+                const unsigned oy = fd_div(rem, p.fd_ow);                                                            \
+                const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW);                                \
+                _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                   \
+                    int y = by + (rowt[i] >> 16);                                                                    \
+                    const int x = min(max(bx + (int)(short)(rowt[i] & 0xffff), 0), p.Ws - 4);                        \
+                    bool inb = pv && rowp[i] != nullptr;                                                             \
+                    if (p.border == BORDER_REFLECT) y = reflect_i(y, p.Hs);                                          \
+                    else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                  \
+                    glds_b128(inb ? rowp[i] + (size_t)n * rowns[i] + (y * p.Ws + x) : wg_zero_page,                  \
+                              sb + TILE + (l * BV_PER + i) * 256);                                                   \
+                }                                                                                                    \
+            } else {                                                                                                 \
                 const int pix = pb + b_pix;                                                                          \
                 const bool pv = pix < pend;                                                                          \
                 const unsigned upix = pv ? (unsigned)pix : 0u;                                                       \
@@ -120,7 +147,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const unsigned rem = upix - n * (unsigned)OHW;                                                       \
                 const unsigned oy = fd_div(rem, p.fd_ow);                                                            \
                 const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;                         \
-                _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                  \
+                _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                   \
                     int y = by + (rowt[i] >> 16), x = bx + (int)(short)(rowt[i] & 0xffff);                           \
                     bool inb = pv && rowp[i] != nullptr;                                                             \
                     if (p.border == BORDER_REFLECT) {                                                                \
@@ -164,6 +191,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int brow0 = TILE + ((wn * 2 + 0) * 32 + l31) * BKP, brow1 = TILE + ((wn * 2 + 1) * 32 + l31) * BKP;
     const int co0 = ((0 + lhi) ^ sw) << 2, co1 = ((2 + lhi) ^ sw) << 2;   // pixel groups 0 and 1 of a stage
     const bool do_bias = p.gb != nullptr && blockIdx.y == 0 && wn == 0;
+    // VEC: horizontal tap offset of this lane's two source rows, and the x position of the current stage in its image row
+    int dxn0 = 0, dxn1 = 0, oxs = 0;
+    const bool refl = p.border == BORDER_REFLECT;
+    if (VEC) {
+        const int ja = j0 + (wn * 2 + 0) * 32 + l31, jb = ja + 32;
+        const unsigned RS = (unsigned)(p.R * p.S);
+        const unsigned ta = (unsigned)ja - fd_div((unsigned)ja, p.fd_rs) * RS, tb = (unsigned)jb - fd_div((unsigned)jb, p.fd_rs) * RS;
+        dxn0 = (int)(ta - fd_div(ta, p.fd_s) * (unsigned)p.S) - p.pad;
+        dxn1 = (int)(tb - fd_div(tb, p.fd_s) * (unsigned)p.S) - p.pad;
+        const unsigned rem = (unsigned)pbeg - fd_div((unsigned)pbeg, p.fd_ohw) * (unsigned)OHW;
+        oxs = (int)(rem - fd_div(rem, p.fd_ow) * (unsigned)p.OW);
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -183,8 +222,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         B_[0] = *reinterpret_cast<const f32x4*>(sb + brow0 + (co_));               \
         B_[1] = *reinterpret_cast<const f32x4*>(sb + brow1 + (co_));               \
     }
-#define WG2_MFMA(A_, B_)                                                                                       \
+#define WG2_MFMA(A_, B_, G_)                                                                                   \
     {                                                                                                              \
+        if (VEC && (G_) == 0 && oxs == 0 && lhi == 0) {          /* first chunk of an image row: dx = -1 rows */    \
+            const f32x4 u = B_[0], v = B_[1];                                                                      \
+            if (dxn0 < 0) { B_[0][0] = refl ? u[1] : 0.f; B_[0][1] = u[0]; B_[0][2] = u[1]; B_[0][3] = u[2]; }     \
+            if (dxn1 < 0) { B_[1][0] = refl ? v[1] : 0.f; B_[1][1] = v[0]; B_[1][2] = v[1]; B_[1][3] = v[2]; }     \
+        }                                                                                                          \
+        if (VEC && (G_) == 1 && oxs == p.OW - BKP && lhi == 1) { /* last chunk of an image row: dx = +1 rows */    \
+            const f32x4 u = B_[0], v = B_[1];                                                                      \
+            if (dxn0 > 0) { B_[0][0] = u[1]; B_[0][1] = u[2]; B_[0][2] = u[3]; B_[0][3] = refl ? u[2] : 0.f; }     \
+            if (dxn1 > 0) { B_[1][0] = v[1]; B_[1][1] = v[2]; B_[1][2] = v[3]; B_[1][3] = refl ? v[2] : 0.f; }     \
+        }                                                                                                          \
         if (do_bias) {                                                                                             \
             bsum0 += (A_[0][0] + A_[0][1]) + (A_[0][2] + A_[0][3]);                                                \
             bsum1 += (A_[1][0] + A_[1][1]) + (A_[1][2] + A_[1][3]);                                                \
@@ -201,15 +250,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     for (int ks = 0; ks < nk; ++ks) {
         WG2_READ(buf, co1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        WG2_MFMA(a0, b0);
+        WG2_MFMA(a0, b0, 0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): this wave is done reading buffer `buf`
         __builtin_amdgcn_s_barrier();                 // stage ks+1 has landed; buffer `buf` is released to the loaders
         buf = buf + 1 == NBUF ? 0 : buf + 1;
         if (ks + 1 < nk) WG2_READ(buf, co0, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        WG2_MFMA(a1, b1);
+        WG2_MFMA(a1, b1, 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (VEC) oxs = oxs + BKP == p.OW ? 0 : oxs + BKP;
     }
 #undef WG2_READ
 #undef WG2_MFMA
@@ -248,7 +298,7 @@ bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy) {
 
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
-                         int target_blocks, hipStream_t st) {
+                         int target_blocks, bool vec_ok, hipStream_t st) {
     Wgrad2Params p;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
@@ -267,5 +317,8 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
     if (splits > 65535) splits = 65535;
     p.pix_per_split = nemar_cdiv(nemar_cdiv(p.P, splits), BKP) * BKP;
     splits = nemar_cdiv(p.P, p.pix_per_split);
-    hipLaunchKernelGGL(wgrad2_kernel, dim3(mt, jt, splits), dim3(NT), 0, st, p);
+    // 16-byte source loads: stride 1, image rows that are whole 16-pixel stages, horizontal tap offsets within +-1
+    const bool vec = vec_ok && stride == 1 && OW % BKP == 0 && W == OW && pad <= 1 && S - 1 - pad <= 1;
+    if (vec) hipLaunchKernelGGL(wgrad2_kernel<true>, dim3(mt, jt, splits), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL(wgrad2_kernel<false>, dim3(mt, jt, splits), dim3(NT), 0, st, p);
 }

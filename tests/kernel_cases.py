@@ -197,6 +197,12 @@ WGRAD_WIDE_CASES = [
     (2, 6, 0, 17, 17, 64, 4, 2, 1, PAD_ZERO),       # k4 s2 -> 8x8
     (1, 16, 0, 8, 8, 130, 1, 1, 0, PAD_ZERO),       # 1x1, 3 row tiles... K = 130 -> 2 tiles
     (9, 4, 0, 12, 12, 33, 3, 1, 1, PAD_REFLECT),    # many splits (P = 1296)
+    # 16-byte source loads (stride 1, OW % 16 == 0): border chunks patched by the MFMA waves
+    (2, 16, 0, 4, 16, 40, 3, 1, 1, PAD_REFLECT),     # every stage is both first and last chunk of a row
+    (1, 16, 0, 6, 32, 64, 3, 1, 1, PAD_ZERO),        # 2 stages per row, zero border
+    (2, 8, 8, 3, 16, 48, 3, 1, 1, PAD_ZERO),         # two sources, H = 3
+    (1, 16, 0, 4, 16, 40, 1, 1, 0, PAD_ZERO),        # 1x1: no border chunks at all
+    (3, 20, 0, 5, 48, 70, 3, 1, 1, PAD_REFLECT),     # 3 stages per row, 2 column tiles, ragged K
 ]
 
 

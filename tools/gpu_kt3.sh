@@ -1,0 +1,2 @@
+#!/bin/bash
+for t in 8=1 8=2 8=3 8=4 8=6; do echo "== $t"; bash tools/gpu_kt.sh kt_$t dgrad 10 $t | grep "igemm_kernel" | cut -c1-120; done
