@@ -140,7 +140,7 @@ __device__ __forceinline__ void decode_pixel(const IgemmParams& p, unsigned rem,
 // (s_waitcnt vmcnt(0) + barrier) after them.  A tile: packed weights, 16 B per lane, dense LDS rows (one wave
 // instruction = 1 KiB).  B tile: one 4-byte gather per lane, 64 consecutive pixels of one reduction row per wave
 // instruction; taps that fall outside a zero-padded source (and tile tails) are pointed at a zero page.
-template <int WM, int WN, int TM, int TN, bool FAST>
+template <int WM, int WN, int TM, int TN, bool FAST, int NBUF = 2>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -155,10 +155,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     // ONE __shared__ object: with several, hipcc guards every ds_read of a stage with s_waitcnt vmcnt(0) while a
     // global_load_lds is in flight (it cannot tell which object the DMA writes), which would serialise the pipeline
     constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_FLOATS + 2 * B_FLOATS + MAX_TAPS];
+    constexpr int LOADS = A_PER + BROWS;          // global->LDS instructions per wave per stage (uniform when NBUF > 2)
+    static_assert(NBUF == 2 || (FAST && A_INSTR % NW == 0), "counted waits need the same number of loads in every wave");
+    static_assert(NBUF >= 2 && NBUF <= 4 && 2 * LOADS < 64, "ring depth");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * A_FLOATS + NBUF * B_FLOATS + MAX_TAPS];
     float* const As0 = smem;
-    float* const Bs0 = smem + 2 * A_FLOATS;
-    int* const s_tap = reinterpret_cast<int*>(smem + 2 * A_FLOATS + 2 * B_FLOATS);
+    float* const Bs0 = smem + NBUF * A_FLOATS;
+    int* const s_tap = reinterpret_cast<int*>(smem + NBUF * A_FLOATS + NBUF * B_FLOATS);
 
     const int tid = threadIdx.x;
     const int wid = tid >> 6, lane = tid & 63;
@@ -259,28 +262,28 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    long long tA[5] = {0, 0, 0, 0, 0}, tB[5] = {0, 0, 0, 0, 0}, tC[5] = {0, 0, 0, 0, 0}, tD[5] = {0, 0, 0, 0, 0};
     // ring mode splits the reduction over blockIdx.z (the atomic epilogue sums the partial results)
     const int nk_all = (p.Kred + BK - 1) / BK;
     const int nk_per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
     const int ks0 = blockIdx.z * nk_per, nk = min(nk_all, ks0 + nk_per);
     if (ks0 >= nk) return;
-    IGEMM_ISSUE_STAGE(ks0 * BK, ks0 & 1);
-    wait_vmem();
-    __syncthreads();
+    // NBUF-deep LDS ring: stages ks+1 .. ks+NBUF-2 stay in flight while stage ks is consumed (counted s_waitcnt vmcnt);
+    // NBUF = 2 is plain double buffering.  One barrier per stage: it publishes stage ks and retires buffer (ks-1) % NBUF.
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d)
+        if (ks0 + d < nk) IGEMM_ISSUE_STAGE((ks0 + d) * BK, (ks0 + d) % NBUF);
     for (int ks = ks0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        // timeline probe (nemar_tune_ptr): s_memtime stamps of 4 consecutive stages, kept in scalar registers so the
-        // probe adds no memory traffic; written out once at the end by workgroup 0
-#define IGEMM_STAMP(i)                                                                   \
-        if (p.tl) {                                                                          \
-            const long long c_ = clock64();                                                  \
-            if (ks == 40) tA[i] = c_; else if (ks == 41) tB[i] = c_;                         \
-            else if (ks == 42) tC[i] = c_; else if (ks == 43) tD[i] = c_;                    \
+        const int buf = ks % NBUF;
+        if (NBUF == 2) {
+            wait_vmem();
+        } else {
+            const int ahead = nk - 1 - ks;            // stages issued beyond ks (capped at NBUF-2)
+            if (ahead >= 2 && NBUF >= 4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * LOADS) & 15) | (((2 * LOADS) >> 4) << 14));
+            else if (ahead >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14));
+            else wait_vmem();
         }
-        IGEMM_STAMP(0)
-        if (ks + 1 < nk && !(p.dbg & 1)) IGEMM_ISSUE_STAGE((ks + 1) * BK, buf ^ 1);
-        IGEMM_STAMP(1)
+        if (!(p.dbg & 4)) __syncthreads();
+        if (ks + NBUF - 1 < nk && !(p.dbg & 1)) IGEMM_ISSUE_STAGE((ks + NBUF - 1) * BK, (ks + NBUF - 1) % NBUF);
         if (!(p.dbg & 2)) {
             // all MFMA operands of the stage into registers first (one LDS round trip per stage), then the MFMAs
             // back to back: reading fragments just-in-time makes hipcc reuse the operand registers, and the
@@ -300,8 +303,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 for (int j = 0; j < TN; ++j) b[k2][j] = Bs0[buf * B_FLOATS + kr * LDB + (wn * TN + j) * 32 + l31];
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads above, in their own registers
-            if (p.tl) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): stamp 2 = operands have arrived
-            IGEMM_STAMP(2)
 #pragma unroll
             for (int k2 = 0; k2 < BK / 2; ++k2)
 #pragma unroll
@@ -309,18 +310,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2 >> 2][i][k2 & 3], b[k2][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of `buf` are done before the next barrier
         }
-        IGEMM_STAMP(3)
-        wait_vmem();       // the next stage has landed in LDS (it had the whole MFMA phase to do so)
-        IGEMM_STAMP(4)
-        if (!(p.dbg & 4)) __syncthreads();
     }
 #undef IGEMM_ISSUE_STAGE
-#undef IGEMM_STAMP
-    if (p.tl && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
-        long long* o = p.tl + wid * 20;
-        for (int i = 0; i < 5; ++i) { o[i] = tA[i]; o[5 + i] = tB[i]; o[10 + i] = tC[i]; o[15 + i] = tD[i]; }
-    }
 
     // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
@@ -823,6 +816,9 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
     else if (t.bm == 128) launch_igemm_cfg<2, 4, 2, 1>(p, fast, st);                  // 128 x 128, 8 waves of 64x32
     else if (t.bm == 64 && t.bn == 128) launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);    // 64 x 128
+    else if (t.bm == 64 && p.ring_p && fast)                                          // ring: 64 x 64, 4-deep LDS ring
+        hipLaunchKernelGGL((igemm_kernel<2, 2, 1, 1, true, 4>), dim3(nemar_cdiv(p.P, 64), nemar_cdiv(p.M, 64), p.ksplit),
+                           dim3(256), g_lds_pad, st, p);
     else if (t.bm == 64) launch_igemm_cfg<2, 2, 1, 1>(p, fast, st);                   // 64 x 64
     else if (t.bn == 256) launch_igemm_cfg<1, 4, 1, 2>(p, fast, st);                  // 32 x 256
     else launch_igemm_cfg<1, 4, 1, 1>(p, fast, st);                                   // 32 x 128

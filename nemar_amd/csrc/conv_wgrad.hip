@@ -31,11 +31,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BORDER_REFLECT = 1;
-constexpr int BM = 128, BN = 128, BKP = 16, NBUF = 3;
+constexpr int BN = 128, BKP = 16, NBUF = 3;
 constexpr int NC = 4, NL = 4, NT = (NC + NL) * 64;
-constexpr int TILE = BM * BKP;          // floats per operand per stage (BM == BN)
-constexpr int STAGE = 2 * TILE;
-constexpr int A_PER = (BM / 16) / NL;   // 16-row gy wave-instructions per loader per stage (2)
 constexpr int B_PER = (BN / 4) / NL;    // scalar path: 4-row source wave-instructions per loader per stage (8)
 constexpr int BV_PER = (BN / 16) / NL;  // vector path: 16-row (16 B per lane) source wave-instructions per loader (2)
 static_assert(NL == 4, "loader l owns the source rows whose swizzle key (row>>2)&3 == l");
@@ -63,8 +60,18 @@ struct Wgrad2Params {
 // (first chunk of an image row for dx = -1, last for dx = +1) is loaded from the clamped address; the MFMA wave that
 // consumes it rotates the three good texels into place and inserts the mirrored texel (reflect) or 0 (zero padding).
 // 4 wave-instructions per loader per stage instead of 10.
-template <bool VEC>
+//
+// Channel tile BM = WM*TMW*32 (the 4 MFMA waves form a WM x (4/WM) grid of TMW x TNW 32x32 MFMA tiles; the column tile is
+// always 128): <2,2,2> = 128 channels, <2,1,2> = 64, <1,1,1> = 32 — narrower layers do not pay for empty MFMA rows.
+template <bool VEC, int WM, int TMW, int TNW>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad2_kernel(Wgrad2Params p) {
+    constexpr int WN = NC / WM;
+    constexpr int BM = WM * TMW * 32;
+    static_assert(WN * TNW * 32 == BN, "column tile is 128");
+    constexpr int TILE = BM * BKP;                       // floats of the gy tile per stage; the source tile follows it
+    constexpr int STAGE = TILE + BN * BKP;
+    constexpr int A_INSTR = BM / 16;                     // 16-row gy wave-instructions per stage (8, 4, 2)
+    constexpr int A_PER = A_INSTR >= NL ? A_INSTR / NL : 1;   // BM = 32: loaders 2,3 re-load rows 0..31 (same data, same slots)
     constexpr int LOADS = A_PER + (VEC ? BV_PER : B_PER);
     constexpr int NROW = VEC ? BV_PER : B_PER;
     __shared__ __attribute__((aligned(16))) float smem[NBUF * STAGE];
@@ -82,7 +89,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // gy: instruction q covers rows 16q..16q+15 x 4 chunks; lane -> (row, stored chunk); swizzle key = (lane>>4)&3
         const int a_row = lane >> 2;
         const int a_pix = 4 * ((lane & 3) ^ ((lane >> 4) & 3));
-        const int a_m = m0 + (l * A_PER) * 16 + a_row;          // first instruction's channel; the next is +16
+        const int a_q0 = (l * A_PER) % A_INSTR;                 // this loader's first gy instruction
+        const int a_m = m0 + a_q0 * 16 + a_row;                 // its channel; the next instruction is +16
         // source: instruction q = l + 4i covers rows 4q..4q+3 x 16 pixels; swizzle key of all its rows = l
         const int b_pix = 4 * (((lane & 15) >> 2) ^ l) + (lane & 3);
         const float* rowp[NROW];
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const float* g = p.gy + ((size_t)n * p.K + a_m) * OHW + rem;                                         \
                 _Pragma("unroll") for (int q = 0; q < A_PER; ++q)                                                    \
                     glds_b128((pix < pend && a_m + 16 * q < p.K) ? g + (size_t)(16 * q) * OHW : wg_zero_page,        \
-                              sb + (l * A_PER + q) * 256);                                                           \
+                              sb + (a_q0 + q) * 256);                                                                \
             }                                                                                                        \
             if (VEC) {                                                                                               \
                 const int pix = pb + a_pix;                                                                          \
@@ -184,63 +192,71 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 
     // ================================ MFMA waves ================================
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int sw = (l31 >> 2) & 3;
-    const int arow0 = ((wm * 2 + 0) * 32 + l31) * BKP, arow1 = ((wm * 2 + 1) * 32 + l31) * BKP;
-    const int brow0 = TILE + ((wn * 2 + 0) * 32 + l31) * BKP, brow1 = TILE + ((wn * 2 + 1) * 32 + l31) * BKP;
+    const int arow = (wm * TMW * 32 + l31) * BKP;            // + i * 32 * BKP for MFMA row tile i
+    const int brow = TILE + (wn * TNW * 32 + l31) * BKP;     // + j * 32 * BKP for MFMA column tile j
     const int co0 = ((0 + lhi) ^ sw) << 2, co1 = ((2 + lhi) ^ sw) << 2;   // pixel groups 0 and 1 of a stage
     const bool do_bias = p.gb != nullptr && blockIdx.y == 0 && wn == 0;
     // VEC: horizontal tap offset of this lane's two source rows, and the x position of the current stage in its image row
-    int dxn0 = 0, dxn1 = 0, oxs = 0;
+    int dxn[TNW], oxs = 0;
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) dxn[j] = 0;
     const bool refl = p.border == BORDER_REFLECT;
     if (VEC) {
-        const int ja = j0 + (wn * 2 + 0) * 32 + l31, jb = ja + 32;
         const unsigned RS = (unsigned)(p.R * p.S);
-        const unsigned ta = (unsigned)ja - fd_div((unsigned)ja, p.fd_rs) * RS, tb = (unsigned)jb - fd_div((unsigned)jb, p.fd_rs) * RS;
-        dxn0 = (int)(ta - fd_div(ta, p.fd_s) * (unsigned)p.S) - p.pad;
-        dxn1 = (int)(tb - fd_div(tb, p.fd_s) * (unsigned)p.S) - p.pad;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const unsigned jj = (unsigned)(j0 + (wn * TNW + j) * 32 + l31);
+            const unsigned t = jj - fd_div(jj, p.fd_rs) * RS;
+            dxn[j] = (int)(t - fd_div(t, p.fd_s) * (unsigned)p.S) - p.pad;
+        }
         const unsigned rem = (unsigned)pbeg - fd_div((unsigned)pbeg, p.fd_ohw) * (unsigned)OHW;
         oxs = (int)(rem - fd_div(rem, p.fd_ow) * (unsigned)p.OW);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TMW][TNW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TNW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum0 = 0.f, bsum1 = 0.f;
-    f32x4 a0[2], b0[2], a1[2], b1[2];
+    float bsum[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) bsum[i] = 0.f;
+    f32x4 a0[TMW], b0[TNW], a1[TMW], b1[TNW];
 
-#define WG2_READ(buf_, co_, A_, B_)                                            \
-    {                                                                              \
-        const float* sb = smem + (buf_) * STAGE;                                   \
-        A_[0] = *reinterpret_cast<const f32x4*>(sb + arow0 + (co_));               \
-        A_[1] = *reinterpret_cast<const f32x4*>(sb + arow1 + (co_));               \
-        B_[0] = *reinterpret_cast<const f32x4*>(sb + brow0 + (co_));               \
-        B_[1] = *reinterpret_cast<const f32x4*>(sb + brow1 + (co_));               \
+#define WG2_READ(buf_, co_, A_, B_)                                                                            \
+    {                                                                                                              \
+        const float* sb = smem + (buf_) * STAGE;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                            \
+            A_[i] = *reinterpret_cast<const f32x4*>(sb + arow + i * 32 * BKP + (co_));                             \
+        _Pragma("unroll") for (int j = 0; j < TNW; ++j)                                                            \
+            B_[j] = *reinterpret_cast<const f32x4*>(sb + brow + j * 32 * BKP + (co_));                             \
     }
 #define WG2_MFMA(A_, B_, G_)                                                                                   \
     {                                                                                                              \
         if (VEC && (G_) == 0 && oxs == 0 && lhi == 0) {          /* first chunk of an image row: dx = -1 rows */    \
-            const f32x4 u = B_[0], v = B_[1];                                                                      \
-            if (dxn0 < 0) { B_[0][0] = refl ? u[1] : 0.f; B_[0][1] = u[0]; B_[0][2] = u[1]; B_[0][3] = u[2]; }     \
-            if (dxn1 < 0) { B_[1][0] = refl ? v[1] : 0.f; B_[1][1] = v[0]; B_[1][2] = v[1]; B_[1][3] = v[2]; }     \
+            _Pragma("unroll") for (int j = 0; j < TNW; ++j) {                                                      \
+                const f32x4 u = B_[j];                                                                             \
+                if (dxn[j] < 0) { B_[j][0] = refl ? u[1] : 0.f; B_[j][1] = u[0]; B_[j][2] = u[1]; B_[j][3] = u[2]; } \
+            }                                                                                                      \
         }                                                                                                          \
         if (VEC && (G_) == 1 && oxs == p.OW - BKP && lhi == 1) { /* last chunk of an image row: dx = +1 rows */    \
-            const f32x4 u = B_[0], v = B_[1];                                                                      \
-            if (dxn0 > 0) { B_[0][0] = u[1]; B_[0][1] = u[2]; B_[0][2] = u[3]; B_[0][3] = refl ? u[2] : 0.f; }     \
-            if (dxn1 > 0) { B_[1][0] = v[1]; B_[1][1] = v[2]; B_[1][2] = v[3]; B_[1][3] = refl ? v[2] : 0.f; }     \
+            _Pragma("unroll") for (int j = 0; j < TNW; ++j) {                                                      \
+                const f32x4 u = B_[j];                                                                             \
+                if (dxn[j] > 0) { B_[j][0] = u[1]; B_[j][1] = u[2]; B_[j][2] = u[3]; B_[j][3] = refl ? u[2] : 0.f; } \
+            }                                                                                                      \
         }                                                                                                          \
         if (do_bias) {                                                                                             \
-            bsum0 += (A_[0][0] + A_[0][1]) + (A_[0][2] + A_[0][3]);                                                \
-            bsum1 += (A_[1][0] + A_[1][1]) + (A_[1][2] + A_[1][3]);                                                \
+            _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                        \
+                bsum[i] += (A_[i][0] + A_[i][1]) + (A_[i][2] + A_[i][3]);                                          \
         }                                                                                                          \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                              \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+            _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                        \
+                _Pragma("unroll") for (int j = 0; j < TNW; ++j)                                                    \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[i][s], B_[j][s], acc[i][j], 0, 0, 0);      \
     }
 
@@ -266,34 +282,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     if (do_bias) {
         // lanes l and l+32 hold the two pixel-halves of channel row l31
-        bsum0 += __shfl_xor(bsum0, 32, 64);
-        bsum1 += __shfl_xor(bsum1, 32, 64);
-        if (lhi == 0) {
-            const int ma = m0 + (wm * 2 + 0) * 32 + l31, mb = ma + 32;
-            if (ma < p.K) atomicAdd(p.gb + ma, bsum0);
-            if (mb < p.K) atomicAdd(p.gb + mb, bsum1);
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int m = m0 + (wm * TMW + i) * 32 + l31;
+            if (lhi == 0 && m < p.K) atomicAdd(p.gb + m, v);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int jj = j0 + (wn * 2 + j) * 32 + l31;
+    for (int j = 0; j < TNW; ++j) {
+        const int jj = j0 + (wn * TNW + j) * 32 + l31;
         if (jj >= p.J) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int m = m0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.K) atomicAdd(p.gw + (size_t)m * p.J + jj, acc[i][j][r]);
             }
     }
 }
 
+template <int WM, int TMW, int TNW>
+void launch_wgrad2(const Wgrad2Params& p, bool vec, dim3 grid, hipStream_t st) {
+    if (vec) hipLaunchKernelGGL((wgrad2_kernel<true, WM, TMW, TNW>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((wgrad2_kernel<false, WM, TMW, TNW>), grid, dim3(NT), 0, st, p);
+}
+
 }  // namespace
 
-// Shapes this kernel takes: wide layers whose gy rows can be read in aligned 16-byte chunks that never straddle two
+// Shapes this kernel takes: layers whose gy rows can be read in aligned 16-byte chunks that never straddle two
 // images (OH*OW % 4 == 0).  Everything else stays on the VGPR-staged kernel in conv.hip.
 bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy) {
-    return K > 32 && (OH * OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0;
+    return K > 4 && (OH * OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0;
 }
 
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
@@ -306,10 +327,12 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
     p.P = N * OH * OW; p.sy = stride; p.sx = stride; p.R = R; p.S = S; p.pad = pad; p.border = pad_mode;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW);
     p.fd_rs = make_fastdiv(R * S); p.fd_s = make_fastdiv(S);
+    const int BM = K <= 32 ? 32 : K <= 64 ? 64 : 128;
     const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(p.J, BN);
     // Split the pixel reduction so that the grid is ONE full round of resident workgroups (2 per CU x 256 CUs): every
     // workgroup starts and ends together, so a grid of 1.1 or 2.04 rounds pays for 2 or 3.  target_blocks is that
     // capacity; the split count is rounded DOWN to fit it, with >= 8 stages per split.
+    if (BM < 128) target_blocks *= 2;   // the narrower tiles need half the LDS and registers: 4 workgroups per CU
     int splits = target_blocks / (mt * jt);
     const int max_splits = nemar_cdiv(p.P, BKP * 8);
     if (splits > max_splits) splits = max_splits;
@@ -319,6 +342,8 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
     splits = nemar_cdiv(p.P, p.pix_per_split);
     // 16-byte source loads: stride 1, image rows that are whole 16-pixel stages, horizontal tap offsets within +-1
     const bool vec = vec_ok && stride == 1 && OW % BKP == 0 && W == OW && pad <= 1 && S - 1 - pad <= 1;
-    if (vec) hipLaunchKernelGGL(wgrad2_kernel<true>, dim3(mt, jt, splits), dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL(wgrad2_kernel<false>, dim3(mt, jt, splits), dim3(NT), 0, st, p);
+    const dim3 grid(mt, jt, splits);
+    if (BM == 128) launch_wgrad2<2, 2, 2>(p, vec, grid, st);
+    else if (BM == 64) launch_wgrad2<2, 1, 2>(p, vec, grid, st);
+    else launch_wgrad2<1, 1, 1>(p, vec, grid, st);
 }

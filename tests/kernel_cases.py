@@ -203,6 +203,12 @@ WGRAD_WIDE_CASES = [
     (2, 8, 8, 3, 16, 48, 3, 1, 1, PAD_ZERO),         # two sources, H = 3
     (1, 16, 0, 4, 16, 40, 1, 1, 0, PAD_ZERO),        # 1x1: no border chunks at all
     (3, 20, 0, 5, 48, 70, 3, 1, 1, PAD_REFLECT),     # 3 stages per row, 2 column tiles, ragged K
+    # narrower channel tiles: K <= 32 -> 32-row tile (1x4 waves), K <= 64 -> 64-row tile
+    (2, 16, 0, 8, 8, 20, 3, 1, 1, PAD_REFLECT),
+    (2, 8, 0, 4, 16, 32, 3, 1, 1, PAD_ZERO),         # 32-row tile with 16-byte source loads
+    (1, 3, 3, 8, 8, 24, 3, 1, 1, PAD_ZERO),          # STN first conv: 3+3 channels -> J = 54
+    (2, 32, 0, 4, 16, 32, 1, 1, 0, PAD_ZERO),        # 1x1
+    (2, 24, 0, 6, 32, 64, 3, 1, 1, PAD_REFLECT),     # 64-row tile, vector loads, 2 column tiles
 ]
 
 
