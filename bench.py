@@ -190,7 +190,7 @@ def main():
                            "frac": flop / sec / 1e12 / FP32_MFMA_PEAK_TF,
                            "traffic": pmc.get("igemm_fwd_resblock", {}).get("traffic_bytes") if std else None,
                            "traffic_source": PMC_FILE if std and pmc else None,
-                           "kernel": "igemm_ws_kernel (conv2d_fwd 256->256 k3 reflect @%dx%d, batch %d)"
+                           "kernel": "igemm_ws2_kernel<4,true> (conv2d_fwd 256->256 k3 reflect @%dx%d, batch %d)"
                                      % (a.size // 4, a.size // 4, a.batch),
                            "launches_timed": n, "avg_launch_us": sec * 1e6,
                            "algorithmic_flop_per_launch": flop}

@@ -34,7 +34,7 @@ int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C,
 bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy);
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
-                         int target_blocks, bool vec_ok, hipStream_t st);
+                         int target_blocks, bool vec_ok, int dbg, hipStream_t st);
 
 namespace {
 
@@ -538,6 +538,8 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
     const int m0 = blockIdx.y * BM, p0 = blockIdx.x * BN;
     const int Cs = p.C0 + p.C1, HW = p.Hs * p.Ws;
     const int nk = (p.Kred + BK - 1) / BK;
+    // experiment: workgroups 256 apart in dispatch order share a CU; start every other one half a barrier period late
+    if ((p.dbg & 256) && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1)) __builtin_amdgcn_s_sleep(15);
 
     if (wid >= MT) {
         // ================================ loader waves ================================
@@ -615,6 +617,7 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
     }
 
     // ================================ MFMA waves ================================
+    if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);           // experiment: issue priority over the loader waves
     const int l31 = lane & 31, lhi = lane >> 5;
     const int a_off = (lhi * BM + wid * 32 + l31) * 4;        // + kg * 2*BM*4 floats for the second 8-row group
     const int b_off = lhi * LDB + 4 * l31;                    // + (8*kg + 2*s) * LDB
@@ -1255,7 +1258,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     }
     if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
         nemar_wgrad2_launch(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
-                            g_wgrad != 2, st);
+                            g_wgrad != 2, g_dbg, st);
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide)");
         return NEMAR_OK;
     }

@@ -51,6 +51,7 @@ struct Wgrad2Params {
     float* gb;
     int P, sy, sx, R, S, pad, border;
     int pix_per_split;
+    int dbg;
     FastDiv fd_ohw, fd_ow, fd_rs, fd_s;
 };
 
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int nk = (pend - pbeg + BKP - 1) / BKP;
     if (nk <= 0) return;
     const int OHW = p.OH * p.OW, HW = p.Hs * p.Ws;
+    if ((p.dbg & 256) && (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1))
+        __builtin_amdgcn_s_sleep(15);   // experiment: de-phase the two workgroups of a CU
 
     if (wid >= NC) {
         // ================================ loader waves ================================
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 
     // ================================ MFMA waves ================================
+    if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);           // experiment: issue priority over the loader waves
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int sw = (l31 >> 2) & 3;
@@ -319,8 +323,9 @@ bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy) {
 
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
-                         int target_blocks, bool vec_ok, hipStream_t st) {
+                         int target_blocks, bool vec_ok, int dbg, hipStream_t st) {
     Wgrad2Params p;
+    p.dbg = dbg;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
     p.gw = gw; p.J = (C0 + C1) * R * S; p.gb = gb;

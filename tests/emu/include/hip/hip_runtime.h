@@ -154,6 +154,7 @@ static inline void __builtin_amdgcn_s_waitcnt(int) {}
 // ---- scalar/uniform builtins ------------------------------------------------------------------
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { emu_sync_block(); }
 
