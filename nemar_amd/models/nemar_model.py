@@ -13,6 +13,7 @@ executes:
     backward_T_and_R.
 """
 import itertools
+import os
 
 import torch
 
@@ -82,6 +83,10 @@ class NEMARModel(BaseModel):
         if self.isTrain and getattr(opt, 'enable_tbvis', False):
             print('TensorBoard visualisation is outside the MI355X hot path (SURVEY.md §2): --enable_tbvis ignored')
         self.tb_visualizer = None
+        # NEMAR_BATCHED_PASSES=1: T's two applications and D's 3 + 2 applications per step run as single batches (valid
+        # without cross-sample ops, i.e. not with BatchNorm).  Measured on MI355X, config 2: 78.15 vs 78.00 ms/step —
+        # no gain (every layer already fills the chip at batch 8), so the reference's call order stays the default.
+        self._batched = opt.norm != 'batch' and os.environ.get('NEMAR_BATCHED_PASSES', '0') == '1'
         self.define_networks()
         if self.isTrain:
             self.criterionGAN = networks.GANLoss(opt.gan_mode)
@@ -142,12 +147,26 @@ class NEMARModel(BaseModel):
 
     # ---- forward -------------------------------------------------------------------------------------------
     def forward(self):
-        self.fake_B = self.netT(self.real_A)
-        warped, reg_term = self.netR(self.real_A, self.real_B, apply_on=[self.real_A, self.fake_B])
-        self.stn_reg_term = reg_term
-        self.registered_real_A = warped[0]
-        self.fake_TR_B = self.netT(self.registered_real_A)     # registration first, then translation
-        self.fake_RT_B = warped[1]                             # translation first, then registration
+        if not self._batched:
+            # the reference's own order (models/nemar_model.py:161-176)
+            self.fake_B = self.netT(self.real_A)
+            warped, reg_term = self.netR(self.real_A, self.real_B, apply_on=[self.real_A, self.fake_B])
+            self.stn_reg_term = reg_term
+            self.registered_real_A = warped[0]
+            self.fake_TR_B = self.netT(self.registered_real_A)     # registration first, then translation
+            self.fake_RT_B = warped[1]                             # translation first, then registration
+        else:
+            # Same graph, evaluated with T's two applications as ONE batch: the deformation depends on (a, b) only, so
+            # R(a) is available before T runs, and T (per-sample InstanceNorm, no cross-sample op) maps [a ; R(a)] to
+            # [T(a) ; T(R(a))].  Every T layer then launches once on 2x the pixels (full second round of workgroups,
+            # one weight-gradient reduction instead of two).
+            n = self.real_A.size(0)
+            field = self.netR.predict(self.real_A, self.real_B)
+            self.registered_real_A = self.netR.warp(field, [self.real_A])[0]
+            both = self.netT(torch.cat([self.real_A, self.registered_real_A], 0))
+            self.fake_B, self.fake_TR_B = both[:n], both[n:]
+            self.fake_RT_B = self.netR.warp(field, [self.fake_B])[0]
+            self.stn_reg_term = self.netR.regularization(field, self.registered_real_A)
         self._resized = {}
 
     def _half(self, name, tensor, level):
@@ -160,6 +179,22 @@ class NEMARModel(BaseModel):
         if key not in self._resized:
             self._resized[key] = ops.resize_bilinear(tensor, sh, sw)
         return self._resized[key]
+
+    def _d_terms_batched(self, specs):
+        """_d_terms for several (image, image_name, target_is_real, weight, detach) at once: the discriminators see the
+        images as one batch (no cross-sample op in D), the loss terms are taken on the per-image slices."""
+        k, n = len(specs), self.real_A.size(0)
+        imgs = [(im.detach() if det else im) for (im, _, _, _, det) in specs]
+        a_rep = torch.cat([self.real_A] * k, 0)
+        out = self.netD(a_rep, torch.cat(imgs, 0))
+        terms = [[self.criterionGAN(out[i * n:(i + 1) * n], tr, w)] for i, (_, _, tr, w, _) in enumerate(specs)]
+        for lvl, netD_S in enumerate(self.netD_multiresolution):
+            a_r = self._half('real_A', self.real_A, lvl + 1)
+            img_r = [self._half(name if det else None, im, lvl + 1) for im, (_, name, _, _, det) in zip(imgs, specs)]
+            out = netD_S(torch.cat([a_r] * k, 0), torch.cat(img_r, 0))
+            for i, (_, _, tr, w, _) in enumerate(specs):
+                terms[i].append(self.criterionGAN(out[i * n:(i + 1) * n], tr, w))
+        return terms
 
     def _d_terms(self, image, image_name, target_is_real, weight, detach):
         """[weight * GANLoss(D_i(real_A_i, image_i), target)] over the full-resolution discriminator and every
@@ -175,9 +210,14 @@ class NEMARModel(BaseModel):
     # ---- discriminator step ---------------------------------------------------------------------------------
     def backward_D(self):
         w = 0.5 * self.opt.lambda_GAN
-        real = self._d_terms(self.real_B, 'real_B', True, w, detach=True)
-        fake_tr = self._d_terms(self.fake_TR_B, 'fake_TR_B', False, w, detach=True)
-        fake_rt = self._d_terms(self.fake_RT_B, 'fake_RT_B', False, w, detach=True)
+        if self._batched:
+            real, fake_tr, fake_rt = self._d_terms_batched([(self.real_B, 'real_B', True, w, True),
+                                                            (self.fake_TR_B, 'fake_TR_B', False, w, True),
+                                                            (self.fake_RT_B, 'fake_RT_B', False, w, True)])
+        else:
+            real = self._d_terms(self.real_B, 'real_B', True, w, detach=True)
+            fake_tr = self._d_terms(self.fake_TR_B, 'fake_TR_B', False, w, detach=True)
+            fake_rt = self._d_terms(self.fake_RT_B, 'fake_RT_B', False, w, detach=True)
         inv = 1.0 / w if w != 0 else 0.0
         self.loss_D_fake_TR = _LazyLoss([(t, inv) for t in fake_tr])
         self.loss_D_fake_RT = _LazyLoss([(t, inv) for t in fake_rt])
@@ -190,9 +230,13 @@ class NEMARModel(BaseModel):
     def backward_T_and_R(self):
         opt = self.opt
         l1_tr = self.criterionL1(self.fake_TR_B, self.real_B, opt.lambda_recon)
-        gan_tr = self._d_terms(self.fake_TR_B, None, True, opt.lambda_GAN, detach=False)
         l1_rt = self.criterionL1(self.fake_RT_B, self.real_B, opt.lambda_recon)
-        gan_rt = self._d_terms(self.fake_RT_B, None, True, opt.lambda_GAN, detach=False)
+        if self._batched:
+            gan_tr, gan_rt = self._d_terms_batched([(self.fake_TR_B, None, True, opt.lambda_GAN, False),
+                                                    (self.fake_RT_B, None, True, opt.lambda_GAN, False)])
+        else:
+            gan_tr = self._d_terms(self.fake_TR_B, None, True, opt.lambda_GAN, detach=False)
+            gan_rt = self._d_terms(self.fake_RT_B, None, True, opt.lambda_GAN, detach=False)
         self.loss_L1_TR = _LazyLoss([(l1_tr, 1.0)])
         self.loss_GAN_TR = _LazyLoss([(t, 1.0) for t in gan_tr])
         self.loss_L1_RT = _LazyLoss([(l1_rt, 1.0)])

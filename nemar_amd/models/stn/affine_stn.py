@@ -70,13 +70,20 @@ class AffineSTN(nn.Module):
         theta = self._get_theta(img_a, img_b)
         return F.affine_grid(theta.view(-1, 2, 3), img_a.size(), align_corners=False)
 
+    # predict -> warp* -> regularization: same split as UnetSTN (see there)
+    def predict(self, img_a, img_b):
+        return self.net(img_a, img_b)
+
+    def warp(self, field, imgs):
+        return ops.warp_affine(field, list(imgs))
+
+    def regularization(self, field, warped_first=None):
+        return self._calculate_regularization_term(field)
+
     def forward(self, img_a, img_b, apply_on=None):
-        dtheta = self.net(img_a, img_b)
-        if apply_on is None:
-            apply_on = [img_a]
-        warped = ops.warp_affine(dtheta, list(apply_on))
-        reg = self._calculate_regularization_term(dtheta)
-        return warped, reg
+        field = self.predict(img_a, img_b)
+        warped = self.warp(field, [img_a] if apply_on is None else apply_on)
+        return warped, self.regularization(field, warped[0])
 
     def _calculate_regularization_term(self, theta):
         """mean|dtheta| (reference :136-138)."""

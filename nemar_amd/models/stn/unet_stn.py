@@ -123,14 +123,22 @@ class UnetSTN(nn.Module):
         ident = torch.stack([x[None, :].expand(self.oh, self.ow), y[:, None].expand(self.oh, self.ow)], 0)
         return (ident[None] + d).permute(0, 2, 3, 1)
 
+    # The forward pass in three pieces, so that a caller can evaluate the deformation once and warp several tensors at
+    # different points of its own graph (NEMARModel runs T on [a, R(a)] as one batch): predict -> warp* -> regularization
+    def predict(self, img_a, img_b):
+        return self._deformation(img_a, img_b)
+
+    def warp(self, field, imgs):
+        return ops.warp_unet(field[1], list(imgs))
+
+    def regularization(self, field, warped_first):
+        return self._calculate_regularization_term(field[0], warped_first)
+
     def forward(self, img_a, img_b, apply_on=None):
         """-> (list of warped tensors in `apply_on` order (default [img_a]), regularisation term)."""
-        deformation, d_up = self._deformation(img_a, img_b)
-        if apply_on is None:
-            apply_on = [img_a]
-        warped = ops.warp_unet(d_up, list(apply_on))
-        reg = self._calculate_regularization_term(deformation, warped[0])
-        return warped, reg
+        field = self.predict(img_a, img_b)
+        warped = self.warp(field, [img_a] if apply_on is None else apply_on)
+        return warped, self.regularization(field, warped[0])
 
     def _calculate_regularization_term(self, deformation, img):
         """sum_i 2^-i * smoothness(resize(d, /2^i), resize(img.detach(), /2^i), alpha) — reference :179-201."""

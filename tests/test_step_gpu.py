@@ -13,3 +13,38 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", list(STEP_CONFIGS))
 def test_step_parity(name):
     step_parity.run(name, check=True)
+
+
+@pytest.mark.parametrize("name", ["affine128", "unet256"])
+def test_batched_passes_match_reference_call_order(name, monkeypatch):
+    """T([a ; R(a)]) / D([real ; fake_TR ; fake_RT]) as single batches (NEMAR_BATCHED_PASSES=1) against the reference's
+    separate calls (the default): same losses, same gradients up to fp32 summation order."""
+    import torch
+    import seeded
+    cfg = STEP_CONFIGS[name]
+    results = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("NEMAR_BATCHED_PASSES", flag)
+        m = step_parity.build_hip_model(name)
+        assert m._batched == (flag == "1")
+        a, b = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+        m.set_input({'A': torch.from_numpy(a), 'B': torch.from_numpy(b), 'A_paths': [''], 'B_paths': ['']})
+        m.forward()
+        m.set_requires_grad([m.netT, m.netR], False)
+        m.optimizer_D.zero_grad()
+        m.backward_D()
+        gd = m.optimizer_D.flat_g.detach().cpu().clone()
+        m.set_requires_grad([m.netT, m.netR], True)
+        m.set_requires_grad([m.netD, *m.netD_multiresolution], False)
+        m.optimizer_R.zero_grad(); m.optimizer_T.zero_grad()
+        m.backward_T_and_R()
+        results.append(dict(losses=m.get_current_losses(), gd=gd, gt=m.optimizer_T.flat_g.detach().cpu().clone(),
+                            gr=m.optimizer_R.flat_g.detach().cpu().clone(), tr=m.fake_TR_B.detach().cpu().clone(),
+                            rt=m.fake_RT_B.detach().cpu().clone()))
+    x, y = results
+    for k in x['losses']:
+        assert abs(x['losses'][k] - y['losses'][k]) <= 2e-5 * max(1.0, abs(y['losses'][k])), (k, x['losses'][k], y['losses'][k])
+    assert (x['tr'] - y['tr']).abs().max() < 1e-5 and (x['rt'] - y['rt']).abs().max() < 1e-5
+    for g in ('gd', 'gt', 'gr'):
+        scale = y[g].abs().max().item()
+        assert (x[g] - y[g]).abs().max().item() <= 2e-3 * scale, (g, (x[g] - y[g]).abs().max().item(), scale)
