@@ -267,23 +267,66 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int nk_per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
     const int ks0 = blockIdx.z * nk_per, nk = min(nk_all, ks0 + nk_per);
     if (ks0 >= nk) return;
-    // NBUF-deep LDS ring: stages ks+1 .. ks+NBUF-2 stay in flight while stage ks is consumed (counted s_waitcnt vmcnt);
-    // NBUF = 2 is plain double buffering.  One barrier per stage: it publishes stage ks and retires buffer (ks-1) % NBUF.
+    // Ring mode: most (tile, tap) pairs have no source texel in range (a top-band ring pixel is reached by the r = 0 taps
+    // only), i.e. an all-zero B tile.  The workgroup collects the set of taps that reach ANY of its pixels and skips the
+    // stages of the others (~2/3 of them for a 3x3 layer).
+    unsigned long long amask = ~0ull;
+    if (p.ring_p) {
+        unsigned lo = 0, hi = 0;
+        for (int t = 0; t < p.taps.n; ++t) {
+            const int tp = s_tap[t];
+            const int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);
+            const bool hit = pvalid && (p.border == BORDER_REFLECT ||
+                                        ((unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws));
+            if (__ballot(hit) != 0ull) { if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32); }
+        }
+        unsigned* const s_mask = reinterpret_cast<unsigned*>(s_tap + MAX_TAPS - 2);   // taps.n <= 49: last slots are free
+        if (tid == 0) { s_mask[0] = 0u; s_mask[1] = 0u; }
+        __syncthreads();
+        if (lane == 0) { atomicOr(&s_mask[0], lo); atomicOr(&s_mask[1], hi); }
+        __syncthreads();
+        amask = ((unsigned long long)s_mask[1] << 32) | s_mask[0];
+    }
+#define IGEMM_STAGE_ACTIVE(ks_)                                                                                   \
+    (amask == ~0ull ||                                                                                                \
+     ((amask >> fd_div((unsigned)((ks_) * BK), p.fd_cs)) &                                                            \
+      ((2ull << (fd_div((unsigned)min((ks_) * BK + BK - 1, p.Kred - 1), p.fd_cs) - fd_div((unsigned)((ks_) * BK), p.fd_cs))) - 1ull)) != 0ull)
+#define IGEMM_NEXT_ACTIVE(var_)  while ((var_) < nk && !IGEMM_STAGE_ACTIVE(var_)) ++(var_)
+    // NBUF-deep LDS ring: up to NBUF-2 further stages stay in flight while one is consumed (counted s_waitcnt vmcnt);
+    // NBUF = 2 is plain double buffering.  One barrier per stage: it publishes the stage and retires the buffer consumed
+    // before it.  `slot` counts consumed stages, `n_iss` issued ones (inactive stages take no slot).
+    int iss = ks0;
+    IGEMM_NEXT_ACTIVE(iss);
+    int first = iss, n_iss = 0;
 #pragma unroll
     for (int d = 0; d < NBUF - 1; ++d)
-        if (ks0 + d < nk) IGEMM_ISSUE_STAGE((ks0 + d) * BK, (ks0 + d) % NBUF);
-    for (int ks = ks0; ks < nk; ++ks) {
-        const int buf = ks % NBUF;
+        if (iss < nk) {
+            IGEMM_ISSUE_STAGE(iss * BK, n_iss % NBUF);
+            ++n_iss;
+            ++iss;
+            IGEMM_NEXT_ACTIVE(iss);
+        }
+    if (first >= nk && p.ring_p) return;          // nothing reaches this tile: it would add zeros
+    int slot = 0;
+    for (int ks = first; ks < nk; ++slot) {
+        const int buf = slot % NBUF;
         if (NBUF == 2) {
             wait_vmem();
         } else {
-            const int ahead = nk - 1 - ks;            // stages issued beyond ks (capped at NBUF-2)
+            const int ahead = n_iss - slot - 1;       // stages issued beyond this one
             if (ahead >= 2 && NBUF >= 4) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * LOADS) & 15) | (((2 * LOADS) >> 4) << 14));
             else if (ahead >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14));
             else wait_vmem();
         }
         if (!(p.dbg & 4)) __syncthreads();
-        if (ks + NBUF - 1 < nk && !(p.dbg & 1)) IGEMM_ISSUE_STAGE((ks + NBUF - 1) * BK, (ks + NBUF - 1) % NBUF);
+        if (iss < nk && !(p.dbg & 1)) {
+            IGEMM_ISSUE_STAGE(iss * BK, n_iss % NBUF);
+            ++n_iss;
+            ++iss;
+            IGEMM_NEXT_ACTIVE(iss);
+        }
+        ++ks;
+        IGEMM_NEXT_ACTIVE(ks);
         if (!(p.dbg & 2)) {
             // all MFMA operands of the stage into registers first (one LDS round trip per stage), then the MFMAs
             // back to back: reading fragments just-in-time makes hipcc reuse the operand registers, and the
@@ -314,6 +357,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         }
     }
 #undef IGEMM_ISSUE_STAGE
+#undef IGEMM_STAGE_ACTIVE
+#undef IGEMM_NEXT_ACTIVE
 
     // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
@@ -1004,6 +1049,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// w2[c][k][r][s] = w[k][c][R-1-r][S-1-s]: the data gradient of a stride-1 convolution is the correlation of gy with
+// these weights (and padding R-1-pad), which lets a layer with <= 4 INPUT channels use the narrow forward kernel
+__global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ w2, int K,
+                                                             int C, int R, int S) {
+    const int total = K * C * R * S;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int s = idx % S, r = (idx / S) % R, k = (idx / (S * R)) % K, c = idx / (S * R * K);
+        w2[idx] = w[(((size_t)k * C + c) * R + (R - 1 - r)) * S + (S - 1 - s)];
+    }
+}
+
 // gb[c] += sum_{n,hw} g[n,c,hw]; grid (C, N, chunks of the plane): tree per workgroup + one atomic
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, float* __restrict__ gb, int N, int C,
                                                         int HW, int chunk) {
@@ -1129,6 +1185,7 @@ NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int
     if (N <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
     size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
     if (pad_mode == BORDER_REFLECT && pad > 0 && stride > 1) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    if (C <= 4) fl += (size_t)C * K * R * S;   // flipped + transposed weights of the narrow path
     return sizeof(float) * fl;
 }
 
@@ -1202,7 +1259,19 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             }
             // A[(t*K + k)][c] = w[k][c + mskip][r][s]
             if (!prepacked) launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
-            launch_igemm(p, st);
+            // <= 4 input channels (the translation net's stem: 29 of 32 MFMA rows would be empty): the zero-padded
+            // data gradient is a <= 4-output-channel correlation of gy — the narrow VALU kernel's job
+            const bool narrow = g_narrow && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 && gx1 == nullptr &&
+                                R - 1 - pad >= 0 && nemar_narrow_eligible(C, 0, R, S, 1, N, H, W);
+            if (narrow) {
+                float* w2 = wsf + pack_stride * (size_t)(stride * stride) + (fold ? (size_t)N * C * Hd * Wd : 0);
+                if (!prepacked)
+                    hipLaunchKernelGGL(flip_transpose_kernel, dim3(nemar_stream_grid((long long)K * C * R * S, 256)),
+                                       dim3(256), 0, st, w, w2, K, C, R, S);
+                nemar_narrow_fwd(gy, w2, nullptr, gx0, N, K, OH, OW, C, R, R - 1 - pad, BORDER_ZERO, ACT_NONE, 0.f, st);
+            } else {
+                launch_igemm(p, st);
+            }
             if (ring) {
                 // same weights (stride 1: every tap, same order), taps re-based to padded coordinates
                 dgrad_taps(p.taps, R, S, 0, 1, 0, 0);

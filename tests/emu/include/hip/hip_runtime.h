@@ -103,6 +103,7 @@ static inline unsigned long long __ballot(int pred) {
     for (int i = 0; i < 64; ++i) if (all[i]) m |= (1ull << i);
     return m;
 }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 static inline int __all(int pred) { return __ballot(pred) == ~0ull; }
 static inline int __any(int pred) { return __ballot(pred) != 0ull; }
 

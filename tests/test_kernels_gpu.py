@@ -119,6 +119,15 @@ def test_conv_ws2_vector_loads(be, mt):
         be.lib.tune(7, 0)
 
 
+def test_conv_bwd_data_narrow_inputs(be):
+    """Data gradient of layers with <= 4 input channels: correlation of gy with flipped/transposed weights on the
+    narrow kernel (+ the border-ring launch for reflect padding)."""
+    K.case_conv_bwd_data(be, 2, 2, 0, 9, 10, 20, 3, 1, 1, K.PAD_ZERO)
+    K.case_conv_bwd_data(be, 2, 4, 0, 9, 10, 40, 4, 1, 1, K.PAD_ZERO)       # k4 p1: output one smaller, padding 2 in the gradient
+    K.case_conv_bwd_data(be, 1, 3, 0, 12, 11, 16, 7, 1, 3, K.PAD_REFLECT)   # T stem
+    K.case_conv_bwd_data(be, 1, 1, 0, 8, 8, 33, 3, 1, 0, K.PAD_ZERO)        # no padding: gradient padding R-1
+
+
 def test_conv_narrow_channel_split(be):
     """Narrow forward with few output tiles and no activation: channel ranges meet in y through atomics."""
     K.case_conv_fwd(be, 2, 40, 0, 9, 10, 1, 4, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)              # D logit conv, 3 ranges
