@@ -112,24 +112,27 @@ struct IgemmParams {
 
 // pixel index inside one image -> (oy, ox).  Ring mode enumerates, in padded coordinates of a (H+2p) x (W+2p) plane:
 // top band (p rows), bottom band (p rows), then for each image row the p left and p right columns.
+__device__ __forceinline__ void decode_ring(unsigned rp, unsigned H, unsigned W, unsigned rem, unsigned& oy, unsigned& ox) {
+    const unsigned Wp = W + 2 * rp, band = rp * Wp;
+    if (rem < 2 * band) {
+        const unsigned q = rem < band ? rem : rem - band;
+        const unsigned r = q / Wp;
+        oy = rem < band ? r : H + rp + r;
+        ox = q - r * Wp;
+    } else {
+        const unsigned q = rem - 2 * band;
+        const unsigned r = q / (2 * rp), e = q - r * (2 * rp);
+        oy = rp + r;
+        ox = e < rp ? e : W + e;
+    }
+}
 __device__ __forceinline__ void decode_pixel(const IgemmParams& p, unsigned rem, unsigned& oy, unsigned& ox) {
     if (p.ring_p == 0) {
         oy = fd_div(rem, p.fd_ow);
         ox = rem - oy * (unsigned)p.OW;
         return;
     }
-    const unsigned rp = (unsigned)p.ring_p, Wp = (unsigned)p.ring_W + 2 * rp, band = rp * Wp;
-    if (rem < 2 * band) {
-        const unsigned q = rem < band ? rem : rem - band;
-        const unsigned r = q / Wp;
-        oy = rem < band ? r : (unsigned)p.ring_H + rp + r;
-        ox = q - r * Wp;
-    } else {
-        const unsigned q = rem - 2 * band;
-        const unsigned r = q / (2 * rp), e = q - r * (2 * rp);
-        oy = rp + r;
-        ox = e < rp ? e : (unsigned)p.ring_W + e;
-    }
+    decode_ring((unsigned)p.ring_p, (unsigned)p.ring_H, (unsigned)p.ring_W, rem, oy, ox);
 }
 
 // WM x WN waves, each TM x TN MFMA tiles of 32x32 (workgroup = WM*WN*64 threads).  FAST: Cs % BK == 0 && C0 % BK == 0,
@@ -373,14 +376,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         decode_pixel(p, rem, oy, ox);
         if (p.ring_p) {
             if (p.dbg & 64) continue;
-            // gradient w.r.t. a reflect-padded border texel: add it to the texel it mirrors
-            const size_t tp = (size_t)reflect((int)oy - p.ring_p, p.ring_H) * p.ring_W + reflect((int)ox - p.ring_p, p.ring_W);
+            // ring results (and the partial sums of the reduction splits) meet in a compact [n][m][ring] scratch: lanes =
+            // consecutive ring positions, so the atomics are coalesced; ring_fold_kernel scatters them onto the image
+            const size_t rlen = (size_t)p.OH * p.OW;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (m < p.M) atomicAdd(p.dst0 + ((size_t)n * p.M + m) * oplane + tp, acc[i][j][r]);
+                    if (m < p.M) atomicAdd(p.dst0 + ((size_t)n * p.M + m) * rlen + rem, acc[i][j][r]);
                 }
             continue;
         }
@@ -1049,6 +1053,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// gx[n,c, mirror(ring position)] += ring[n,c,q]: scatters the compact ring gradient onto the texels the reflect padding copied
+__global__ __launch_bounds__(256) void ring_fold_kernel(const float* __restrict__ ring, float* __restrict__ gx, int H, int W,
+                                                        int pad, int ring_len, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long nc = idx / ring_len;
+        const unsigned q = (unsigned)(idx - nc * ring_len);
+        unsigned py, px;
+        decode_ring((unsigned)pad, (unsigned)H, (unsigned)W, q, py, px);
+        const int ty = reflect((int)py - pad, H), tx = reflect((int)px - pad, W);
+        atomicAdd(gx + nc * (long long)H * W + (long long)ty * W + tx, ring[idx]);
+    }
+}
+
 // w2[c][k][r][s] = w[k][c][R-1-r][S-1-s]: the data gradient of a stride-1 convolution is the correlation of gy with
 // these weights (and padding R-1-pad), which lets a layer with <= 4 INPUT channels use the narrow forward kernel
 __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ w2, int K,
@@ -1186,6 +1204,8 @@ NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int
     size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
     if (pad_mode == BORDER_REFLECT && pad > 0 && stride > 1) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
     if (C <= 4) fl += (size_t)C * K * R * S;   // flipped + transposed weights of the narrow path
+    if (pad_mode == BORDER_REFLECT && pad > 0 && stride == 1)   // compact border-ring gradient
+        fl += (size_t)N * C * (2 * pad * (W + 2 * pad) + 2 * pad * H);
     return sizeof(float) * fl;
 }
 
@@ -1289,8 +1309,13 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 }
                 p.OH = 1; p.OW = ring_len; p.P = N * ring_len;
                 p.fd_ohw = make_fastdiv(ring_len); p.fd_ow = make_fastdiv(ring_len);
-                p.dst0 = gx0 ? gx0 : gx1; p.dst1 = nullptr; p.M0 = Mc;
+                float* ring_buf = wsf + pack_stride * (size_t)(stride * stride) + (C <= 4 ? (size_t)C * K * R * S : 0);
+                const long long ring_total = (long long)N * Mc * ring_len;
+                (void)hipMemsetAsync(ring_buf, 0, sizeof(float) * (size_t)ring_total, st);
+                p.dst0 = ring_buf; p.dst1 = nullptr; p.M0 = Mc;
                 launch_igemm(p, st);
+                hipLaunchKernelGGL(ring_fold_kernel, dim3(nemar_stream_grid(ring_total, 256)), dim3(256), 0, st,
+                                   (const float*)ring_buf, gx0 ? gx0 : gx1, H, W, pad, ring_len, ring_total);
             }
         }
     if (fold) {
