@@ -210,7 +210,8 @@ def main():
                                        if std and pmc else None,
                                        "kernels": gs}
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        with contextlib.redirect_stdout(sys.stderr):     # the net constructors print; stdout carries the JSON line only
+            out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
 
 
