@@ -104,6 +104,8 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (weak scaling)')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--opt', action='append', default=[], metavar='FLAG',
+                    help='extra reference-style option for other BASELINE configs, e.g. --opt=--multi_resolution --opt=2')
     a = ap.parse_args()
 
     from nemar_amd import distributed as dist
@@ -115,7 +117,7 @@ def main():
 
     from nemar_amd import ops
     from nemar_amd.models import create_model
-    opt = build_opt(a.batch, a.size)
+    opt = build_opt(a.batch, a.size, a.opt)
     opt.gpu_ids = [local]
     torch.manual_seed(0)                      # identical initial weights on every rank (also broadcast at setup)
     ops.manual_seed(1234 + rank)              # dropout stream per rank
@@ -168,7 +170,8 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic U[-1,1) A/B pairs resident in HBM; reference-equivalent random init",
         "config": {"workload": "BASELINE configs[1]: --stn_type unet --stn_cfg A, resnet_9blocks T, basic PatchGAN D, "
-                               "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32" % (a.size, a.size, a.batch),
+                               "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32%s"
+                               % (a.size, a.size, a.batch, (" + " + " ".join(a.opt)) if a.opt else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"},
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
