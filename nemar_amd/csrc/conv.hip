@@ -563,7 +563,6 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 //   * fragments of the next 8 reduction rows are prefetched into a second register set before the 16 MFMAs of the
 //     current 8 rows are issued; the stage barrier sits between the two halves of a stage, when the reads of the current
 //     buffer have all been issued, so neither LDS latency nor the barrier idles the matrix pipe.
-constexpr int W2_NBUF = 3;
 // MT = MFMA waves = 32-channel row tiles (BM = 32*MT: 128 / 64 / 32 output channels per workgroup).
 // VEC = the B tile is staged with 16-byte global->LDS loads: lane = 4 consecutive output pixels of one reduction row
 // (stride-1 layers with OW % 4 == 0 and |dx| <= 1: the four source texels are consecutive in memory, at an address that
@@ -571,8 +570,11 @@ constexpr int W2_NBUF = 3;
 // source row by one texel is loaded from the clamped address instead, and the MFMA wave that consumes it rotates the
 // three good texels into place and inserts the mirrored texel (reflect) or 0 (zero padding) — a handful of
 // v_cndmask per stage on the two border lanes of a row.  8 wave-instructions per stage instead of 32.
-template <int MT, bool VEC>
+// SPB = stages per barrier.  1: 3-deep stage ring, one workgroup barrier per 16 reduction rows.  2: 4 stage slots used as
+// two 32-row halves — the loaders fill one half while the MFMA waves consume the other, one barrier per 32 rows.
+template <int MT, bool VEC, int SPB = 1>
 __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p) {
+    constexpr int W2_NBUF = SPB == 1 ? 3 : 4;
     constexpr int BM = 32 * MT, BN = 128, LDB = VEC ? BN : BN + 4;
     constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
     constexpr int A_PER_LOADER = BK * BM / 256 / 2;          // 1 KiB wave-instructions of A per loader per stage (MT)
@@ -615,35 +617,74 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
             wsrc[q] = p.wp + ((size_t)blk * p.Mpad + m0 + m) * 4;
             a_lds[q] = inst * 256;
         }
-#define WS2_ISSUE(ks_)                                                                                               \
+        // The loader is a state machine over consecutive stages: everything that repeats is a pointer bump.  (Per-stage
+        // tap-table lookups in the kernel arguments, divisions and border arithmetic between the loads made the loader
+        // the last wave at the stage barrier: two extra scalar branches in this loop cost the whole kernel 7 %.)
+        int a_buf = 0;                                        // LDS ring slot of the next stage
+        int tap_t = 0, ch0 = 0;                               // tap / channel offset of the next stage
+        const float* cp = s0n;                                // source plane of channel ch0 (+ this lane's row offset)
+        int sp_off = 0;                                       // y * Ws + x of this lane for the current tap
+        bool inb = false;
+        int ndy = p.taps.dy[0], ndx = p.taps.dx[0];           // offsets of the tap about to start (pre-loaded a tap ahead)
+#define WS2_ENTER_TAP()                                                                                              \
         {                                                                                                            \
-            const int k0 = (ks_) * BK, buf = (ks_) % W2_NBUF;                                                        \
-            _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q)                                                 \
-                if (!(p.dbg & 32)) glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + buf * A_FLOATS + a_lds[q]);        \
-            const unsigned t = fd_div((unsigned)k0, p.fd_cs);                                                        \
-            const int ch0 = k0 - (int)t * Cs;                                                                        \
-            int y = by + p.taps.dy[t], x = bx + p.taps.dx[t];                                                        \
-            bool inb = pvalid;                                                                                       \
+            int y = by + ndy, x = bx + ndx;                                                                          \
+            inb = pvalid;                                                                                            \
             if (p.border == BORDER_REFLECT) y = reflect(y, p.Hs);                                                    \
             else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                          \
             if (VEC) x = min(max(x, 0), p.Ws - 4);                                                                   \
             else if (p.border == BORDER_REFLECT) x = reflect(x, p.Ws);                                               \
             else inb = inb && (unsigned)x < (unsigned)p.Ws;                                                          \
-            const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;             \
-            base += inb ? y * p.Ws + x : 0;                                                                          \
+            sp_off = inb ? y * p.Ws + x : 0;                                                                         \
+            const int tn = min(tap_t + 1, p.taps.n - 1);                                                             \
+            ndy = p.taps.dy[tn];                                                                                     \
+            ndx = p.taps.dx[tn];                                                                                     \
+        }
+        WS2_ENTER_TAP();
+#define WS2_ISSUE_NEXT()                                                                                             \
+        {                                                                                                            \
+            _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q) {                                               \
+                glds_b128(wsrc[q], As0 + a_buf * A_FLOATS + a_lds[q]);                                               \
+                wsrc[q] += (size_t)BK * p.Mpad;                                                                      \
+            }                                                                                                        \
+            const float* base = cp + sp_off;                                                                         \
             if (VEC) {                                                                                               \
                 _Pragma("unroll") for (int i = 0; i < B_PER_LOADER; ++i)                                             \
-                    if (!(p.dbg & 16) || i == 0)                                                                     \
-                        glds_b128(inb ? base + (size_t)(2 * i) * HW : p.zero,                                        \
-                                  Bs0 + buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256);                            \
+                    glds_b128(inb ? base + (size_t)(2 * i) * HW : p.zero,                                            \
+                              Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256);                              \
             } else {                                                                                                 \
                 _Pragma("unroll") for (int r = 0; r < BK; ++r)                                                       \
-                    if (!(p.dbg & 16) || (r & 3) == 0)                                                               \
-                        glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + buf * B_FLOATS + r * LDB + ldr * 64);   \
+                    glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + a_buf * B_FLOATS + r * LDB + ldr * 64);     \
+            }                                                                                                        \
+            a_buf = a_buf + 1 == W2_NBUF ? 0 : a_buf + 1;                                                            \
+            ch0 += BK;                                                                                               \
+            cp += (size_t)BK * HW;                                                                                   \
+            if (ch0 == p.C0 && p.C1) cp = s1n;                                                                       \
+            if (ch0 == Cs) {                                                                                         \
+                ch0 = 0;                                                                                             \
+                cp = s0n;                                                                                            \
+                ++tap_t;                                                                                             \
+                WS2_ENTER_TAP();                                                                                     \
             }                                                                                                        \
         }
+#define WS2_ISSUE(ks_) WS2_ISSUE_NEXT()     /* stages are issued strictly in order */
 #define WS2_WAIT_ONE_IN_FLIGHT() \
         __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS_PER_STAGE & 15) | ((LOADS_PER_STAGE >> 4) << 14))
+        if (SPB == 2) {
+            WS2_ISSUE(0);
+            if (nk > 1) WS2_ISSUE(1);
+            wait_vmem();
+            __builtin_amdgcn_s_barrier();             // stages 0, 1 are in LDS
+            if (nk > 2) WS2_ISSUE(2);
+            if (nk > 3) WS2_ISSUE(3);
+            for (int S = 0; 2 * S < nk; ++S) {
+                wait_vmem();                          // stages 2S+2, 2S+3 have landed (a whole 32-row half to do so)
+                __builtin_amdgcn_s_barrier();         // and every MFMA wave has finished reading stages 2S, 2S+1
+                if (2 * S + 4 < nk) WS2_ISSUE(2 * S + 4);
+                if (2 * S + 5 < nk) WS2_ISSUE(2 * S + 5);
+            }
+            return;
+        }
         WS2_ISSUE(0);
         if (nk > 1) {
             WS2_ISSUE(1);
@@ -661,6 +702,8 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
             if (ks + 3 < nk) WS2_ISSUE(ks + 3);
         }
 #undef WS2_ISSUE
+#undef WS2_ISSUE_NEXT
+#undef WS2_ENTER_TAP
 #undef WS2_WAIT_ONE_IN_FLIGHT
         return;
     }
@@ -681,6 +724,13 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
         last_grp = (int)gox == p.OW - 4;
     }
     const bool refl = p.border == BORDER_REFLECT;
+    // sign of every tap's dx, 2 bits per tap (<= 32 taps on the VEC path: |dx| <= 1 means at most a 3x3 footprint... any
+    // tap count up to 32 is representable); current tap / channel offset advance with the stages
+    unsigned long long dxbits = 0ull;
+    int tap_i = 0, tap_ch = 0;
+    if (VEC)
+        for (int t = 0; t < p.taps.n && t < 32; ++t)
+            dxbits |= (unsigned long long)(p.taps.dx[t] < 0 ? 1u : p.taps.dx[t] > 0 ? 2u : 0u) << (2 * t);
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -719,27 +769,98 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
             _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[s], B_[s][t], acc[t], 0, 0, 0);               \
     }
+    // timeline probe (nemar_tune_ptr): s_memtime stamps of stages 40..43 of every MFMA wave of workgroup (0,0), kept in
+    // scalar registers and written once at the end: 6 stamps per stage = loop top | reads issued | MFMA block 1 issued |
+    // lgkmcnt(0) | barrier passed | MFMA block 2 issued
+    long long ts[4][6];
+    const bool probe = p.tl != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+#define WS2_STAMP(i_)                                                     \
+    if (probe && ks >= 40 && ks < 44) {                                       \
+        const long long c_ = clock64();                                       \
+        if (ks == 40) ts[0][i_] = c_; else if (ks == 41) ts[1][i_] = c_;      \
+        else if (ks == 42) ts[2][i_] = c_; else ts[3][i_] = c_;               \
+    }
+    if (SPB == 2) {
+        bool fix_l = false, fix_r = false;
+#define WS2_STAGE_FLAGS()                                                       \
+        {                                                                       \
+            const unsigned dc_ = VEC ? (unsigned)(dxbits >> (2 * tap_i)) & 3u : 0u; \
+            fix_l = dc_ == 1u;                                                  \
+            fix_r = dc_ == 2u;                                                  \
+            if (VEC) {                                                          \
+                tap_ch += BK;                                                   \
+                if (tap_ch >= Cs) { tap_ch -= Cs; ++tap_i; }                    \
+            }                                                                   \
+        }
+        __builtin_amdgcn_s_barrier();                 // stages 0, 1 are in LDS
+        WS2_READ(0, 0, a0, b0);
+        for (int s0 = 0; s0 < nk; s0 += 2) {
+            const int slot0 = s0 & 3, slot1 = (s0 + 1) & 3;
+            const bool has1 = s0 + 1 < nk;
+            WS2_STAGE_FLAGS();                        // border flags of stage s0
+            WS2_READ(slot0, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            WS2_MFMA(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) {
+                WS2_READ(slot1, 0, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                WS2_MFMA(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                WS2_STAGE_FLAGS();                    // border flags of stage s0 + 1
+                WS2_READ(slot1, 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                WS2_MFMA(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): this wave is done reading both stages of the half
+            __builtin_amdgcn_s_barrier();             // the next half has landed; this one goes back to the loaders
+            if (s0 + 2 < nk) WS2_READ((s0 + 2) & 3, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            WS2_MFMA(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WS2_STAGE_FLAGS
+    } else {
     __builtin_amdgcn_s_barrier();                     // stage 0 is in LDS
     WS2_READ(0, 0, a0, b0);
     int buf = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        // the tap of this stage decides which border groups need patching (wave-uniform)
-        const int dxs = VEC ? (int)p.taps.dx[fd_div((unsigned)(ks * BK), p.fd_cs)] : 0;
-        const bool fix_l = dxs < 0, fix_r = dxs > 0;
+        // the tap of this stage decides which border groups need patching (wave-uniform, from registers: a table
+        // lookup in the kernel arguments here costs a scalar-memory round trip per stage)
+        const unsigned dcode = VEC ? (unsigned)(dxbits >> (2 * tap_i)) & 3u : 0u;
+        const bool fix_l = dcode == 1u, fix_r = dcode == 2u;
+        if (VEC) {
+            tap_ch += BK;
+            if (tap_ch >= Cs) { tap_ch -= Cs; ++tap_i; }
+        }
+        WS2_STAMP(0)
         WS2_READ(buf, 1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        WS2_STAMP(1)
         WS2_MFMA(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
+        WS2_STAMP(2)
         __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): this wave is done reading buffer `buf`
+        WS2_STAMP(3)
         __builtin_amdgcn_s_barrier();                 // stage ks+1 has landed; buffer `buf` goes back to the loaders
+        WS2_STAMP(4)
         buf = buf + 1 == W2_NBUF ? 0 : buf + 1;
         if (ks + 1 < nk) WS2_READ(buf, 0, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         WS2_MFMA(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        WS2_STAMP(5)
     }
+    }   // SPB == 1
 #undef WS2_READ
 #undef WS2_MFMA
+#undef WS2_STAMP
+    if (SPB == 1 && probe && lane == 0 && nk >= 44) {
+        long long* o = p.tl + wid * 24;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 6; ++j) o[i * 6 + j] = ts[i][j];
+    }
 
     // ---- epilogue: lane owns pixels p0 + 4*l31 + {0..3} (tile t -> pixel t) of 16 channel rows ---------------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
@@ -850,14 +971,17 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         t.bm = p.M > 32 ? 64 : 32;
         t.bn = p.M > 32 ? 64 : 128;
     }
-    if (fast && !p.ring_p && (g_cfg128 == 0 || g_cfg128 == 5) && (t.bm == 128 || g_ws2_mt)) {
+    if (fast && !p.ring_p && (g_cfg128 == 0 || g_cfg128 == 5 || g_cfg128 == 6) && (t.bm == 128 || g_ws2_mt)) {
         // wave-specialised kernel: 128 pixels x 32*MT channels.  Measured: MT = 4 beats every generic configuration on
         // layers big enough for 128x128 tiles; MT = 1, 2 (fewer MFMAs per staged B tile) lose to the generic 64x64 /
         // 32x256 kernels and are only reachable through the tuning switch.
         int mt = g_ws2_mt ? g_ws2_mt : 4;
-        bool vec = g_cfg128 == 0 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4;
+        bool vec = g_cfg128 != 5 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4 && p.taps.n <= 32;
         for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
-        if (mt == 4) launch_ws2<4>(p, vec, st);
+        if (mt == 4 && vec && g_cfg128 == 6)          // experiment: one barrier per 32 reduction rows
+            hipLaunchKernelGGL((igemm_ws2_kernel<4, true, 2>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(6 * 64),
+                               g_lds_pad, st, p);
+        else if (mt == 4) launch_ws2<4>(p, vec, st);
         else if (mt == 2) launch_ws2<2>(p, vec, st);
         else launch_ws2<1>(p, vec, st);
         return;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-#define WG2_ISSUE(ks_)                                                                                           \
+#define WG2_ISSUE_AT(ks_)                                                                                           \
         {                                                                                                            \
             const int pb = pbeg + (ks_) * BKP;                                                                       \
             float* const sb = smem + ((ks_) % NBUF) * STAGE;                                                         \
@@ -172,6 +172,60 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }                                                                                                    \
             }                                                                                                        \
         }
+        // Stages are issued strictly in order, so the VEC loader is a state machine: the lane's 4-pixel chunk moves 16
+        // pixels per stage (never across an image row mid-chunk: OW % 16 == 0), and everything that only changes with the
+        // row or the image is recomputed there.  (The loaders are the last waves at the stage barrier; see conv.hip.)
+        int v_pix = pbeg + a_pix;                       // first pixel of this lane's chunk in the next stage
+        int v_buf = 0;
+        int v_ox = 0, v_oy = 0;
+        const float* v_ga = p.gy;                       // gy + (n*K + a_m)*OHW + rem of the chunk
+        const float* v_rb[NROW];                        // source row base incl. the image offset
+        int v_yo[NROW];                                 // y * Ws of the row's tap at the current oy, or -1: outside (zero border)
+        if (VEC) {
+            const unsigned upix = (unsigned)min(v_pix, p.P - 1);
+            const unsigned n = fd_div(upix, p.fd_ohw);
+            const unsigned rem = upix - n * (unsigned)OHW;
+            v_oy = (int)fd_div(rem, p.fd_ow);
+            v_ox = (int)rem - v_oy * p.OW;
+            v_ga = p.gy + ((size_t)n * p.K + a_m) * OHW + rem;
+#pragma unroll
+            for (int i = 0; i < NROW; ++i) v_rb[i] = rowp[i] ? rowp[i] + (size_t)n * rowns[i] : nullptr;
+        }
+#define WG2_ROW_Y()                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                           \
+            int y = v_oy * p.sy + (rowt[i] >> 16);                                                                   \
+            if (p.border == BORDER_REFLECT) y = reflect_i(y, p.Hs);                                                  \
+            v_yo[i] = ((unsigned)y < (unsigned)p.Hs && v_rb[i] != nullptr) ? y * p.Ws : -1;                          \
+        }
+        if (VEC) { WG2_ROW_Y(); }
+#define WG2_ISSUE_NEXT_VEC()                                                                                         \
+        {                                                                                                            \
+            float* const sb = smem + v_buf * STAGE;                                                                  \
+            const bool pv = v_pix < pend;                                                                            \
+            _Pragma("unroll") for (int q = 0; q < A_PER; ++q)                                                        \
+                glds_b128((pv && a_m + 16 * q < p.K) ? v_ga + (size_t)(16 * q) * OHW : wg_zero_page,                 \
+                          sb + (a_q0 + q) * 256);                                                                    \
+            _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                       \
+                const int x = min(max(v_ox + (int)(short)(rowt[i] & 0xffff), 0), p.Ws - 4);                          \
+                glds_b128((pv && v_yo[i] >= 0) ? v_rb[i] + (v_yo[i] + x) : wg_zero_page,                             \
+                          sb + TILE + (l * BV_PER + i) * 256);                                                       \
+            }                                                                                                        \
+            v_buf = v_buf + 1 == NBUF ? 0 : v_buf + 1;                                                               \
+            v_pix += BKP;                                                                                            \
+            v_ga += BKP;                                                                                             \
+            v_ox += BKP;                                                                                             \
+            if (v_ox >= p.OW) {                                                                                      \
+                v_ox -= p.OW;                                                                                        \
+                if (++v_oy == p.OH) {                                                                                \
+                    v_oy = 0;                                                                                        \
+                    v_ga += (size_t)(p.K - 1) * OHW;                                                                 \
+                    _Pragma("unroll") for (int i = 0; i < NROW; ++i)                                                 \
+                        if (v_rb[i]) v_rb[i] += rowns[i];                                                            \
+                }                                                                                                    \
+                WG2_ROW_Y();                                                                                         \
+            }                                                                                                        \
+        }
+#define WG2_ISSUE(ks_)  if (VEC) WG2_ISSUE_NEXT_VEC() else WG2_ISSUE_AT(ks_)
 #define WG2_WAIT_ONE_IN_FLIGHT() __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14))
         WG2_ISSUE(0);
         if (nk > 1) {
@@ -190,6 +244,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (ks + 3 < nk) WG2_ISSUE(ks + 3);
         }
 #undef WG2_ISSUE
+#undef WG2_ISSUE_AT
+#undef WG2_ISSUE_NEXT_VEC
+#undef WG2_ROW_Y
 #undef WG2_WAIT_ONE_IN_FLIGHT
         return;
     }

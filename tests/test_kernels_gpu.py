@@ -84,7 +84,7 @@ def test_conv_bwd_weight_wide(be, N, C0, C1, H, W, Kc, R, stride, pad, pm):
     K.case_conv_bwd_weight(be, N, C0, C1, H, W, Kc, R, stride, pad, pm)
 
 
-@pytest.mark.parametrize("cfg", [0, 5, 4, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 6, 5, 4, 1, 2])
 def test_conv_forced_128_tiles(be, cfg):
     """The 128x128 workgroup shapes (wave-specialised gen 2 / gen 1, 4-wave, 8-wave) on small problems: nemar_tune key 6
     lowers the grid-size threshold that normally reserves them for large layers."""
@@ -94,6 +94,7 @@ def test_conv_forced_128_tiles(be, cfg):
         K.case_conv_fwd(be, 2, 16, 0, 9, 10, 70, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_LRELU)   # ragged M and P, scalar stores
         K.case_conv_fwd(be, 2, 16, 16, 8, 12, 130, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_RELU)     # concat, 2 M tiles, 16 B stores
         K.case_conv_fwd(be, 3, 32, 0, 8, 8, 128, 4, 2, 1, K.PAD_ZERO)                          # k4 s2
+        K.case_conv_fwd(be, 2, 16, 0, 6, 8, 40, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_RELU)      # 9 stages: odd tail of the 2-stage barrier variant
         K.case_conv_bwd_data(be, 2, 70, 0, 8, 8, 32, 3, 1, 1, K.PAD_REFLECT)                   # dgrad: M = 70 source chans
         K.case_conv_bwd_data(be, 2, 130, 0, 8, 8, 16, 4, 2, 1, K.PAD_ZERO)                     # parity classes (strided out)
         K.case_conv_transpose_fwd(be, 2, 16, 72, 5, 6, 3, 1)
