@@ -215,6 +215,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    int f_tap = -1, f_off = 0;      // FAST staging: tap whose border arithmetic is cached, this lane's y*Ws+x for it
+    bool f_inb = false;
 #define IGEMM_ISSUE_STAGE(k0_, buf_)                                                                                 \
     {                                                                                                                \
         const int k0 = (k0_);                                                                                        \
@@ -223,19 +225,24 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 glds_b128(wsrc[q] + (size_t)k0 * p.Mpad, As0 + (buf_) * A_FLOATS + a_lds[q]);                                       \
         }                                                                                                            \
         if (FAST) {                                                                                                  \
-            const unsigned t = fd_div((unsigned)k0, p.fd_cs);                                                        \
-            const int ch0 = k0 - (int)t * Cs;                                                                        \
-            const int tp = s_tap[t];                                                                                 \
-            int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);                                             \
-            bool inb = pvalid && k0 < p.Kred;                                                                        \
-            if (p.border == BORDER_REFLECT) {                                                                        \
-                y = reflect(y, p.Hs);                                                                                \
-                x = reflect(x, p.Ws);                                                                                \
-            } else {                                                                                                 \
-                inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                           \
+            const int t = (int)fd_div((unsigned)k0, p.fd_cs);                                                        \
+            const int ch0 = k0 - t * Cs;                                                                             \
+            if (t != f_tap) {          /* border arithmetic + tap-table read once per tap, not per stage */          \
+                f_tap = t;                                                                                           \
+                const int tp = s_tap[t];                                                                             \
+                int y = by + (tp >> 16), x = bx + (int)(short)(tp & 0xffff);                                         \
+                f_inb = pvalid;                                                                                      \
+                if (p.border == BORDER_REFLECT) {                                                                    \
+                    y = reflect(y, p.Hs);                                                                            \
+                    x = reflect(x, p.Ws);                                                                            \
+                } else {                                                                                             \
+                    f_inb = f_inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                   \
+                }                                                                                                    \
+                f_off = f_inb ? y * p.Ws + x : 0;                                                                    \
             }                                                                                                        \
+            const bool inb = f_inb && k0 < p.Kred;                                                                   \
             const float* base = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;           \
-            base += (size_t)rgrp * HW + (inb ? y * p.Ws + x : 0);                                                    \
+            base += (size_t)rgrp * HW + f_off;                                                                       \
             _Pragma("unroll") for (int i = 0; i < BROWS; ++i)                                                        \
                 glds_b32(inb ? base + (size_t)(RGRP * i) * HW : p.zero,                                              \
                          Bs0 + (buf_) * B_FLOATS + (rgrp + RGRP * i) * LDB + seg * 64);       \
@@ -572,13 +579,14 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 // v_cndmask per stage on the two border lanes of a row.  8 wave-instructions per stage instead of 32.
 // SPB = stages per barrier.  1: 3-deep stage ring, one workgroup barrier per 16 reduction rows.  2: 4 stage slots used as
 // two 32-row halves — the loaders fill one half while the MFMA waves consume the other, one barrier per 32 rows.
-template <int MT, bool VEC, int SPB = 1>
-__global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p) {
+template <int MT, bool VEC, int SPB = 1, int NL = 2>   // NL = loader waves (4 only with VEC)
+__global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p) {
+    static_assert(NL == 2 || (VEC && NL == 4), "loader split");
     constexpr int W2_NBUF = SPB == 1 ? 3 : 4;
     constexpr int BM = 32 * MT, BN = 128, LDB = VEC ? BN : BN + 4;
     constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
-    constexpr int A_PER_LOADER = BK * BM / 256 / 2;          // 1 KiB wave-instructions of A per loader per stage (MT)
-    constexpr int B_PER_LOADER = VEC ? BK / 4 : BK;          // VEC: 2 rows x 128 px per instruction; else 1 row x 64 px
+    constexpr int A_PER_LOADER = BK * BM / 256 / NL;         // 1 KiB wave-instructions of A per loader per stage
+    constexpr int B_PER_LOADER = VEC ? BK / 2 / NL : BK;     // VEC: 2 rows x 128 px per instruction; else 1 row x 64 px
     constexpr int LOADS_PER_STAGE = A_PER_LOADER + B_PER_LOADER;
     static_assert(BK == 16, "a stage is two 8-row fragment groups");
     __shared__ __attribute__((aligned(16))) float smem[W2_NBUF * (A_FLOATS + B_FLOATS)];
@@ -604,7 +612,7 @@ __global__ __launch_bounds__((MT + 2) * 64) void igemm_ws2_kernel(IgemmParams p)
         const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
         const unsigned oy = fd_div(rem, p.fd_ow);
         const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;
-        const int rofs = VEC ? ldr * 8 + (lane >> 5) : 0;  // first reduction row (channel offset inside the stage) of this lane
+        const int rofs = VEC ? ldr * (BK / NL) + (lane >> 5) : 0;  // first reduction row (channel offset in the stage) of this lane
         const float* s0n = p.src0 + ((size_t)n * p.C0 + rofs) * HW;
         const float* s1n = p.C1 ? p.src1 + ((size_t)n * p.C1 + rofs) * HW : s0n;
         const float* wsrc[A_PER_LOADER];
@@ -971,14 +979,17 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         t.bm = p.M > 32 ? 64 : 32;
         t.bn = p.M > 32 ? 64 : 128;
     }
-    if (fast && !p.ring_p && (g_cfg128 == 0 || g_cfg128 == 5 || g_cfg128 == 6) && (t.bm == 128 || g_ws2_mt)) {
+    if (fast && !p.ring_p && (g_cfg128 == 0 || (g_cfg128 >= 5 && g_cfg128 <= 7)) && (t.bm == 128 || g_ws2_mt)) {
         // wave-specialised kernel: 128 pixels x 32*MT channels.  Measured: MT = 4 beats every generic configuration on
         // layers big enough for 128x128 tiles; MT = 1, 2 (fewer MFMAs per staged B tile) lose to the generic 64x64 /
         // 32x256 kernels and are only reachable through the tuning switch.
         int mt = g_ws2_mt ? g_ws2_mt : 4;
         bool vec = g_cfg128 != 5 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4 && p.taps.n <= 32;
         for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
-        if (mt == 4 && vec && g_cfg128 == 6)          // experiment: one barrier per 32 reduction rows
+        if (mt == 4 && vec && g_cfg128 == 7)          // experiment: 4 loader waves
+            hipLaunchKernelGGL((igemm_ws2_kernel<4, true, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64),
+                               g_lds_pad, st, p);
+        else if (mt == 4 && vec && g_cfg128 == 6)     // experiment: one barrier per 32 reduction rows
             hipLaunchKernelGGL((igemm_ws2_kernel<4, true, 2>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(6 * 64),
                                g_lds_pad, st, p);
         else if (mt == 4) launch_ws2<4>(p, vec, st);

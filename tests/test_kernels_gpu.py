@@ -84,7 +84,7 @@ def test_conv_bwd_weight_wide(be, N, C0, C1, H, W, Kc, R, stride, pad, pm):
     K.case_conv_bwd_weight(be, N, C0, C1, H, W, Kc, R, stride, pad, pm)
 
 
-@pytest.mark.parametrize("cfg", [0, 6, 5, 4, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 7, 6, 5, 4, 1, 2])
 def test_conv_forced_128_tiles(be, cfg):
     """The 128x128 workgroup shapes (wave-specialised gen 2 / gen 1, 4-wave, 8-wave) on small problems: nemar_tune key 6
     lowers the grid-size threshold that normally reserves them for large layers."""
