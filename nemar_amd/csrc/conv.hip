@@ -60,6 +60,7 @@ __device__ __forceinline__ int reflect(int i, int n) {
 
 struct TapTable {
     int n;
+    int dyx[MAX_TAPS];   // (dy << 16) | (dx & 0xffff): one dword per tap so that a wave-uniform lookup is a scalar load
     short dy[MAX_TAPS], dx[MAX_TAPS];
     int wofs[MAX_TAPS];  // offset of the tap inside one [R][S] filter (pack kernel only)
 };
@@ -633,10 +634,10 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         const float* cp = s0n;                                // source plane of channel ch0 (+ this lane's row offset)
         int sp_off = 0;                                       // y * Ws + x of this lane for the current tap
         bool inb = false;
-        int ndy = p.taps.dy[0], ndx = p.taps.dx[0];           // offsets of the tap about to start (pre-loaded a tap ahead)
+        int ndyx = p.taps.dyx[0];                             // offsets of the tap about to start (pre-loaded a tap ahead)
 #define WS2_ENTER_TAP()                                                                                              \
         {                                                                                                            \
-            int y = by + ndy, x = bx + ndx;                                                                          \
+            int y = by + (ndyx >> 16), x = bx + (int)(short)(ndyx & 0xffff);                                         \
             inb = pvalid;                                                                                            \
             if (p.border == BORDER_REFLECT) y = reflect(y, p.Hs);                                                    \
             else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                          \
@@ -644,9 +645,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             else if (p.border == BORDER_REFLECT) x = reflect(x, p.Ws);                                               \
             else inb = inb && (unsigned)x < (unsigned)p.Ws;                                                          \
             sp_off = inb ? y * p.Ws + x : 0;                                                                         \
-            const int tn = min(tap_t + 1, p.taps.n - 1);                                                             \
-            ndy = p.taps.dy[tn];                                                                                     \
-            ndx = p.taps.dx[tn];                                                                                     \
+            ndyx = p.taps.dyx[__builtin_amdgcn_readfirstlane(min(tap_t + 1, p.taps.n - 1))];                         \
         }
         WS2_ENTER_TAP();
 #define WS2_ISSUE_NEXT()                                                                                             \
@@ -1258,6 +1257,7 @@ void fwd_taps(TapTable& t, int R, int S, int pad) {
         for (int s = 0; s < S; ++s) {
             t.dy[r * S + s] = (short)(r - pad);
             t.dx[r * S + s] = (short)(s - pad);
+            t.dyx[r * S + s] = ((r - pad) << 16) | ((s - pad) & 0xffff);
             t.wofs[r * S + s] = r * S + s;
         }
 }
@@ -1271,6 +1271,7 @@ void dgrad_taps(TapTable& t, int R, int S, int pad, int stride, int ph, int pw) 
             if ((pw + pad - s) % stride != 0) continue;
             t.dy[t.n] = (short)((ph + pad - r) / stride);
             t.dx[t.n] = (short)((pw + pad - s) / stride);
+            t.dyx[t.n] = ((int)t.dy[t.n] << 16) | ((int)t.dx[t.n] & 0xffff);
             t.wofs[t.n] = r * S + s;
             t.n++;
         }
@@ -1411,6 +1412,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             if (p.taps.n == 0) {
                 // no tap reaches this class (e.g. k1 s2): gradient is bias-only / zero; run with one zero tap
                 p.taps.n = 1; p.taps.dy[0] = -32000; p.taps.dx[0] = -32000; p.taps.wofs[0] = 0; p.Kred = K;
+                p.taps.dyx[0] = (-32000 << 16) | (-32000 & 0xffff);
             }
             // A[(t*K + k)][c] = w[k][c + mskip][r][s]
             if (!prepacked) launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
