@@ -953,12 +953,16 @@ void launch_ws2(const IgemmParams& p, bool vec, hipStream_t st) {
 // Tile selection.  The channel tile follows M; the pixel tile shrinks when the grid would leave most of the 256 CUs
 // idle (the small-spatial discriminator / bottleneck layers): ~2 workgroups per CU is the target.
 struct TileChoice { int bm, bn; };
-TileChoice igemm_tile(int M, int P) {
+TileChoice igemm_tile(int M, int P, int stages) {
     const int kMinBlocks = g_min_blocks;
     TileChoice t;
     if (M > 64) {
+        // 128x128 (wave-specialised for FAST shapes) needs ~1.5 workgroups per CU — or, measured on D's k4 layers, just
+        // ~1 per CU when the reduction is deep enough (>= 64 stages) to amortise the lock-step prologue/epilogue
         t.bm = 128; t.bn = 128;
-        if ((long long)nemar_cdiv(M, 128) * nemar_cdiv(P, 128) < kMinBlocks) { t.bm = 64; t.bn = 64; }
+        const long long tiles = (long long)nemar_cdiv(M, 128) * nemar_cdiv(P, 128);
+        const int need = (stages >= 64 && kMinBlocks > 200) ? 200 : kMinBlocks;
+        if (tiles < need) { t.bm = 64; t.bn = 64; }
     } else if (M > 32) {
         t.bm = 64; t.bn = 128;
         if ((long long)nemar_cdiv(P, 128) < kMinBlocks) t.bn = 64;
@@ -973,7 +977,7 @@ int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 256) * 256 : 32; }
 void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
-    TileChoice t = igemm_tile(p.M, p.P);
+    TileChoice t = igemm_tile(p.M, p.P, nemar_cdiv(p.Kred, BK));
     if (p.ring_p) {   // few pixels, full reduction depth: small tiles so the launch spreads over the CUs (generic kernel only)
         t.bm = p.M > 32 ? 64 : 32;
         t.bn = p.M > 32 ? 64 : 128;
