@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 WG2_ROW_Y();                                                                                         \
             }                                                                                                        \
         }
-#define WG2_ISSUE(ks_)  if (VEC) WG2_ISSUE_NEXT_VEC() else WG2_ISSUE_AT(ks_)
+#define WG2_ISSUE(ks_)  { if (VEC) WG2_ISSUE_NEXT_VEC() else WG2_ISSUE_AT(ks_) }
 #define WG2_WAIT_ONE_IN_FLIGHT() __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14))
         WG2_ISSUE(0);
         if (nk > 1) {
