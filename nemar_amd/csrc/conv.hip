@@ -781,12 +781,16 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     // lgkmcnt(0) | barrier passed | MFMA block 2 issued
     long long ts[4][6];
     const bool probe = p.tl != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+#ifdef NEMAR_TIMELINE      /* the probe's s_memtime + waits perturb the loop's wait counts: compiled in on demand only */
 #define WS2_STAMP(i_)                                                     \
     if (probe && ks >= 40 && ks < 44) {                                       \
         const long long c_ = clock64();                                       \
         if (ks == 40) ts[0][i_] = c_; else if (ks == 41) ts[1][i_] = c_;      \
         else if (ks == 42) ts[2][i_] = c_; else ts[3][i_] = c_;               \
     }
+#else
+#define WS2_STAMP(i_)
+#endif
     if (SPB == 2) {
         bool fix_l = false, fix_r = false;
 #define WS2_STAGE_FLAGS()                                                       \
@@ -863,11 +867,15 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
 #undef WS2_READ
 #undef WS2_MFMA
 #undef WS2_STAMP
+#ifdef NEMAR_TIMELINE
     if (SPB == 1 && probe && lane == 0 && nk >= 44) {
         long long* o = p.tl + wid * 24;
         for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 6; ++j) o[i * 6 + j] = ts[i][j];
     }
+#else
+    (void)ts; (void)probe;
+#endif
 
     // ---- epilogue: lane owns pixels p0 + 4*l31 + {0..3} (tile t -> pixel t) of 16 channel rows ---------------------
     const size_t oplane = (size_t)p.OHf * p.OWf;

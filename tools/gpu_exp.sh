@@ -8,7 +8,5 @@ for l in sys.stdin:
     print('fwd %7.1f us %5.1f TF | dgrad %7.1f us %5.1f TF | wgrad %7.1f us %5.1f TF' % (d['fwd_us'], d['fwd_TF'], d['dgrad_us'], d['dgrad_TF'], d['wgrad_us'], d['wgrad_TF']))
 "; }
 run
-run --tune 9 0
-timeout 900 python -m pytest tests/test_step_gpu.py tests/test_nets_gpu.py -x -q 2>&1 | tail -2
 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('bench: %.2f img/s  %.2f ms/step  roofline %.1f TF (%.0f us)' % (d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_us']))"
