@@ -297,24 +297,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         _Pragma("unroll") for (int j = 0; j < TNW; ++j)                                                            \
             B_[j] = *reinterpret_cast<const f32x4*>(sb + brow + j * 32 * BKP + (co_));                             \
     }
+// The border patches and the bias sum are wave-uniform rarities (first/last chunk of an image row; column-tile 0 only).
+// Left to the compiler they are if-converted into v_cndmask / v_pk_add work that every wave executes in every block,
+// scheduled BETWEEN the MFMAs (each stray VALU slot between MFMAs costs 6-40 cycles of matrix pipe).  The empty volatile
+// asm keeps them real branches; the sched_barrier keeps the 16 MFMAs back to back.
 #define WG2_MFMA(A_, B_, G_)                                                                                   \
     {                                                                                                              \
-        if (VEC && (G_) == 0 && oxs == 0 && lhi == 0) {          /* first chunk of an image row: dx = -1 rows */    \
+        if (VEC && (G_) == 0 && oxs == 0) {                       /* first chunk of an image row: dx = -1 rows */  \
+            asm volatile("" ::: "memory");                                                                         \
             _Pragma("unroll") for (int j = 0; j < TNW; ++j) {                                                      \
                 const f32x4 u = B_[j];                                                                             \
-                if (dxn[j] < 0) { B_[j][0] = refl ? u[1] : 0.f; B_[j][1] = u[0]; B_[j][2] = u[1]; B_[j][3] = u[2]; } \
+                const bool fx = lhi == 0 && dxn[j] < 0;                                                            \
+                B_[j][0] = fx ? (refl ? u[1] : 0.f) : u[0];                                                        \
+                B_[j][1] = fx ? u[0] : u[1];                                                                       \
+                B_[j][2] = fx ? u[1] : u[2];                                                                       \
+                B_[j][3] = fx ? u[2] : u[3];                                                                       \
             }                                                                                                      \
         }                                                                                                          \
-        if (VEC && (G_) == 1 && oxs == p.OW - BKP && lhi == 1) { /* last chunk of an image row: dx = +1 rows */    \
+        if (VEC && (G_) == 1 && oxs == p.OW - BKP) {              /* last chunk of an image row: dx = +1 rows */   \
+            asm volatile("" ::: "memory");                                                                         \
             _Pragma("unroll") for (int j = 0; j < TNW; ++j) {                                                      \
                 const f32x4 u = B_[j];                                                                             \
-                if (dxn[j] > 0) { B_[j][0] = u[1]; B_[j][1] = u[2]; B_[j][2] = u[3]; B_[j][3] = refl ? u[2] : 0.f; } \
+                const bool fx = lhi == 1 && dxn[j] > 0;                                                            \
+                B_[j][0] = fx ? u[1] : u[0];                                                                       \
+                B_[j][1] = fx ? u[2] : u[1];                                                                       \
+                B_[j][2] = fx ? u[3] : u[2];                                                                       \
+                B_[j][3] = fx ? (refl ? u[2] : 0.f) : u[3];                                                        \
             }                                                                                                      \
         }                                                                                                          \
         if (do_bias) {                                                                                             \
+            asm volatile("" ::: "memory");                                                                         \
             _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                        \
                 bsum[i] += (A_[i][0] + A_[i][1]) + (A_[i][2] + A_[i][3]);                                          \
         }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                              \
             _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                        \
                 _Pragma("unroll") for (int j = 0; j < TNW; ++j)                                                    \
