@@ -582,12 +582,12 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 // two 32-row halves — the loaders fill one half while the MFMA waves consume the other, one barrier per 32 rows.
 template <int MT, bool VEC, int SPB = 1, int NL = 2>   // NL = loader waves (4 only with VEC)
 __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p) {
-    static_assert(NL == 2 || (VEC && NL == 4), "loader split");
+    static_assert(NL == 2 || NL == 4, "loader split");
     constexpr int W2_NBUF = SPB == 1 ? 3 : 4;
     constexpr int BM = 32 * MT, BN = 128, LDB = VEC ? BN : BN + 4;
     constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
     constexpr int A_PER_LOADER = BK * BM / 256 / NL;         // 1 KiB wave-instructions of A per loader per stage
-    constexpr int B_PER_LOADER = VEC ? BK / 2 / NL : BK;     // VEC: 2 rows x 128 px per instruction; else 1 row x 64 px
+    constexpr int B_PER_LOADER = VEC ? BK / 2 / NL : BK / (NL / 2);   // VEC: 2 rows x 128 px per instruction; else 1 row x 64 px
     constexpr int LOADS_PER_STAGE = A_PER_LOADER + B_PER_LOADER;
     static_assert(BK == 16, "a stage is two 8-row fragment groups");
     __shared__ __attribute__((aligned(16))) float smem[W2_NBUF * (A_FLOATS + B_FLOATS)];
@@ -606,14 +606,15 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         const int ldr = wid - MT;
         // VEC: lane = (pixel group lane&31, row parity lane>>5), this loader's rows are ldr*8 .. ldr*8+7
         // else: lane = pixel of 64-pixel segment `ldr`, rows 0..15
-        const int pix = VEC ? p0 + 4 * (lane & 31) : p0 + ldr * 64 + lane;
+        const int seg = ldr & 1, row0 = (ldr >> 1) * B_PER_LOADER;     // non-VEC: 64-pixel segment and first row of this loader
+        const int pix = VEC ? p0 + 4 * (lane & 31) : p0 + seg * 64 + lane;
         const bool pvalid = pix < p.P;
         const unsigned upix = pvalid ? (unsigned)pix : 0u;
         const unsigned n = fd_div(upix, p.fd_ohw);
         const unsigned rem = upix - n * (unsigned)(p.OH * p.OW);
         const unsigned oy = fd_div(rem, p.fd_ow);
         const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;
-        const int rofs = VEC ? ldr * (BK / NL) + (lane >> 5) : 0;  // first reduction row (channel offset in the stage) of this lane
+        const int rofs = VEC ? ldr * (BK / NL) + (lane >> 5) : row0;  // first reduction row (channel offset in the stage) of this lane
         const float* s0n = p.src0 + ((size_t)n * p.C0 + rofs) * HW;
         const float* s1n = p.C1 ? p.src1 + ((size_t)n * p.C1 + rofs) * HW : s0n;
         const float* wsrc[A_PER_LOADER];
@@ -660,8 +661,9 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
                     glds_b128(inb ? base + (size_t)(2 * i) * HW : p.zero,                                            \
                               Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256);                              \
             } else {                                                                                                 \
-                _Pragma("unroll") for (int r = 0; r < BK; ++r)                                                       \
-                    glds_b32(inb ? base + (size_t)r * HW : p.zero, Bs0 + a_buf * B_FLOATS + r * LDB + ldr * 64);     \
+                _Pragma("unroll") for (int r = 0; r < B_PER_LOADER; ++r)                                             \
+                    glds_b32(inb ? base + (size_t)r * HW : p.zero,                                                   \
+                             Bs0 + a_buf * B_FLOATS + (row0 + r) * LDB + seg * 64);                                  \
             }                                                                                                        \
             a_buf = a_buf + 1 == W2_NBUF ? 0 : a_buf + 1;                                                            \
             ch0 += BK;                                                                                               \
@@ -930,6 +932,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
+static int g_nl4_scalar = 1;     // tuning switch (key 11): 4 loader waves for the gathered-B wave-specialised kernel
+static int g_deep64 = 0;         // tuning switch (key 10): 4-deep LDS ring for every FAST 64x64 launch (default: ring launches only)
 static int g_ring_split = 0;     // tuning switch (key 8): reduction splits of the reflect-border ring launch (0 = auto)
 static int g_ws2_mt = 0;         // tuning switch (key 7): force the wave-specialised kernel's channel tile (1, 2, 4 x 32)
 static int g_min_blocks = 384;   // tuning switch (key 6): workgroups below which the pixel/channel tile shrinks
@@ -997,7 +1001,10 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         int mt = g_ws2_mt ? g_ws2_mt : 4;
         bool vec = g_cfg128 != 5 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4 && p.taps.n <= 32;
         for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
-        if (mt == 4 && vec && g_cfg128 == 7)          // experiment: 4 loader waves
+        if (mt == 4 && !vec && g_nl4_scalar)          // gathered (non-VEC) B tile: 4 loader waves share the 32 4-byte loads
+            hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64),
+                               g_lds_pad, st, p);
+        else if (mt == 4 && vec && g_cfg128 == 7)     // experiment: 4 loader waves
             hipLaunchKernelGGL((igemm_ws2_kernel<4, true, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64),
                                g_lds_pad, st, p);
         else if (mt == 4 && vec && g_cfg128 == 6)     // experiment: one barrier per 32 reduction rows
@@ -1014,7 +1021,7 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     else if (t.bm == 128 && g_cfg128 == 1) launch_igemm_cfg<2, 2, 2, 2>(p, fast, st); // 128 x 128, 4 waves of 64x64
     else if (t.bm == 128) launch_igemm_cfg<2, 4, 2, 1>(p, fast, st);                  // 128 x 128, 8 waves of 64x32
     else if (t.bm == 64 && t.bn == 128) launch_igemm_cfg<1, 4, 2, 1>(p, fast, st);    // 64 x 128
-    else if (t.bm == 64 && p.ring_p && fast)                                          // ring: 64 x 64, 4-deep LDS ring
+    else if (t.bm == 64 && fast && (p.ring_p || g_deep64))                            // 64 x 64, 4-deep LDS ring
         hipLaunchKernelGGL((igemm_kernel<2, 2, 1, 1, true, 4>), dim3(nemar_cdiv(p.P, 64), nemar_cdiv(p.M, 64), p.ksplit),
                            dim3(256), g_lds_pad, st, p);
     else if (t.bm == 64) launch_igemm_cfg<2, 2, 1, 1>(p, fast, st);                   // 64 x 64
@@ -1542,6 +1549,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
     if (key == 4) { g_wgrad = value; return NEMAR_OK; }
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
+    if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
+    if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }
     if (key == 8) { g_ring_split = value > 0 ? value : 0; return NEMAR_OK; }
     if (key == 7) { g_ws2_mt = (value == 1 || value == 2 || value == 4) ? value : 0; return NEMAR_OK; }
     if (key == 5) { g_wgrad_blocks = value > 0 ? value : 512; return NEMAR_OK; }
