@@ -597,9 +597,15 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.y * BM, p0 = blockIdx.x * BN;
     const int Cs = p.C0 + p.C1, HW = p.Hs * p.Ws;
-    const int nk = (p.Kred + BK - 1) / BK;
-    // experiment: workgroups 256 apart in dispatch order share a CU; start every other one half a barrier period late
-    if ((p.dbg & 256) && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1)) __builtin_amdgcn_s_sleep(15);
+    // grid.z > 1: the reduction is split over workgroups (few, deep tiles — D's 256->512 k4 data gradient is 128 tiles x 512
+    // stages); partial results meet in the zero-filled destination through atomics (no bias / activation in that mode)
+    const int nk_all = (p.Kred + BK - 1) / BK;
+    const int nk_per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int ks0 = blockIdx.z * nk_per;
+    const int nk = min(nk_all, ks0 + nk_per) - ks0;          // stages of this workgroup (indices below are relative)
+    if (nk <= 0) return;
+    const int k_start = ks0 * BK;
+    const int tap_start = (int)fd_div((unsigned)k_start, p.fd_cs), ch_start = k_start - tap_start * Cs;
 
     if (wid >= MT) {
         // ================================ loader waves ================================
@@ -631,11 +637,13 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         // tap-table lookups in the kernel arguments, divisions and border arithmetic between the loads made the loader
         // the last wave at the stage barrier: two extra scalar branches in this loop cost the whole kernel 7 %.)
         int a_buf = 0;                                        // LDS ring slot of the next stage
-        int tap_t = 0, ch0 = 0;                               // tap / channel offset of the next stage
-        const float* cp = s0n;                                // source plane of channel ch0 (+ this lane's row offset)
+        int tap_t = tap_start, ch0 = ch_start;                // tap / channel offset of the next stage
+        const float* cp = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;   // plane of channel ch0
         int sp_off = 0;                                       // y * Ws + x of this lane for the current tap
         bool inb = false;
-        int ndyx = p.taps.dyx[0];                             // offsets of the tap about to start (pre-loaded a tap ahead)
+        int ndyx = p.taps.dyx[__builtin_amdgcn_readfirstlane(tap_start)];   // offsets of the tap about to start
+#pragma unroll
+        for (int q = 0; q < A_PER_LOADER; ++q) wsrc[q] += (size_t)k_start * p.Mpad;
 #define WS2_ENTER_TAP()                                                                                              \
         {                                                                                                            \
             int y = by + (ndyx >> 16), x = bx + (int)(short)(ndyx & 0xffff);                                         \
@@ -736,7 +744,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     // sign of every tap's dx, 2 bits per tap (<= 32 taps on the VEC path: |dx| <= 1 means at most a 3x3 footprint... any
     // tap count up to 32 is representable); current tap / channel offset advance with the stages
     unsigned long long dxbits = 0ull;
-    int tap_i = 0, tap_ch = 0;
+    int tap_i = tap_start, tap_ch = ch_start;
     if (VEC)
         for (int t = 0; t < p.taps.n && t < 32; ++t)
             dxbits |= (unsigned long long)(p.taps.dx[t] < 0 ? 1u : p.taps.dx[t] > 0 ? 2u : 0u) << (2 * t);
@@ -885,8 +893,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     const int opix0 = p0 + 4 * l31;
     if (opix0 >= p.P) return;
     // 16-byte stores when the 4 pixels are consecutive, in range and aligned in the destination
-    const bool vec = p.osx == 1 && p.osy == 1 && p.oox == 0 && p.ooy == 0 && (p.OW & 3) == 0 && p.OW == p.OWf &&
-                     p.OH == p.OHf && opix0 + 3 < p.P &&
+    const bool vec = gridDim.z == 1 && p.osx == 1 && p.osy == 1 && p.oox == 0 && p.ooy == 0 && (p.OW & 3) == 0 &&
+                     p.OW == p.OWf && p.OH == p.OHf && opix0 + 3 < p.P &&
                      ((reinterpret_cast<uintptr_t>(p.dst0) | reinterpret_cast<uintptr_t>(p.dst1)) & 15) == 0;
     if (vec) {
         const unsigned n = fd_div((unsigned)opix0, p.fd_ohw);
@@ -920,6 +928,10 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             const int m = m0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (m < p.M) {
                 float v = acc[t][r];
+                if (gridDim.z > 1) {             // split reduction: sum into the zero-filled destination
+                    atomicAdd(p.dst0 + ((size_t)n * p.M0 + m) * oplane + sp, v);
+                    continue;
+                }
                 if (p.bias) v += p.bias[m];
                 v = apply_act(v, p.act, p.slope);
                 if (m < p.M0) {
@@ -932,6 +944,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
+static int g_ksplit = 1;         // tuning switch (key 12): allow reduction splits in the wave-specialised data gradient
 static int g_nl4_scalar = 1;     // tuning switch (key 11): 4 loader waves for the gathered-B wave-specialised kernel
 static int g_deep64 = 0;         // tuning switch (key 10): 4-deep LDS ring for every FAST 64x64 launch (default: ring launches only)
 static int g_ring_split = 0;     // tuning switch (key 8): reduction splits of the reflect-border ring launch (0 = auto)
@@ -957,7 +970,7 @@ void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
 
 template <int MT>
 void launch_ws2(const IgemmParams& p, bool vec, hipStream_t st) {
-    dim3 grid(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 32 * MT)), block((MT + 2) * 64);
+    dim3 grid(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 32 * MT), p.ring_p ? 1 : p.ksplit), block((MT + 2) * 64);
     if (vec) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true>), grid, block, g_lds_pad, st, p);
     else hipLaunchKernelGGL((igemm_ws2_kernel<MT, false>), grid, block, g_lds_pad, st, p);
 }
@@ -965,15 +978,15 @@ void launch_ws2(const IgemmParams& p, bool vec, hipStream_t st) {
 // Tile selection.  The channel tile follows M; the pixel tile shrinks when the grid would leave most of the 256 CUs
 // idle (the small-spatial discriminator / bottleneck layers): ~2 workgroups per CU is the target.
 struct TileChoice { int bm, bn; };
-TileChoice igemm_tile(int M, int P, int stages) {
+TileChoice igemm_tile(int M, int P, int stages, int ksplit = 1) {
     const int kMinBlocks = g_min_blocks;
     TileChoice t;
     if (M > 64) {
         // 128x128 (wave-specialised for FAST shapes) needs ~1.5 workgroups per CU — or, measured on D's k4 layers, just
         // ~1 per CU when the reduction is deep enough (>= 64 stages) to amortise the lock-step prologue/epilogue
         t.bm = 128; t.bn = 128;
-        const long long tiles = (long long)nemar_cdiv(M, 128) * nemar_cdiv(P, 128);
-        const int need = (stages >= 64 && kMinBlocks > 200) ? 200 : kMinBlocks;
+        const long long tiles = (long long)nemar_cdiv(M, 128) * nemar_cdiv(P, 128) * ksplit;
+        const int need = (stages / ksplit >= 64 && kMinBlocks > 200) ? 200 : kMinBlocks;
         if (tiles < need) { t.bm = 64; t.bn = 64; }
     } else if (M > 32) {
         t.bm = 64; t.bn = 128;
@@ -989,7 +1002,7 @@ int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 256) * 256 : 32; }
 void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
-    TileChoice t = igemm_tile(p.M, p.P, nemar_cdiv(p.Kred, BK));
+    TileChoice t = igemm_tile(p.M, p.P, nemar_cdiv(p.Kred, BK), p.ring_p ? 1 : p.ksplit);
     if (p.ring_p) {   // few pixels, full reduction depth: small tiles so the launch spreads over the CUs (generic kernel only)
         t.bm = p.M > 32 ? 64 : 32;
         t.bn = p.M > 32 ? 64 : 128;
@@ -1002,8 +1015,8 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         bool vec = g_cfg128 != 5 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4 && p.taps.n <= 32;
         for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
         if (mt == 4 && !vec && g_nl4_scalar)          // gathered (non-VEC) B tile: 4 loader waves share the 32 4-byte loads
-            hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64),
-                               g_lds_pad, st, p);
+            hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128), p.ksplit),
+                               dim3(8 * 64), g_lds_pad, st, p);
         else if (mt == 4 && vec && g_cfg128 == 7)     // experiment: 4 loader waves
             hipLaunchKernelGGL((igemm_ws2_kernel<4, true, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(8 * 64),
                                g_lds_pad, st, p);
@@ -1437,6 +1450,21 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             if (!prepacked) launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
             // <= 4 input channels (the translation net's stem: 29 of 32 MFMA rows would be empty): the zero-padded
             // data gradient is a <= 4-output-channel correlation of gy — the narrow VALU kernel's job
+            // few, deep tiles (D's 256->512 k4 layer: 128 tiles of 128x128, 512 stages): split the reduction so that every CU
+            // gets a workgroup; the partial sums meet in the zero-filled gradient through atomics
+            if (g_ksplit && g_cfg128 == 0 && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 &&
+                gx1 == nullptr && Mc > 64 && K % BK == 0) {
+                const long long tiles = (long long)nemar_cdiv(Mc, 128) * nemar_cdiv(p.P, 128);
+                const int stages = nemar_cdiv(p.Kred, BK);
+                if (tiles < 200 && stages >= 256) {
+                    int ks = nemar_cdiv(256, (int)tiles);
+                    if (ks > stages / 128) ks = stages / 128;
+                    if (ks > 1) {
+                        p.ksplit = ks;
+                        (void)hipMemsetAsync(gx0, 0, sizeof(float) * (size_t)N * C * H * W, st);
+                    }
+                }
+            }
             const bool narrow = g_narrow && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 && gx1 == nullptr &&
                                 R - 1 - pad >= 0 && nemar_narrow_eligible(C, 0, R, S, 1, N, H, W);
             if (narrow) {
@@ -1549,6 +1577,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
     if (key == 4) { g_wgrad = value; return NEMAR_OK; }
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
+    if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
     if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }
     if (key == 8) { g_ring_split = value > 0 ? value : 0; return NEMAR_OK; }

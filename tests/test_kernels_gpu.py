@@ -120,6 +120,13 @@ def test_conv_ws2_vector_loads(be, mt):
         be.lib.tune(7, 0)
 
 
+def test_conv_bwd_data_split_reduction(be):
+    """Few, deep tiles (256 stages): the wave-specialised data gradient splits the reduction over grid.z and sums through
+    atomics into the zero-filled gradient."""
+    K.case_conv_bwd_data(be, 1, 70, 0, 6, 6, 256, 4, 1, 1, K.PAD_ZERO)      # D's 256->512 k4 layer in small
+    K.case_conv_bwd_data(be, 2, 128, 0, 4, 8, 512, 3, 1, 1, K.PAD_REFLECT)  # + border ring on top of the split main pass
+
+
 def test_conv_bwd_data_narrow_inputs(be):
     """Data gradient of layers with <= 4 input channels: correlation of gy with flipped/transposed weights on the
     narrow kernel (+ the border-ring launch for reflect padding)."""

@@ -7,9 +7,7 @@ for l in sys.stdin:
     except Exception: continue
     print('%-30s fwd %7.1f us %5.1f TF | dgrad %7.1f us %5.1f TF | wgrad %7.1f us %5.1f TF' % (d['layer'][:30], d['fwd_us'], d['fwd_TF'], d['dgrad_us'], d['dgrad_TF'], d['wgrad_us'], d['wgrad_TF']))
 "; }
-run --only D.l
-run --only D.l --tune 11 0
-run --only down
-run --only down --tune 11 0
+run --only D.l4
+run --only D.l4 --tune 12 0
 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('bench: %.2f img/s  %.2f ms/step  roofline %.1f TF (%.0f us)' % (d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_us']))"
