@@ -6,6 +6,10 @@ for l in sys.stdin:
     except Exception: continue
     print('%-30s fwd %7.1f us %5.1f TF | dgrad %7.1f us %5.1f TF | wgrad %7.1f us %5.1f TF' % (d['layer'][:30], d['fwd_us'], d['fwd_TF'], d['dgrad_us'], d['dgrad_TF'], d['wgrad_us'], d['wgrad_TF']))
 "; }
-run
-run --tune 7 2
-run --tune 7 1
+run --only down
+run --only down --tune 6 200
+run --only down --tune 6 120
+run --only D.l2
+run --only D.l2 --tune 6 200
+run --only R.
+run --only R. --tune 6 200
