@@ -404,6 +404,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.M) {
                     float v = acc[i][j][r];
+                    if (gridDim.z > 1) {
+                        // split reduction (tiny, deep problems: a 2x2-pixel 128->128 layer is 72 serial stages in one or
+                        // two workgroups): partial sums meet in the zero-filled destination, split 0 carries the bias
+                        if (p.bias && blockIdx.z == 0) v += p.bias[m];
+                        atomicAdd(p.dst0 + ((size_t)n * p.M0 + m) * oplane + sp, v);
+                        continue;
+                    }
                     if (p.bias) v += p.bias[m];
                     v = apply_act(v, p.act, p.slope);
                     if (m < p.M0) {
@@ -929,6 +936,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             if (m < p.M) {
                 float v = acc[t][r];
                 if (gridDim.z > 1) {             // split reduction: sum into the zero-filled destination
+                    if (p.bias && blockIdx.z == 0) v += p.bias[m];
                     atomicAdd(p.dst0 + ((size_t)n * p.M0 + m) * oplane + sp, v);
                     continue;
                 }
@@ -961,7 +969,7 @@ static int g_lds_pad = 0;  // tuning switch: extra dynamic LDS bytes per workgro
 template <int WM, int WN, int TM, int TN>
 void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM), p.ring_p ? p.ksplit : 1), block(WM * WN * 64);
+    dim3 grid(nemar_cdiv(p.P, BN), nemar_cdiv(p.M, BM), p.ksplit), block(WM * WN * 64);
     if (fast)
         hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, g_lds_pad, st, p);
     else
@@ -1283,6 +1291,19 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
     }
 }
 
+// Reduction split for tiny, deep problems on the generic kernels (the launch would otherwise be a handful of workgroups
+// each walking the whole reduction at memory latency): enough splits for ~256 workgroups, >= 4 stages each.
+int small_problem_split(int M, int P, int Kred) {
+    const TileChoice t = igemm_tile(M, P, nemar_cdiv(Kred, BK));
+    if (t.bm == 128) return 1;
+    const long long tiles = (long long)nemar_cdiv(M, t.bm) * nemar_cdiv(P, t.bn);
+    const int stages = nemar_cdiv(Kred, BK);
+    if (tiles >= 128 || stages < 16) return 1;
+    int ks = nemar_cdiv(256, (int)tiles);
+    if (ks > stages / 4) ks = stages / 4;
+    return ks < 1 ? 1 : ks;
+}
+
 void fwd_taps(TapTable& t, int R, int S, int pad) {
     t.n = R * S;
     for (int r = 0; r < R; ++r)
@@ -1359,6 +1380,10 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.N = N; p.P = N * OH * OW;
     p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope; p.pad = pad;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
+    if (g_ksplit && act == ACT_NONE) {
+        p.ksplit = small_problem_split(K, p.P, p.Kred);
+        if (p.ksplit > 1) (void)hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * K * OH * OW, st);
+    }
     launch_igemm(p, st);
     NEMAR_CHECK_LAUNCH("conv2d_fwd");
     return NEMAR_OK;
@@ -1464,6 +1489,11 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                         (void)hipMemsetAsync(gx0, 0, sizeof(float) * (size_t)N * C * H * W, st);
                     }
                 }
+            }
+            if (g_ksplit && p.ksplit == 1 && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 &&
+                gx1 == nullptr && Mc > 4) {
+                p.ksplit = small_problem_split(Mc, p.P, p.Kred);
+                if (p.ksplit > 1) (void)hipMemsetAsync(gx0, 0, sizeof(float) * (size_t)N * C * H * W, st);
             }
             const bool narrow = g_narrow && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 && gx1 == nullptr &&
                                 R - 1 - pad >= 0 && nemar_narrow_eligible(C, 0, R, S, 1, N, H, W);
