@@ -1,5 +1,6 @@
 """Per-stage s_memtime timeline of the wave-specialised igemm's MFMA waves (workgroup (0,0), stages 40..43) on the
-T resblock conv.  usage: timeline_ws2.py [key=value ...]"""
+T resblock conv.  Needs a build with -DNEMAR_TIMELINE (the probe is compiled out by default: its s_memtime waits perturb the
+loop).  usage: timeline_ws2.py [key=value ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
