@@ -612,6 +612,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     const int nk = min(nk_all, ks0 + nk_per) - ks0;          // stages of this workgroup (indices below are relative)
     if (nk <= 0) return;
     const int k_start = ks0 * BK;
+    // experiment (nemar_tune 2=256): workgroups 256 apart in dispatch order share a CU; start every other one late
+    if ((p.dbg & 256) && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1)) __builtin_amdgcn_s_sleep(20);
     const int tap_start = (int)fd_div((unsigned)k_start, p.fd_cs), ch_start = k_start - tap_start * Cs;
 
     if (wid >= MT) {
