@@ -100,11 +100,23 @@ int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, in
                           int prepacked, void* stream);
 /* Weight gradient, ACCUMULATED into gw [K,C0+C1,R,S] and, when gb != NULL, the bias gradient ACCUMULATED into
  * gb [K] in the same pass (the caller zero-fills once per optimizer step; the translation net receives two passes
- * per step).  Pixel reduction is split across workgroups, fp32 atomics. */
+ * per step).  Pixel reduction is split across workgroups, fp32 atomics.
+ * Data gradients may also split their reduction (few-tile deep layers, reflect border ring) and then sum through fp32
+ * atomics: backward results are reproducible up to summation order; forward results are bitwise reproducible. */
 int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
                             int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
                             int pad_mode, void* stream);
-/* Tuning switches for A/B measurements (tools/): key 0 = workgroup shape of the 128x128 conv tile (0: 8 waves, 1: 4). */
+/* Tuning switches for A/B measurements (tools/, tests/): not part of the operator contract, defaults = measured best.
+ *   0  conv tile family for 128x128-capable shapes: 0 wave-specialised (default), 5 same without 16-byte B loads,
+ *      6 one barrier per 32 reduction rows, 7 four loader waves, 4 first-generation wave-specialised, 1/2/3 generic
+ *   1  extra dynamic LDS per workgroup (occupancy experiments)      2  ablation / experiment bit mask
+ *   3  narrow (<= 4 channel) VALU kernels on/off                     4  weight gradient: 0 default, 1 first generation,
+ *                                                                       2 wave-specialised without 16-byte source loads
+ *   5  weight-gradient workgroup target (default 512)                6  grid-size threshold of the tile choice (384)
+ *   7  force the wave-specialised channel tile (1, 2, 4 x 32)        8  reduction splits of the reflect ring launch
+ *   10 4-deep LDS ring for every 64x64 launch                        11 four loader waves for gathered B tiles (on)
+ *   12 reduction splits in data gradients (on)                       13 reduction splits in tiny forward convs (off:
+ *                                                                       keeps the forward pass bitwise reproducible) */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */
