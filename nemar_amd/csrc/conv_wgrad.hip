@@ -120,56 +120,71 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-#define WG2_ISSUE_AT(ks_)                                                                                           \
+        // Scalar (gathered, 4 bytes per lane) source path: same idea as the VEC state machine below — the lane's gy chunk
+        // and its source pixel advance 16 pixels per stage; divisions only at kernel start, row / image wrap by carry.
+        int s_apix = pbeg + a_pix, s_arem = 0, s_buf = 0;
+        const float* s_ga = p.gy;
+        int s_bpix = pbeg + b_pix, s_oy = 0, s_ox = 0;
+        const float* s_rb[NROW];
+        int s_yo[NROW];
+        if (!VEC) {
+            {
+                const unsigned up = (unsigned)min(s_apix, p.P - 1);
+                const unsigned n = fd_div(up, p.fd_ohw);
+                s_arem = (int)(up - n * (unsigned)OHW);
+                s_ga = p.gy + ((size_t)n * p.K + a_m) * OHW + s_arem;
+            }
+            const unsigned up = (unsigned)min(s_bpix, p.P - 1);
+            const unsigned n = fd_div(up, p.fd_ohw);
+            const unsigned rem = up - n * (unsigned)OHW;
+            s_oy = (int)fd_div(rem, p.fd_ow);
+            s_ox = (int)rem - s_oy * p.OW;
+#pragma unroll
+            for (int i = 0; i < NROW; ++i) s_rb[i] = rowp[i] ? rowp[i] + (size_t)n * rowns[i] : nullptr;
+        }
+#define WG2_ROW_Y_SCALAR()                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                           \
+            int y = s_oy * p.sy + (rowt[i] >> 16);                                                                   \
+            if (p.border == BORDER_REFLECT) y = reflect_i(y, p.Hs);                                                  \
+            s_yo[i] = ((unsigned)y < (unsigned)p.Hs && s_rb[i] != nullptr) ? y * p.Ws : -1;                          \
+        }
+        if (!VEC) { WG2_ROW_Y_SCALAR(); }
+#define WG2_ISSUE_NEXT_SCALAR()                                                                                      \
         {                                                                                                            \
-            const int pb = pbeg + (ks_) * BKP;                                                                       \
-            float* const sb = smem + ((ks_) % NBUF) * STAGE;                                                         \
-            {                                                                                                        \
-                const int pix = pb + a_pix;                                                                          \
-                const unsigned n = fd_div((unsigned)pix, p.fd_ohw);                                                  \
-                const unsigned rem = (unsigned)pix - n * (unsigned)OHW;                                              \
-                const float* g = p.gy + ((size_t)n * p.K + a_m) * OHW + rem;                                         \
-                _Pragma("unroll") for (int q = 0; q < A_PER; ++q)                                                    \
-                    glds_b128((pix < pend && a_m + 16 * q < p.K) ? g + (size_t)(16 * q) * OHW : wg_zero_page,        \
-                              sb + (a_q0 + q) * 256);                                                                \
+            float* const sb = smem + s_buf * STAGE;                                                                  \
+            const bool pva = s_apix < pend;                                                                          \
+            _Pragma("unroll") for (int q = 0; q < A_PER; ++q)                                                        \
+                glds_b128((pva && a_m + 16 * q < p.K) ? s_ga + (size_t)(16 * q) * OHW : wg_zero_page,                \
+                          sb + (a_q0 + q) * 256);                                                                    \
+            const bool pvb = s_bpix < pend;                                                                          \
+            const int bx = s_ox * p.sx;                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                       \
+                int x = bx + (int)(short)(rowt[i] & 0xffff);                                                         \
+                bool inb = pvb && s_yo[i] >= 0;                                                                      \
+                if (p.border == BORDER_REFLECT) x = reflect_i(x, p.Ws);                                              \
+                else inb = inb && (unsigned)x < (unsigned)p.Ws;                                                      \
+                glds_b32(inb ? s_rb[i] + (s_yo[i] + x) : wg_zero_page, sb + TILE + (l + 4 * i) * 64);                \
             }                                                                                                        \
-            if (VEC) {                                                                                               \
-                const int pix = pb + a_pix;                                                                          \
-                const bool pv = pix < pend;                                                                          \
-                const unsigned upix = pv ? (unsigned)pix : 0u;                                                       \
-                const unsigned n = fd_div(upix, p.fd_ohw);                                                           \
-                const unsigned rem = upix - n * (unsigned)OHW;                                                       \
-                const unsigned oy = fd_div(rem, p.fd_ow);                                                            \
-                const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW);                                \
-                _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                   \
-                    int y = by + (rowt[i] >> 16);                                                                    \
-                    const int x = min(max(bx + (int)(short)(rowt[i] & 0xffff), 0), p.Ws - 4);                        \
-                    bool inb = pv && rowp[i] != nullptr;                                                             \
-                    if (p.border == BORDER_REFLECT) y = reflect_i(y, p.Hs);                                          \
-                    else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                  \
-                    glds_b128(inb ? rowp[i] + (size_t)n * rowns[i] + (y * p.Ws + x) : wg_zero_page,                  \
-                              sb + TILE + (l * BV_PER + i) * 256);                                                   \
-                }                                                                                                    \
-            } else {                                                                                                 \
-                const int pix = pb + b_pix;                                                                          \
-                const bool pv = pix < pend;                                                                          \
-                const unsigned upix = pv ? (unsigned)pix : 0u;                                                       \
-                const unsigned n = fd_div(upix, p.fd_ohw);                                                           \
-                const unsigned rem = upix - n * (unsigned)OHW;                                                       \
-                const unsigned oy = fd_div(rem, p.fd_ow);                                                            \
-                const int by = (int)oy * p.sy, bx = (int)(rem - oy * (unsigned)p.OW) * p.sx;                         \
-                _Pragma("unroll") for (int i = 0; i < NROW; ++i) {                                                   \
-                    int y = by + (rowt[i] >> 16), x = bx + (int)(short)(rowt[i] & 0xffff);                           \
-                    bool inb = pv && rowp[i] != nullptr;                                                             \
-                    if (p.border == BORDER_REFLECT) {                                                                \
-                        y = reflect_i(y, p.Hs);                                                                      \
-                        x = reflect_i(x, p.Ws);                                                                      \
-                    } else {                                                                                         \
-                        inb = inb && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;                   \
+            s_buf = s_buf + 1 == NBUF ? 0 : s_buf + 1;                                                               \
+            s_apix += BKP;                                                                                           \
+            s_arem += BKP;                                                                                           \
+            s_ga += BKP;                                                                                             \
+            while (s_arem >= OHW) {                                                                                  \
+                s_arem -= OHW;                                                                                       \
+                s_ga += (size_t)(p.K - 1) * OHW;                                                                     \
+            }                                                                                                        \
+            s_bpix += BKP;                                                                                           \
+            s_ox += BKP;                                                                                             \
+            if (s_ox >= p.OW) {                                                                                      \
+                while (s_ox >= p.OW) {                                                                               \
+                    s_ox -= p.OW;                                                                                    \
+                    if (++s_oy == p.OH) {                                                                            \
+                        s_oy = 0;                                                                                    \
+                        _Pragma("unroll") for (int i = 0; i < NROW; ++i)                                             \
+                            if (s_rb[i]) s_rb[i] += rowns[i];                                                        \
                     }                                                                                                \
-                    glds_b32(inb ? rowp[i] + (size_t)n * rowns[i] + (y * p.Ws + x) : wg_zero_page,                   \
-                             sb + TILE + (l + 4 * i) * 64);                                                          \
                 }                                                                                                    \
+                WG2_ROW_Y_SCALAR();                                                                                  \
             }                                                                                                        \
         }
         // Stages are issued strictly in order, so the VEC loader is a state machine: the lane's 4-pixel chunk moves 16
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 WG2_ROW_Y();                                                                                         \
             }                                                                                                        \
         }
-#define WG2_ISSUE(ks_)  { if (VEC) WG2_ISSUE_NEXT_VEC() else WG2_ISSUE_AT(ks_) }
+#define WG2_ISSUE(ks_)  { if (VEC) WG2_ISSUE_NEXT_VEC() else WG2_ISSUE_NEXT_SCALAR() }   /* stages in order */
 #define WG2_WAIT_ONE_IN_FLIGHT() __builtin_amdgcn_s_waitcnt(0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14))
         WG2_ISSUE(0);
         if (nk > 1) {
@@ -244,7 +259,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (ks + 3 < nk) WG2_ISSUE(ks + 3);
         }
 #undef WG2_ISSUE
-#undef WG2_ISSUE_AT
+#undef WG2_ISSUE_NEXT_SCALAR
+#undef WG2_ROW_Y_SCALAR
 #undef WG2_ISSUE_NEXT_VEC
 #undef WG2_ROW_Y
 #undef WG2_WAIT_ONE_IN_FLIGHT
