@@ -42,6 +42,7 @@ SIGNATURES = {
     "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "nemar_tune": (_i, [_i, _i]),
+    "nemar_grid_sample_tune": (_i, [_i]),
     "nemar_tune_ptr": (_i, [_vp]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),

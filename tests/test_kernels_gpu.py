@@ -25,6 +25,17 @@ def test_grid_sample_ragged_and_resampled(be):
     K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=8, W=8, Ho=8, Wo=8, scale=0.1, need_gin=False)
     K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=8, W=8, Ho=8, Wo=8, scale=0.1, accumulate=True)
     K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=3, H=8, W=8, Ho=8, Wo=8, scale=0.1, accumulate=True)
+    # the LDS-tile grad_input variant (nemar_grid_sample_tune(1)) on several 16x64 tiles: halo overlap between neighbours
+    # (small offsets), the global-atomic fallback for corners outside a tile's region (large offsets), > 4 channels
+    be.lib.grid_sample_tune(1)
+    try:
+        K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.02)
+        K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.5)
+        K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=1, H=36, W=70, Ho=36, Wo=70, scale=0.3, accumulate=True)
+        K.case_grid_sample(be, K.GRID_UNET, N=1, C=6, H=12, W=16, Ho=12, Wo=16, scale=0.1)
+    finally:
+        be.lib.grid_sample_tune(0)
+    K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.5)       # default variant, same shape
 
 
 @pytest.mark.parametrize("mode,scale", [(K.GRID_UNET, 0.0), (K.GRID_UNET, 2.0 / 256), (K.GRID_UNET, 0.1),
