@@ -140,6 +140,9 @@ int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, floa
  * act_bwd: gx = gy * f'(.) expressed with the activation OUTPUT y (f fused into a conv epilogue):
  *     nn.LeakyReLU / nn.ReLU / nn.Tanh — reference models/networks.py:377,576 ; models/stn/layers.py:61-64. */
 int nemar_act_bwd(const float* gy, const float* y, float* gx, long long n, int act, float slope, void* stream);
+/* y = act(x) as a stand-alone pass (nn.ReLU / nn.LeakyReLU / nn.Tanh where no producer epilogue can carry it: the U-Net
+ * generator's skip path, reference models/networks.py:516-553).  Backward = nemar_act_bwd on the output. */
+int nemar_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream);
 /* nn.MaxPool2d(2) — reference models/stn/layers.py:174.  x [planes,H,W] -> y [planes,H/2,W/2].
  * bwd: gx = (addend ? addend : 0) + unpool(gy); the argmax (first maximum, row-major) is recomputed from x. */
 int nemar_maxpool2_fwd(const float* x, float* y, int planes, int H, int W, void* stream);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
+    "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "nemar_maxpool2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "nemar_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -37,6 +37,31 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         gx[i] = gy[i] * dact_from_out(y[i], act, slope);
 }
 
+// stand-alone activation (the U-Net generator's skip path needs relu() of a tensor whose producer already fused another
+// activation; everywhere else activations ride in a conv / InstanceNorm epilogue)
+__device__ __forceinline__ float act_apply_f(float v, int act, float slope) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int act,
+                                                      float slope) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 r;
+        r.x = act_apply_f(v.x, act, slope);
+        r.y = act_apply_f(v.y, act, slope);
+        r.z = act_apply_f(v.z, act, slope);
+        r.w = act_apply_f(v.w, act, slope);
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = act_apply_f(x[i], act, slope);
+}
+
 // ---- 2x2 max pool ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                                                            int Ho, int Wo, long long total) {
@@ -223,6 +248,16 @@ NEMAR_API int nemar_act_bwd(const float* gy, const float* y, float* gx, long lon
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nemar_stream_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, gy, y,
                        gx, n, act, slope);
     NEMAR_CHECK_LAUNCH("act_bwd");
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(x && y && n > 0, "act_fwd: bad arguments");
+    NEMAR_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "act_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(nemar_stream_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n,
+                       act, slope);
+    NEMAR_CHECK_LAUNCH("act_fwd");
     return NEMAR_OK;
 }
 

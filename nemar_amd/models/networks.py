@@ -165,7 +165,7 @@ def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
 
 _RESNET_BLOCKS = {'resnet_9blocks': 9, 'resnet_6blocks': 6, 'resnet_3blocks': 3, 'resnet_4blocks': 4,
                   'resnet_5blocks': 5}
-_UNET_DOWNS = {'unet_64': 5, 'unet_128': 7, 'unet_256': 8}
+_UNET_DOWNS = {'unet_128': 7, 'unet_256': 8}       # reference :157-160
 
 
 def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02,
@@ -176,10 +176,7 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, in
         net = ResnetGenerator(input_nc, output_nc, ngf, norm_layer=norm_layer, use_dropout=use_dropout,
                               n_blocks=_RESNET_BLOCKS[netG])
     elif netG in _UNET_DOWNS:
-        # reference :157-162 (UnetGenerator, k4 s2 conv / transposed conv).  The kernels cover its layers, but the
-        # module is not wired yet — SURVEY.md Appendix D lists it as a follow-up conv target, not a NeMAR default.
-        raise NotImplementedError('Generator model name [%s] is not wired to the MI355X kernels yet; '
-                                  'use resnet_{3,4,5,6,9}blocks' % netG)
+        net = UnetGenerator(input_nc, output_nc, _UNET_DOWNS[netG], ngf, norm_layer=norm_layer, use_dropout=use_dropout)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % netG)
     return init_net(net, init_type, init_gain, gpu_ids)
@@ -214,6 +211,77 @@ class GANLoss(nn.Module):
 
     def __call__(self, prediction, target_is_real, weight=1.0):
         return ops.gan_loss(prediction, bool(target_is_real), self.gan_mode, weight)
+
+
+# ------------------------------------------------------------------------------------------------------
+class UnetSkipConnectionBlock(nn.Module):
+    """|-- down: LeakyReLU, conv k4 s2 [, norm] -- submodule -- up: ReLU, convT k4 s2 [, norm][, dropout] --| with the
+    identity skip concatenated in front (reference :486-553).  Parameter slots follow the reference's nn.Sequential
+    positions (outermost: model.0 / model.1 (submodule) / model.3; innermost: model.1 / model.3; otherwise model.1 /
+    model.3 (submodule) / model.5).
+
+    The reference's first layer is an in-place LeakyReLU, so the tensor it concatenates as "x" is already
+    LeakyReLU(x), and the parent's in-place ReLU then acts on the whole concatenation.  Here the activations ride in the
+    producers' epilogues instead: a block RECEIVES LeakyReLU(x) (fused into the parent's conv / InstanceNorm) and
+    RETURNS ReLU(cat[LeakyReLU(x), up]) = cat[ReLU(x), ReLU(up)] (ReLU fused into its own InstanceNorm / convT)."""
+
+    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False,
+                 norm_layer='instance', use_dropout=False):
+        super().__init__()
+        self.outermost, self.innermost, self.norm, self.use_dropout = outermost, innermost, norm_layer, use_dropout
+        use_bias = norm_layer == 'instance'
+        if input_nc is None:
+            input_nc = outer_nc
+        m = self.model = Slots()
+        if outermost:
+            _ref(self, 'down', m.put(0, ConvParams(input_nc, inner_nc, 4, bias=use_bias)))
+            _ref(self, 'sub', m.put(1, submodule))
+            _ref(self, 'up', m.put(3, ConvParams(inner_nc * 2, outer_nc, 4, bias=True, transposed=True)))
+        elif innermost:
+            _ref(self, 'down', m.put(1, ConvParams(input_nc, inner_nc, 4, bias=use_bias)))
+            object.__setattr__(self, 'sub', None)
+            _ref(self, 'up', m.put(3, ConvParams(inner_nc, outer_nc, 4, bias=use_bias, transposed=True)))
+        else:
+            _ref(self, 'down', m.put(1, ConvParams(input_nc, inner_nc, 4, bias=use_bias)))
+            _ref(self, 'sub', m.put(3, submodule))
+            _ref(self, 'up', m.put(5, ConvParams(inner_nc * 2, outer_nc, 4, bias=use_bias, transposed=True)))
+
+    def forward(self, a):
+        """a: the block input (outermost) or LeakyReLU(block input) (otherwise)."""
+        if self.outermost:
+            child_in = ops.conv2d(a, self.down.weight, self.down.bias, 2, 1, ops.PAD_ZERO, act=ops.ACT_LRELU)
+            s = self.sub(child_in)
+            return ops.conv_transpose2d(s, self.up.weight, self.up.bias, 2, 1, 0, act=ops.ACT_TANH)
+        if self.innermost:
+            s = ops.conv2d(a, self.down.weight, self.down.bias, 2, 1, ops.PAD_ZERO, act=ops.ACT_RELU)
+        else:
+            d = ops.conv2d(a, self.down.weight, self.down.bias, 2, 1, ops.PAD_ZERO,
+                           act=ops.ACT_NONE if self.norm else ops.ACT_LRELU)
+            s = self.sub(_norm_act(d, self.norm, ops.ACT_LRELU))
+        u = ops.conv_transpose2d(s, self.up.weight, self.up.bias, 2, 1, 0, act=ops.ACT_NONE if self.norm else ops.ACT_RELU)
+        u = _norm_act(u, self.norm, ops.ACT_RELU)
+        if self.use_dropout:
+            u = ops.dropout(u, 0.5, self.training)      # commutes with the parent's ReLU (scale >= 0)
+        return torch.cat([ops.activation(a, ops.ACT_RELU), u], 1)
+
+
+class UnetGenerator(nn.Module):
+    """U-Net generator built from the innermost block outwards (reference :449-483)."""
+
+    def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_layer='instance', use_dropout=False):
+        super().__init__()
+        block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=None, norm_layer=norm_layer, innermost=True)
+        for _ in range(num_downs - 5):
+            block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=block, norm_layer=norm_layer,
+                                            use_dropout=use_dropout)
+        block = UnetSkipConnectionBlock(ngf * 4, ngf * 8, submodule=block, norm_layer=norm_layer)
+        block = UnetSkipConnectionBlock(ngf * 2, ngf * 4, submodule=block, norm_layer=norm_layer)
+        block = UnetSkipConnectionBlock(ngf, ngf * 2, submodule=block, norm_layer=norm_layer)
+        self.model = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=block, outermost=True,
+                                             norm_layer=norm_layer)
+
+    def forward(self, x):
+        return self.model(x)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -236,6 +236,31 @@ class _ConvTranspose2d(Function):
         return gx, None, None, None, None, None, None, None
 
 
+class _Activation(Function):
+    """Stand-alone activation (only where no conv / InstanceNorm epilogue can carry it)."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.act_fwd(_p(x), _p(y), x.numel(), act, slope, _stream())
+        ctx.save_for_backward(y)
+        ctx.act, ctx.slope = act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _c(gy)
+        gx = torch.empty_like(gy)
+        L.act_bwd(_p(gy), _p(y), _p(gx), gy.numel(), ctx.act, ctx.slope, _stream())
+        return gx, None, None
+
+
+def activation(x, act, slope=0.2):
+    return x if act == ACT_NONE else _Activation.apply(x, act, slope)
+
+
 def conv_transpose2d(x, weight, bias=None, stride=2, pad=1, out_pad=1, act=ACT_NONE, slope=0.2):
     return _ConvTranspose2d.apply(x, weight, bias, stride, pad, out_pad, act, slope)
 

@@ -112,6 +112,32 @@ def run_op_fixtures():
     print('ops fixtures:', len(out))
 
 
+def run_unet_generator():
+    """The reference's UnetGenerator (`--netG unet_128`, models/networks.py:449-553) forward + backward on seeded
+    weights / input: full output, input gradient and every parameter gradient's L2 norm + a 64-element head."""
+    import functools
+    from models import networks as ref_networks
+    torch.manual_seed(0)
+    norm = functools.partial(torch.nn.InstanceNorm2d, affine=False, track_running_stats=False)
+    out = {}
+    for tag, use_dropout in (('plain', False),):
+        net = ref_networks.UnetGenerator(3, 3, 7, ngf=4, norm_layer=norm, use_dropout=use_dropout)
+        load_seeded(net, 77, None)
+        x = torch.from_numpy(seeded.seeded_images(2, 3, 128, 128, 78)[0]).clone().requires_grad_(True)
+        r = torch.from_numpy(seeded.seeded_images(2, 3, 128, 128, 79)[1])
+        y = net(x)
+        (y * r).sum().backward()
+        out[tag + '/y'] = y.detach().numpy()
+        out[tag + '/gx'] = x.grad.numpy()
+        out[tag + '/keys'] = np.array([k for k, _ in net.state_dict().items()])
+        out[tag + '/shapes'] = np.array([str(tuple(v.shape)) for _, v in net.state_dict().items()])
+        for k, p in net.named_parameters():
+            out[tag + '/gnorm/' + k] = np.array(float(p.grad.norm()))
+            out[tag + '/ghead/' + k] = p.grad.reshape(-1)[:64].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'unet_generator.npz'), **out)
+    print('unet generator fixture:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -119,6 +145,8 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     if a.only in (None, 'ops'):
         run_op_fixtures()
+    if a.only in (None, 'unet_generator'):
+        run_unet_generator()
     for name, cfg in STEP_CONFIGS.items():
         if a.only in (None, name):
             run_step_config(name, cfg)

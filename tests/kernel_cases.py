@@ -251,6 +251,9 @@ def case_pointwise(be, seed=0):
         d_gy, d_y = be.dev(gy), be.dev(y)          # keep the device buffers alive across the call
         be.lib.act_bwd(be.ptr(d_gy), be.ptr(d_y), be.ptr(d_g), n, act, 0.2, be.stream)
         _assert_close(be.np(d_g), want, atol=1e-6, rtol=1e-6, what="act_bwd")
+        d_pre, d_out = be.dev(pre), be.full((n,), np.nan)                 # stand-alone activation (U-Net skip path)
+        be.lib.act_fwd(be.ptr(d_pre), be.ptr(d_out), n, act, 0.2, be.stream)
+        _assert_close(be.np(d_out), O.act_fwd(pre.astype(np.float64), act), atol=1e-6, rtol=1e-6, what="act_fwd")
     # maxpool (even, odd sizes; ties)
     for (H, W) in ((8, 10), (7, 9), (2, 2)):
         x = rng.integers(-3, 4, (2, 3, H, W)).astype(np.float32)     # many exact ties

@@ -112,3 +112,36 @@ def test_registration_network(stn_type, size):
     # per-tensor deviations are the fp32 conditioning of the reference's own algorithm (see tests/step_parity.py)
     _check_grads(net, P, 3e-2)
     assert float((xf.grad.cpu() - xfr.grad).abs().max() / xfr.grad.abs().max()) < 1e-3   # grid_sample grad_input
+
+
+def test_unet_generator_matches_reference_fixture():
+    """`--netG unet_128` (reference models/networks.py:449-553) on the MI355X kernels against outputs and gradients recorded
+    from the reference itself (tests/golden/unet_generator.npz, seeded weights / inputs)."""
+    import os
+    import numpy as np
+    import seeded
+    from nemar_amd.models import networks
+    from step_parity import load_seeded_into
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'unet_generator.npz'))
+    net = networks.define_G(3, 3, 4, 'unet_128', 'instance', False, 'normal', 0.02, [0])
+    load_seeded_into(net, 77, None)
+    x = torch.from_numpy(seeded.seeded_images(2, 3, 128, 128, 78)[0]).cuda().requires_grad_(True)
+    r = torch.from_numpy(seeded.seeded_images(2, 3, 128, 128, 79)[1]).cuda()
+    params = dict(net.named_parameters())
+    for p in params.values():
+        p.grad = torch.zeros_like(p)          # weight-gradient kernels accumulate
+    y = net(x)
+    (y * r).sum().backward()
+    assert (y.detach().cpu().numpy() - g['plain/y']).__abs__().max() < 2e-5
+    gx = x.grad.cpu().numpy()
+    assert np.abs(gx - g['plain/gx']).max() <= 2e-4 * np.abs(g['plain/gx']).max()
+    gmax = max(float(g['plain/gnorm/' + k]) for k in params)
+    for k, p in params.items():
+        want = float(g['plain/gnorm/' + k])
+        got = float(p.grad.norm())
+        if want < 1e-4 * gmax:                 # conv biases in front of InstanceNorm: exactly-zero gradient + rounding noise
+            assert got < 1e-3 * gmax, (k, got, want, gmax)
+            continue
+        assert abs(got - want) <= 2e-4 * want, (k, got, want)
+        head = p.grad.reshape(-1)[:64].cpu().numpy()
+        assert np.abs(head - g['plain/ghead/' + k]).max() <= 5e-4 * max(np.abs(g['plain/ghead/' + k]).max(), want / 10), k

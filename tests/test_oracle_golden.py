@@ -107,3 +107,12 @@ def test_build_state_dict_layout_matches_reference(name):
     for nm, net in (('T', netT), ('R', netR), ('D', netD)):
         mine = [[k, list(v.shape)] for k, v in net.state_dict().items()]
         assert mine == ks[nm], (nm, [a for a, b in zip(mine, ks[nm]) if a != b][:3])
+
+
+def test_unet_generator_state_dict_layout_matches_reference():
+    """`--netG unet_128`: same keys, shapes and order as the reference's UnetGenerator (fixture recorded from it)."""
+    from nemar_amd.models import networks
+    g = np.load(os.path.join(GOLD, 'unet_generator.npz'))
+    net = networks.define_G(3, 3, 4, 'unet_128', 'instance', False, 'normal', 0.02, [])
+    mine = [(k, str(tuple(v.shape))) for k, v in net.state_dict().items()]
+    assert mine == list(zip([str(k) for k in g['plain/keys']], [str(s) for s in g['plain/shapes']]))
