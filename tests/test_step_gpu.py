@@ -12,7 +12,19 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name", list(STEP_CONFIGS))
 def test_step_parity(name):
-    step_parity.run(name, check=True)
+    """Every row of step_parity.run must hold.  One family of rows gets a second, independent attempt: the discriminator
+    gradient on identical inputs compares two fp32 implementations across LeakyReLU / InstanceNorm, and roughly one run
+    in twenty a pre-activation of these tiny test discriminators (ndf = 8) lies within rounding distance of zero, so the
+    two implementations take different slopes there and every gradient below that layer moves by 1e-3..1e-2 of its max
+    (measured with tools/flaky_step.py; which run it hits changes because the previous step's weight gradient is summed
+    with atomics, i.e. the weights differ in the last bit from run to run).  A systematic error fails both attempts;
+    any other row failing fails the test immediately."""
+    rows = step_parity.run(name, check=False)
+    bad = [r for r in rows if not r[3]]
+    if bad and all('grad/D on identical fakes' in r[0] for r in bad):
+        rows = step_parity.run(name, check=False)
+        bad = [r for r in rows if not r[3]]
+    assert not bad, bad[:5]
 
 
 @pytest.mark.parametrize("name", ["affine128", "unet256"])
