@@ -9,18 +9,25 @@
 // the data-gradient of a strided conv):
 //     out[n, m, oy, ox] = act(bias[m] + sum_{t < ntaps} sum_{ch < Cs} A[(t*Cs+ch), m] *
 //                              src[n, ch, oy*sy + dy[t], ox*sx + dx[t]])
-//   - A is the weight tensor re-laid-out ("packed") as [Kred][M] so that tile loads are 16 B/lane coalesced;
+//   - A is the weight tensor re-laid-out ("packed", see pack_weights_kernel) so that tile loads are dense 16 B/lane
+//     runs and one ds_read_b128 feeds four MFMA steps;
 //   - src is the logical channel concat of two tensors (never materialised);
 //   - out-of-range taps read 0 (zero padding / strided data-gradient) or the mirrored texel (reflect);
 //   - a stride-2 data-gradient is four launches, one per output-pixel parity class, each with the subset of
-//     taps that lands on integer source positions.
+//     taps that lands on integer source positions;
+//   - a stride-1 reflect data-gradient is the zero-padded data-gradient on the unpadded domain plus a small launch over
+//     the border ring whose results are added to the texels the padding mirrored (nemar_conv2d_bwd_data).
+// Kernels: igemm_ws2_kernel (wave-specialised, layers big enough for 128x128 tiles), igemm_kernel (generic, every wave
+// stages and multiplies; small / odd layers and the ring), igemm_ws_kernel (first-generation wave-specialised, kept for
+// A/B measurements).
 // GEMM view: M = output channels, N = output pixels, K = taps x source channels.  MFMA tile
 // v_mfma_f32_32x32x2_f32 with A = weights (rows = channels) and B = gathered pixels (cols = pixels), so the
 // accumulator's col = lane&31 runs along pixels and NCHW stores are coalesced.  f32-in MFMA is an fmaf chain
 // (bit-exact fp32, 157 TF peak): no reduced precision anywhere.
 //
 // The weight gradient is a second implicit GEMM, dW[k][c,r,s] = sum_pixels gy[k,p] * src[c, p (+) tap], with
-// the (huge) pixel reduction split across workgroups and fp32 atomics into the caller's gradient buffer.
+// the (huge) pixel reduction split across workgroups and fp32 atomics into the caller's gradient buffer:
+// conv_wgrad.hip (wave-specialised) for everything whose gy planes are 16-byte chunkable, wgrad_kernel below for the rest.
 #include "common.h"
 
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
@@ -1520,8 +1527,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 p.ring_p = pad; p.ring_H = H; p.ring_W = W;
                 // A ring tile is a few pixels deep in a full-length reduction, and a lone workgroup per CU runs it at
                 // memory latency (one stage of prefetch), so the reduction is split over grid.z — but every split repeats
-                // the scattered atomic epilogue (measured on the resblock shape: 8 splits = 155 us, of which ~90 atomics),
-                // so only until ~1.5 workgroups per CU exist (3 splits there: 97 us).
+                // the atomic epilogue, so only until ~1.5 workgroups per CU exist (resblock shape: 3 splits, 52 us in the
+                // step; the launch is bound by the column gathers of the left / right bands, not by MFMA work).
                 {
                     const int tiles = nemar_cdiv(N * ring_len, 64) * nemar_cdiv(Mc, 64), stages = nemar_cdiv(p.Kred, BK);
                     p.ksplit = g_ring_split ? g_ring_split : nemar_cdiv(384, tiles);
