@@ -679,15 +679,15 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
                 glds_b128(wsrc[q], As0 + a_buf * A_FLOATS + a_lds[q]);                                               \
                 wsrc[q] += (size_t)BK * p.Mpad;                                                                      \
             }                                                                                                        \
-            const float* base = cp + sp_off;                                                                         \
+            /* masked lanes read the zero page with stride 0: one select per stage instead of one per load */       \
+            const float* base = inb ? cp + sp_off : p.zero;                                                          \
+            const size_t bstep = inb ? (size_t)HW : (size_t)0;                                                       \
             if (VEC) {                                                                                               \
                 _Pragma("unroll") for (int i = 0; i < B_PER_LOADER; ++i)                                             \
-                    glds_b128(inb ? base + (size_t)(2 * i) * HW : p.zero,                                            \
-                              Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256);                              \
+                    glds_b128(base + (size_t)(2 * i) * bstep, Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256); \
             } else {                                                                                                 \
                 _Pragma("unroll") for (int r = 0; r < B_PER_LOADER; ++r)                                             \
-                    glds_b32(inb ? base + (size_t)r * HW : p.zero,                                                   \
-                             Bs0 + a_buf * B_FLOATS + (row0 + r) * LDB + seg * 64);                                  \
+                    glds_b32(base + (size_t)r * bstep, Bs0 + a_buf * B_FLOATS + (row0 + r) * LDB + seg * 64);        \
             }                                                                                                        \
             a_buf = a_buf + 1 == W2_NBUF ? 0 : a_buf + 1;                                                            \
             ch0 += BK;                                                                                               \
