@@ -119,8 +119,8 @@ def main():
     from nemar_amd.models import create_model
     opt = build_opt(a.batch, a.size, a.opt)
     opt.gpu_ids = [local]
-    torch.manual_seed(0)                      # identical initial weights on every rank (also broadcast at setup)
-    ops.manual_seed(1234 + rank)              # dropout stream per rank
+    torch.manual_seed(0)      # identical initial weights on every rank (also broadcast at setup); NEMARModel seeds the
+                              # dropout stream with torch.initial_seed() + rank
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):

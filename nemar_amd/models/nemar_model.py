@@ -87,6 +87,8 @@ class NEMARModel(BaseModel):
         # without cross-sample ops, i.e. not with BatchNorm).  Measured on MI355X, config 2: 78.15 vs 78.00 ms/step —
         # no gain (every layer already fills the chip at batch 8), so the reference's call order stays the default.
         self._batched = opt.norm != 'batch' and os.environ.get('NEMAR_BATCHED_PASSES', '0') == '1'
+        # dropout masks: one Philox stream per process, governed by torch.manual_seed() and different on every rank
+        ops.manual_seed(torch.initial_seed() + dist.rank())
         self.define_networks()
         if self.isTrain:
             self.criterionGAN = networks.GANLoss(opt.gan_mode)
@@ -170,8 +172,9 @@ class NEMARModel(BaseModel):
         self._resized = {}
 
     def _half(self, name, tensor, level):
-        """tensor bilinearly resized to 1/2^level resolution (reference :185-188 etc.); constants are cached per
-        step instead of being recomputed for every discriminator pass."""
+        """tensor bilinearly resized to 1/2^level resolution (reference :185-188 etc.).  Only the step's INPUTS (real_A,
+        real_B: `name` given) are cached — they are resized once instead of once per discriminator pass and the cache dies
+        with set_input(); generated images are resized where they are used."""
         sh, sw = self.real_A.size(2) // (2 ** level), self.real_A.size(3) // (2 ** level)
         if name is None:
             return ops.resize_bilinear(tensor, sh, sw)
@@ -190,7 +193,7 @@ class NEMARModel(BaseModel):
         terms = [[self.criterionGAN(out[i * n:(i + 1) * n], tr, w)] for i, (_, _, tr, w, _) in enumerate(specs)]
         for lvl, netD_S in enumerate(self.netD_multiresolution):
             a_r = self._half('real_A', self.real_A, lvl + 1)
-            img_r = [self._half(name if det else None, im, lvl + 1) for im, (_, name, _, _, det) in zip(imgs, specs)]
+            img_r = [self._half(name, im, lvl + 1) for im, (_, name, _, _, det) in zip(imgs, specs)]
             out = netD_S(torch.cat([a_r] * k, 0), torch.cat(img_r, 0))
             for i, (_, _, tr, w, _) in enumerate(specs):
                 terms[i].append(self.criterionGAN(out[i * n:(i + 1) * n], tr, w))
@@ -203,7 +206,7 @@ class NEMARModel(BaseModel):
         terms = [self.criterionGAN(self.netD(self.real_A, img), target_is_real, weight)]
         for i, netD_S in enumerate(self.netD_multiresolution):
             a_r = self._half('real_A', self.real_A, i + 1)
-            img_r = self._half(image_name if detach else None, img, i + 1)
+            img_r = self._half(image_name, img, i + 1)
             terms.append(self.criterionGAN(netD_S(a_r, img_r), target_is_real, weight))
         return terms
 
@@ -212,12 +215,12 @@ class NEMARModel(BaseModel):
         w = 0.5 * self.opt.lambda_GAN
         if self._batched:
             real, fake_tr, fake_rt = self._d_terms_batched([(self.real_B, 'real_B', True, w, True),
-                                                            (self.fake_TR_B, 'fake_TR_B', False, w, True),
-                                                            (self.fake_RT_B, 'fake_RT_B', False, w, True)])
+                                                            (self.fake_TR_B, None, False, w, True),
+                                                            (self.fake_RT_B, None, False, w, True)])
         else:
             real = self._d_terms(self.real_B, 'real_B', True, w, detach=True)
-            fake_tr = self._d_terms(self.fake_TR_B, 'fake_TR_B', False, w, detach=True)
-            fake_rt = self._d_terms(self.fake_RT_B, 'fake_RT_B', False, w, detach=True)
+            fake_tr = self._d_terms(self.fake_TR_B, None, False, w, detach=True)
+            fake_rt = self._d_terms(self.fake_RT_B, None, False, w, detach=True)
         inv = 1.0 / w if w != 0 else 0.0
         self.loss_D_fake_TR = _LazyLoss([(t, inv) for t in fake_tr])
         self.loss_D_fake_RT = _LazyLoss([(t, inv) for t in fake_rt])

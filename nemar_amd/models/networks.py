@@ -34,7 +34,7 @@ class ConvParams(nn.Module):
         # nn.Conv2d's default (kaiming-uniform a=sqrt(5)) so an un-initialised net is still sane
         fan_in = (out_ch if transposed else in_ch) * k * k
         bound = 1.0 / math.sqrt(fan_in)
-        nn.init.uniform_(self.weight, -bound * math.sqrt(3.0), bound * math.sqrt(3.0))
+        nn.init.uniform_(self.weight, -bound, bound)
         if self.bias is not None:
             nn.init.uniform_(self.bias, -bound, bound)
 
@@ -46,8 +46,8 @@ class LinearParams(nn.Module):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(out_f, in_f))
         self.bias = nn.Parameter(torch.zeros(out_f))
-        bound = 1.0 / math.sqrt(in_f)
-        nn.init.uniform_(self.weight, -bound * math.sqrt(3.0), bound * math.sqrt(3.0))
+        bound = 1.0 / math.sqrt(in_f)       # nn.Linear's default: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +1/sqrt(fan_in))
+        nn.init.uniform_(self.weight, -bound, bound)
         nn.init.uniform_(self.bias, -bound, bound)
 
 
@@ -150,6 +150,7 @@ def init_weights(net, init_type='normal', init_gain=0.02):
                 nn.init.orthogonal_(w, gain=init_gain)
             if m.bias is not None:
                 nn.init.constant_(m.bias.data, 0.0)
+    ops.invalidate_packed_weights()      # .data writes do not bump tensor._version: drop every cached packed image
     print('initialize network with %s' % init_type)
 
 
@@ -370,6 +371,7 @@ class ResnetGenerator(nn.Module):
 
     def init_to_identity(self):
         self.head.weight.data.normal_(mean=0.0, std=1e-5)
+        ops.invalidate_packed_weights()
 
 
 class NLayerDiscriminator(nn.Module):

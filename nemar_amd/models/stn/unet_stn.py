@@ -22,14 +22,16 @@ sampling_align_corners = False
 sampling_mode = 'bilinear'
 
 # encoder widths / decoder widths / options per configuration (reference :11-25).  'A' is the reference's only
-# configuration; further entries can be added through the same dicts (BASELINE.json config 5 asks for a deeper one).
-ndf = {'A': [32, 64, 64, 64, 64, 64, 64], }
-nuf = {'A': [64, 64, 64, 64, 64, 64, 32], }
-use_down_resblocks = {'A': True, }
-resnet_nblocks = {'A': 3, }
-refine_output = {'A': True, }
-down_activation = {'A': 'leaky_relu', }
-up_activation = {'A': 'leaky_relu', }
+# configuration.
+# 'deep' (BASELINE.json config 5, 1024x1024): two more levels, so that the bottleneck is again 2x2 at 1024x1024 — not in the
+# reference, whose ResUnet code builds it from the same dict entries (tests/golden/make_golden.py does exactly that).
+ndf = {'A': [32, 64, 64, 64, 64, 64, 64], 'deep': [32, 64, 64, 64, 64, 64, 64, 64, 64], }
+nuf = {'A': [64, 64, 64, 64, 64, 64, 32], 'deep': [64, 64, 64, 64, 64, 64, 64, 64, 32], }
+use_down_resblocks = {'A': True, 'deep': True, }
+resnet_nblocks = {'A': 3, 'deep': 3, }
+refine_output = {'A': True, 'deep': True, }
+down_activation = {'A': 'leaky_relu', 'deep': 'leaky_relu', }
+up_activation = {'A': 'leaky_relu', 'deep': 'leaky_relu', }
 
 
 class ResUnet(nn.Module):

@@ -76,20 +76,30 @@ def _workspace(nbytes, device):
 # ---- packed-weight cache ---------------------------------------------------------------------------------------------
 # The MFMA kernels read weights in a packed [reduction][channel] layout.  Packing is a tiny kernel, but a step applies
 # every weight tensor several times (T: 2 forward + 2 backward passes, D: 5), so each (weight, direction) keeps its own
-# packed workspace until the values change: FlatAdam.step() / load_state_dict bump the epoch, in-place torch ops bump
-# tensor._version.
-_param_epoch = [0]
+# packed workspace until the values change: FlatAdam.step() bumps the epoch of ITS OWN parameters (the discriminator's
+# update does not re-pack the translation / registration nets), invalidate_packed_weights() bumps the global one, in-place
+# torch ops bump tensor._version.
+class PackEpoch:
+    """Value generation of a group of weights: bumped when their values change outside torch's version counter."""
+    __slots__ = ('n',)
+
+    def __init__(self):
+        self.n = 0
+
+
+_param_epoch = PackEpoch()      # everything (re-initialisation through .data, checkpoint loads)
 _pack_cache = {}
 
 
 def invalidate_packed_weights():
-    _param_epoch[0] += 1
+    _param_epoch.n += 1
 
 
 def _packed(weight, kind, nbytes):
     """-> (workspace tensor, prepacked flag) for `weight` used in direction `kind`."""
     key = (id(weight), kind)
-    token = (_param_epoch[0], weight._version, weight.data_ptr(), tuple(weight.shape))
+    own = getattr(weight, '_pack_epoch', None)
+    token = (_param_epoch.n, own.n if own is not None else 0, weight._version, weight.data_ptr(), tuple(weight.shape))
     ent = _pack_cache.get(key)
     # id() and device addresses are recycled once a tensor dies: an entry is only valid for the very object it was
     # made for (weak reference), with unchanged values (epoch, _version) at an unchanged address
@@ -354,7 +364,9 @@ _dropout_state = {"seed": 0x5EED5EED, "offset": 0}
 
 
 def manual_seed(seed):
-    """Seed of the counter-based dropout generator (per process; ranks should pass different seeds)."""
+    """Seed of the counter-based dropout generator.  NEMARModel seeds it from torch.initial_seed() + rank, so that
+    torch.manual_seed() governs it and data-parallel ranks draw different masks (as torch's per-process RNG does in the
+    reference)."""
     _dropout_state["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
     _dropout_state["offset"] = 0
 
@@ -574,9 +586,11 @@ class FlatAdam:
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self._epoch = PackEpoch()
         invalidate_packed_weights()
         with torch.no_grad():
             for p, o in zip(self.params, offs):
+                p._pack_epoch = self._epoch
                 view = self.flat_p[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
@@ -587,7 +601,7 @@ class FlatAdam:
         self.flat_g.zero_()
 
     def step(self):
-        invalidate_packed_weights()
+        self._epoch.n += 1
         self.step_count += 1
         g = self.param_groups[0]
         L.adam_step(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, float(g["lr"]),

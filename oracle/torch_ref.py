@@ -18,9 +18,9 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
-UNET_NDF = {'A': [32, 64, 64, 64, 64, 64, 64]}
-UNET_NUF = {'A': [64, 64, 64, 64, 64, 64, 32]}
-UNET_NRES = {'A': 3}
+UNET_NDF = {'A': [32, 64, 64, 64, 64, 64, 64], 'deep': [32, 64, 64, 64, 64, 64, 64, 64, 64]}
+UNET_NUF = {'A': [64, 64, 64, 64, 64, 64, 32], 'deep': [64, 64, 64, 64, 64, 64, 64, 64, 32]}
+UNET_NRES = {'A': 3, 'deep': 3}
 
 
 # ---- building blocks -------------------------------------------------------------------------------------
@@ -174,14 +174,15 @@ class RefModel:
 
     def __init__(self, sd_T, sd_R, sd_D, sd_D_mr=(), *, n_blocks, stn_type='unet', gan_mode='vanilla', lr=2e-4,
                  beta1=0.5, lambda_GAN=1.0, lambda_recon=100.0, lambda_smooth=0.0, alpha=0.0, multires_reg=1,
-                 dtype=torch.float32):
+                 stn_cfg='A', dtype=torch.float32):
         """dtype=torch.float64 gives the 'true value' run used to calibrate fp32 tolerances (conditioning)."""
         self.dtype = dtype
         leaf = lambda sd: OrderedDict((k, v.detach().clone().to(dtype).requires_grad_(True)) for k, v in sd.items())
         self.T, self.R, self.D = leaf(sd_T), leaf(sd_R), leaf(sd_D)
         self.D_mr = [leaf(s) for s in sd_D_mr]
         self.cfg = dict(n_blocks=n_blocks, stn_type=stn_type, gan_mode=gan_mode, lambda_GAN=lambda_GAN,
-                        lambda_recon=lambda_recon, lambda_smooth=lambda_smooth, alpha=alpha, multires_reg=multires_reg)
+                        lambda_recon=lambda_recon, lambda_smooth=lambda_smooth, alpha=alpha, multires_reg=multires_reg,
+                        stn_cfg=stn_cfg)
         mk = lambda ps: torch.optim.Adam(ps, lr=lr, betas=(beta1, 0.999))
         self.opt_T = mk(list(self.T.values()))
         self.opt_R = mk(list(self.R.values()))
@@ -211,7 +212,7 @@ class RefModel:
 
     def _netR(self, a, b, apply_on):
         if self.cfg['stn_type'] == 'unet':
-            return unet_stn(self.R, a, b, apply_on, self.cfg['alpha'], self.cfg['multires_reg'])
+            return unet_stn(self.R, a, b, apply_on, self.cfg['alpha'], self.cfg['multires_reg'], self.cfg['stn_cfg'])
         return affine_stn(self.R, a, b, apply_on)
 
     def _d_all(self, a, img, real):

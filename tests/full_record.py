@@ -1,0 +1,51 @@
+"""What a full-width step is reduced to (scalars + small crops), shared by the fixture generator — which runs the
+REFERENCE's NEMARModel (tests/golden/make_golden.py, build container only) — and by the `-m gpu` test, which runs the
+MI355X build's NEMARModel through the very same function (tests/test_step_full_gpu.py)."""
+import numpy as np
+import torch
+
+import seeded
+
+
+def proj(t, seed, stream):
+    """<t, r> / sqrt(numel) with r the seeded U[-1,1) vector (seed, stream): one scalar that moves with every element."""
+    r = torch.from_numpy(seeded.uniform((t.numel(),), seed, stream)).double()
+    return float((t.detach().double().cpu().reshape(-1) * r).sum().item() / np.sqrt(t.numel()))
+
+
+def full_step_record(m, A, B, seed):
+    """One optimize_parameters() of `m` (anything with NEMARModel's attributes) on the numpy batch (A, B)."""
+    out = {}
+    p0 = next(m.netT.parameters())
+    a, b = torch.from_numpy(A).to(p0.device, p0.dtype), torch.from_numpy(B).to(p0.device, p0.dtype)
+    with torch.no_grad():
+        off = m.netR.offset_map(a, b)            # the deformation field, before the update
+    out['offsets/mean'], out['offsets/absmean'] = off.double().mean().item(), off.double().abs().mean().item()
+    out['offsets/proj'] = proj(off, seed, 900)
+    out['offsets/cropc'] = _cropc(off)
+    m.set_input({'A': a, 'B': b, 'A_paths': ['a'], 'B_paths': ['b']})
+    m.optimize_parameters()
+    for k, v in m.get_current_losses().items():
+        out['loss/' + k] = float(v)
+    out['reg'] = float(m.stn_reg_term)
+    for i, nm in enumerate(('fake_B', 'registered_real_A', 'fake_TR_B', 'fake_RT_B')):
+        t = getattr(m, nm).detach()
+        out['mean/' + nm], out['absmean/' + nm] = t.double().mean().item(), t.double().abs().mean().item()
+        out['proj/' + nm] = proj(t, seed, 901 + i)
+        out['crop0/' + nm] = t[:, :, :8, :8].double().cpu().numpy().copy()
+        out['cropc/' + nm] = _cropc(t)
+    nets = [('T', m.netT), ('R', m.netR), ('D', m.netD)] + [('Dmr%d' % i, d) for i, d in enumerate(m.netD_multiresolution)]
+    for nm, net in nets:
+        for j, (k, p) in enumerate(net.named_parameters()):
+            if p.grad is not None:
+                out['gradnorm/%s/%s' % (nm, k)] = p.grad.double().norm().item()
+                out['gradproj/%s/%s' % (nm, k)] = proj(p.grad, seed, 1000 + j)
+                out['gradmax/%s/%s' % (nm, k)] = p.grad.double().abs().max().item()
+            out['psum/%s/%s' % (nm, k)] = p.detach().double().sum().item()
+            out['pabs/%s/%s' % (nm, k)] = p.detach().double().abs().sum().item()
+    return out
+
+
+def _cropc(t):
+    h, w = t.shape[2] // 2, t.shape[3] // 2
+    return t[:, :, h - 4:h + 4, w - 4:w + 4].double().cpu().numpy().copy()

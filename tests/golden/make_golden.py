@@ -25,7 +25,8 @@ sys.modules['torch.utils.tensorboard'] = tb          # the only missing import o
 import torch  # noqa: E402
 
 import seeded  # noqa: E402
-from step_configs import STEP_CONFIGS, make_opt  # noqa: E402
+from full_record import full_step_record  # noqa: E402
+from step_configs import STEP_CONFIGS, FULL_CONFIGS, DEEP_STN_CFG, make_opt  # noqa: E402
 
 
 KEYS = {}
@@ -79,6 +80,42 @@ def run_step_config(name, cfg):
     print(name, {k: float(v) for k, v in out.items() if '/loss/' in k and k.startswith('s0')})
 
 
+def run_full_config(name, cfg):
+    """Full-width step of the reference in fp32 AND fp64 (tests/step_configs.FULL_CONFIGS)."""
+    import time
+    from models.nemar_model import NEMARModel
+    import models.stn.unet_stn as ref_unet
+    for key, val in DEEP_STN_CFG.items():            # the 'deep' cfg: new entries in the reference's own dicts
+        getattr(ref_unet, key)['deep'] = val
+    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    out = {}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        if tag == 'f64' and not cfg.get('f64', True):
+            continue          # 1024x1024 in fp64 does not fit this container's memory/time: see tests/test_step_gpu.py
+        t0 = time.time()
+        torch.set_default_dtype(dt)
+        try:
+            opt = make_opt(cfg)
+            torch.manual_seed(0)
+            m = NEMARModel(opt)
+            m.setup(opt)
+            load_seeded(m.netT, cfg['seed'] + 1, cfg.get('overrides_T'))
+            load_seeded(m.netR, cfg['seed'] + 2, cfg.get('overrides_R'))
+            load_seeded(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
+            for i, d in enumerate(m.netD_multiresolution):
+                load_seeded(d, cfg['seed'] + 10 + i, cfg.get('overrides_D'))
+            assert next(m.netT.parameters()).dtype == dt
+            rec = full_step_record(m, A, B, cfg['seed'])
+        finally:
+            torch.set_default_dtype(torch.float32)
+        for k, v in rec.items():
+            out['%s/%s' % (tag, k)] = np.asarray(v, dtype=np.float64)
+        print(name, tag, '%.1fs' % (time.time() - t0), {k: round(v, 6) for k, v in rec.items() if k.startswith('loss/')},
+              flush=True)
+        del m
+    np.savez_compressed(os.path.join(HERE, 'step_%s.npz' % name), **out)
+
+
 def run_op_fixtures():
     from models.stn.stn_losses import smoothness_loss
     from models.stn.unet_stn import UnetSTN
@@ -110,6 +147,33 @@ def run_op_fixtures():
             out['gan/%s/%d/grad' % (mode, real)] = x.grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, 'ops_reference.npz'), **out)
     print('ops fixtures:', len(out))
+
+
+def run_init_stats():
+    """Per-tensor (numel, mean, std) of the reference's own initialisation: define_G / define_D through
+    init_net (models/networks.py:62-113), UnetSTN / AffineSTN through their per-Conv initialisers incl. the quirks —
+    decoder convs always kaiming (`init_fun` typo, models/stn/unet_stn.py:62-63), 'zeros' = N(0, 1e-5)
+    (models/stn/layers.py:46-47), affine head N(0, 5e-4) (models/stn/affine_stn.py:75-76)."""
+    import json
+    from models import networks as ref_networks
+    from models import stn as ref_stn
+    from step_configs import FULL_CONFIGS
+    out = {}
+    torch.manual_seed(1234)
+    nets = {
+        'T': ref_networks.define_G(3, 3, 64, 'resnet_9blocks', 'instance', True, 'normal', 0.02, []),
+        'D': ref_networks.define_D(6, 64, 'basic', 3, 'instance', 'normal', 0.02, []),
+        'R_unet': ref_stn.define_stn(make_opt(FULL_CONFIGS['c2_full']), 'unet'),
+        'R_unet_noident': ref_stn.define_stn(argparse.Namespace(**{**vars(make_opt(FULL_CONFIGS['c2_full'])),
+                                                                    'stn_no_identity_init': True}), 'unet'),
+        'R_affine': ref_stn.define_stn(make_opt(STEP_CONFIGS['affine128']), 'affine'),
+    }
+    for nm, net in nets.items():
+        out[nm] = [[k, int(v.numel()), float(v.double().mean()), float(v.double().std()) if v.numel() > 1 else 0.0]
+                   for k, v in net.state_dict().items()]
+    with open(os.path.join(HERE, 'init_stats.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('init stats:', {k: len(v) for k, v in out.items()})
 
 
 def run_unet_generator():
@@ -145,11 +209,16 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     if a.only in (None, 'ops'):
         run_op_fixtures()
+    if a.only in (None, 'init'):
+        run_init_stats()
     if a.only in (None, 'unet_generator'):
         run_unet_generator()
     for name, cfg in STEP_CONFIGS.items():
         if a.only in (None, name):
             run_step_config(name, cfg)
+    for name, cfg in FULL_CONFIGS.items():
+        if a.only in (None, name, 'full'):
+            run_full_config(name, cfg)
     if a.only is None:
         import json
         with open(os.path.join(HERE, 'state_dict_keys.json'), 'w') as f:

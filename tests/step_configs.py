@@ -18,6 +18,34 @@ STEP_CONFIGS = {
                           overrides_R={'offset_map.output.conv2d.weight': 0.05}),
 }
 
+# Full-width steps at the BASELINE.json shapes (ngf = ndf = 64, resnet_9blocks): the production kernel dispatch
+# (128x128 wave-specialised tiles, one-round weight-gradient splits, ...) compared with fixtures recorded from TWO runs of
+# the reference itself (fp32 and fp64 — the gap between them calibrates each quantity's tolerance).  Scalars only
+# (losses, image statistics, per-parameter gradient norms / seeded projections, post-Adam checksums): SURVEY.md §8c.
+FULL_CONFIGS = {
+    # C2: unet cfg 'A', 256x256 (the bench workload, at batch 1)
+    'c2_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=256, batch=1, seed=41,
+                    lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+    # C3: + multi-resolution discriminators, batch 2
+    'c3_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=256, batch=2, seed=43,
+                    lambda_smooth=10.0, multi_resolution=2, steps=1,
+                    overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+    # C4: 512x512, bilateral smoothness, multi-resolution regulariser
+    'c4_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=512, batch=2, seed=47,
+                    lambda_smooth=10.0, stn_bilateral_alpha=1.5, stn_multires_reg=2, steps=1,
+                    overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+    # C5: 1024x1024, the deeper registration net (stn_cfg 'deep': 9 levels -> 2x2 bottleneck at 1024x1024)
+    'c5_full': dict(stn_type='unet', stn_cfg='deep', netG='resnet_9blocks', ngf=64, ndf=64, size=1024, batch=1,
+                    seed=53, lambda_smooth=10.0, steps=1, f64=False, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+}
+
+# BASELINE.json config 5's "deep" registration cfg does not exist in the reference (models/stn/unet_stn.py:11-25 defines
+# 'A' only); the build adds it through the same dict mechanism, and the fixture generator injects the same entries into
+# the imported reference's dicts (data, not code) so that the reference's own ResUnet builds it.
+DEEP_STN_CFG = dict(ndf=[32, 64, 64, 64, 64, 64, 64, 64, 64], nuf=[64, 64, 64, 64, 64, 64, 64, 64, 32],
+                    use_down_resblocks=True, resnet_nblocks=3, refine_output=True, down_activation='leaky_relu',
+                    up_activation='leaky_relu')
+
 
 def make_opt(cfg, gpu_ids=()):
     return argparse.Namespace(
@@ -26,7 +54,7 @@ def make_opt(cfg, gpu_ids=()):
         norm='instance', init_type='normal', init_gain=0.02, no_dropout=True, direction='AtoB',
         img_height=cfg['size'], img_width=cfg['size'], lr=2e-4, beta1=0.5, gan_mode=cfg.get('gan_mode', 'vanilla'),
         lambda_GAN=1.0, lambda_recon=100.0, lambda_smooth=cfg.get('lambda_smooth', 0.0), enable_tbvis=False,
-        multi_resolution=cfg.get('multi_resolution', 1), stn_cfg='A', stn_type=cfg['stn_type'],
+        multi_resolution=cfg.get('multi_resolution', 1), stn_cfg=cfg.get('stn_cfg', 'A'), stn_type=cfg['stn_type'],
         stn_bilateral_alpha=cfg.get('stn_bilateral_alpha', 0.0), stn_no_identity_init=False,
         stn_multires_reg=cfg.get('stn_multires_reg', 1), lr_policy='linear', epoch_count=1, niter=100,
         niter_decay=100, continue_train=False, verbose=False, batch_size=cfg['batch'], load_iter=0, epoch='latest',

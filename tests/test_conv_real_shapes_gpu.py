@@ -1,0 +1,177 @@
+"""`-m gpu`: the convolution entry points at the REAL shapes of the bench step (BASELINE config 2, batch 8), with the
+library's DEFAULT tile selection — the dispatch that the small kernel cases never reach (igemm_ws2_kernel<4,true> on
+512 workgroups, wgrad2_kernel<true,2,2,2> one-round splits, the reflect data gradient at 64x64, the four parity
+classes of the stride-2 data gradients, the narrow 7x7 kernels at 256x256).
+
+Oracle: torch CPU convolutions (the reference's own arithmetic).  Two tiers per case:
+  * fp64 on a SUBSET of channels that touches every 32-channel MFMA row tile / every weight-gradient tile (an exact
+    value; the subset keeps the CPU time to a second or two): tolerance atol 2e-5 + rtol 2e-5 (fwd/dgrad), 5e-5 (wgrad);
+  * fp32 on the FULL tensor (MKLDNN, a different summation order than ours): max-abs error <= 2e-4 of the tensor's max.
+All through the C ABI (include/nemar_hip.h), exactly as nemar_amd/ops.py calls it."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backends import HipBackend
+
+pytestmark = pytest.mark.gpu
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+
+@pytest.fixture(scope="module")
+def be(hip_lib):
+    return HipBackend(hip_lib)
+
+
+def _subset(n, k=12):
+    """channel subset hitting both ends of every 32-wide tile boundary region"""
+    if n <= k:
+        return list(range(n))
+    pts = {0, 1, n - 1, n - 2}
+    for b in range(32, n, 32):
+        pts.update((b - 1, b))
+    pts = sorted(p for p in pts if 0 <= p < n)
+    if len(pts) > k:
+        idx = np.linspace(0, len(pts) - 1, k).round().astype(int)
+        pts = [pts[i] for i in idx]
+    return pts
+
+
+def _conv_cpu(x, w, b, stride, pad, pm):
+    if pm == PAD_REFLECT and pad:
+        x = F.pad(x, (pad, pad, pad, pad), mode='reflect')
+        pad = 0
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+def _close(got, want, atol, rtol, what):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want)
+    lim = atol + rtol * np.abs(want)
+    if not np.all(err <= lim):
+        i = np.unravel_index(np.argmax(err - lim), err.shape)
+        raise AssertionError("%s: max|err|=%.3e at %s (got %.6g want %.6g)" % (what, err.max(), i, got[i], want[i]))
+
+
+# name, N, C0, C1, H, W, K, R, stride, pad, pad_mode
+SHAPES = [
+    ("T resblock 256->256 k3 reflect 64x64", 8, 256, 0, 64, 64, 256, 3, 1, 1, PAD_REFLECT),
+    ("D layer4 256->512 k4 s1 32x32->31x31", 8, 256, 0, 32, 32, 512, 4, 1, 1, PAD_ZERO),
+    ("R up_1 64+32->32 k3 256x256", 8, 64, 32, 256, 256, 32, 3, 1, 1, PAD_ZERO),
+    ("T down1 64->128 k3 s2 256x256", 8, 64, 0, 256, 256, 128, 3, 2, 1, PAD_ZERO),
+    ("T down2 128->256 k3 s2 128x128", 8, 128, 0, 128, 128, 256, 3, 2, 1, PAD_ZERO),
+    ("D layer2 64->128 k4 s2 128x128", 8, 64, 0, 128, 128, 128, 4, 2, 1, PAD_ZERO),
+    ("D layer3 128->256 k4 s2 64x64", 8, 128, 0, 64, 64, 256, 4, 2, 1, PAD_ZERO),
+    ("D layer1 3+3->64 k4 s2 256x256", 8, 3, 3, 256, 256, 64, 4, 2, 1, PAD_ZERO),
+    ("D logits 512->1 k4 s1 31x31", 8, 512, 0, 31, 31, 1, 4, 1, 1, PAD_ZERO),
+    ("T stem 3->64 k7 reflect 256x256", 8, 3, 0, 256, 256, 64, 7, 1, 3, PAD_REFLECT),
+    ("T head 64->3 k7 reflect 256x256", 8, 64, 0, 256, 256, 3, 7, 1, 3, PAD_REFLECT),
+    ("R resblock 32->32 k3 reflect 256x256", 8, 32, 0, 256, 256, 32, 3, 1, 1, PAD_REFLECT),
+    ("R resblock 64->64 k3 reflect 128x128", 8, 64, 0, 128, 128, 64, 3, 1, 1, PAD_REFLECT),
+    ("R down_1 3+3->32 k3 256x256", 8, 3, 3, 256, 256, 32, 3, 1, 1, PAD_ZERO),
+    ("R bottleneck 128->128 k3 reflect 2x2", 8, 128, 0, 2, 2, 128, 3, 1, 1, PAD_REFLECT),
+    ("R output 32->2 k3 256x256", 8, 32, 0, 256, 256, 2, 3, 1, 1, PAD_ZERO),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_conv_real_shape(be, shape):
+    name, N, C0, C1, H, W, K, R, stride, pad, pm = shape
+    C = C0 + C1
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    x = torch.rand((N, C, H, W), generator=g) * 2 - 1
+    w = torch.randn((K, C, R, R), generator=g) / np.sqrt(C * R * R)
+    b = torch.randn((K,), generator=g)
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    gy = torch.randn((N, K, OH, OW), generator=g)
+    lib, P = be.lib, be.ptr
+    d_x0, d_x1 = be.dev(x[:, :C0].numpy()), (be.dev(x[:, C0:].numpy()) if C1 else None)
+    d_w, d_b, d_gy = be.dev(w.numpy()), be.dev(b.numpy()), be.dev(gy.numpy())
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    d_y = be.full((N, K, OH, OW), np.nan)
+    wsb = lib.conv2d_fwd_workspace(K, C, R, R)
+    ws = be.bytes_buf(wsb)
+    lib.conv2d_fwd(P(d_x0), C0, P(d_x1), C1, P(d_w), P(d_b), P(d_y), N, H, W, K, R, R, stride, pad, pm, 0, 0.2, P(ws),
+                   wsb, 0, be.stream)
+    y = be.np(d_y)
+    ks = _subset(K)
+    want = _conv_cpu(x.double(), w[ks].double(), b[ks].double(), stride, pad, pm).numpy()
+    _close(y[:, ks], want, 2e-5, 2e-5, name + " fwd (fp64 subset)")
+    full = _conv_cpu(x, w, b, stride, pad, pm).numpy()
+    assert np.abs(y - full).max() <= 2e-4 * np.abs(full).max(), (name, "fwd full", np.abs(y - full).max())
+
+    # ---- data gradient ---------------------------------------------------------------------------------------
+    if not (pm == PAD_REFLECT and C1):
+        d_g0 = be.full((N, C0, H, W), np.nan)
+        d_g1 = be.full((N, C1, H, W), np.nan) if C1 else None
+        wsb = lib.conv2d_bwd_data_workspace(N, C, H, W, K, R, R, stride, pad, pm)
+        ws = be.bytes_buf(wsb)
+        lib.conv2d_bwd_data(P(d_gy), P(d_w), None, 0, 0.0, P(d_g0), C0, P(d_g1), C1, N, H, W, K, OH, OW, R, R, stride,
+                            pad, pm, P(ws), wsb, 0, be.stream)
+        gx = np.concatenate([be.np(d_g0)] + ([be.np(d_g1)] if C1 else []), axis=1)
+        cs = _subset(C)
+        xs = torch.zeros((N, len(cs), H, W), dtype=torch.float64, requires_grad=True)
+        _conv_cpu(xs, w[:, cs].double(), None, stride, pad, pm).backward(gy.double())
+        _close(gx[:, cs], xs.grad.numpy(), 3e-5, 2e-5, name + " dgrad (fp64 subset)")
+        xf = torch.zeros((N, C, H, W), requires_grad=True)
+        _conv_cpu(xf, w, None, stride, pad, pm).backward(gy)
+        ref = xf.grad.numpy()
+        assert np.abs(gx - ref).max() <= 2e-4 * np.abs(ref).max(), (name, "dgrad full", np.abs(gx - ref).max())
+
+    # ---- weight + bias gradient (accumulating) -----------------------------------------------------------------
+    gys = gy / np.sqrt(N * OH * OW)
+    d_gys = be.dev(gys.numpy())
+    d_gw, d_gb = be.full((K, C, R, R), 0.5), be.full((K,), 0.125)
+    lib.conv2d_bwd_weight(P(d_x0), C0, P(d_x1), C1, P(d_gys), P(d_gw), P(d_gb), N, H, W, K, OH, OW, R, R, stride, pad,
+                          pm, be.stream)
+    gw, gb = be.np(d_gw) - 0.5, be.np(d_gb) - 0.125
+    ks = _subset(K)
+    wz = torch.zeros((len(ks), C, R, R), dtype=torch.float64, requires_grad=True)
+    bz = torch.zeros((len(ks),), dtype=torch.float64, requires_grad=True)
+    _conv_cpu(x.double(), wz, bz, stride, pad, pm).backward(gys[:, ks].double())
+    _close(gw[ks], wz.grad.numpy(), 5e-5, 5e-5, name + " wgrad (fp64 subset)")
+    _close(gb[ks], bz.grad.numpy(), 5e-5, 5e-5, name + " bias grad (fp64 subset)")
+    wf = torch.zeros((K, C, R, R), requires_grad=True)
+    _conv_cpu(x, wf, None, stride, pad, pm).backward(gys)
+    ref = wf.grad.numpy()
+    assert np.abs(gw - ref).max() <= 2e-4 * np.abs(ref).max() + 2e-6, (name, "wgrad full", np.abs(gw - ref).max())
+
+
+CONVT = [("T up1 convT 256->128 k3 s2 64x64->128x128", 8, 256, 128, 64, 64, 3, 1),
+         ("T up2 convT 128->64 k3 s2 128x128->256x256", 8, 128, 64, 128, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("shape", CONVT, ids=[s[0] for s in CONVT])
+def test_conv_transpose_real_shape(be, shape):
+    name, N, Ci, Co, H, W, R, op = shape
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    x = torch.rand((N, Ci, H, W), generator=g) * 2 - 1
+    w = torch.randn((Ci, Co, R, R), generator=g) / np.sqrt(Ci * R * R)
+    b = torch.randn((Co,), generator=g)
+    lib, P = be.lib, be.ptr
+    Ho, Wo = (H - 1) * 2 - 2 + R + op, (W - 1) * 2 - 2 + R + op
+    d_x, d_w, d_b = be.dev(x.numpy()), be.dev(w.numpy()), be.dev(b.numpy())
+    d_y = be.full((N, Co, Ho, Wo), np.nan)
+    wsb = lib.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, R, 2, 1, PAD_ZERO)
+    ws = be.bytes_buf(wsb)
+    lib.conv2d_bwd_data(P(d_x), P(d_w), P(d_b), 0, 0.0, P(d_y), Co, None, 0, N, Ho, Wo, Ci, H, W, R, R, 2, 1, PAD_ZERO,
+                        P(ws), wsb, 0, be.stream)
+    y = be.np(d_y)
+    cs = _subset(Co)
+    want = F.conv_transpose2d(x.double(), w[:, cs].double(), b[cs].double(), stride=2, padding=1, output_padding=op).numpy()
+    _close(y[:, cs], want, 2e-5, 2e-5, name + " fwd (fp64 subset)")
+    full = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=op).numpy()
+    assert np.abs(y - full).max() <= 2e-4 * np.abs(full).max()
+    # weight gradient of the transposed conv = conv weight gradient with the roles of input and gradient swapped
+    gy = torch.randn((N, Co, Ho, Wo), generator=g) / np.sqrt(N * Ho * Wo)
+    d_gy = be.dev(gy.numpy())
+    d_gw = be.full((Ci, Co, R, R), 0.0)
+    lib.conv2d_bwd_weight(P(d_gy), Co, None, 0, P(d_x), P(d_gw), None, N, Ho, Wo, Ci, H, W, R, R, 2, 1, PAD_ZERO, be.stream)
+    wf = w.clone().requires_grad_(True)
+    F.conv_transpose2d(x, wf, None, stride=2, padding=1, output_padding=op).backward(gy)
+    ref = wf.grad.numpy()
+    assert np.abs(be.np(d_gw) - ref).max() <= 2e-4 * np.abs(ref).max() + 2e-6, name

@@ -1,0 +1,129 @@
+"""`-m gpu`: FULL-WIDTH NEMARModel.optimize_parameters() (ngf = ndf = 64, resnet_9blocks: the production kernel
+dispatch — 128x128 wave-specialised tiles, one-round weight-gradient splits, vector loaders) at the BASELINE.json
+shapes C2..C5, against fixtures recorded from the reference itself (tests/golden/make_golden.py --only full: the
+reference's NEMARModel run in fp32 AND fp64 on the same seeded weights / inputs).
+
+Every compared quantity q obeys   |q_build - q_ref64| <= base(q) + 4 * |q_ref32 - q_ref64| :
+the fp64 run is the true value of the reference's algorithm, and the reference's own fp32-vs-fp64 gap measures how
+ill-conditioned q is (sign() in the L1 gradient, ReLU / LeakyReLU / max-pool masks, floor() in the sampler).  base(q) is
+the fp32 rounding floor of the quantity's class, written below.  The 1024x1024 config has no fp64 run (it does not fit
+the build container); its gap per quantity class is taken from the 512x512 config's measured relative gaps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import seeded
+from full_record import full_step_record
+from step_configs import FULL_CONFIGS, make_opt
+from step_parity import load_seeded_into
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+# class -> (relative base, absolute base); gradients are relative to the tensor's own norm
+BASE = {
+    'loss': (1e-4, 1e-6), 'reg': (1e-4, 1e-7), 'mean': (0.0, 2e-5), 'absmean': (2e-5, 2e-6), 'proj': (0.0, 2e-4),
+    'crop0': (0.0, 5e-5), 'cropc': (0.0, 5e-5), 'offsets': (2e-5, 2e-6),
+    'gradnorm': (2e-3, 0.0), 'gradproj': (2e-3, 0.0), 'gradmax': (1e-2, 0.0), 'psum': (5e-5, 0.0), 'pabs': (5e-5, 0.0),
+}
+
+
+def _class_of(key):
+    return key.split('/')[0]
+
+
+def _rel_gaps_by_class(g):
+    """max over the scalar quantities of a class of |f32 - f64| / scale (for fixtures recorded with both runs)."""
+    out = {}
+    for k in g.files:
+        if not k.startswith('f64/'):
+            continue
+        q = k[4:]
+        a, b = g['f32/' + q], g[k]
+        cls = _class_of(q)
+        if cls.startswith('grad'):
+            scale = float(g['f64/gradnorm/' + q.split('/', 1)[1]])
+            if scale < 1e-5 * _net_gmax(g, q.split('/')[1], 'f64'):
+                continue
+        elif cls in ('psum', 'pabs'):
+            scale = float(g['f64/pabs/' + q.split('/', 1)[1]])
+        else:
+            scale = max(float(np.abs(b).max()), 1.0 if cls in ('loss', 'crop0', 'cropc', 'mean', 'proj') else 1e-30)
+        out.setdefault(cls, []).append(float(np.abs(a - b).max()) / max(scale, 1e-30))
+    return {c: float(np.quantile(v, 0.9)) for c, v in out.items()}
+
+
+def _net_gmax(g, net, tag):
+    pre = '%s/gradnorm/%s/' % (tag, net)
+    return max(float(g[k]) for k in g.files if k.startswith(pre))
+
+
+def build(name):
+    from nemar_amd.models import create_model
+    cfg = FULL_CONFIGS[name]
+    opt = make_opt(cfg, gpu_ids=[0])
+    m = create_model(opt)
+    m.setup(opt)
+    load_seeded_into(m.netT, cfg['seed'] + 1, cfg.get('overrides_T'))
+    load_seeded_into(m.netR, cfg['seed'] + 2, cfg.get('overrides_R'))
+    load_seeded_into(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
+    for i, d in enumerate(m.netD_multiresolution):
+        load_seeded_into(d, cfg['seed'] + 10 + i, cfg.get('overrides_D'))
+    return m
+
+
+def compare(name, rec, report=None):
+    g = np.load(os.path.join(GOLD, 'step_%s.npz' % name))
+    have64 = any(k.startswith('f64/') for k in g.files)
+    truth = 'f64' if have64 else 'f32'
+    class_gap = None
+    if not have64:
+        class_gap = _rel_gaps_by_class(np.load(os.path.join(GOLD, 'step_c4_full.npz')))
+    rows = []
+    for k in sorted(g.files):
+        if not k.startswith(truth + '/'):
+            continue
+        q = k[len(truth) + 1:]
+        if q not in rec:
+            continue
+        want = g[k]
+        got = np.asarray(rec[q], dtype=np.float64)
+        cls = _class_of(q)
+        rel, ab = BASE[cls]
+        if cls.startswith('grad'):
+            tail = q.split('/', 1)[1]
+            scale = float(g['%s/gradnorm/%s' % (truth, tail)])
+            if scale < 1e-5 * _net_gmax(g, q.split('/')[1], truth):
+                continue              # conv biases in front of InstanceNorm: exactly-zero gradient + rounding noise
+        elif cls in ('psum', 'pabs'):
+            scale = float(g['%s/pabs/%s' % (truth, q.split('/', 1)[1])])
+        else:
+            scale = float(np.abs(want).max())
+        if have64:
+            gap = float(np.abs(g['f32/' + q] - want).max())
+        else:
+            gap = class_gap.get(cls, 0.0) * max(scale, 1.0 if cls in ('loss', 'crop0', 'cropc', 'mean', 'proj') else 0.0)
+        tol = rel * scale + ab + 4.0 * gap
+        err = float(np.abs(got - want).max())
+        rows.append((q, err, tol, err <= tol))
+    if report:
+        with open(report, 'a') as f:
+            f.write('== %s (%d rows, truth = reference %s)\n' % (name, len(rows), truth))
+            for r in rows:
+                f.write('%-86s err=%.3e tol=%.1e %s\n' % (r[0], r[1], r[2], 'ok' if r[3] else 'FAIL'))
+    return rows
+
+
+@pytest.mark.parametrize("name", list(FULL_CONFIGS))
+def test_full_width_step_vs_reference(name):
+    cfg = FULL_CONFIGS[name]
+    m = build(name)
+    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    rec = full_step_record(m, A, B, cfg['seed'])
+    torch.cuda.synchronize()
+    rows = compare(name, rec, report=os.environ.get('NEMAR_FULL_REPORT'))
+    assert len(rows) > 300, len(rows)
+    bad = [r for r in rows if not r[3]]
+    assert not bad, (len(bad), bad[:8])
