@@ -6,7 +6,17 @@ reference's NEMARModel run in fp32 AND fp64 on the same seeded weights / inputs)
 Every compared quantity q obeys   |q_build - q_ref64| <= base(q) + 4 * |q_ref32 - q_ref64| :
 the fp64 run is the true value of the reference's algorithm, and the reference's own fp32-vs-fp64 gap measures how
 ill-conditioned q is (sign() in the L1 gradient, ReLU / LeakyReLU / max-pool masks, floor() in the sampler).  base(q) is
-the fp32 rounding floor of the quantity's class, written below.  The 1024x1024 config has no fp64 run (it does not fit
+the fp32 rounding floor of the quantity's class, written below.  Two refinements, both measured on the first full-width
+run (gpurun_out/r2a/full_rows.txt: every loss / image / weight-gradient row inside the bound, the build's gradient errors
+statistically equal to the reference's own fp32 gaps — R net median 6e-4 vs 1.7e-3):
+  * one tensor's own |f32 - f64| is a single draw of a heavy-tailed quantity, so a gradient row uses
+    max(own gap, upper-quartile relative gap of its network) — otherwise a tensor whose reference run happened to land close
+    (R's 2-element output bias: 6e-4 where its weight shows 1.8e-3) gets a bound tighter than its conditioning;
+  * post-Adam checksums: the first Adam step moves every element by lr * sign(g), so an element whose gradient is at
+    rounding distance of zero moves by 2 lr = 4e-4 between ANY two fp32 implementations; three such elements are
+    allowed per tensor on top of the relative bound, and biases in front of an InstanceNorm (true gradient exactly zero,
+    i.e. pure rounding noise with a random sign) are not compared.
+The 1024x1024 config has no fp64 run (it does not fit
 the build container); its gap per quantity class is taken from the 512x512 config's measured relative gaps."""
 import os
 
@@ -55,6 +65,17 @@ def _rel_gaps_by_class(g):
     return {c: float(np.quantile(v, 0.9)) for c, v in out.items()}
 
 
+def _net_grad_gap(g, net):
+    """upper quartile over the weight tensors of one network of |gradnorm_f32 - gradnorm_f64| / gradnorm_f64"""
+    pre = 'f64/gradnorm/%s/' % net
+    rel = [abs(float(g['f32/' + k[4:]]) - float(g[k])) / max(float(g[k]), 1e-30)
+           for k in g.files if k.startswith(pre) and k.endswith('weight')]
+    return float(np.quantile(rel, 0.75)) if rel else 0.0
+
+
+LR = 2e-4
+
+
 def _net_gmax(g, net, tag):
     pre = '%s/gradnorm/%s/' % (tag, net)
     return max(float(g[k]) for k in g.files if k.startswith(pre))
@@ -92,17 +113,22 @@ def compare(name, rec, report=None):
         got = np.asarray(rec[q], dtype=np.float64)
         cls = _class_of(q)
         rel, ab = BASE[cls]
-        if cls.startswith('grad'):
+        if cls.startswith('grad') or cls in ('psum', 'pabs'):
             tail = q.split('/', 1)[1]
-            scale = float(g['%s/gradnorm/%s' % (truth, tail)])
-            if scale < 1e-5 * _net_gmax(g, q.split('/')[1], truth):
+            gk = '%s/gradnorm/%s' % (truth, tail)
+            if gk in g.files and float(g[gk]) < 1e-5 * _net_gmax(g, tail.split('/')[0], truth):
                 continue              # conv biases in front of InstanceNorm: exactly-zero gradient + rounding noise
+        if cls.startswith('grad'):
+            scale = float(g['%s/gradnorm/%s' % (truth, tail)])
         elif cls in ('psum', 'pabs'):
-            scale = float(g['%s/pabs/%s' % (truth, q.split('/', 1)[1])])
+            scale = float(g['%s/pabs/%s' % (truth, tail)])
+            ab = 3 * 2 * LR
         else:
             scale = float(np.abs(want).max())
         if have64:
             gap = float(np.abs(g['f32/' + q] - want).max())
+            if cls.startswith('grad'):
+                gap = max(gap, _net_grad_gap(g, tail.split('/')[0]) * scale)
         else:
             gap = class_gap.get(cls, 0.0) * max(scale, 1.0 if cls in ('loss', 'crop0', 'cropc', 'mean', 'proj') else 0.0)
         tol = rel * scale + ab + 4.0 * gap
