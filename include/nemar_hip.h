@@ -8,7 +8,8 @@
  *   - plain C: pointers + sizes, no torch types.  Every pointer is DEVICE memory owned by the caller;
  *     tensors are contiguous NCHW float32.  The library never allocates, frees or synchronises.
  *   - every launch goes on `stream` (a hipStream_t passed as void*; NULL = the null stream), so the caller's
- *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream; no global state.
+ *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream.  The only process-global
+ *     state are the nemar_tune* measurement switches below (defaults = the product configuration).
  *   - return value: 0 on success, negative on error (NEMAR_EINVAL bad shape/pointer/unsupported,
  *     NEMAR_ELAUNCH HIP launch error, NEMAR_EWORKSPACE workspace too small); nemar_last_error() returns the
  *     message of the calling thread's last failure.  Python glue raises on non-zero.
@@ -103,12 +104,17 @@ int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, in
                           int prepacked, void* stream);
 /* Weight gradient, ACCUMULATED into gw [K,C0+C1,R,S] and, when gb != NULL, the bias gradient ACCUMULATED into
  * gb [K] in the same pass (the caller zero-fills once per optimizer step; the translation net receives two passes
- * per step).  Pixel reduction is split across workgroups, fp32 atomics.
- * Data gradients may also split their reduction (few-tile deep layers, reflect border ring) and then sum through fp32
- * atomics: backward results are reproducible up to summation order; forward results are bitwise reproducible. */
+ * per step) — autograd's conv backward + AccumulateGrad under loss.backward(), reference models/nemar_model.py:223,260.
+ * The pixel reduction is split across workgroups; every split stores its partial result to its own slab of `workspace`
+ * and a second launch adds the slabs in split order.  Split data gradients (few-tile deep layers) do the same, so the
+ * whole backward pass of the conv family is BITWISE REPRODUCIBLE run to run, like the forward pass (and like the
+ * reference's CPU path).  nemar_tune(14, 0) restores the round-1 fp32-atomic accumulation for A/B timing
+ * (then workspace may be NULL). */
+size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, int K, int OH, int OW, int R, int S, int stride,
+                                         int pad);
 int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
                             int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
-                            int pad_mode, void* stream);
+                            int pad_mode, void* workspace, size_t ws_bytes, void* stream);
 /* Tuning switches for A/B measurements (tools/, tests/): not part of the operator contract, defaults = measured best.
  *   0  conv tile family for 128x128-capable shapes: 0 wave-specialised (default), 5 same without 16-byte B loads,
  *      6 one barrier per 32 reduction rows, 7 four loader waves, 4 first-generation wave-specialised, 1/2/3 generic
@@ -116,14 +122,16 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   3  narrow (<= 4 channel) VALU kernels on/off                     4  weight gradient: 0 default, 1 first generation,
  *                                                                       2 wave-specialised without 16-byte source loads
  *   5  weight-gradient workgroup target (default 512)                6  grid-size threshold of the tile choice (384)
- *   7  force the wave-specialised channel tile (1, 2, 4 x 32)        8  reduction splits of the reflect ring launch
- *   10 4-deep LDS ring for every 64x64 launch                        11 four loader waves for gathered B tiles (on)
- *   12 reduction splits in data gradients (on)                       13 reduction splits in tiny forward convs (off:
- *                                                                       keeps the forward pass bitwise reproducible) */
+ *   7  force the wave-specialised channel tile (1, 2, 4 x 32)        8  3x3 reflect data gradient: border folded into the
+ *                                                                       main launch (1, default) / separate ring launch (0)
+ *   10 4-deep LDS ring for every 64x64 launch
+ *   11 four loader waves for gathered B tiles (on)                   12 reduction splits in data gradients (on)
+ *   14 fixed-order split reductions (1, default) / fp32 atomics in the weight + bias gradients (0) */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
-/* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient). */
-int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream);
+/* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient; two fixed-order stages through `workspace`). */
+size_t nemar_bias_grad_workspace(int N, int C, int HW);
+int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- K3 (+K5): InstanceNorm2d(affine=False, track_running_stats=False) with fused activation / residual -------
  * nn.InstanceNorm2d — reference models/networks.py:24 (used :351,358,373,426,439,584,592), models/stn/layers.py:16;

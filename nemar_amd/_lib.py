@@ -39,8 +39,11 @@ SIGNATURES = {
     "nemar_conv2d_bwd_data_workspace": (_sz, [_i] * 10),
     "nemar_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _fl, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _i, _vp, _sz, _i, _vp]),
-    "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "nemar_conv2d_bwd_weight_workspace": (_sz, [_i] * 11),
+    "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz,
+                                     _vp]),
+    "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
+    "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "nemar_tune": (_i, [_i, _i]),
     "nemar_grid_sample_tune": (_i, [_i]),
     "nemar_tune_ptr": (_i, [_vp]),

@@ -33,15 +33,20 @@
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
 bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW);
 int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int K, int R,
-                     int pad, int border, int act, float slope, hipStream_t st);
+                     int pad, int border, int act, float slope, float* part, size_t part_floats, hipStream_t st);
+int nemar_narrow_wgrad_splits(int N, int C, int OH, int OW);
 int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int R, int pad,
-                       int border, hipStream_t st);
+                       int border, float* part, hipStream_t st);
 
 // conv_wgrad.hip: wave-specialised weight gradient for wide layers
 bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy);
+void nemar_wgrad2_plan(int K, int J, int P, int target_blocks, int* splits_out, int* pix_per_split_out);
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
-                         int target_blocks, bool vec_ok, int dbg, hipStream_t st);
+                         int target_blocks, bool vec_ok, int dbg, float* part, hipStream_t st);
+// reduce.hip: dst (+)= sum of `splits` slabs in split order (the deterministic second stage of every split reduction)
+void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
+                        hipStream_t st);
 
 namespace {
 
@@ -114,6 +119,12 @@ struct IgemmParams {
     // ring mode (ring_p > 0): the "pixels" of this launch are the border ring of width ring_p around a ring_H x ring_W
     // image, in padded coordinates; OH*OW = ring length; results are atomically ADDED at the reflected in-image position
     int ring_p, ring_H, ring_W, ksplit;
+    // ksplit > 1 (reduction split over grid.z: few, deep tiles): split z stores its partial tile to slab z of `part`
+    // (same indexing as dst0) and nemar_sum_partials adds the slabs in order — no atomics, bitwise reproducible
+    float* part; long long part_stride;
+    // reflect data gradient without a ring launch (wave-specialised 16-byte-load kernel, 3x3 pad 1): pre-folded border rows
+    // [2][3][N][K][Ws] and border column groups [2][N][K][Hs][4] of the source (reflect_aux_kernel)
+    int rf; const float* rf_row; const float* rf_col;
     FastDiv fd_ohw, fd_ow, fd_cs;
     TapTable taps;
 };
@@ -324,7 +335,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             ++iss;
             IGEMM_NEXT_ACTIVE(iss);
         }
-    if (first >= nk && p.ring_p) return;          // nothing reaches this tile: it would add zeros
     int slot = 0;
     for (int ks = first; ks < nk; ++slot) {
         const int buf = slot % NBUF;
@@ -381,6 +391,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     // ---- epilogue: bias + activation, NCHW store (lane&31 runs along pixels => coalesced rows) -----------------
     const size_t oplane = (size_t)p.OHf * p.OWf;
     const int M1 = p.M - p.M0;
+    // split reduction (tiny, deep problems: a 2x2-pixel 128->128 layer is 72 serial stages in one or two workgroups): this
+    // split's partial tile goes to its own slab (no bias / activation in this mode: the launcher guarantees it)
+    float* const d0 = gridDim.z > 1 ? p.part + (size_t)blockIdx.z * (size_t)p.part_stride : p.dst0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int opix = p0 + (wn * TN + j) * 32 + l31;
@@ -390,16 +403,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         unsigned oy, ox;
         decode_pixel(p, rem, oy, ox);
         if (p.ring_p) {
-            if (p.dbg & 64) continue;
-            // ring results (and the partial sums of the reduction splits) meet in a compact [n][m][ring] scratch: lanes =
-            // consecutive ring positions, so the atomics are coalesced; ring_fold_kernel scatters them onto the image
+            // ring results go to a compact [n][m][ring] scratch (lanes = consecutive ring positions: coalesced stores);
+            // ring_gather_kernel adds them to the texels the reflect padding mirrored
             const size_t rlen = (size_t)p.OH * p.OW;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (m < p.M) atomicAdd(p.dst0 + ((size_t)n * p.M + m) * rlen + rem, acc[i][j][r]);
+                    if (m < p.M) d0[((size_t)n * p.M + m) * rlen + rem] = acc[i][j][r];
                 }
             continue;
         }
@@ -411,17 +423,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.M) {
                     float v = acc[i][j][r];
-                    if (gridDim.z > 1) {
-                        // split reduction (tiny, deep problems: a 2x2-pixel 128->128 layer is 72 serial stages in one or
-                        // two workgroups): partial sums meet in the zero-filled destination, split 0 carries the bias
-                        if (p.bias && blockIdx.z == 0) v += p.bias[m];
-                        atomicAdd(p.dst0 + ((size_t)n * p.M0 + m) * oplane + sp, v);
-                        continue;
-                    }
                     if (p.bias) v += p.bias[m];
                     v = apply_act(v, p.act, p.slope);
                     if (m < p.M0) {
-                        if (p.dst0) p.dst0[((size_t)n * p.M0 + m) * oplane + sp] = v;
+                        if (d0) d0[((size_t)n * p.M0 + m) * oplane + sp] = v;
                     } else {
                         p.dst1[((size_t)n * M1 + (m - p.M0)) * oplane + sp] = v;
                     }
@@ -654,15 +659,21 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         // the last wave at the stage barrier: two extra scalar branches in this loop cost the whole kernel 7 %.)
         int a_buf = 0;                                        // LDS ring slot of the next stage
         int tap_t = tap_start, ch0 = ch_start;                // tap / channel offset of the next stage
-        const float* cp = (ch0 < p.C0) ? s0n + (size_t)ch0 * HW : s1n + (size_t)(ch0 - p.C0) * HW;   // plane of channel ch0
-        int sp_off = 0;                                       // y * Ws + x of this lane for the current tap
+        // Per tap, every lane resolves ONCE where its texels of channel 0 live (`lbase`) and how far apart consecutive
+        // channels are (`lstride`); per stage only `lp` moves.  Lanes whose tap falls outside a zero-padded source read the
+        // zero page with stride 0.  Reflect data gradient (p.rf, see reflect_aux_kernel): lanes on a border row / in a
+        // border column group read the pre-folded side buffers instead of gy, with those buffers' channel pitch.
+        const float* lp = p.zero;                             // this lane's address for reduction row `rofs` of the next stage
+        size_t lstride = 0;                                   // floats between consecutive channels at that address
+        int sp_off = 0;                                       // y * Ws + x of this lane for the current tap (in-range lanes)
         bool inb = false;
         int ndyx = p.taps.dyx[__builtin_amdgcn_readfirstlane(tap_start)];   // offsets of the tap about to start
 #pragma unroll
         for (int q = 0; q < A_PER_LOADER; ++q) wsrc[q] += (size_t)k_start * p.Mpad;
-#define WS2_ENTER_TAP()                                                                                              \
+#define WS2_ENTER_TAP(ch_)                                                                                           \
         {                                                                                                            \
-            int y = by + (ndyx >> 16), x = bx + (int)(short)(ndyx & 0xffff);                                         \
+            const int dy = ndyx >> 16, dx = (int)(short)(ndyx & 0xffff);                                             \
+            int y = by + dy, x = bx + dx;                                                                            \
             inb = pvalid;                                                                                            \
             if (p.border == BORDER_REFLECT) y = reflect(y, p.Hs);                                                    \
             else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                          \
@@ -670,34 +681,46 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             else if (p.border == BORDER_REFLECT) x = reflect(x, p.Ws);                                               \
             else inb = inb && (unsigned)x < (unsigned)p.Ws;                                                          \
             sp_off = inb ? y * p.Ws + x : 0;                                                                         \
+            const float* lbase = inb ? s0n + sp_off : p.zero;                                                        \
+            lstride = inb ? (size_t)HW : (size_t)0;                                                                  \
+            if (VEC && p.rf && pvalid) {                                                                             \
+                const bool top = dy == 1 && by == 1, bot = dy == -1 && by == p.Hs - 2;                               \
+                if (top || bot) {            /* whole row pre-folded: [top|bot][dx+1][n][k][Ws] */                   \
+                    lstride = (size_t)p.Ws;                                                                          \
+                    lbase = p.rf_row + ((((size_t)(bot ? 3 : 0) + (dx + 1)) * p.N + n) * p.C0 + rofs) * p.Ws + x;     \
+                } else if (inb && ((dx == 1 && bx == 0) || (dx == -1 && bx == p.Ws - 4))) {                         \
+                    /* border column group pre-folded: [left|right][n][k][Hs][4] */                                  \
+                    lstride = (size_t)p.Hs * 4;                                                                      \
+                    lbase = p.rf_col + ((((size_t)(dx == 1 ? 0 : 1) * p.N + n) * p.C0 + rofs) * p.Hs + y) * 4;       \
+                }                                                                                                    \
+            }                                                                                                        \
+            lp = lbase + (size_t)(ch_) * lstride;                                                                    \
             ndyx = p.taps.dyx[__builtin_amdgcn_readfirstlane(min(tap_t + 1, p.taps.n - 1))];                         \
         }
-        WS2_ENTER_TAP();
+        // the first tap may be entered mid-way (split reductions): ch_start channels in, possibly already in source 1
+        WS2_ENTER_TAP(ch0 < p.C0 ? ch0 : 0);
+        if (ch0 >= p.C0 && p.C1) lp = inb ? s1n + sp_off + (size_t)(ch0 - p.C0) * HW : p.zero;
 #define WS2_ISSUE_NEXT()                                                                                             \
         {                                                                                                            \
             _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q) {                                               \
                 glds_b128(wsrc[q], As0 + a_buf * A_FLOATS + a_lds[q]);                                               \
                 wsrc[q] += (size_t)BK * p.Mpad;                                                                      \
             }                                                                                                        \
-            /* masked lanes read the zero page with stride 0: one select per stage instead of one per load */       \
-            const float* base = inb ? cp + sp_off : p.zero;                                                          \
-            const size_t bstep = inb ? (size_t)HW : (size_t)0;                                                       \
             if (VEC) {                                                                                               \
                 _Pragma("unroll") for (int i = 0; i < B_PER_LOADER; ++i)                                             \
-                    glds_b128(base + (size_t)(2 * i) * bstep, Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256); \
+                    glds_b128(lp + (size_t)(2 * i) * lstride, Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256); \
             } else {                                                                                                 \
                 _Pragma("unroll") for (int r = 0; r < B_PER_LOADER; ++r)                                             \
-                    glds_b32(base + (size_t)r * bstep, Bs0 + a_buf * B_FLOATS + (row0 + r) * LDB + seg * 64);        \
+                    glds_b32(lp + (size_t)r * lstride, Bs0 + a_buf * B_FLOATS + (row0 + r) * LDB + seg * 64);        \
             }                                                                                                        \
             a_buf = a_buf + 1 == W2_NBUF ? 0 : a_buf + 1;                                                            \
             ch0 += BK;                                                                                               \
-            cp += (size_t)BK * HW;                                                                                   \
-            if (ch0 == p.C0 && p.C1) cp = s1n;                                                                       \
+            lp += (size_t)BK * lstride;                                                                              \
+            if (ch0 == p.C0 && p.C1) lp = inb ? s1n + sp_off : p.zero;                                               \
             if (ch0 == Cs) {                                                                                         \
                 ch0 = 0;                                                                                             \
-                cp = s0n;                                                                                            \
                 ++tap_t;                                                                                             \
-                WS2_ENTER_TAP();                                                                                     \
+                WS2_ENTER_TAP(0);                                                                                    \
             }                                                                                                        \
         }
 #define WS2_ISSUE(ks_) WS2_ISSUE_NEXT()     /* stages are issued strictly in order */
@@ -908,10 +931,12 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     const int M1 = p.M - p.M0;
     const int opix0 = p0 + 4 * l31;
     if (opix0 >= p.P) return;
+    // split reduction: this split's partial tile goes to its own slab (no bias / activation / second destination then)
+    float* const d0 = gridDim.z > 1 ? p.part + (size_t)blockIdx.z * (size_t)p.part_stride : p.dst0;
     // 16-byte stores when the 4 pixels are consecutive, in range and aligned in the destination
-    const bool vec = gridDim.z == 1 && p.osx == 1 && p.osy == 1 && p.oox == 0 && p.ooy == 0 && (p.OW & 3) == 0 &&
+    const bool vec = p.osx == 1 && p.osy == 1 && p.oox == 0 && p.ooy == 0 && (p.OW & 3) == 0 &&
                      p.OW == p.OWf && p.OH == p.OHf && opix0 + 3 < p.P &&
-                     ((reinterpret_cast<uintptr_t>(p.dst0) | reinterpret_cast<uintptr_t>(p.dst1)) & 15) == 0;
+                     ((reinterpret_cast<uintptr_t>(d0) | reinterpret_cast<uintptr_t>(p.dst1)) & 15) == 0;
     if (vec) {
         const unsigned n = fd_div((unsigned)opix0, p.fd_ohw);
         const unsigned rem = (unsigned)opix0 - n * (unsigned)(p.OH * p.OW);
@@ -923,7 +948,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
                 f32x4 v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = apply_act(acc[t][r] + bv, p.act, p.slope);
-                float* dst = (m < p.M0) ? (p.dst0 ? p.dst0 + ((size_t)n * p.M0 + m) * oplane + rem : nullptr)
+                float* dst = (m < p.M0) ? (d0 ? d0 + ((size_t)n * p.M0 + m) * oplane + rem : nullptr)
                                         : p.dst1 + ((size_t)n * M1 + (m - p.M0)) * oplane + rem;
                 if (dst) *reinterpret_cast<f32x4*>(dst) = v;
             }
@@ -944,15 +969,10 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             const int m = m0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (m < p.M) {
                 float v = acc[t][r];
-                if (gridDim.z > 1) {             // split reduction: sum into the zero-filled destination
-                    if (p.bias && blockIdx.z == 0) v += p.bias[m];
-                    atomicAdd(p.dst0 + ((size_t)n * p.M0 + m) * oplane + sp, v);
-                    continue;
-                }
                 if (p.bias) v += p.bias[m];
                 v = apply_act(v, p.act, p.slope);
                 if (m < p.M0) {
-                    if (p.dst0) p.dst0[((size_t)n * p.M0 + m) * oplane + sp] = v;
+                    if (d0) d0[((size_t)n * p.M0 + m) * oplane + sp] = v;
                 } else {
                     p.dst1[((size_t)n * M1 + (m - p.M0)) * oplane + sp] = v;
                 }
@@ -961,11 +981,12 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
-static int g_ksplit_fwd = 0;     // tuning switch (key 13): reduction splits in tiny FORWARD convolutions (non-deterministic sums)
+static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
+static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise
+                                 // reproducible backward pass), 0 = fp32 atomics in the weight / bias gradients (round-1 scheme)
 static int g_ksplit = 1;         // tuning switch (key 12): allow reduction splits in the wave-specialised data gradient
 static int g_nl4_scalar = 1;     // tuning switch (key 11): 4 loader waves for the gathered-B wave-specialised kernel
 static int g_deep64 = 0;         // tuning switch (key 10): 4-deep LDS ring for every FAST 64x64 launch (default: ring launches only)
-static int g_ring_split = 0;     // tuning switch (key 8): reduction splits of the reflect-border ring launch (0 = auto)
 static int g_ws2_mt = 0;         // tuning switch (key 7): force the wave-specialised kernel's channel tile (1, 2, 4 x 32)
 static int g_min_blocks = 384;   // tuning switch (key 6): workgroups below which the pixel/channel tile shrinks
 static int g_cfg128 = 0;   // tuning switch (nemar_tune key 0): 0 = ws2 (all FAST shapes), 5 = ws2 without 16-byte B loads; 128x128 only: 1 = 4-wave, 2 = 8-wave, 3 = 256x128, 4 = ws gen 1
@@ -1017,6 +1038,20 @@ TileChoice igemm_tile(int M, int P, int stages, int ksplit = 1) {
 }
 int igemm_mpad(int M) { return M > 32 ? nemar_cdiv(M, 256) * 256 : 32; }
 
+// Does this launch go to the wave-specialised kernel (128 pixels x 32*MT channels), and with 16-byte B loads?  Measured:
+// MT = 4 beats every generic configuration on layers big enough for 128x128 tiles; MT = 1, 2 (fewer MFMAs per staged B
+// tile) lose to the generic 64x64 / 32x256 kernels and are only reachable through the tuning switch.
+bool route_ws2(const IgemmParams& p, bool* vec_out) {
+    const int Cs = p.C0 + p.C1;
+    const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
+    const TileChoice t = igemm_tile(p.M, p.P, nemar_cdiv(p.Kred, BK), p.ring_p ? 1 : p.ksplit);
+    if (!(fast && !p.ring_p && (g_cfg128 == 0 || (g_cfg128 >= 5 && g_cfg128 <= 7)) && (t.bm == 128 || g_ws2_mt))) return false;
+    bool vec = g_cfg128 != 5 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4 && p.taps.n <= 32;
+    for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
+    *vec_out = vec;
+    return true;
+}
+
 void launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int Cs = p.C0 + p.C1;
     const bool fast = (Cs % BK == 0) && (p.C0 % BK == 0);
@@ -1025,13 +1060,9 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         t.bm = p.M > 32 ? 64 : 32;
         t.bn = p.M > 32 ? 64 : 128;
     }
-    if (fast && !p.ring_p && (g_cfg128 == 0 || (g_cfg128 >= 5 && g_cfg128 <= 7)) && (t.bm == 128 || g_ws2_mt)) {
-        // wave-specialised kernel: 128 pixels x 32*MT channels.  Measured: MT = 4 beats every generic configuration on
-        // layers big enough for 128x128 tiles; MT = 1, 2 (fewer MFMAs per staged B tile) lose to the generic 64x64 /
-        // 32x256 kernels and are only reachable through the tuning switch.
+    bool vec = false;
+    if (route_ws2(p, &vec)) {
         int mt = g_ws2_mt ? g_ws2_mt : 4;
-        bool vec = g_cfg128 != 5 && p.sx == 1 && (p.OW & 3) == 0 && p.Ws == p.OW && p.Ws >= 4 && p.taps.n <= 32;
-        for (int i = 0; i < p.taps.n && vec; ++i) vec = p.taps.dx[i] >= -1 && p.taps.dx[i] <= 1;
         if (mt == 4 && !vec && g_nl4_scalar)          // gathered (non-VEC) B tile: 4 loader waves share the 32 4-byte loads
             hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128), p.ksplit),
                                dim3(8 * 64), g_lds_pad, st, p);
@@ -1082,6 +1113,8 @@ struct WgradParams {
     const float* gy; int K, OH, OW;
     float* gw; int J;  // J = Cs * R * S columns, j = c*R*S + r*S + s (the tensor's own memory order)
     float* gb;         // optional [K]: += sum_pixels gy (bias gradient), folded into the A-tile loads of column-tile 0
+    float* part;       // [splits][K*J] slabs then [splits][K] bias slabs (nullptr: fp32 atomics into gw / gb)
+    float* partb;
     int N, P, sy, sx, R, S, pad, border;
     int pix_per_split;
     int dbg;   // ablation (nemar_tune key 2): 1 = skip staging loads, 2 = skip MFMAs, 8 = skip the atomic epilogue
@@ -1212,15 +1245,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         __syncthreads();
     }
     if (nk <= 0 || (p.dbg & 8)) return;
+    float* const gw = p.part ? p.part + (size_t)blockIdx.z * ((size_t)p.K * p.J) : p.gw;
     if (do_bias) {
         // this thread summed gy over its pixel rows for channels cgrp + 8i; fold the 32 pixel lanes of each half-wave
+        float* const gb = p.part ? p.partb + (size_t)blockIdx.z * p.K : p.gb;
 #pragma unroll
         for (int i = 0; i < ACOLS; ++i) {
             float v = bsum[i];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             const int m = m0 + cgrp + 8 * i;
-            if (prow == 0 && m < p.K) atomicAdd(p.gb + m, v);
+            if (prow == 0 && m < p.K) {
+                if (p.part) gb[m] = v;
+                else atomicAdd(gb + m, v);
+            }
         }
     }
 #pragma unroll
@@ -1232,22 +1270,106 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.K) atomicAdd(p.gw + (size_t)m * p.J + jj, acc[i][j][r]);
+                if (m < p.K) {
+                    if (p.part) gw[(size_t)m * p.J + jj] = acc[i][j][r];
+                    else atomicAdd(gw + (size_t)m * p.J + jj, acc[i][j][r]);
+                }
             }
     }
 }
 
-// gx[n,c, mirror(ring position)] += ring[n,c,q]: scatters the compact ring gradient onto the texels the reflect padding copied
-__global__ __launch_bounds__(256) void ring_fold_kernel(const float* __restrict__ ring, float* __restrict__ gx, int H, int W,
-                                                        int pad, int ring_len, long long total) {
+// Reflect data gradient, 3x3 / pad 1, without a ring launch.  The gradient of reflect-pad + conv w.r.t. texel (h,w) is the
+// zero-padded data gradient plus, for the texels one step inside the border, the gradient of the padded texel they were
+// mirrored to:  gx[1][w] gets  w[r=0] * gy[0]  on top of  w[r=0] * gy[2]  — i.e. tap dy = +1 must read gy[2] + gy[0] at output
+// row 1 (and tap dy = -1 reads gy[H-3] + gy[H-1] at row H-2; columns likewise for dx = +-1 at columns 1 / W-2).  Those sums
+// depend on the tap, so they cannot live in gy itself; they are pre-folded into two small side buffers that the loader lanes of
+// igemm_ws2_kernel read INSTEAD of gy when their (tap, row / column group) is one of the special ones:
+//   rows [v][d][n][k][xs]    v = 0: rows 2 + 0 (top), 1: rows H-3 + H-1 (bottom);  d = dx + 1 selects the column fold baked
+//                            into that row: d = 2 adds texel 0 to texel 2, d = 0 adds texel W-1 to texel W-3
+//   cols [e][n][k][y][j]     e = 0 (dx = +1): source columns 1..4 of row y with column 0 added to column 2;
+//                            e = 1 (dx = -1): source columns W-5..W-2 with column W-1 added to column W-3
+// (one 16-byte group = what the first / last 4-pixel output group of a row loads for that tap).
+__global__ __launch_bounds__(256) void reflect_aux_kernel(const float* __restrict__ gy, float* __restrict__ rows,
+                                                          float* __restrict__ cols, int N, int K, int H, int W) {
+    const long long nrow = 6ll * N * K * W, ncol = 8ll * N * K * H;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nrow + ncol;
+         idx += (long long)gridDim.x * blockDim.x) {
+        if (idx < nrow) {
+            const int xs = (int)(idx % W);
+            long long t = idx / W;
+            const int k = (int)(t % K); t /= K;
+            const int n = (int)(t % N);
+            const int vd = (int)(t / N), v = vd / 3, d = vd - 3 * v;
+            const float* g = gy + ((size_t)n * K + k) * H * W;
+            const float* ra = g + (size_t)(v == 0 ? 2 : H - 3) * W;
+            const float* rb = g + (size_t)(v == 0 ? 0 : H - 1) * W;
+            float val = ra[xs] + rb[xs];
+            if (d == 2 && xs == 2) val += ra[0] + rb[0];
+            if (d == 0 && xs == W - 3) val += ra[W - 1] + rb[W - 1];
+            rows[idx] = val;
+        } else {
+            const long long c = idx - nrow;
+            const int j = (int)(c & 3);
+            long long t = c >> 2;
+            const int y = (int)(t % H); t /= H;
+            const int k = (int)(t % K); t /= K;
+            const int n = (int)(t % N);
+            const int e = (int)(t / N);
+            const float* r = gy + (((size_t)n * K + k) * H + y) * W;
+            float val;
+            if (e == 0) val = r[1 + j] + (j == 1 ? r[0] : 0.f);
+            else val = r[W - 5 + j] + (j == 2 ? r[W - 1] : 0.f);
+            cols[c] = val;
+        }
+    }
+}
+
+// Inverse of decode_ring: padded position (py, px) of the border ring -> index in the compact ring layout.
+__device__ __forceinline__ unsigned encode_ring(unsigned rp, unsigned H, unsigned W, unsigned py, unsigned px) {
+    const unsigned Wp = W + 2 * rp, band = rp * Wp;
+    if (py < rp) return py * Wp + px;
+    if (py >= H + rp) return band + (py - H - rp) * Wp + px;
+    return 2 * band + (py - rp) * (2 * rp) + (px < rp ? px : px - W);
+}
+
+// gx[n,c,ty,tx] += sum of the ring texels that mirror onto (ty,tx), in a fixed order (gather: one thread per affected texel,
+// no atomics).  Affected texels: rows 1..pad and H-1-pad..H-2 (whole rows), and columns 1..pad, W-1-pad..W-2 of every row.
+// The launch enumerates, per (n,c) plane, `nrows` listed rows x W columns, then H rows x `ncols` listed columns (a texel of
+// the second part that lies in a listed row was handled by the first part and is skipped).
+struct RingBand { int nrows, ncols; int rows[8], cols[8]; };
+__global__ __launch_bounds__(256) void ring_gather_kernel(const float* __restrict__ ring, float* __restrict__ gx, int H, int W,
+                                                          int pad, int ring_len, RingBand band, long long planes) {
+    const int per_plane = band.nrows * W + H * band.ncols;
+    const long long total = planes * per_plane;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const long long nc = idx / ring_len;
-        const unsigned q = (unsigned)(idx - nc * ring_len);
-        unsigned py, px;
-        decode_ring((unsigned)pad, (unsigned)H, (unsigned)W, q, py, px);
-        const int ty = reflect((int)py - pad, H), tx = reflect((int)px - pad, W);
-        atomicAdd(gx + nc * (long long)H * W + (long long)ty * W + tx, ring[idx]);
+        const long long nc = idx / per_plane;
+        int e = (int)(idx - nc * per_plane), ty, tx;
+        if (e < band.nrows * W) {
+            ty = band.rows[e / W];
+            tx = e % W;
+        } else {
+            e -= band.nrows * W;
+            ty = e / band.ncols;
+            tx = band.cols[e % band.ncols];
+            bool listed = false;
+            for (int i = 0; i < band.nrows; ++i) listed = listed || band.rows[i] == ty;
+            if (listed) continue;
+        }
+        // padded rows / columns that mirror onto ty / tx (interior candidate first)
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = ty + pad;
+        if (ty >= 1 && ty <= pad) ys[ny++] = pad - ty;
+        if (ty <= H - 2 && ty >= H - 1 - pad) ys[ny++] = 2 * (H - 1) - ty + pad;
+        xs[nx++] = tx + pad;
+        if (tx >= 1 && tx <= pad) xs[nx++] = pad - tx;
+        if (tx <= W - 2 && tx >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - tx + pad;
+        const float* r = ring + nc * ring_len;
+        float sum = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b)
+                if (a | b) sum += r[encode_ring((unsigned)pad, (unsigned)H, (unsigned)W, (unsigned)ys[a], (unsigned)xs[b])];
+        gx[nc * (long long)H * W + (long long)ty * W + tx] += sum;
     }
 }
 
@@ -1262,9 +1384,9 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __rest
     }
 }
 
-// gb[c] += sum_{n,hw} g[n,c,hw]; grid (C, N, chunks of the plane): tree per workgroup + one atomic
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, float* __restrict__ gb, int N, int C,
-                                                        int HW, int chunk) {
+// round-1 form (nemar_tune(14, 0)): one atomic per workgroup
+__global__ __launch_bounds__(256) void bias_grad_atomic_kernel(const float* __restrict__ g, float* __restrict__ gb, int N, int C,
+                                                               int HW, int chunk) {
     __shared__ float red[16];
     const int c = blockIdx.x, n = blockIdx.y;
     const int beg = blockIdx.z * chunk, end = min(HW, beg + chunk);
@@ -1273,6 +1395,20 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     for (int i = beg + threadIdx.x; i < end; i += blockDim.x) acc += q[i];
     const float t = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(gb + c, t);
+}
+
+// part[(n * chunks + z) * C + c] = sum of g[n,c, chunk z of the plane]; grid (C, N, chunks): fixed tree per workgroup, one
+// plain store; nemar_sum_partials adds the N * chunks slabs into gb in order (bitwise reproducible bias gradient)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, float* __restrict__ part, int N, int C,
+                                                        int HW, int chunk) {
+    __shared__ float red[16];
+    const int c = blockIdx.x, n = blockIdx.y;
+    const int beg = blockIdx.z * chunk, end = min(HW, beg + chunk);
+    const float* q = g + ((size_t)n * C + c) * HW;
+    float acc = 0.f;
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) acc += q[i];
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) part[((size_t)n * gridDim.z + blockIdx.z) * C + c] = t;
 }
 
 // gx[n,c,h,w] = sum of the padded-domain gradient gp over every padded position that mirrors onto (h,w)
@@ -1341,6 +1477,65 @@ void dgrad_taps(TapTable& t, int R, int S, int pad, int stride, int ph, int pw) 
     }
 }
 
+
+// every split of a reduction must own at least one stage (its slab is summed unconditionally)
+int normalize_ksplit(int Kred, int ksplit) {
+    if (ksplit <= 1) return 1;
+    const int nk_all = nemar_cdiv(Kred, BK);
+    const int nk_per = nemar_cdiv(nk_all, ksplit);
+    return nemar_cdiv(nk_all, nk_per);
+}
+
+// Workspace layout of nemar_conv2d_bwd_data (floats), shared by the size query and the operator:
+//   [packed weights x stride^2 parity classes][padded-domain scratch (strided reflect)][flipped weights (C <= 4)]
+//   [compact border-ring gradient (stride-1 reflect)][ksplit slabs of the gradient (split reductions)]
+struct DgradLayout {
+    size_t pack_stride, padded_off, w2_off, ring_off, slab_off, aux_rows_off, aux_cols_off, total;
+    int ring_len, ksplit;
+    bool ring, fold;
+};
+DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
+    DgradLayout L;
+    const bool refl = pad_mode == BORDER_REFLECT && pad > 0;
+    L.ring = refl && stride == 1;
+    L.fold = refl && !L.ring;
+    L.pack_stride = packed_floats(C, K * R * S);             // upper bound over parity classes and channel skips
+    size_t o = L.pack_stride * (size_t)(stride * stride);
+    L.padded_off = o;
+    if (L.fold) o += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    L.w2_off = o;
+    if (C <= 4) o += (size_t)C * K * R * S;
+    L.ring_off = o;
+    L.ring_len = L.ring ? 2 * pad * (W + 2 * pad) + 2 * pad * H : 0;
+    o += (size_t)N * C * L.ring_len;
+    // split reductions (stride 1, single destination, no bias / activation — the operator re-checks those): few, deep
+    // 128x128 tiles (D's 256->512 k4 layer: 128 tiles x 512 stages) get one workgroup per CU; tiny deep problems on the
+    // generic kernels (the 2x2 .. 32x32-pixel layers of the registration net) ~256 workgroups of >= 4 stages
+    L.ksplit = 1;
+    if (g_ksplit && stride == 1 && !L.fold && C > 4) {
+        const int P = N * H * W, Kred = K * R * S, stages = nemar_cdiv(Kred, BK);
+        if (g_cfg128 == 0 && C > 64 && K % BK == 0) {
+            const long long tiles = (long long)nemar_cdiv(C, 128) * nemar_cdiv(P, 128);
+            if (tiles < 200 && stages >= 256) {
+                int ks = nemar_cdiv(256, (int)tiles);
+                if (ks > stages / 128) ks = stages / 128;
+                if (ks > 1) L.ksplit = ks;
+            }
+        }
+        if (L.ksplit == 1) L.ksplit = small_problem_split(C, P, Kred);
+        L.ksplit = normalize_ksplit(Kred, L.ksplit);
+    }
+    L.slab_off = o;
+    if (L.ksplit > 1) o += (size_t)L.ksplit * N * C * H * W;
+    // side buffers of the ring-free reflect data gradient (source = gy [N,K,H,W] for a 3x3 / pad 1 layer)
+    L.aux_rows_off = o;
+    if (L.ring && pad == 1 && R == 3 && S == 3) o += 6ull * N * K * W;
+    L.aux_cols_off = o;
+    if (L.ring && pad == 1 && R == 3 && S == 3) o += 8ull * N * K * H;
+    L.total = o;
+    return L;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1372,7 +1567,10 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     }
     hipStream_t st = (hipStream_t)stream;
     if (nemar_narrow_eligible(K, C1, R, S, stride, N, OH, OW) && g_narrow) {
-        nemar_narrow_fwd(x0, w, bias, y, N, C, H, W, K, R, pad, pad_mode, act, slope, st);
+        // the narrow kernels read the weights in place: the packed-weight workspace doubles as the slab space of their
+        // channel-split mode (the split count is capped to what fits, see nemar_narrow_fwd)
+        nemar_narrow_fwd(x0, w, bias, y, N, C, H, W, K, R, pad, pad_mode, act, slope,
+                         g_deterministic ? (float*)workspace : nullptr, ws_bytes / sizeof(float), st);
         NEMAR_CHECK_LAUNCH("conv2d_fwd (narrow)");
         return NEMAR_OK;
     }
@@ -1383,22 +1581,15 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.wp = (const float*)workspace; p.M = K; p.Mpad = igemm_mpad(K); p.Kred = C * R * S;
     p.zero = p.wp + packed_core_floats(K, C * R * S);
     p.dbg = g_dbg; p.tl = g_tl;
-    p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1;
+    p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
+    p.rf = 0; p.rf_row = nullptr; p.rf_col = nullptr;
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
     p.N = N; p.P = N * OH * OW;
     p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope; p.pad = pad;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
-    // Off by default: atomics make the forward pass non-bitwise-reproducible, and 1e-7 differences upstream of a
-    // LeakyReLU / max-pool decision occasionally flip it (seen as a rare 40x outlier in the discriminator-gradient parity
-    // test).  The backward passes (data gradient, ring, weight gradient) keep their split reductions: nothing
-    // discontinuous is evaluated downstream of them.
-    if (g_ksplit_fwd && act == ACT_NONE) {
-        p.ksplit = small_problem_split(K, p.P, p.Kred);
-        if (p.ksplit > 1) (void)hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * K * OH * OW, st);
-    }
-    launch_igemm(p, st);
+    launch_igemm(p, st);       // forward convolutions never split their reduction
     NEMAR_CHECK_LAUNCH("conv2d_fwd");
     return NEMAR_OK;
 }
@@ -1408,12 +1599,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
 NEMAR_API size_t nemar_conv2d_bwd_data_workspace(int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                                                  int pad_mode) {
     if (N <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
-    size_t fl = packed_floats(C, K * R * S) * (size_t)(stride * stride);  // upper bound over parity classes
-    if (pad_mode == BORDER_REFLECT && pad > 0 && stride > 1) fl += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
-    if (C <= 4) fl += (size_t)C * K * R * S;   // flipped + transposed weights of the narrow path
-    if (pad_mode == BORDER_REFLECT && pad > 0 && stride == 1)   // compact border-ring gradient
-        fl += (size_t)N * C * (2 * pad * (W + 2 * pad) + 2 * pad * H);
-    return sizeof(float) * fl;
+    return sizeof(float) * dgrad_layout(N, C, H, W, K, R, S, stride, pad, pad_mode).total;
 }
 
 NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, int act, float slope,
@@ -1433,9 +1619,10 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     NEMAR_REQUIRE(pad_mode != BORDER_REFLECT || (pad < H && pad < W), "conv2d_bwd_data: reflect pad too large");
     NEMAR_REQUIRE(!refl || (!bias && act == ACT_NONE && gx1 == nullptr),
                   "conv2d_bwd_data: reflect mode supports a single destination without bias/activation");
-    const size_t need = nemar_conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode);
-    if (ws_bytes < need) {
-        nemar_set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+    NEMAR_REQUIRE(!refl || stride > 1 || pad <= 4, "conv2d_bwd_data: reflect pad %d > 4 unsupported", pad);
+    const DgradLayout L = dgrad_layout(N, C, H, W, K, R, S, stride, pad, pad_mode);
+    if (ws_bytes < sizeof(float) * L.total) {
+        nemar_set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, sizeof(float) * L.total);
         return NEMAR_EWORKSPACE;
     }
     NEMAR_REQUIRE((long long)N * (H + 2 * pad) * (W + 2 * pad) < (1ll << 31) && (long long)K * OH * OW < (1ll << 31) &&
@@ -1443,17 +1630,17 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                   "conv2d_bwd_data: problem too large for 32-bit tile indexing");
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)workspace;
-    const size_t pack_stride = packed_floats(C, K * R * S);
+    const size_t pack_stride = L.pack_stride;
     // Reflect padding.  The gradient w.r.t. the PADDED input splits into the image interior — exactly the zero-padded
     // data gradient, computed on the unpadded domain — and the border ring, whose texels are mirrors of in-image
-    // texels: a second, small launch evaluates the same implicit GEMM at the ring positions only and atomically adds each
-    // result to the texel it mirrors (stride 1).  Strided reflect convolutions (not on the hot path) keep the simple
-    // form: differentiate on the padded domain into scratch, then fold.
-    const bool ring = refl && stride == 1;
-    const bool fold = refl && !ring;
+    // texels: a second, small launch evaluates the same implicit GEMM at the ring positions only into a compact scratch,
+    // and ring_gather_kernel adds each ring texel to the texel it mirrors (stride 1; gather form, no atomics).  Strided
+    // reflect convolutions (not on the hot path) keep the simple form: differentiate on the padded domain into
+    // scratch, then fold.
+    const bool ring = L.ring, fold = L.fold;
     const int Hd = fold ? H + 2 * pad : H, Wd = fold ? W + 2 * pad : W;
     const int padd = fold ? 0 : pad;
-    float* padded = fold ? wsf + pack_stride * (size_t)(stride * stride) : nullptr;
+    float* padded = fold ? wsf + L.padded_off : nullptr;
     // skipping the first C0 channels when gx0 == NULL: start the M range at C0
     const int mskip = (gx0 == nullptr) ? C0 : 0;
     int cls = 0;
@@ -1474,7 +1661,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             p.N = N; p.P = N * OHc * OWc;
             p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
             p.pad = pad;
-            p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1;
+            p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
+            p.rf = 0; p.rf_row = nullptr; p.rf_col = nullptr;
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
@@ -1483,67 +1671,65 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             if (p.taps.n == 0) {
                 // no tap reaches this class (e.g. k1 s2): gradient is bias-only / zero; run with one zero tap
                 p.taps.n = 1; p.taps.dy[0] = -32000; p.taps.dx[0] = -32000; p.taps.wofs[0] = 0; p.Kred = K;
-                p.taps.dyx[0] = (-32000 << 16) | (-32000 & 0xffff);
+                p.taps.dyx[0] = (int)(((unsigned)-32000 << 16) | ((unsigned)-32000 & 0xffffu));
             }
             // A[(t*K + k)][c] = w[k][c + mskip][r][s]
             if (!prepacked) launch_pack(w + (size_t)mskip * R * S, wp, Mc, K, R * S, C * R * S, p.taps, st);
             // <= 4 input channels (the translation net's stem: 29 of 32 MFMA rows would be empty): the zero-padded
             // data gradient is a <= 4-output-channel correlation of gy — the narrow VALU kernel's job
-            // few, deep tiles (D's 256->512 k4 layer: 128 tiles of 128x128, 512 stages): split the reduction so that every CU
-            // gets a workgroup; the partial sums meet in the zero-filled gradient through atomics
-            if (g_ksplit && g_cfg128 == 0 && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 &&
-                gx1 == nullptr && Mc > 64 && K % BK == 0) {
-                const long long tiles = (long long)nemar_cdiv(Mc, 128) * nemar_cdiv(p.P, 128);
-                const int stages = nemar_cdiv(p.Kred, BK);
-                if (tiles < 200 && stages >= 256) {
-                    int ks = nemar_cdiv(256, (int)tiles);
-                    if (ks > stages / 128) ks = stages / 128;
-                    if (ks > 1) {
-                        p.ksplit = ks;
-                        (void)hipMemsetAsync(gx0, 0, sizeof(float) * (size_t)N * C * H * W, st);
-                    }
-                }
-            }
-            if (g_ksplit && p.ksplit == 1 && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 &&
-                gx1 == nullptr && Mc > 4) {
-                p.ksplit = small_problem_split(Mc, p.P, p.Kred);
-                if (p.ksplit > 1) (void)hipMemsetAsync(gx0, 0, sizeof(float) * (size_t)N * C * H * W, st);
-            }
             const bool narrow = g_narrow && stride == 1 && !fold && !bias && act == ACT_NONE && mskip == 0 && gx1 == nullptr &&
                                 R - 1 - pad >= 0 && nemar_narrow_eligible(C, 0, R, S, 1, N, H, W);
+            bool ring_done = false;
             if (narrow) {
-                float* w2 = wsf + pack_stride * (size_t)(stride * stride) + (fold ? (size_t)N * C * Hd * Wd : 0);
+                float* w2 = wsf + L.w2_off;
                 if (!prepacked)
                     hipLaunchKernelGGL(flip_transpose_kernel, dim3(nemar_stream_grid((long long)K * C * R * S, 256)),
                                        dim3(256), 0, st, w, w2, K, C, R, S);
-                nemar_narrow_fwd(gy, w2, nullptr, gx0, N, K, OH, OW, C, R, R - 1 - pad, BORDER_ZERO, ACT_NONE, 0.f, st);
+                nemar_narrow_fwd(gy, w2, nullptr, gx0, N, K, OH, OW, C, R, R - 1 - pad, BORDER_ZERO, ACT_NONE, 0.f, nullptr, 0, st);
             } else {
+                // split reductions (see dgrad_layout): each split stores its partial gradient to its own slab, summed in order
+                if (L.ksplit > 1 && !bias && act == ACT_NONE && mskip == 0 && gx1 == nullptr) {
+                    p.ksplit = L.ksplit;
+                    p.part = wsf + L.slab_off;
+                    p.part_stride = (long long)N * C * H * W;
+                }
+                // 3x3 reflect layers that run on the wave-specialised 16-byte-load kernel fold the border INTO the main launch
+                // (reflect_aux_kernel); everything else adds the border ring with a second launch below
+                bool vec = false;
+                if (ring && g_reflect_aux && pad == 1 && R == 3 && S == 3 && H >= 4 && W >= 8 && route_ws2(p, &vec) && vec) {
+                    float* rows = wsf + L.aux_rows_off;
+                    float* cols = wsf + L.aux_cols_off;
+                    hipLaunchKernelGGL(reflect_aux_kernel, dim3(nemar_stream_grid(6ll * N * K * W + 8ll * N * K * H, 256)),
+                                       dim3(256), 0, st, gy, rows, cols, N, K, H, W);
+                    p.rf = 1; p.rf_row = rows; p.rf_col = cols;
+                    ring_done = true;
+                }
                 launch_igemm(p, st);
+                if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, gx0, p.part_stride, false, st);
+                p.rf = 0;
             }
-            if (ring) {
+            if (ring && !ring_done) {
                 // same weights (stride 1: every tap, same order), taps re-based to padded coordinates
                 dgrad_taps(p.taps, R, S, 0, 1, 0, 0);
-                const int ring_len = 2 * pad * (W + 2 * pad) + 2 * pad * H;
+                const int ring_len = L.ring_len;
                 p.ring_p = pad; p.ring_H = H; p.ring_W = W;
-                // A ring tile is a few pixels deep in a full-length reduction, and a lone workgroup per CU runs it at
-                // memory latency (one stage of prefetch), so the reduction is split over grid.z — but every split repeats
-                // the atomic epilogue, so only until ~1.5 workgroups per CU exist (resblock shape: 3 splits, 52 us in the
-                // step; the launch is bound by the column gathers of the left / right bands, not by MFMA work).
-                {
-                    const int tiles = nemar_cdiv(N * ring_len, 64) * nemar_cdiv(Mc, 64), stages = nemar_cdiv(p.Kred, BK);
-                    p.ksplit = g_ring_split ? g_ring_split : nemar_cdiv(384, tiles);
-                    if (p.ksplit > nemar_cdiv(stages, 8)) p.ksplit = nemar_cdiv(stages, 8);
-                    if (p.ksplit < 1) p.ksplit = 1;
-                }
+                p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
                 p.OH = 1; p.OW = ring_len; p.P = N * ring_len;
                 p.fd_ohw = make_fastdiv(ring_len); p.fd_ow = make_fastdiv(ring_len);
-                float* ring_buf = wsf + pack_stride * (size_t)(stride * stride) + (C <= 4 ? (size_t)C * K * R * S : 0);
-                const long long ring_total = (long long)N * Mc * ring_len;
-                (void)hipMemsetAsync(ring_buf, 0, sizeof(float) * (size_t)ring_total, st);
+                float* ring_buf = wsf + L.ring_off;
                 p.dst0 = ring_buf; p.dst1 = nullptr; p.M0 = Mc;
                 launch_igemm(p, st);
-                hipLaunchKernelGGL(ring_fold_kernel, dim3(nemar_stream_grid(ring_total, 256)), dim3(256), 0, st,
-                                   (const float*)ring_buf, gx0 ? gx0 : gx1, H, W, pad, ring_len, ring_total);
+                RingBand band;
+                band.nrows = band.ncols = 0;
+                for (int t = 0; t < H; ++t)
+                    if ((t >= 1 && t <= pad) || (t <= H - 2 && t >= H - 1 - pad)) band.rows[band.nrows++] = t;
+                for (int t = 0; t < W; ++t)
+                    if ((t >= 1 && t <= pad) || (t <= W - 2 && t >= W - 1 - pad)) band.cols[band.ncols++] = t;
+                const long long planes = (long long)N * Mc;
+                const long long work = planes * ((long long)band.nrows * W + (long long)H * band.ncols);
+                if (work > 0)
+                    hipLaunchKernelGGL(ring_gather_kernel, dim3(nemar_stream_grid(work, 256)), dim3(256), 0, st,
+                                       (const float*)ring_buf, gx0 ? gx0 : gx1, H, W, pad, ring_len, band, planes);
             }
         }
     if (fold) {
@@ -1555,11 +1741,49 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     return NEMAR_OK;
 }
 
+// ---- weight gradient ------------------------------------------------------------------------------------------------
+namespace {
+void legacy_wgrad_plan(int K, int J, int P, int* splits_out, int* pix_per_split_out) {
+    const bool wide = K > 32;
+    const int BM = wide ? 128 : 32, BN = wide ? 128 : 256;
+    const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(J, BN);
+    // split the pixel reduction so that ~4 workgroups per CU exist, but keep >= 8 stages per split
+    int splits = nemar_cdiv(1024, mt * jt);
+    const int max_splits = nemar_cdiv(P, WBK * 8);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    *pix_per_split_out = nemar_cdiv(nemar_cdiv(P, splits), WBK) * WBK;
+    *splits_out = nemar_cdiv(P, *pix_per_split_out);
+}
+constexpr int BIAS_CHUNK = 4096;
+}  // namespace
+
+// Scratch of the weight / bias gradient: per-split slabs of the fixed-order reduction (max over the kernels the shape can
+// be routed to; the routing also depends on the alignment of gy, unknown here).
+NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, int K, int OH, int OW, int R, int S,
+                                                   int stride, int pad) {
+    if (N <= 0 || C <= 0 || K <= 0 || OH <= 0 || OW <= 0 || R <= 0 || S <= 0) return 0;
+    const int J = C * R * S, P = N * OH * OW;
+    size_t fl = 0;
+    int splits, pps;
+    nemar_wgrad2_plan(K, J, P, g_wgrad_blocks, &splits, &pps);
+    fl = (size_t)splits * ((size_t)K * J + K);
+    legacy_wgrad_plan(K, J, P, &splits, &pps);
+    const size_t f2 = (size_t)splits * ((size_t)K * J + K);
+    if (f2 > fl) fl = f2;
+    if (K <= 4) {
+        const size_t f3 = (size_t)nemar_narrow_wgrad_splits(N, C, OH, OW) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
+        if (f3 > fl) fl = f3;
+    }
+    return sizeof(float) * fl;
+}
+
 // gw[K][C][R][S] += d loss / d w, and (gb != NULL) gb[K] += sum_pixels gy   (always accumulate: the caller
 // zero-fills once per optimizer step)
 NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw,
                                       float* gb, int N, int H, int W, int K, int OH, int OW, int R, int S, int stride,
-                                      int pad, int pad_mode, void* stream) {
+                                      int pad, int pad_mode, void* workspace, size_t ws_bytes, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x0 && gy && gw, "conv2d_bwd_weight: null pointer");
     NEMAR_REQUIRE(C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv2d_bwd_weight: bad channel split");
@@ -1567,46 +1791,61 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     NEMAR_REQUIRE(pad_mode == BORDER_ZERO || (pad < H && pad < W), "conv2d_bwd_weight: reflect pad too large");
     NEMAR_REQUIRE((long long)N * OH * OW < (1ll << 31) && (long long)(C0 + C1) * H * W < (1ll << 31),
                   "conv2d_bwd_weight: problem too large for 32-bit tile indexing");
+    float* part = nullptr;
+    if (g_deterministic) {
+        const size_t need = nemar_conv2d_bwd_weight_workspace(N, C0 + C1, H, W, K, OH, OW, R, S, stride, pad);
+        if (!workspace || ws_bytes < need) {
+            nemar_set_error("conv2d_bwd_weight: workspace %zu < %zu", workspace ? ws_bytes : (size_t)0, need);
+            return NEMAR_EWORKSPACE;
+        }
+        part = (float*)workspace;
+    }
     hipStream_t st = (hipStream_t)stream;
+    const int J = (C0 + C1) * R * S;
     if (nemar_narrow_eligible(K, C1, R, S, stride, N, OH, OW) && g_narrow) {
-        nemar_narrow_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad, pad_mode, st);
+        nemar_narrow_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad, pad_mode, part, st);
         if (gb) {
-            const int chunk = 4096;
-            hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, nemar_cdiv(OH * OW, chunk)), dim3(256), 0, st, gy, gb, N, K,
-                               OH * OW, chunk);
+            const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
+            float* pb = part ? part + (size_t)nemar_narrow_wgrad_splits(N, C0, OH, OW) * K * J : nullptr;
+            if (pb) {
+                hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, pb, N, K, OH * OW, BIAS_CHUNK);
+                nemar_sum_partials(pb, K, N * chunks, gb, K, true, st);
+            } else {
+                hipLaunchKernelGGL(bias_grad_atomic_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, gb, N, K, OH * OW, BIAS_CHUNK);
+            }
         }
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
     if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
         nemar_wgrad2_launch(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
-                            g_wgrad != 2, g_dbg, st);
+                            g_wgrad != 2, g_dbg, part, st);
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide)");
         return NEMAR_OK;
     }
     WgradParams p;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
-    p.gw = gw; p.gb = gb; p.J = (C0 + C1) * R * S;
+    p.gw = gw; p.gb = gb; p.J = J;
     p.N = N; p.P = N * OH * OW; p.sy = stride; p.sx = stride; p.R = R; p.S = S; p.pad = pad; p.border = pad_mode;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW);
     p.dbg = g_dbg;
     const bool wide = K > 32;
     const int BM = wide ? 128 : 32, BN = wide ? 128 : 256;
     const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(p.J, BN);
-    // split the pixel reduction so that ~4 workgroups per CU exist, but keep >= 8 stages per split
-    int splits = nemar_cdiv(1024, mt * jt);
-    const int max_splits = nemar_cdiv(p.P, WBK * 8);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    p.pix_per_split = nemar_cdiv(nemar_cdiv(p.P, splits), WBK) * WBK;
-    splits = nemar_cdiv(p.P, p.pix_per_split);
+    int splits;
+    legacy_wgrad_plan(K, p.J, p.P, &splits, &p.pix_per_split);
+    p.part = part;
+    p.partb = part ? part + (size_t)splits * K * J : nullptr;
     dim3 grid(mt, jt, splits), block(256);
     if (wide)
         hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
     else
         hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 2>), grid, block, 0, st, p);
+    if (part) {
+        nemar_sum_partials(part, (long long)K * J, splits, gw, (long long)K * J, true, st);
+        if (gb) nemar_sum_partials(p.partb, K, splits, gb, K, true, st);
+    }
     NEMAR_CHECK_LAUNCH("conv2d_bwd_weight");
     return NEMAR_OK;
 }
@@ -1621,24 +1860,41 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 3) { g_narrow = value; return NEMAR_OK; }
     if (key == 4) { g_wgrad = value; return NEMAR_OK; }
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
-    if (key == 13) { g_ksplit_fwd = value != 0; return NEMAR_OK; }
+    if (key == 14) { g_deterministic = value != 0; return NEMAR_OK; }
+    if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
     if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }
-    if (key == 8) { g_ring_split = value > 0 ? value : 0; return NEMAR_OK; }
     if (key == 7) { g_ws2_mt = (value == 1 || value == 2 || value == 4) ? value : 0; return NEMAR_OK; }
     if (key == 5) { g_wgrad_blocks = value > 0 ? value : 512; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
 }
 
+NEMAR_API size_t nemar_bias_grad_workspace(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return sizeof(float) * (size_t)N * nemar_cdiv(HW, BIAS_CHUNK) * C;
+}
+
 // gb[C] += sum over N and the plane of g [N,C,HW]   (bias gradient; also ConvTranspose2d's)
-NEMAR_API int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* stream) {
+NEMAR_API int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* workspace, size_t ws_bytes,
+                              void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(g && gb && N > 0 && C > 0 && HW > 0, "bias_grad: bad arguments");
-    const int chunk = 4096;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C, N, nemar_cdiv(HW, chunk)), dim3(256), 0, (hipStream_t)stream, g, gb, N, C,
-                       HW, chunk);
+    const int chunks = nemar_cdiv(HW, BIAS_CHUNK);
+    if (g_deterministic) {
+        const size_t need = nemar_bias_grad_workspace(N, C, HW);
+        if (!workspace || ws_bytes < need) {
+            nemar_set_error("bias_grad: workspace %zu < %zu", workspace ? ws_bytes : (size_t)0, need);
+            return NEMAR_EWORKSPACE;
+        }
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(C, N, chunks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace, N, C,
+                           HW, BIAS_CHUNK);
+        nemar_sum_partials((const float*)workspace, C, N * chunks, gb, C, true, (hipStream_t)stream);
+    } else {
+        hipLaunchKernelGGL(bias_grad_atomic_kernel, dim3(C, N, chunks), dim3(256), 0, (hipStream_t)stream, g, gb, N, C, HW,
+                           BIAS_CHUNK);
+    }
     NEMAR_CHECK_LAUNCH("bias_grad");
     return NEMAR_OK;
 }

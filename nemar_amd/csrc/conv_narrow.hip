@@ -32,7 +32,8 @@ struct NarrowParams {
     int N, C, H, W, OH, OW, pad, border, act;
     float slope;
     int tiles_x, tiles_y, tiles_total;
-    int csplit;   // forward: channel ranges per image (grid.z = N * csplit); > 1 => partial sums are atomically added to y
+    int csplit;   // forward: channel ranges per image (grid.z = N * csplit); > 1 => range cs stores its partial sums to slab cs
+    float* part;  // slabs of the split modes (forward: [csplit][N*M*OH*OW]; weight gradient: [gridDim.x][K*C*R*R])
 };
 
 // fill the LDS halo tile of channels [c0, c0+CH) for the output tile whose origin is (oy0, ox0)
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(NarrowParams p) {
     __shared__ float tile[CH * LH * LW];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     // grid.z = image x channel range.  With csplit > 1 (deep, spatially small layers: the discriminator's logit conv has
-    // 32 output tiles for 512 channels) each workgroup reduces its own channel range and the partial sums meet in y by
-    // fp32 atomics; y was zero-filled by the launcher and range 0 carries the bias (no activation in this mode).
+    // 32 output tiles for 512 channels) each workgroup reduces its own channel range into slab `cs` of the workspace and
+    // nemar_sum_partials adds the slabs in order (bitwise reproducible); range 0 carries the bias (no activation in this mode).
     const int n = blockIdx.z / p.csplit, cs = blockIdx.z - n * p.csplit;
     const int cper = ((p.C + p.csplit - 1) / p.csplit + CH - 1) / CH * CH;
     const int cbeg = cs * cper, cend = min(p.C, cbeg + cper);
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(NarrowParams p) {
     if (oy < p.OH && ox < p.OW) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            float* dst = p.y + (((size_t)n * M + m) * p.OH + oy) * p.OW + ox;
-            if (p.csplit > 1) atomicAdd(dst, acc[m]);
-            else *dst = act_apply(acc[m], p.act, p.slope);
+            const size_t o = (((size_t)n * M + m) * p.OH + oy) * p.OW + ox;
+            if (p.csplit > 1) p.part[(size_t)cs * ((size_t)p.N * M * p.OH * p.OW) + o] = acc[m];
+            else p.y[o] = act_apply(acc[m], p.act, p.slope);
         }
     }
 }
@@ -163,7 +164,11 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowParams p) {
         const int ch = pr / (R * R), t = pr - ch * (R * R);
         if (pr < NPAIR && c0 + ch < p.C) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) atomicAdd(p.gw + (size_t)k * CRS + (size_t)(c0 + ch) * R * R + t, acc[q][k]);
+            for (int k = 0; k < K; ++k) {
+                const size_t o = (size_t)k * CRS + (size_t)(c0 + ch) * R * R + t;
+                if (p.part) p.part[(size_t)blockIdx.x * ((size_t)K * CRS) + o] = acc[q][k];
+                else atomicAdd(p.gw + o, acc[q][k]);
+            }
         }
     }
 }
@@ -195,45 +200,71 @@ bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int O
            nemar_cdiv(OH, TH) <= 65535;
 }
 
+void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
+                        hipStream_t st);
+
+// channel ranges of the forward split mode: few output tiles and many channels (no activation) — so the launch fills the chip
+static int narrow_fwd_csplit(int N, int C, int OH, int OW, int act) {
+    const int tiles_total = nemar_cdiv(OW, TW) * nemar_cdiv(OH, TH) * N;
+    const int chunks = nemar_cdiv(C, CH);
+    int csplit = 1;
+    if (act == 0 && tiles_total < 512 && chunks > 1) {
+        csplit = nemar_cdiv(1024, tiles_total);
+        if (csplit > chunks) csplit = chunks;
+    }
+    return csplit;
+}
+
+// `part` / `part_floats`: slab space of the channel-split mode (nullptr: no split); the split count is capped to what fits
 int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int K, int R,
-                     int pad, int border, int act, float slope, hipStream_t st) {
+                     int pad, int border, int act, float slope, float* part, size_t part_floats, hipStream_t st) {
     NarrowParams p;
-    p.x = x; p.w = w; p.bias = bias; p.y = y; p.gy = nullptr; p.gw = nullptr;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.gy = nullptr; p.gw = nullptr; p.part = part;
     p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
     p.pad = pad; p.border = border; p.act = act; p.slope = slope;
     p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
-    // few output tiles and many channels: split the channel reduction so the launch fills the chip
-    p.csplit = 1;
-    const int chunks = nemar_cdiv(C, CH);
-    if (act == 0 && p.tiles_total < 512 && chunks > 1) {
-        p.csplit = nemar_cdiv(1024, p.tiles_total);
-        if (p.csplit > chunks) p.csplit = chunks;
-        // ranges are whole CH-channel chunks: drop ranges that would be empty
+    const size_t out_floats = (size_t)N * K * p.OH * p.OW;
+    p.csplit = part ? narrow_fwd_csplit(N, C, p.OH, p.OW, act) : 1;
+    if ((size_t)p.csplit * out_floats > part_floats) p.csplit = (int)(part_floats / out_floats);
+    if (p.csplit < 1) p.csplit = 1;
+    if (p.csplit > 1) {
+        // ranges are whole CH-channel chunks: drop ranges that would be empty (every slab must be written)
         const int cper = nemar_cdiv(nemar_cdiv(C, p.csplit), CH) * CH;
         p.csplit = nemar_cdiv(C, cper);
     }
-    if (p.csplit > 1) (void)hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * K * p.OH * p.OW, st);
     dim3 grid(p.tiles_x, p.tiles_y, N * p.csplit);
     if (R == 3) launch_fwd_r<3>(p, K, grid, st);
     else if (R == 4) launch_fwd_r<4>(p, K, grid, st);
     else launch_fwd_r<7>(p, K, grid, st);
+    if (p.csplit > 1) nemar_sum_partials(part, (long long)out_floats, p.csplit, y, (long long)out_floats, false, st);
     return 0;
 }
 
+// workgroups along x of the narrow weight gradient = number of slabs of its fixed-order reduction
+int nemar_narrow_wgrad_splits(int N, int C, int OH, int OW) {
+    const int tiles_total = nemar_cdiv(OW, TW) * nemar_cdiv(OH, TH) * N;
+    const int chunks = nemar_cdiv(C, CH);
+    int gx = nemar_cdiv(1024, chunks);           // ~4 workgroups per CU in total
+    if (gx > tiles_total) gx = tiles_total;
+    return gx < 1 ? 1 : gx;
+}
+
 int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int R, int pad,
-                       int border, hipStream_t st) {
+                       int border, float* part, hipStream_t st) {
     NarrowParams p;
-    p.x = x; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.gy = gy; p.gw = gw;
+    p.x = x; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.gy = gy; p.gw = gw; p.part = part;
     p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
     p.pad = pad; p.border = border; p.act = 0; p.slope = 0.f; p.csplit = 1;
     p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
     const int chunks = nemar_cdiv(C, CH);
-    int gx = nemar_cdiv(1024, chunks);           // ~4 workgroups per CU in total
-    if (gx > p.tiles_total) gx = p.tiles_total;
-    if (gx < 1) gx = 1;
+    const int gx = nemar_narrow_wgrad_splits(N, C, p.OH, p.OW);
     dim3 grid(gx, chunks);
     if (R == 3) launch_wgrad_r<3>(p, K, grid, st);
     else if (R == 4) launch_wgrad_r<4>(p, K, grid, st);
     else launch_wgrad_r<7>(p, K, grid, st);
+    if (part) {
+        const long long KJ = (long long)K * C * R * R;
+        nemar_sum_partials(part, KJ, gx, gw, KJ, true, st);
+    }
     return 0;
 }

@@ -7,7 +7,9 @@
 //     gw[m][j] += sum_{p in split} gy[m][p] * src[c(j)][p (+) tap(j)],     j = c*R*S + r*S + s
 //
 // GEMM view: rows m = output channels, columns j = the weight tensor's own (c,r,s) order, reduction = output pixels,
-// split across workgroups (grid.z) with fp32 atomics into the caller's gradient buffer.  Both operands are stored in
+// split across workgroups (grid.z).  Each split stores its tile to its own slab of the caller's workspace (plain stores)
+// and nemar_sum_partials adds the slabs into the gradient buffer in split order: bitwise reproducible.  (part == nullptr:
+// fp32 atomics straight into the gradient buffer, the round-1 scheme, kept for A/B timing behind nemar_tune(14, 0).)  Both operands are stored in
 // memory with the REDUCTION index (pixels) contiguous, which is what makes this kernel different from the forward one:
 //   * LDS tiles are [row][16 pixels] (64 B rows), filled by direct global->LDS loads: gy rows 16 B per lane, source
 //     rows one gathered texel per lane (tap shift + zero/reflect border resolved per lane, masked lanes read a zero page);
@@ -24,6 +26,9 @@
 //     and the stage barrier are hidden behind matrix work.
 // Bias gradient (gb[m] += sum_p gy[m][p]) falls out of the A fragments of column-tile 0.
 #include "common.h"
+
+void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
+                        hipStream_t st);
 
 namespace {
 
@@ -49,6 +54,8 @@ struct Wgrad2Params {
     const float* gy; int K, OH, OW;
     float* gw; int J;
     float* gb;
+    float* part;       // [splits][K*J] slabs then [splits][K] bias slabs (nullptr: atomics into gw / gb)
+    float* partb;
     int P, sy, sx, R, S, pad, border;
     int pix_per_split;
     int dbg;
@@ -373,13 +380,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #undef WG2_READ
 #undef WG2_MFMA
 
+    float* const gw = p.part ? p.part + (size_t)blockIdx.z * ((size_t)p.K * p.J) : p.gw;
     if (do_bias) {
         // lanes l and l+32 hold the two pixel-halves of channel row l31
+        float* const gb = p.part ? p.partb + (size_t)blockIdx.z * p.K : p.gb;
 #pragma unroll
         for (int i = 0; i < TMW; ++i) {
             const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
             const int m = m0 + (wm * TMW + i) * 32 + l31;
-            if (lhi == 0 && m < p.K) atomicAdd(p.gb + m, v);
+            if (lhi == 0 && m < p.K) {
+                if (p.part) gb[m] = v;
+                else atomicAdd(gb + m, v);
+            }
         }
     }
 #pragma unroll
@@ -391,7 +403,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.K) atomicAdd(p.gw + (size_t)m * p.J + jj, acc[i][j][r]);
+                if (m < p.K) {
+                    if (p.part) gw[(size_t)m * p.J + jj] = acc[i][j][r];
+                    else atomicAdd(gw + (size_t)m * p.J + jj, acc[i][j][r]);
+                }
             }
     }
 }
@@ -410,9 +425,26 @@ bool nemar_wgrad2_eligible(int K, int OH, int OW, const float* gy) {
     return K > 4 && (OH * OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0;
 }
 
+// Split plan shared by the workspace query and the launch.  The pixel reduction is split so that the grid is ONE full
+// round of resident workgroups (2 per CU x 256 CUs): every workgroup starts and ends together, so a grid of 1.1 or 2.04
+// rounds pays for 2 or 3.  target_blocks is that capacity; the split count is rounded DOWN to fit it, >= 8 stages per split.
+void nemar_wgrad2_plan(int K, int J, int P, int target_blocks, int* splits_out, int* pix_per_split_out) {
+    const int BM = K <= 32 ? 32 : K <= 64 ? 64 : 128;
+    const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(J, BN);
+    if (BM < 128) target_blocks *= 2;   // the narrower tiles need half the LDS and registers: 4 workgroups per CU
+    int splits = target_blocks / (mt * jt);
+    const int max_splits = nemar_cdiv(P, BKP * 8);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const int pps = nemar_cdiv(nemar_cdiv(P, splits), BKP) * BKP;
+    *pix_per_split_out = pps;
+    *splits_out = nemar_cdiv(P, pps);       // every split owns at least one pixel: every slab is written in full
+}
+
 void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
-                         int target_blocks, bool vec_ok, int dbg, hipStream_t st) {
+                         int target_blocks, bool vec_ok, int dbg, float* part, hipStream_t st) {
     Wgrad2Params p;
     p.dbg = dbg;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
@@ -423,21 +455,19 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
     p.fd_rs = make_fastdiv(R * S); p.fd_s = make_fastdiv(S);
     const int BM = K <= 32 ? 32 : K <= 64 ? 64 : 128;
     const int mt = nemar_cdiv(K, BM), jt = nemar_cdiv(p.J, BN);
-    // Split the pixel reduction so that the grid is ONE full round of resident workgroups (2 per CU x 256 CUs): every
-    // workgroup starts and ends together, so a grid of 1.1 or 2.04 rounds pays for 2 or 3.  target_blocks is that
-    // capacity; the split count is rounded DOWN to fit it, with >= 8 stages per split.
-    if (BM < 128) target_blocks *= 2;   // the narrower tiles need half the LDS and registers: 4 workgroups per CU
-    int splits = target_blocks / (mt * jt);
-    const int max_splits = nemar_cdiv(p.P, BKP * 8);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    p.pix_per_split = nemar_cdiv(nemar_cdiv(p.P, splits), BKP) * BKP;
-    splits = nemar_cdiv(p.P, p.pix_per_split);
+    int splits;
+    nemar_wgrad2_plan(K, p.J, p.P, target_blocks, &splits, &p.pix_per_split);
+    const size_t KJ = (size_t)K * p.J;
+    p.part = part;
+    p.partb = part ? part + (size_t)splits * KJ : nullptr;
     // 16-byte source loads: stride 1, image rows that are whole 16-pixel stages, horizontal tap offsets within +-1
     const bool vec = vec_ok && stride == 1 && OW % BKP == 0 && W == OW && pad <= 1 && S - 1 - pad <= 1;
     const dim3 grid(mt, jt, splits);
     if (BM == 128) launch_wgrad2<2, 2, 2>(p, vec, grid, st);
     else if (BM == 64) launch_wgrad2<2, 1, 2>(p, vec, grid, st);
     else launch_wgrad2<1, 1, 1>(p, vec, grid, st);
+    if (part) {
+        nemar_sum_partials(part, (long long)KJ, splits, gw, (long long)KJ, true, st);
+        if (gb) nemar_sum_partials(p.partb, K, splits, gb, K, true, st);
+    }
 }

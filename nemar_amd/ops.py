@@ -181,11 +181,17 @@ class _Conv2d(Function):
         want_b = need_b and ctx.bias is not None
         if need_w:
             gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
+            wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
             L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
-                                R, S, stride, pad, pad_mode, st)
+                                R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st)
         elif want_b:
-            L.bias_grad(_p(g), _p(_grad_buffer(ctx.bias)), N, K, OH * OW, st)
+            _bias_grad(g, _grad_buffer(ctx.bias), N, K, OH * OW, st)
         return gx, gx2, None, None, None, None, None, None, None, None
+
+
+def _bias_grad(g, gb, N, C, HW, st):
+    wsb = L.bias_grad_workspace(N, C, HW)
+    L.bias_grad(_p(g), _p(gb), N, C, HW, _p(_workspace(wsb, g.device)), wsb, st)
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2, x2=None, wshape=None):
@@ -239,10 +245,11 @@ class _ConvTranspose2d(Function):
             L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
                          0.0, _p(ws), wsb, hit, st)
         if ctx.needs_input_grad[1]:
+            wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
             L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
-                                S, stride, pad, PAD_ZERO, st)
+                                S, stride, pad, PAD_ZERO, _p(_workspace(wsb, g.device)), wsb, st)
         if ctx.needs_input_grad[2] and ctx.bias is not None:
-            L.bias_grad(_p(g), _p(_grad_buffer(ctx.bias)), N, Co, Ho * Wo, st)
+            _bias_grad(g, _grad_buffer(ctx.bias), N, Co, Ho * Wo, st)
         return gx, None, None, None, None, None, None, None
 
 

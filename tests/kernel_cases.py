@@ -177,12 +177,14 @@ def case_conv_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, seed=
     d_gy = be.dev(gy)
     d_gw = be.full((K, C, R, R), 0.5)          # accumulate semantics
     d_gbf = be.full((K,), 0.125)
+    ws, wsb = _ws(be, be.lib.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, R, stride, pad))
     be.lib.conv2d_bwd_weight(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_gy), be.ptr(d_gw), be.ptr(d_gbf), N, H, W, K,
-                             OH, OW, R, R, stride, pad, pad_mode, be.stream)
+                             OH, OW, R, R, stride, pad, pad_mode, be.ptr(ws), wsb, be.stream)
     _assert_close(be.np(d_gw), want_gw + 0.5, atol=2e-5, rtol=2e-5, what="conv2d_bwd_weight")
     _assert_close(be.np(d_gbf), want_gb + 0.125, atol=2e-5, rtol=2e-5, what="conv2d_bwd_weight fused bias grad")
     d_gb = be.full((K,), -0.25)
-    be.lib.bias_grad(be.ptr(d_gy), be.ptr(d_gb), N, K, OH * OW, be.stream)
+    ws, wsb = _ws(be, be.lib.bias_grad_workspace(N, K, OH * OW))
+    be.lib.bias_grad(be.ptr(d_gy), be.ptr(d_gb), N, K, OH * OW, be.ptr(ws), wsb, be.stream)
     _assert_close(be.np(d_gb), want_gb - 0.25, atol=2e-5, rtol=2e-5, what="bias_grad")
 
 

@@ -126,8 +126,10 @@ def test_conv_real_shape(be, shape):
     gys = gy / np.sqrt(N * OH * OW)
     d_gys = be.dev(gys.numpy())
     d_gw, d_gb = be.full((K, C, R, R), 0.5), be.full((K,), 0.125)
+    wsb = lib.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, R, stride, pad)
+    ws = be.bytes_buf(wsb)
     lib.conv2d_bwd_weight(P(d_x0), C0, P(d_x1), C1, P(d_gys), P(d_gw), P(d_gb), N, H, W, K, OH, OW, R, R, stride, pad,
-                          pm, be.stream)
+                          pm, P(ws), wsb, be.stream)
     gw, gb = be.np(d_gw) - 0.5, be.np(d_gb) - 0.125
     ks = _subset(K)
     wz = torch.zeros((len(ks), C, R, R), dtype=torch.float64, requires_grad=True)
@@ -170,7 +172,10 @@ def test_conv_transpose_real_shape(be, shape):
     gy = torch.randn((N, Co, Ho, Wo), generator=g) / np.sqrt(N * Ho * Wo)
     d_gy = be.dev(gy.numpy())
     d_gw = be.full((Ci, Co, R, R), 0.0)
-    lib.conv2d_bwd_weight(P(d_gy), Co, None, 0, P(d_x), P(d_gw), None, N, Ho, Wo, Ci, H, W, R, R, 2, 1, PAD_ZERO, be.stream)
+    wsb = lib.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, R, 2, 1)
+    ws = be.bytes_buf(wsb)
+    lib.conv2d_bwd_weight(P(d_gy), Co, None, 0, P(d_x), P(d_gw), None, N, Ho, Wo, Ci, H, W, R, R, 2, 1, PAD_ZERO, P(ws), wsb,
+                          be.stream)
     wf = w.clone().requires_grad_(True)
     F.conv_transpose2d(x, wf, None, stride=2, padding=1, output_padding=op).backward(gy)
     ref = wf.grad.numpy()

@@ -131,19 +131,9 @@ def test_conv_ws2_vector_loads(be, mt):
         be.lib.tune(7, 0)
 
 
-def test_conv_fwd_split_reduction_switch(be):
-    """Forward reduction splits are off by default (bitwise-reproducible forward pass); the switch still works."""
-    be.lib.tune(13, 1)
-    try:
-        K.case_conv_fwd(be, 1, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE)    # STN bottleneck layer
-        K.case_conv_fwd(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE, bias=False)
-    finally:
-        be.lib.tune(13, 0)
-
-
 def test_conv_bwd_data_split_reduction(be):
-    """Few, deep tiles (256 stages): the wave-specialised data gradient splits the reduction over grid.z and sums through
-    atomics into the zero-filled gradient."""
+    """Few, deep tiles (256 stages): the wave-specialised data gradient splits the reduction over grid.z; every split stores
+    its partial gradient to its own slab and the slabs are summed in split order."""
     K.case_conv_bwd_data(be, 1, 70, 0, 6, 6, 256, 4, 1, 1, K.PAD_ZERO)      # D's 256->512 k4 layer in small
     K.case_conv_bwd_data(be, 2, 128, 0, 4, 8, 512, 3, 1, 1, K.PAD_REFLECT)  # + border ring on top of the split main pass
 

@@ -71,8 +71,10 @@ def main():
         else:
             t_d = timeit(lambda: lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx0), C0, P(gx1), C1, N, H, H, K, OH,
                                                      OH, R, R, s, p, pm, P(ws2), wsb, 1, st()), a.iters, 2)
+        wwb = lib.conv2d_bwd_weight_workspace(N, C, H, H, K, OH, OH, R, R, s, p)
+        ws3 = torch.empty(wwb // 4 + 16, device=dev)
         t_w = timeit(lambda: lib.conv2d_bwd_weight(P(x0), C0, P(x1), C1, P(gy), P(gw), P(b), N, H, H, K, OH, OH, R, R,
-                                                   s, p, pm, st()), a.iters, 2)
+                                                   s, p, pm, P(ws3), wwb, st()), a.iters, 2)
         print(json.dumps(dict(layer=name, gflop=flop / 1e9, fwd_us=t_f * 1e6, fwd_TF=flop / t_f / 1e12,
                               dgrad_us=t_d * 1e6, dgrad_TF=flop / t_d / 1e12, wgrad_us=t_w * 1e6,
                               wgrad_TF=flop / t_w / 1e12)))

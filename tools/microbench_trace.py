@@ -28,7 +28,9 @@ for line in open(sys.argv[1]):
     elif op == "dgrad":
         f = lambda pre: lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx0), C0, P(gx1), C1, N, H, W, K, OH, OW, R, R, s, p, pm, P(ws), wsb, pre, st())
     else:
-        f = lambda pre: lib.conv2d_bwd_weight(P(x0), C0, P(x1), C1, P(gy), P(gw), P(b), N, H, W, K, OH, OW, R, R, s, p, pm, st())
+        wwb = lib.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, R, s, p)
+        ws3 = torch.empty(wwb // 4 + 16, device=dev)
+        f = lambda pre, ws3=ws3, wwb=wwb: lib.conv2d_bwd_weight(P(x0), C0, P(x1), C1, P(gy), P(gw), P(b), N, H, W, K, OH, OW, R, R, s, p, pm, P(ws3), wwb, st())
     f(0)
     t = timeit(lambda: f(1), 10, 2)
     flop = 2.0 * N * K * OH * OW * C * R * R

@@ -14,11 +14,12 @@ N, C, K, H, R, s, p, pm = 8, 256, 256, 64, 3, 1, 1, 1
 x = torch.randn(N, C, H, H, device=dev); w = torch.randn(K, C, R, R, device=dev) * 0.05; b = torch.randn(K, device=dev)
 y = torch.empty(N, K, H, H, device=dev); gy = torch.randn(N, K, H, H, device=dev); gx = torch.empty_like(x); gw = torch.zeros_like(w)
 wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm)); ws = torch.empty(wsb // 4 + 16, device=dev)
+wwb = lib.conv2d_bwd_weight_workspace(N, C, H, H, K, H, H, R, R, s, p); ws3 = torch.empty(wwb // 4 + 16, device=dev)
 for _ in range(iters):
     if which == 'fwd':
         lib.conv2d_fwd(P(x), C, None, 0, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, 1, 0.2, P(ws), wsb, 0, st())
     elif which == 'dgrad':
         lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx), C, None, 0, N, H, H, K, H, H, R, R, s, p, pm, P(ws), wsb, 0, st())
     else:
-        lib.conv2d_bwd_weight(P(x), C, None, 0, P(gy), P(gw), P(b), N, H, H, K, H, H, R, R, s, p, pm, st())
+        lib.conv2d_bwd_weight(P(x), C, None, 0, P(gy), P(gw), P(b), N, H, H, K, H, H, R, R, s, p, pm, P(ws3), wwb, st())
 torch.cuda.synchronize()
