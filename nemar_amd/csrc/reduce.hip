@@ -9,27 +9,43 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// dst[i] = (accumulate ? dst[i] : 0) + bias[i / bias_div] + sum_{s < splits} part[s * stride + i]   (s ascending)
+// dst[i] = (accumulate ? dst[i] : 0) + sum_{s < splits} part[s * stride + i], with a FIXED association order:
+// lane y of a column adds slabs y, y+16, y+32, ... in ascending order, then the 16 lane sums are added in ascending y, then
+// dst.  Workgroup = 16 x 16 threads: x = 16 consecutive float4 (one 256-byte run per slab row: coalesced), y = slab lane —
+// so a reduction over hundreds of small slabs (narrow layers: 341 slabs of 9216 floats) is as parallel as one over a few
+// large ones (256->256 3x3: 14 slabs of 590k floats), instead of one thread walking all slabs at memory latency.
 template <bool VEC>
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, long long stride, int splits,
                                                            float* __restrict__ dst, long long n, int accumulate) {
-    const long long step = (long long)gridDim.x * blockDim.x;
-    if (VEC) {
-        const long long n4 = n >> 2;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
-            f32x4 acc = *reinterpret_cast<const f32x4*>(part + 4 * i);
-            for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(part + (long long)s * stride + 4 * i);
-            f32x4* d = reinterpret_cast<f32x4*>(dst + 4 * i);
-            if (accumulate) acc += *d;
-            *d = acc;
+    __shared__ f32x4 red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const long long cols = VEC ? (n >> 2) : n;            // columns of 4 floats (VEC) or 1 float
+    for (long long c0 = (long long)blockIdx.x * 16; c0 < cols; c0 += (long long)gridDim.x * 16) {
+        const long long c = c0 + tx;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (c < cols) {
+            for (int s = ty; s < splits; s += 16) {
+                const float* q = part + (long long)s * stride;
+                if (VEC) acc += *reinterpret_cast<const f32x4*>(q + 4 * c);
+                else acc[0] += q[c];
+            }
         }
-    } else {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-            float acc = part[i];
-            for (int s = 1; s < splits; ++s) acc += part[(long long)s * stride + i];
-            if (accumulate) acc += dst[i];
-            dst[i] = acc;
+        red[ty][tx] = acc;
+        __syncthreads();
+        if (ty == 0 && c < cols) {
+            f32x4 t = red[0][tx];
+#pragma unroll
+            for (int y = 1; y < 16; ++y) t += red[y][tx];
+            if (VEC) {
+                f32x4* d = reinterpret_cast<f32x4*>(dst + 4 * c);
+                if (accumulate) t += *d;
+                *d = t;
+            } else {
+                if (accumulate) t[0] += dst[c];
+                dst[c] = t[0];
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -38,10 +54,14 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st) {
     const bool vec = (n & 3) == 0 && (stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const long long cols = vec ? (n >> 2) : n;
+    long long blocks = (cols + 15) / 16;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
     if (vec)
-        hipLaunchKernelGGL((sum_partials_kernel<true>), dim3(nemar_stream_grid(n >> 2, 256)), dim3(256), 0, st, part, stride,
-                           splits, dst, n, accumulate ? 1 : 0);
+        hipLaunchKernelGGL((sum_partials_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, dst, n,
+                           accumulate ? 1 : 0);
     else
-        hipLaunchKernelGGL((sum_partials_kernel<false>), dim3(nemar_stream_grid(n, 256)), dim3(256), 0, st, part, stride,
-                           splits, dst, n, accumulate ? 1 : 0);
+        hipLaunchKernelGGL((sum_partials_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, dst, n,
+                           accumulate ? 1 : 0);
 }
