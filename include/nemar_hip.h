@@ -49,13 +49,21 @@ const char* nemar_last_error(void);   /* thread-local message of the last failin
 int nemar_grid_sample_fwd(const float* in, const float* grid_src, int grid_mode, float* out,
                           int N, int C, int H, int W, int Ho, int Wo, void* stream);
 /* gin [N,C,H,W] may be NULL (source is data, e.g. real_A).  ggrid has the layout of grid_src
- * (EXPLICIT [N,Ho,Wo,2]; UNET [N,2,Ho,Wo]; AFFINE [N,6]). */
+ * (EXPLICIT [N,Ho,Wo,2]; UNET [N,2,Ho,Wo]; AFFINE [N,6]).
+ * With a workspace (and same-size input/output, C <= 4: the training path) grad_input is computed WITHOUT floating-point
+ * atomics and is bitwise reproducible: a gather per 64x16 destination tile for pixels that sample within 3 texels of their
+ * own position, 64-bit fixed-point atomics (40 bits below max |gout|) for the others; the affine grid gradient is summed
+ * in a fixed order.  Workspace contract: nemar_grid_sample_bwd_workspace() bytes, of which the leading
+ * nemar_grid_sample_bwd_zeroed_bytes() must be ZERO on entry of the first call and are left zero by every call (the
+ * fixed-point accumulator); the rest is scratch.  workspace == NULL: fp32-atomic scatter (any shape; not reproducible). */
+size_t nemar_grid_sample_bwd_workspace(int N, int C, int H, int W);
+size_t nemar_grid_sample_bwd_zeroed_bytes(int N, int C, int H, int W);
 int nemar_grid_sample_bwd(const float* in, const float* grid_src, int grid_mode, const float* gout,
                           float* gin, int accum_gin, float* ggrid, int accum_ggrid,
-                          int N, int C, int H, int W, int Ho, int Wo, void* stream);
-/* grad_input scatter variant: 0 (default) = global fp32 atomics, 1 = accumulated through an LDS tile per 16x64 output
- * tile (1.4-4x faster once the deformation is not near-identity, 1.6x slower when it is; warp.hip has the numbers). */
-int nemar_grid_sample_tune(int tiled_scatter);
+                          int N, int C, int H, int W, int Ho, int Wo, void* workspace, size_t ws_bytes, void* stream);
+/* grad_input variant for A/B measurements: 0 (default) = gather + fixed point (needs the workspace), 1 = fp32 atomics through an
+ * LDS tile per 16x64 output tile, 2 = global fp32 atomics (warp.hip has the numbers). */
+int nemar_grid_sample_tune(int variant);
 
 /* ---- K12: deformation smoothness / bilateral regulariser -------------------------------------------------
  * smoothness_loss(deformation, img, alpha)   reference models/stn/stn_losses.py:4-30,

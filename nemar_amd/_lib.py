@@ -30,7 +30,9 @@ SIGNATURES = {
     "nemar_version": (_i, []),
     "nemar_last_error": (C.c_char_p, []),
     "nemar_grid_sample_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "nemar_grid_sample_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "nemar_grid_sample_bwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "nemar_grid_sample_bwd_zeroed_bytes": (_sz, [_i, _i, _i, _i]),
+    "nemar_grid_sample_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nemar_smoothness_workspace": (_sz, [_i, _i, _i]),
     "nemar_smoothness_fwd": (_i, [_vp, _vp, _i, _fl, _fl, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "nemar_smoothness_bwd": (_i, [_vp, _vp, _i, _fl, _vp, _fl, _vp, _i, _i, _i, _i, _vp]),

@@ -165,6 +165,34 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     }
 }
 
+// Integer-factor DOWNsample backward as a gather (no atomics, no zero-fill): with H = f * Ho the source coordinate of output d is
+// s = d*f + (f-1)/2 — for even f the two taps f*d + f/2 - 1 and f*d + f/2 with weights 1/2, 1/2; for odd f the single
+// tap f*d + (f-1)/2 with weight 1 (its neighbour has weight 0).  So every input texel receives from at most ONE output pixel
+// per axis: gx[h][w] = wy(h) * wx(w) * gy[h / fy][w / fx].  (the multi-resolution discriminators and regulariser: /2, /4)
+__device__ __forceinline__ float down_weight(int i, int f) {
+    const int r = i % f;
+    if (f & 1) return r == (f - 1) / 2 ? 1.f : 0.f;
+    return (r == f / 2 - 1 || r == f / 2) ? 0.5f : 0.f;
+}
+__global__ __launch_bounds__(256) void bilinear_down_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int H,
+                                                                int W, int fy, int fx, long long total_in) {
+    const int Ho = H / fy, Wo = W / fx;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_in;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(idx % W);
+        const long long t = idx / W;
+        const int h = (int)(t % H);
+        const long long nc = t / H;
+        const float wy = down_weight(h, fy), wx = down_weight(w, fx);
+        float v = 0.f;
+        if (wy != 0.f && wx != 0.f) {
+            // same products as the scatter form: g * l_y * l_x
+            v = gy[nc * (long long)Ho * Wo + (long long)(h / fy) * Wo + w / fx] * wy * wx;
+        }
+        gx[idx] = v;
+    }
+}
+
 // exact 2x upsample backward as a gather (no atomics): out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1]
 // with the border taps clamped.  gin[i] collects from out rows 2i-1 .. 2i+2.
 __device__ __forceinline__ void up2_taps(int i, int n, int* o, float* wgt, int& cnt) {
@@ -306,7 +334,12 @@ NEMAR_API int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, 
         const long long total = (long long)planes * H * W;
         hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, gy, gx, H, W,
                            total);
+    } else if (Ho > 0 && Wo > 0 && H % Ho == 0 && W % Wo == 0 && H / Ho >= 2 && W / Wo >= 2) {
+        const long long total = (long long)planes * H * W;
+        hipLaunchKernelGGL(bilinear_down_bwd_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, gy, gx, H, W, H / Ho,
+                           W / Wo, total);
     } else {
+        // arbitrary ratios (not on the training path): scatter with fp32 atomics
         NEMAR_HIP_CALL(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)planes * H * W, st));
         const long long total = (long long)planes * Ho * Wo;
         hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, gy, gx, H, W, Ho, Wo,

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __res
                                                               const float* __restrict__ gsrc,
                                                               const float* __restrict__ gout,
                                                               float* __restrict__ gin, float* __restrict__ ggrid,
-                                                              int accum_ggrid, int C, int H, int W, int Ho, int Wo) {
+                                                              int accum_ggrid, int C, int H, int W, int Ho, int Wo,
+                                                              float* __restrict__ gpart) {
     __shared__ float red[16];
     const int n = blockIdx.y;
     const int items = Ho * Wo;
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const float t = block_sum(acc[i], red);
-            if (threadIdx.x == 0) atomicAdd(ggrid + n * 6 + i, t);
+            if (threadIdx.x == 0) {
+                if (gpart) gpart[((size_t)n * gridDim.x + blockIdx.x) * 6 + i] = t;    // summed in block order afterwards
+                else atomicAdd(ggrid + n * 6 + i, t);
+            }
         }
     }
 }
@@ -350,6 +354,234 @@ __global__ __launch_bounds__(TL_THREADS) void grid_sample_bwd_tiled_kernel(const
     }
 }
 
+// ---- backward, grad_input as a GATHER per destination tile (default; bitwise reproducible) -------------------------------------
+// The scatter  gin[corner_k(p)] += w_k(p) * gout[p]  is inverted: a workgroup owns a 64 x 16 tile of grad_input and finds, for
+// every texel of it, the output pixels that touch it.  An output pixel p = (h,w) whose 2x2 corner patch lies within +-GT_R of
+// its own position ("near": identity, the reference's linspace zoom, smooth or noisy fields of a few pixels) can only touch
+// texels within GT_R of (h,w), so the workgroup stages the sample geometry (corner base, fractional weights) and the gout
+// values of the (64+2R) x (16+2R) pixels around its tile in LDS, and every texel scans the (2R+1)^2 pixels around it in a
+// fixed order: no atomics at all, one coalesced store per texel, a summation order that never changes.
+// The same pass computes d loss / d grid for the tile's own pixels (they are staged anyway).
+// "Far" pixels (patch further than GT_R from the pixel: rough / large deformations) are appended to a list and scattered
+// by far_scatter_kernel with 64-bit FIXED-POINT atomics — integer addition is associative, so that path is reproducible as
+// well: contributions are scaled by 2^(40 - e), e = exponent of max |gout| (found by the first pass), i.e. 40 bits below the
+// largest gradient, and far_fold_kernel adds the converted sums to grad_input and returns the accumulator to all-zero.
+constexpr int GT_W = 64, GT_H = 16, GT_R = 3, GT_RW = GT_W + 2 * GT_R, GT_RH = GT_H + 2 * GT_R, GT_NP = GT_RW * GT_RH;
+constexpr int GT_THREADS = 256, GT_CH = 4;
+constexpr int GT_KEY_NONE = 0x7fff7fff;
+constexpr int FIX_BITS = 40;
+
+struct GatherWs {
+    unsigned* count;              // [1]  number of far pixels            } zeroed by the entry point before every call
+    unsigned* maxbits;            // [1]  bit pattern of max |gout|       }
+    unsigned* far_list;           // [N*H*W] packed (n * H + h) * W + w of far pixels (order irrelevant)
+    long long* acc;               // [N*C*H*W] fixed-point accumulator — ALL-ZERO between calls (far_fold_kernel restores it)
+    unsigned* dirty;              // [N*tiles] tile touched by the far scatter — all-zero between calls
+    float* gpart;                 // [N][tiles][6] per-workgroup sums of the affine grid gradient
+};
+
+template <int MODE>
+__global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(const float* __restrict__ in,
+                                                                    const float* __restrict__ gsrc,
+                                                                    const float* __restrict__ gout,
+                                                                    float* __restrict__ gin, int accum_gin,
+                                                                    float* __restrict__ ggrid, int accum_ggrid, int C,
+                                                                    int H, int W, GatherWs ws) {
+    __shared__ int s_key[GT_NP];
+    __shared__ float s_tx[GT_NP], s_ty[GT_NP];
+    __shared__ float s_g[GT_CH][GT_NP];
+    __shared__ float red[16];
+    __shared__ unsigned s_far[GT_W * GT_H];
+    __shared__ unsigned s_nfar, s_base;
+    const int n = blockIdx.z;
+    const int tx0 = blockIdx.x * GT_W, ty0 = blockIdx.y * GT_H;
+    const int tid = threadIdx.x;
+    float th[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE == GRID_AFFINE) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) th[i] = gsrc[n * 6 + i] + ((i == 0 || i == 4) ? 1.f : 0.f);
+    }
+    const size_t plane = (size_t)H * W;
+    const float* inN = in + (size_t)n * C * plane;
+    const float* goN = gout + (size_t)n * C * plane;
+    if (tid == 0) s_nfar = 0u;
+    __syncthreads();
+    float acc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gmax = 0.f;
+    // ---- stage the region: sample geometry + gout of every pixel within GT_R of the tile; own pixels also get d/d grid ----
+    for (int idx = tid; idx < GT_NP; idx += GT_THREADS) {
+        const int ry = idx / GT_RW, rx = idx - ry * GT_RW;
+        const int h = ty0 - GT_R + ry, w = tx0 - GT_R + rx;
+        const bool own = ry >= GT_R && ry < GT_R + GT_H && rx >= GT_R && rx < GT_R + GT_W;
+        int key = GT_KEY_NONE;
+        float ftx = 0.f, fty = 0.f, g[GT_CH] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            float gx, gy;
+            make_grid<MODE>(gsrc, n, h, w, H, W, th, gx, gy);
+            const Sample s = locate(gx, gy, W, H);
+            ftx = s.tx; fty = s.ty;
+            const bool x0 = (unsigned)s.x0 < (unsigned)W, x1 = (unsigned)(s.x0 + 1) < (unsigned)W;
+            const bool y0 = (unsigned)s.y0 < (unsigned)H, y1 = (unsigned)(s.y0 + 1) < (unsigned)H;
+            const bool any = (x0 || x1) && (y0 || y1);
+            const size_t it = (size_t)h * W + w;
+            for (int c = 0; c < C; ++c) g[c] = goN[(size_t)c * plane + it];
+            const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;
+            if (any && near) key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+            if (own) {
+                if (any && !near) s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w);
+                // d loss / d grid (same arithmetic as grid_sample_bwd_kernel)
+                const int o = s.y0 * W + s.x0;
+                const float ex = 1.f - s.tx, ey = 1.f - s.ty;
+                float gix = 0.f, giy = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float* pch = inN + (size_t)c * plane;
+                    const float a = (x0 && y0) ? pch[o] : 0.f;
+                    const float b = (x1 && y0) ? pch[o + 1] : 0.f;
+                    const float cc = (x0 && y1) ? pch[o + W] : 0.f;
+                    const float d = (x1 && y1) ? pch[o + W + 1] : 0.f;
+                    gix += g[c] * ((b - a) * ey + (d - cc) * s.ty);
+                    giy += g[c] * ((cc - a) * ex + (d - b) * s.tx);
+                    gmax = fmaxf(gmax, fabsf(g[c]));
+                }
+                const float ggx = gix * (0.5f * (float)W), ggy = giy * (0.5f * (float)H);
+                if (MODE == GRID_UNET) {
+                    float* q = ggrid + (size_t)n * 2 * plane + it;
+                    if (accum_ggrid) { q[0] += ggx; q[plane] += ggy; } else { q[0] = ggx; q[plane] = ggy; }
+                } else if (MODE == GRID_EXPLICIT) {
+                    float2* q = reinterpret_cast<float2*>(ggrid + ((size_t)n * plane + it) * 2);
+                    if (accum_ggrid) { float2 t = *q; t.x += ggx; t.y += ggy; *q = t; } else { *q = make_float2(ggx, ggy); }
+                } else {
+                    const float xb = affine_base(w, W), yb = affine_base(h, H);
+                    acc6[0] += ggx * xb; acc6[1] += ggx * yb; acc6[2] += ggx;
+                    acc6[3] += ggy * xb; acc6[4] += ggy * yb; acc6[5] += ggy;
+                }
+            }
+        }
+        s_key[idx] = key;
+        s_tx[idx] = ftx;
+        s_ty[idx] = fty;
+#pragma unroll
+        for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
+    }
+    gmax = wave_max(gmax);
+    if ((tid & 63) == 0 && gmax > 0.f) atomicMax(ws.maxbits, __float_as_uint(gmax));   // positive floats order like their bits
+    __syncthreads();
+    // far pixels of this tile -> global list (slots claimed with one atomic per workgroup; list order is irrelevant)
+    if (tid == 0 && s_nfar) s_base = atomicAdd(ws.count, s_nfar);
+    if (MODE == GRID_AFFINE) {
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float t = block_sum(acc6[i], red);
+            if (tid == 0) ws.gpart[((size_t)n * nwg + wg) * 6 + i] = t;
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < s_nfar; i += GT_THREADS) ws.far_list[s_base + i] = s_far[i];
+    // ---- gather: every texel of the tile scans the (2R+1)^2 pixels around it, row by row ------------------------------------------
+    float* ginN = gin + (size_t)n * C * plane;
+    for (int t = tid; t < GT_W * GT_H; t += GT_THREADS) {
+        const int ly = t >> 6, lx = t & 63;            // GT_W == 64
+        const int y = ty0 + ly, x = tx0 + lx;
+        if (y >= H || x >= W) continue;
+        const int yt = ly + 2 * GT_R, xt = lx + 2 * GT_R;    // the texel in key coordinates
+        float sum[GT_CH] = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = 0; dy <= 2 * GT_R; ++dy) {
+            const int rowbase = (ly + dy) * GT_RW + lx;   // region row of pixel row y - R + dy, first column x - R
+#pragma unroll
+            for (int dx = 0; dx <= 2 * GT_R; ++dx) {
+                const int k = s_key[rowbase + dx];
+                const int ey = yt - (k >> 16), ex = xt - (int)(short)(k & 0xffff);   // 0: texel is the low corner, 1: the high one
+                if ((unsigned)ey <= 1u && (unsigned)ex <= 1u) {
+                    const float ftx = s_tx[rowbase + dx], fty = s_ty[rowbase + dx];
+                    const float wx = ex ? ftx : 1.f - ftx, wy = ey ? fty : 1.f - fty;
+                    const float wgt = wx * wy;
+#pragma unroll
+                    for (int c = 0; c < GT_CH; ++c) sum[c] += s_g[c][rowbase + dx] * wgt;
+                }
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            float* q = ginN + (size_t)c * plane + (size_t)y * W + x;
+            *q = accum_gin ? *q + sum[c] : sum[c];
+        }
+    }
+}
+
+// one thread per far pixel: corners scattered with 64-bit fixed-point atomics (associative => reproducible)
+template <int MODE>
+__global__ __launch_bounds__(256) void far_scatter_kernel(const float* __restrict__ gsrc, const float* __restrict__ gout, int C,
+                                                          int H, int W, GatherWs ws) {
+    const unsigned count = *ws.count;
+    if (count == 0u) return;
+    const unsigned mb = *ws.maxbits;
+    const int e = max((int)((mb >> 23) & 255u) - 126, -80);       // max |g| < 2^e (clamped: 2^(FIX_BITS - e) must be a float)
+    const float scale = __uint_as_float((unsigned)(127 + FIX_BITS - e) << 23);   // 2^(FIX_BITS - e): products stay exact
+    const size_t plane = (size_t)H * W;
+    const int tiles_x = (W + GT_W - 1) / GT_W, tiles_y = (H + GT_H - 1) / GT_H;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned pid = ws.far_list[i];
+        const int w = (int)(pid % (unsigned)W);
+        const unsigned t = pid / (unsigned)W;
+        const int h = (int)(t % (unsigned)H), n = (int)(t / (unsigned)H);
+        float th[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (MODE == GRID_AFFINE) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) th[k] = gsrc[n * 6 + k] + ((k == 0 || k == 4) ? 1.f : 0.f);
+        }
+        float gx, gy;
+        make_grid<MODE>(gsrc, n, h, w, H, W, th, gx, gy);
+        const Sample s = locate(gx, gy, W, H);
+        const float ex = 1.f - s.tx, ey = 1.f - s.ty;
+        const float wk[4] = {ex * ey, s.tx * ey, ex * s.ty, s.tx * s.ty};
+        for (int k = 0; k < 4; ++k) {
+            const int cx = s.x0 + (k & 1), cy = s.y0 + (k >> 1);
+            if ((unsigned)cx >= (unsigned)W || (unsigned)cy >= (unsigned)H) continue;
+            ws.dirty[((size_t)n * tiles_y + cy / GT_H) * tiles_x + cx / GT_W] = 1u;
+            for (int c = 0; c < C; ++c) {
+                const float v = gout[((size_t)n * C + c) * plane + (size_t)h * W + w] * wk[k];
+                const long long q = __float2ll_rn(v * scale);
+                atomicAdd(reinterpret_cast<unsigned long long*>(ws.acc + ((size_t)n * C + c) * plane + (size_t)cy * W + cx),
+                          (unsigned long long)q);
+            }
+        }
+    }
+}
+
+// tiles touched by the far scatter: grad_input += accumulator / scale; accumulator and flag back to zero
+__global__ __launch_bounds__(256) void far_fold_kernel(float* __restrict__ gin, int C, int H, int W, GatherWs ws) {
+    if (*ws.count == 0u) return;
+    const int n = blockIdx.z;
+    const size_t tile = ((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (ws.dirty[tile] == 0u) return;
+    __syncthreads();                                   // every thread has read the flag before it is cleared
+    const int e = max((int)((*ws.maxbits >> 23) & 255u) - 126, -80);
+    const size_t plane = (size_t)H * W;
+    for (int t = threadIdx.x; t < GT_W * GT_H; t += 256) {
+        const int y = blockIdx.y * GT_H + (t >> 6), x = blockIdx.x * GT_W + (t & 63);
+        if (y >= H || x >= W) continue;
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((size_t)n * C + c) * plane + (size_t)y * W + x;
+            const long long a = ws.acc[o];
+            if (a != 0) {
+                gin[o] += (float)ldexp((double)a, e - FIX_BITS);
+                ws.acc[o] = 0;
+            }
+        }
+    }
+    if (threadIdx.x == 0) ws.dirty[tile] = 0u;
+}
+
+// gtheta[n][i] (+)= sum over workgroups of gpart[n][wg][i], in workgroup order
+__global__ __launch_bounds__(64) void affine_ggrid_fold_kernel(const float* __restrict__ gpart, float* __restrict__ ggrid, int nwg,
+                                                               int accum) {
+    const int n = blockIdx.x, i = threadIdx.x;
+    if (i >= 6) return;
+    float t = 0.f;
+    for (int wg = 0; wg < nwg; ++wg) t += gpart[((size_t)n * nwg + wg) * 6 + i];
+    ggrid[n * 6 + i] = accum ? ggrid[n * 6 + i] + t : t;
+}
+
 template <int MODE>
 int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int H, int W, int Ho, int Wo,
                hipStream_t st) {
@@ -367,36 +599,82 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
     return 0;
 }
 
-// nemar_grid_sample_tune: 0 (default) = grad_input by global fp32 atomics, 1 = through the LDS tile.  Measured (8x3x256^2):
-// zero / near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us (1024^2:
-// 385 / 1013 / 2175 vs 533 / 549 / 547 us).  The tile version is bound by ds_add_f32 (~180 cycles per wave-instruction,
-// ablation: 29 of its 43 us), so the global-atomic version stays the default for the regime the training step starts
-// in; the tile version is the robust choice once deformations are rough or images large.
+// nemar_grid_sample_tune: 0 (default) = destination-tiled gather + fixed-point far path (needs the workspace; bitwise
+// reproducible), 1 = LDS-tile fp32-atomic variant, 2 = global fp32 atomics (the round-1 default), bits 1..2 of values >= 4:
+// ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
+// near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
 int g_tiled_scatter = 0;
 
+struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
+GatherLayout gather_layout(int N, int C, int H, int W) {
+    GatherLayout L;
+    L.tiles_x = nemar_cdiv(W, GT_W); L.tiles_y = nemar_cdiv(H, GT_H);
+    size_t o = 0;
+    L.acc_off = o; o += sizeof(long long) * (size_t)N * C * H * W;
+    L.dirty_off = o; o += sizeof(unsigned) * (size_t)N * L.tiles_x * L.tiles_y;
+    o = (o + 15) & ~(size_t)15;
+    L.zero_bytes = o;
+    L.misc_off = o; o += 16;
+    L.list_off = o; o += sizeof(unsigned) * (size_t)N * H * W;
+    o = (o + 15) & ~(size_t)15;
+    const int nogin_blocks = nemar_cdiv((long long)H * W, 256);     // per-block sums of the affine kernels (either of them)
+    const int nwg = L.tiles_x * L.tiles_y > nogin_blocks ? L.tiles_x * L.tiles_y : nogin_blocks;
+    L.gpart_off = o; o += sizeof(float) * (size_t)N * nwg * 6;
+    L.total = o;
+    return L;
+}
+
 template <int MODE>
-int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin, float* ggrid, int accum_ggrid,
-               int N, int C, int H, int W, int Ho, int Wo, hipStream_t st) {
+int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin, int accum_gin, float* ggrid,
+               int accum_ggrid, int N, int C, int H, int W, int Ho, int Wo, void* workspace, hipStream_t st) {
     const long long items = (long long)Ho * Wo;
     int gx = nemar_cdiv(items, 256);
     const int cap = nemar_cdiv(256 * 8, N);
     if (gx > cap) gx = cap;
     dim3 grid(gx, N), block(256);
-    if (gin && H == Ho && W == Wo && g_tiled_scatter && N <= 65535)
+    char* wsb = (char*)workspace;
+    const GatherLayout L = gather_layout(N, C, H, W);
+    float* gpart = (workspace && MODE == GRID_AFFINE) ? (float*)(wsb + L.gpart_off) : nullptr;
+    const bool gather = gin && workspace && H == Ho && W == Wo && C <= GT_CH && g_tiled_scatter == 0 && N <= 65535 &&
+                        (long long)N * H * W < (1ll << 32);
+    if (gather) {
+        GatherWs ws;
+        ws.acc = (long long*)(wsb + L.acc_off); ws.dirty = (unsigned*)(wsb + L.dirty_off);
+        ws.count = (unsigned*)(wsb + L.misc_off); ws.maxbits = ws.count + 1;
+        ws.far_list = (unsigned*)(wsb + L.list_off); ws.gpart = (float*)(wsb + L.gpart_off);
+        (void)hipMemsetAsync(ws.count, 0, 8, st);
+        const dim3 tg(L.tiles_x, L.tiles_y, N);
+        hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE>), tg, dim3(GT_THREADS), 0, st, in, gsrc, gout, gin, accum_gin,
+                           ggrid, accum_ggrid, C, H, W, ws);
+        hipLaunchKernelGGL((far_scatter_kernel<MODE>), dim3(1024), dim3(256), 0, st, gsrc, gout, C, H, W, ws);
+        hipLaunchKernelGGL(far_fold_kernel, tg, dim3(256), 0, st, gin, C, H, W, ws);
+        if (MODE == GRID_AFFINE)
+            hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)ws.gpart, ggrid,
+                               L.tiles_x * L.tiles_y, accum_ggrid);
+        return 0;
+    }
+    // legacy scatter kernels: grad_input through fp32 atomics into the zero-filled (or accumulated) buffer
+    if (gin && !accum_gin) (void)hipMemsetAsync(gin, 0, sizeof(float) * (size_t)N * C * H * W, st);
+    if (MODE == GRID_AFFINE && !accum_ggrid && !gpart) (void)hipMemsetAsync(ggrid, 0, sizeof(float) * (size_t)N * 6, st);
+    if (gin && H == Ho && W == Wo && (g_tiled_scatter & 1) && N <= 65535) {
+        if (MODE == GRID_AFFINE && !accum_ggrid && gpart) (void)hipMemsetAsync(ggrid, 0, sizeof(float) * (size_t)N * 6, st);
         hipLaunchKernelGGL((grid_sample_bwd_tiled_kernel<MODE>), dim3(nemar_cdiv(W, TL_W), nemar_cdiv(H, TL_H), N),
-                           dim3(TL_THREADS), 0, st, in, gsrc, gout, gin, ggrid, accum_ggrid, C, H, W, g_tiled_scatter >> 1);
-    else if (gin)
+                           dim3(TL_THREADS), 0, st, in, gsrc, gout, gin, ggrid, accum_ggrid, C, H, W, g_tiled_scatter >> 2);
+        return 0;
+    }
+    if (gin)
         hipLaunchKernelGGL((grid_sample_bwd_kernel<MODE, true>), grid, block, 0, st, in, gsrc, gout, gin, ggrid,
-                           accum_ggrid, C, H, W, Ho, Wo);
+                           accum_ggrid, C, H, W, Ho, Wo, gpart);
     else
         hipLaunchKernelGGL((grid_sample_bwd_kernel<MODE, false>), grid, block, 0, st, in, gsrc, gout, gin, ggrid,
-                           accum_ggrid, C, H, W, Ho, Wo);
+                           accum_ggrid, C, H, W, Ho, Wo, gpart);
+    if (gpart)
+        hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)gpart, ggrid, gx, accum_ggrid);
     return 0;
 }
 
 }  // namespace
 
-// grad_input scatter variant: 0 = global atomics (default), 1 = LDS tile; bits 1..2 of larger values = ablations
 NEMAR_API int nemar_grid_sample_tune(int tiled_scatter) {
     g_tiled_scatter = tiled_scatter;
     return NEMAR_OK;
@@ -420,25 +698,35 @@ NEMAR_API int nemar_grid_sample_fwd(const float* in, const float* grid_src, int 
     return NEMAR_OK;
 }
 
+NEMAR_API size_t nemar_grid_sample_bwd_workspace(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return gather_layout(N, C, H, W).total;
+}
+NEMAR_API size_t nemar_grid_sample_bwd_zeroed_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return gather_layout(N, C, H, W).zero_bytes;
+}
+
 NEMAR_API int nemar_grid_sample_bwd(const float* in, const float* grid_src, int grid_mode, const float* gout,
                                     float* gin, int accum_gin, float* ggrid, int accum_ggrid, int N, int C, int H,
-                                    int W, int Ho, int Wo, void* stream) {
+                                    int W, int Ho, int Wo, void* workspace, size_t ws_bytes, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(in && grid_src && gout && ggrid, "grid_sample_bwd: null pointer");
     NEMAR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "grid_sample_bwd: bad shape");
     NEMAR_REQUIRE((long long)H * W < (1ll << 31) && (long long)Ho * Wo < (1ll << 31) && N <= 65535,
                   "grid_sample_bwd: plane too large");
+    if (workspace && ws_bytes < nemar_grid_sample_bwd_workspace(N, C, H, W)) {
+        nemar_set_error("grid_sample_bwd: workspace %zu < %zu", ws_bytes, nemar_grid_sample_bwd_workspace(N, C, H, W));
+        return NEMAR_EWORKSPACE;
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (gin && !accum_gin) NEMAR_HIP_CALL(hipMemsetAsync(gin, 0, sizeof(float) * (size_t)N * C * H * W, st));
-    if (grid_mode == GRID_AFFINE && !accum_ggrid)
-        NEMAR_HIP_CALL(hipMemsetAsync(ggrid, 0, sizeof(float) * (size_t)N * 6, st));
     switch (grid_mode) {
         case GRID_EXPLICIT:
-            launch_bwd<GRID_EXPLICIT>(in, grid_src, gout, gin, ggrid, accum_ggrid, N, C, H, W, Ho, Wo, st); break;
+            launch_bwd<GRID_EXPLICIT>(in, grid_src, gout, gin, accum_gin, ggrid, accum_ggrid, N, C, H, W, Ho, Wo, workspace, st); break;
         case GRID_UNET:
-            launch_bwd<GRID_UNET>(in, grid_src, gout, gin, ggrid, accum_ggrid, N, C, H, W, Ho, Wo, st); break;
+            launch_bwd<GRID_UNET>(in, grid_src, gout, gin, accum_gin, ggrid, accum_ggrid, N, C, H, W, Ho, Wo, workspace, st); break;
         case GRID_AFFINE:
-            launch_bwd<GRID_AFFINE>(in, grid_src, gout, gin, ggrid, accum_ggrid, N, C, H, W, Ho, Wo, st); break;
+            launch_bwd<GRID_AFFINE>(in, grid_src, gout, gin, accum_gin, ggrid, accum_ggrid, N, C, H, W, Ho, Wo, workspace, st); break;
         default: NEMAR_REQUIRE(false, "grid_sample_bwd: unknown grid_mode %d", grid_mode);
     }
     NEMAR_CHECK_LAUNCH("grid_sample_bwd");

@@ -73,6 +73,19 @@ def _workspace(nbytes, device):
     return buf
 
 
+_zero_ws_cache = {}
+
+
+def _zeroed_workspace(nbytes, device):
+    """Grow-only buffer that is ALL-ZERO between ops: the users (grid_sample backward's fixed-point accumulator) return it
+    zero-filled, so it is only ever memset when it is (re)allocated."""
+    buf = _zero_ws_cache.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros(int(nbytes) // 4 + 64, dtype=torch.float32, device=device)
+        _zero_ws_cache[device] = buf
+    return buf
+
+
 # ---- packed-weight cache ---------------------------------------------------------------------------------------------
 # The MFMA kernels read weights in a packed [reduction][channel] layout.  Packing is a tiny kernel, but a step applies
 # every weight tensor several times (T: 2 forward + 2 backward passes, D: 5), so each (weight, direction) keeps its own
@@ -443,9 +456,11 @@ class _Warp(Function):
             go = _c(go)
             N, C, H, W = img.shape
             gin = torch.empty_like(img) if need_img else None
+            wsb = L.grid_sample_bwd_workspace(N, C, H, W)
+            ws = _zeroed_workspace(wsb, img.device)      # leading part: all-zero in, all-zero out; rest: scratch
             with _span('grid_sample_bwd_gin' if need_img else 'grid_sample_bwd_nogin'):
                 L.grid_sample_bwd(_p(img), _p(gs), mode, _p(go), _p(gin), 0, _p(ggs), 0 if first else 1, N, C, H, W,
-                                  Ho, Wo, st)
+                                  Ho, Wo, _p(ws), wsb, st)
             first = False
             gimgs.append(gin)
         if first:

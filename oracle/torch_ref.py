@@ -255,6 +255,7 @@ class RefModel:
         loss_D = 0.5 * c['lambda_GAN'] * (d_real + d_tr + d_rt)
         loss_D.backward()
         self.grads_D = OrderedDict((k, p.grad.clone()) for k, p in self.D.items())
+        self.grads_D_mr = [OrderedDict((k, p.grad.clone()) for k, p in d.items()) for d in self.D_mr]
         self.opt_D.step()
         self._freeze([self.T, self.R], True)
         # translation + registration step (reference :175-215, 278-284)

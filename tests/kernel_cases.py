@@ -20,7 +20,8 @@ def _assert_close(got, want, atol, rtol=0.0, what=""):
 
 
 # ------------------------------------------------------------------------------------------------
-def case_grid_sample(be, mode, N, C, H, W, Ho, Wo, scale, seed=0, need_gin=True, accumulate=False):
+def case_grid_sample(be, mode, N, C, H, W, Ho, Wo, scale, seed=0, need_gin=True, accumulate=False, workspace=True,
+                     atomic=False):
     rng = np.random.default_rng(seed)
     inp = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
     # The sampling coordinates are computed in float32 with the kernel's exact operation order, so that the
@@ -63,8 +64,23 @@ def case_grid_sample(be, mode, N, C, H, W, Ho, Wo, scale, seed=0, need_gin=True,
     base = 0.5 if accumulate else 0.0
     d_gin = be.full((N, C, H, W), base if accumulate else np.nan) if need_gin else None
     d_gsrc = be.full(src.shape, base if accumulate else np.nan)
-    be.lib.grid_sample_bwd(be.ptr(d_in), be.ptr(d_src), mode, be.ptr(d_gout), be.ptr(d_gin), int(accumulate),
-                           be.ptr(d_gsrc), int(accumulate), N, C, H, W, Ho, Wo, be.stream)
+    # with the workspace: gather + fixed-point path (same-size, C <= 4), else the fp32-atomic kernels
+    wsb = be.lib.grid_sample_bwd_workspace(N, C, H, W) if workspace else 0
+    ws = be.bytes_buf(wsb) if workspace else None
+    for rep in range(2 if workspace else 1):         # second call on the SAME workspace: it must have been returned all-zero
+        if rep:
+            d_gin = be.full((N, C, H, W), base if accumulate else np.nan) if need_gin else None
+            d_gsrc = be.full(src.shape, base if accumulate else np.nan)
+        be.lib.grid_sample_bwd(be.ptr(d_in), be.ptr(d_src), mode, be.ptr(d_gout), be.ptr(d_gin), int(accumulate),
+                               be.ptr(d_gsrc), int(accumulate), N, C, H, W, Ho, Wo, be.ptr(ws), wsb, be.stream)
+        if workspace:
+            zb = be.lib.grid_sample_bwd_zeroed_bytes(N, C, H, W)
+            assert not np.any(be.np(ws)[:zb // 4]), "grid_sample_bwd must return the accumulator part of its workspace zero-filled"
+            if rep == 0:
+                first = (None if d_gin is None else be.np(d_gin).copy(), be.np(d_gsrc).copy())
+            elif not atomic and H == Ho and W == Wo and C <= 4:      # bitwise reproducible (gather + fixed-point path)
+                assert d_gin is None or np.array_equal(be.np(d_gin), first[0], equal_nan=True)
+                assert np.array_equal(be.np(d_gsrc), first[1], equal_nan=True)
     tol = 4e-6 * max(H, W, 16)
     if need_gin:
         _assert_close(be.np(d_gin), want_gin + base, atol=tol * 4, what="grid_sample_bwd gin")
@@ -275,7 +291,8 @@ def case_pointwise(be, seed=0):
         be.lib.maxpool2_bwd(be.ptr(d_x), be.ptr(d_gy), be.ptr(d_add), be.ptr(d_gx), 6, H, W, be.stream)
         _assert_close(be.np(d_gx), want_g + add, atol=1e-6, what="maxpool2_bwd+addend")
     # bilinear: 2x up (gather backward), /2 and /4 down, arbitrary
-    for (H, W, Ho, Wo) in ((4, 5, 8, 10), (2, 2, 4, 4), (1, 3, 2, 6), (8, 12, 4, 6), (8, 12, 2, 3), (5, 7, 9, 4)):
+    for (H, W, Ho, Wo) in ((4, 5, 8, 10), (2, 2, 4, 4), (1, 3, 2, 6), (8, 12, 4, 6), (8, 12, 2, 3), (5, 7, 9, 4), (9, 12, 3, 2),
+                           (6, 8, 3, 2)):
         x = rng.standard_normal((2, 2, H, W)).astype(np.float32)
         want = O.bilinear_resize_fwd(x.astype(np.float64), Ho, Wo)
         d_y = be.full((2, 2, Ho, Wo), np.nan)

@@ -109,6 +109,8 @@ def run(name, report=None, check=True):
         hip.fake_RT_B = ref.fake_RT_B.detach().to(hip.device)
         hip.backward_D()
         gD_forced = {k: p.grad.detach().cpu().numpy().copy() for k, p in hip.netD.named_parameters()}
+        gDmr_forced = [{k: p.grad.detach().cpu().numpy().copy() for k, p in d.named_parameters()}
+                       for d in hip.netD_multiresolution]
         hip.fake_TR_B, hip.fake_RT_B = own
         hip.optimizer_D.zero_grad()
         hip.backward_D()
@@ -148,22 +150,24 @@ def run(name, report=None, check=True):
         # D step on identical inputs: per-tensor max-abs error relative to the tensor's max (fp32 oracle)
         gmax = max(float(v.abs().max()) for v in ref.grads_D.values())
         worst, errs = (0.0, None), []
-        for k, v in ref.grads_D.items():
+        pairs = [(k, v, gD_forced[k]) for k, v in ref.grads_D.items()]
+        for i, (gref, gmine) in enumerate(zip(ref.grads_D_mr, gDmr_forced)):     # reduced-resolution discriminators too
+            pairs += [('mr%d.%s' % (i, k), v, gmine[k]) for k, v in gref.items()]
+        for k, v, mine in pairs:
             vmax = float(v.abs().max())
             if vmax < 1e-5 * gmax:
                 continue                  # conv biases in front of InstanceNorm: exactly-zero gradient + noise
-            e = _maxabs(gD_forced[k], v.numpy()) / vmax
+            e = _maxabs(mine, v.numpy()) / vmax
             errs.append(e)
             if e > worst[0]:
                 worst = (e, k)
-        # Two tiers.  Typical tensor: 2e-4.  Worst tensor: 2e-2 — roughly one run in twelve, one pre-activation of this
-        # tiny discriminator lies within fp32 rounding distance of 0 and the LeakyReLU slope differs between the two
-        # implementations (the weights themselves vary in the last bit from run to run: atomic summation order in the
-        # previous step's weight gradient); that single decision moves the gradients of its layer and the layers below it
-        # by up to ~1 % of their max (measured 0.8-1.0 %), while layers above it stay at the 1e-5 level.  A systematic
-        # error would move the median.
+        # Typical tensor 2e-4, worst tensor 1e-3 of the tensor's max.  (Round 1 allowed 2e-2 on the worst tensor plus a second
+        # attempt: one LeakyReLU pre-activation of these tiny discriminators at rounding distance of 0 moves a layer's gradient
+        # by ~1 %, and whether a run hit one changed from run to run with the atomically summed weights of the previous step.
+        # The backward pass is now bitwise reproducible, so the seeded configurations either contain such a knife edge or
+        # they do not — they do not.)
         add(pre + 'grad/D on identical fakes, median tensor', float(np.median(errs)), 2e-4)
-        add(pre + 'grad/D on identical fakes, worst tensor (%s)' % worst[1], worst[0], 2e-2)
+        add(pre + 'grad/D on identical fakes, worst tensor (%s)' % worst[1], worst[0], 1e-3)
         # full-step gradients (own forward values): direction agreement with the fp64 oracle per network / tensor
         for nm, mine, g64 in (('T', gT, ref64.grads_T), ('R', gR, ref64.grads_R), ('D', gD, ref64.grads_D)):
             gmax = max(float(v.abs().max()) for v in g64.values())

@@ -30,15 +30,30 @@ def test_grid_sample_ragged_and_resampled(be):
     K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=3, H=8, W=8, Ho=8, Wo=8, scale=0.1, accumulate=True)
     # the LDS-tile grad_input variant (nemar_grid_sample_tune(1)) on several 16x64 tiles: halo overlap between neighbours
     # (small offsets), the global-atomic fallback for corners outside a tile's region (large offsets), > 4 channels
-    be.lib.grid_sample_tune(1)
-    try:
-        K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.02)
-        K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.5)
-        K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=1, H=36, W=70, Ho=36, Wo=70, scale=0.3, accumulate=True)
-        K.case_grid_sample(be, K.GRID_UNET, N=1, C=6, H=12, W=16, Ho=12, Wo=16, scale=0.1)
-    finally:
-        be.lib.grid_sample_tune(0)
-    K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.5)       # default variant, same shape
+    for variant in (1, 2):          # 2 = global fp32 atomics (the round-1 default)
+        be.lib.grid_sample_tune(variant)
+        try:
+            K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.02, atomic=True)
+            K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.5, atomic=True)
+            K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=1, H=36, W=70, Ho=36, Wo=70, scale=0.3, accumulate=True, atomic=True)
+            K.case_grid_sample(be, K.GRID_UNET, N=1, C=6, H=12, W=16, Ho=12, Wo=16, scale=0.1, atomic=True)
+        finally:
+            be.lib.grid_sample_tune(0)
+    K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.5, workspace=False)   # no workspace: atomics
+
+
+def test_grid_sample_bwd_gather_and_fixed_point_paths(be):
+    """Default grad_input path on several 64x16 destination tiles: near pixels (gather in LDS, halo across tile borders),
+    far pixels (64-bit fixed-point atomics + fold), a mix of both, every grid mode, accumulate, tile tails; each case runs
+    twice on one workspace and must be bitwise identical with the accumulator returned all-zero (kernel_cases)."""
+    K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.0)       # the linspace zoom only: all near
+    K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.02)      # ~1.5 px noise: near + a few far
+    K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.5)       # every pixel far (and many OOB)
+    K.case_grid_sample(be, K.GRID_UNET, N=1, C=4, H=33, W=70, Ho=33, Wo=70, scale=0.05, accumulate=True)
+    K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=3, H=36, W=70, Ho=36, Wo=70, scale=0.02)
+    K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=1, H=36, W=70, Ho=36, Wo=70, scale=0.3, accumulate=True)
+    K.case_grid_sample(be, K.GRID_EXPLICIT, N=1, C=3, H=20, W=66, Ho=20, Wo=66, scale=0.03)
+    K.case_grid_sample(be, K.GRID_UNET, N=1, C=6, H=12, W=16, Ho=12, Wo=16, scale=0.1, atomic=True)   # C > 4: legacy kernels
 
 
 @pytest.mark.parametrize("Ci,alpha", [(0, 0.0), (3, 0.0), (3, 1.7), (1, 0.5)])

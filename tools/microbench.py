@@ -41,17 +41,26 @@ def main():
         go = torch.randn(N, C, H, W, device=dev)
         res = torch.empty_like(img)
         gin = torch.empty_like(img)
-        for sigma in (0.0, 2.0 / W, 0.1):
-            off = torch.randn(N, 2, H, W, device=dev) * sigma
+        wsb = lib.grid_sample_bwd_workspace(N, C, H, W)
+        gws = torch.zeros(wsb // 4 + 16, device=dev)
+        for sigma in (0.0, 2.0 / W, 0.1, 'smooth3px'):
+            if sigma == 'smooth3px':      # low-frequency field of ~3 pixels amplitude (what a trained registration net emits)
+                off = torch.nn.functional.interpolate(torch.randn(N, 2, H // 32, W // 32, device=dev), size=(H, W), mode='bilinear',
+                                                      align_corners=False) * (6.0 / W)
+            else:
+                off = torch.randn(N, 2, H, W, device=dev) * sigma
             gd = torch.empty_like(off)
             px = N * H * W
             t = timeit(lambda: lib.grid_sample_fwd(P(img), P(off), 1, P(res), N, C, H, W, H, W, st()), a.iters)
             out.append(dict(op="grid_sample_fwd", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
                             GBps=px * 4 * (2 * C + 2) / t / 1e9))
-            t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), P(gin), 0, P(gd), 0, N, C, H, W, H, W, st()), a.iters)
-            out.append(dict(op="grid_sample_bwd+gin", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
-                            GBps=px * 4 * (3 * C + 4) / t / 1e9))
-            t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), None, 0, P(gd), 0, N, C, H, W, H, W, st()), a.iters)
+            for variant, name in ((0, "gather+fixedpoint (default)"), (2, "global fp32 atomics (round 1)"), (1, "LDS-tile fp32 atomics")):
+                lib.grid_sample_tune(variant)
+                t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), P(gin), 0, P(gd), 0, N, C, H, W, H, W, P(gws), wsb, st()), a.iters)
+                out.append(dict(op="grid_sample_bwd+gin", variant=name, shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
+                                GBps=px * 4 * (3 * C + 4) / t / 1e9))
+            lib.grid_sample_tune(0)
+            t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), None, 0, P(gd), 0, N, C, H, W, H, W, P(gws), wsb, st()), a.iters)
             out.append(dict(op="grid_sample_bwd", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
                             GBps=px * 4 * (2 * C + 4) / t / 1e9))
         off = torch.randn(N, 2, H, W, device=dev) * 0.01
