@@ -408,14 +408,19 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     __syncthreads();
     float acc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gmax = 0.f;
-    // ---- stage the region: sample geometry + gout of every pixel within GT_R of the tile; own pixels also get d/d grid ----
-    for (int idx = tid; idx < GT_NP; idx += GT_THREADS) {
-        const int ry = idx / GT_RW, rx = idx - ry * GT_RW;
-        const int h = ty0 - GT_R + ry, w = tx0 - GT_R + rx;
-        const bool own = ry >= GT_R && ry < GT_R + GT_H && rx >= GT_R && rx < GT_R + GT_W;
+    // Local arrays are only ever indexed by unrolled constants (a run-time channel index would put them in scratch memory).
+    // ---- stage 1: the tile's own pixels (4 per thread, independent iterations: their loads overlap): geometry + gout -> LDS,
+    //      d loss / d grid -> global, far pixels -> list ------------------------------------------------------------------------
+    constexpr int OWN_PT = GT_W * GT_H / GT_THREADS;
+#pragma unroll
+    for (int i = 0; i < OWN_PT; ++i) {
+        const int t = tid + i * GT_THREADS;
+        const int ly = t >> 6, lx = t & 63;
+        const int h = ty0 + ly, w = tx0 + lx;
+        const int idx = (ly + GT_R) * GT_RW + lx + GT_R;
         int key = GT_KEY_NONE;
         float ftx = 0.f, fty = 0.f, g[GT_CH] = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+        if (h < H && w < W) {
             float gx, gy;
             make_grid<MODE>(gsrc, n, h, w, H, W, th, gx, gy);
             const Sample s = locate(gx, gy, W, H);
@@ -424,16 +429,17 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             const bool y0 = (unsigned)s.y0 < (unsigned)H, y1 = (unsigned)(s.y0 + 1) < (unsigned)H;
             const bool any = (x0 || x1) && (y0 || y1);
             const size_t it = (size_t)h * W + w;
-            for (int c = 0; c < C; ++c) g[c] = goN[(size_t)c * plane + it];
             const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;
             if (any && near) key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
-            if (own) {
-                if (any && !near) s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w);
-                // d loss / d grid (same arithmetic as grid_sample_bwd_kernel)
-                const int o = s.y0 * W + s.x0;
-                const float ex = 1.f - s.tx, ey = 1.f - s.ty;
-                float gix = 0.f, giy = 0.f;
-                for (int c = 0; c < C; ++c) {
+            if (any && !near) s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w);
+            // d loss / d grid (same arithmetic as grid_sample_bwd_kernel)
+            const int o = s.y0 * W + s.x0;
+            const float ex = 1.f - s.tx, ey = 1.f - s.ty;
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int c = 0; c < GT_CH; ++c) {
+                if (c < C) {
+                    g[c] = goN[(size_t)c * plane + it];
                     const float* pch = inN + (size_t)c * plane;
                     const float a = (x0 && y0) ? pch[o] : 0.f;
                     const float b = (x1 && y0) ? pch[o + 1] : 0.f;
@@ -443,18 +449,58 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
                     giy += g[c] * ((cc - a) * ex + (d - b) * s.tx);
                     gmax = fmaxf(gmax, fabsf(g[c]));
                 }
-                const float ggx = gix * (0.5f * (float)W), ggy = giy * (0.5f * (float)H);
-                if (MODE == GRID_UNET) {
-                    float* q = ggrid + (size_t)n * 2 * plane + it;
-                    if (accum_ggrid) { q[0] += ggx; q[plane] += ggy; } else { q[0] = ggx; q[plane] = ggy; }
-                } else if (MODE == GRID_EXPLICIT) {
-                    float2* q = reinterpret_cast<float2*>(ggrid + ((size_t)n * plane + it) * 2);
-                    if (accum_ggrid) { float2 t = *q; t.x += ggx; t.y += ggy; *q = t; } else { *q = make_float2(ggx, ggy); }
-                } else {
-                    const float xb = affine_base(w, W), yb = affine_base(h, H);
-                    acc6[0] += ggx * xb; acc6[1] += ggx * yb; acc6[2] += ggx;
-                    acc6[3] += ggy * xb; acc6[4] += ggy * yb; acc6[5] += ggy;
-                }
+            }
+            const float ggx = gix * (0.5f * (float)W), ggy = giy * (0.5f * (float)H);
+            if (MODE == GRID_UNET) {
+                float* q = ggrid + (size_t)n * 2 * plane + it;
+                if (accum_ggrid) { q[0] += ggx; q[plane] += ggy; } else { q[0] = ggx; q[plane] = ggy; }
+            } else if (MODE == GRID_EXPLICIT) {
+                float2* q = reinterpret_cast<float2*>(ggrid + ((size_t)n * plane + it) * 2);
+                if (accum_ggrid) { float2 t2 = *q; t2.x += ggx; t2.y += ggy; *q = t2; } else { *q = make_float2(ggx, ggy); }
+            } else {
+                const float xb = affine_base(w, W), yb = affine_base(h, H);
+                acc6[0] += ggx * xb; acc6[1] += ggx * yb; acc6[2] += ggx;
+                acc6[3] += ggy * xb; acc6[4] += ggy * yb; acc6[5] += ggy;
+            }
+        }
+        s_key[idx] = key;
+        s_tx[idx] = ftx;
+        s_ty[idx] = fty;
+#pragma unroll
+        for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
+    }
+    // ---- stage 2: the halo ring (pixels within GT_R of the tile that belong to neighbouring tiles): geometry + gout only -----
+    constexpr int HALO_N = GT_NP - GT_W * GT_H;                 // top / bottom bands of GT_R rows, then GT_R columns left / right
+    for (int e = tid; e < HALO_N; e += GT_THREADS) {
+        int ry, rx;
+        if (e < 2 * GT_R * GT_RW) {
+            const int r = e / GT_RW;
+            rx = e - r * GT_RW;
+            ry = r < GT_R ? r : GT_H + r;
+        } else {
+            const int q = e - 2 * GT_R * GT_RW;
+            const int r = q / (2 * GT_R), c2 = q - r * (2 * GT_R);
+            ry = GT_R + r;
+            rx = c2 < GT_R ? c2 : GT_W + c2;
+        }
+        const int idx = ry * GT_RW + rx;
+        const int h = ty0 - GT_R + ry, w = tx0 - GT_R + rx;
+        int key = GT_KEY_NONE;
+        float ftx = 0.f, fty = 0.f, g[GT_CH] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            float gx, gy;
+            make_grid<MODE>(gsrc, n, h, w, H, W, th, gx, gy);
+            const Sample s = locate(gx, gy, W, H);
+            ftx = s.tx; fty = s.ty;
+            const bool anyx = (unsigned)s.x0 < (unsigned)W || (unsigned)(s.x0 + 1) < (unsigned)W;
+            const bool anyy = (unsigned)s.y0 < (unsigned)H || (unsigned)(s.y0 + 1) < (unsigned)H;
+            const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;
+            if (anyx && anyy && near) {
+                key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+                const size_t it = (size_t)h * W + w;
+#pragma unroll
+                for (int c = 0; c < GT_CH; ++c)
+                    if (c < C) g[c] = goN[(size_t)c * plane + it];
             }
         }
         s_key[idx] = key;
@@ -478,32 +524,54 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     }
     __syncthreads();
     for (unsigned i = tid; i < s_nfar; i += GT_THREADS) ws.far_list[s_base + i] = s_far[i];
-    // ---- gather: every texel of the tile scans the (2R+1)^2 pixels around it, row by row ------------------------------------------
-    float* ginN = gin + (size_t)n * C * plane;
-    for (int t = tid; t < GT_W * GT_H; t += GT_THREADS) {
-        const int ly = t >> 6, lx = t & 63;            // GT_W == 64
-        const int y = ty0 + ly, x = tx0 + lx;
-        if (y >= H || x >= W) continue;
-        const int yt = ly + 2 * GT_R, xt = lx + 2 * GT_R;    // the texel in key coordinates
-        float sum[GT_CH] = {0.f, 0.f, 0.f, 0.f};
-        for (int dy = 0; dy <= 2 * GT_R; ++dy) {
-            const int rowbase = (ly + dy) * GT_RW + lx;   // region row of pixel row y - R + dy, first column x - R
+    // ---- gather: a thread owns 4 vertically adjacent texels (column lx, rows 4*rg .. 4*rg+3) and walks the 10 x 7 staged
+    //      pixels around them once, in a fixed order; a pixel whose corner base is (ky, kx) touches texel rows ky, ky+1 and
+    //      columns kx, kx+1 with the bilinear weights of grid_sample ------------------------------------------------------------
+    const int lx = tid & 63, rg = tid >> 6;
+    const int xt = lx + 2 * GT_R, yt0 = 4 * rg + 2 * GT_R;
+    float sum[4][GT_CH];
 #pragma unroll
-            for (int dx = 0; dx <= 2 * GT_R; ++dx) {
-                const int k = s_key[rowbase + dx];
-                const int ey = yt - (k >> 16), ex = xt - (int)(short)(k & 0xffff);   // 0: texel is the low corner, 1: the high one
-                if ((unsigned)ey <= 1u && (unsigned)ex <= 1u) {
-                    const float ftx = s_tx[rowbase + dx], fty = s_ty[rowbase + dx];
-                    const float wx = ex ? ftx : 1.f - ftx, wy = ey ? fty : 1.f - fty;
-                    const float wgt = wx * wy;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int c = 0; c < GT_CH; ++c) sum[c] += s_g[c][rowbase + dx] * wgt;
+        for (int c = 0; c < GT_CH; ++c) sum[i][c] = 0.f;
+    for (int rr = 0; rr < 4 + 2 * GT_R; ++rr) {
+        const int rowbase = (4 * rg + rr) * GT_RW + lx;
+#pragma unroll
+        for (int dx = 0; dx <= 2 * GT_R; ++dx) {
+            const int k = s_key[rowbase + dx];
+            const int ex = xt - (int)(short)(k & 0xffff);       // 0: the texel column is the pixel's left corner, 1: its right one
+            const int a = (k >> 16) - yt0;                      // texel a is the pixel's top corner row, a + 1 its bottom one
+            if ((unsigned)ex <= 1u && a >= -1 && a <= 3) {
+                const float ftx = s_tx[rowbase + dx], fty = s_ty[rowbase + dx];
+                const float wx = ex ? ftx : 1.f - ftx;
+                const float wtop = wx * (1.f - fty), wbot = wx * fty;   // == ex*ey / tx*ey / ex*ty / tx*ty of the scatter form
+                float g[GT_CH];
+#pragma unroll
+                for (int c = 0; c < GT_CH; ++c) g[c] = s_g[c][rowbase + dx];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float wgt = (i == a) ? wtop : wbot;
+                    if (i == a || i == a + 1) {
+#pragma unroll
+                        for (int c = 0; c < GT_CH; ++c) sum[i][c] += g[c] * wgt;
+                    }
                 }
             }
         }
-        for (int c = 0; c < C; ++c) {
-            float* q = ginN + (size_t)c * plane + (size_t)y * W + x;
-            *q = accum_gin ? *q + sum[c] : sum[c];
+    }
+    float* ginN = gin + (size_t)n * C * plane;
+    const int x = tx0 + lx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = ty0 + 4 * rg + i;
+        if (y < H && x < W) {
+#pragma unroll
+            for (int c = 0; c < GT_CH; ++c) {
+                if (c < C) {
+                    float* q = ginN + (size_t)c * plane + (size_t)y * W + x;
+                    *q = accum_gin ? *q + sum[i][c] : sum[i][c];
+                }
+            }
         }
     }
 }

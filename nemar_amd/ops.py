@@ -76,13 +76,15 @@ def _workspace(nbytes, device):
 _zero_ws_cache = {}
 
 
-def _zeroed_workspace(nbytes, device):
-    """Grow-only buffer that is ALL-ZERO between ops: the users (grid_sample backward's fixed-point accumulator) return it
-    zero-filled, so it is only ever memset when it is (re)allocated."""
-    buf = _zero_ws_cache.get(device)
+def _zeroed_workspace(nbytes, key):
+    """Buffer whose users keep a prefix ALL-ZERO between calls (grid_sample backward's fixed-point accumulator returns it
+    zero-filled, so it is memset exactly once, when allocated).  How long that prefix is depends on the problem shape, so
+    there is one buffer per (device, shape) `key` — a shared grow-only buffer would hand scratch bytes of a small problem
+    to a larger one as "zeroed"."""
+    buf = _zero_ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.zeros(int(nbytes) // 4 + 64, dtype=torch.float32, device=device)
-        _zero_ws_cache[device] = buf
+        buf = torch.zeros(int(nbytes) // 4 + 64, dtype=torch.float32, device=key[0])
+        _zero_ws_cache[key] = buf
     return buf
 
 
@@ -457,7 +459,7 @@ class _Warp(Function):
             N, C, H, W = img.shape
             gin = torch.empty_like(img) if need_img else None
             wsb = L.grid_sample_bwd_workspace(N, C, H, W)
-            ws = _zeroed_workspace(wsb, img.device)      # leading part: all-zero in, all-zero out; rest: scratch
+            ws = _zeroed_workspace(wsb, (img.device, N, C, H, W))    # leading part: all-zero in, all-zero out; rest: scratch
             with _span('grid_sample_bwd_gin' if need_img else 'grid_sample_bwd_nogin'):
                 L.grid_sample_bwd(_p(img), _p(gs), mode, _p(go), _p(gin), 0, _p(ggs), 0 if first else 1, N, C, H, W,
                                   Ho, Wo, _p(ws), wsb, st)
