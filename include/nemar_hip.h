@@ -134,7 +134,8 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *                                                                       main launch (1, default) / separate ring launch (0)
  *   10 4-deep LDS ring for every 64x64 launch
  *   11 four loader waves for gathered B tiles (on)                   12 reduction splits in data gradients (on)
- *   14 fixed-order split reductions (1, default) / fp32 atomics in the weight + bias gradients (0) */
+ *   14 fixed-order split reductions (1, default) / fp32 atomics in the weight + bias gradients (0)
+ *   15 XCD-aware workgroup -> tile mapping of the wave-specialised kernels (1, default) */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient; two fixed-order stages through `workspace`). */

@@ -125,6 +125,7 @@ struct IgemmParams {
     // reflect data gradient without a ring launch (wave-specialised 16-byte-load kernel, 3x3 pad 1): pre-folded border rows
     // [2][3][N][K][Ws] and border column groups [2][N][K][Hs][4] of the source (reflect_aux_kernel)
     int rf; const float* rf_row; const float* rf_col;
+    int xcd;             // XCD-aware workgroup -> tile mapping of the wave-specialised kernel (grid.x % 8 == 0)
     FastDiv fd_ohw, fd_ow, fd_cs;
     TapTable taps;
 };
@@ -614,7 +615,19 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     float* const Bs0 = smem + W2_NBUF * A_FLOATS;
 
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const int m0 = blockIdx.y * BM, p0 = blockIdx.x * BN;
+    // Workgroup -> tile.  Consecutive workgroup ids land on consecutive XCDs (id % 8), each with its own L2; neighbouring
+    // pixel tiles share half of their source rows (a 3x3 tile of two image rows reads four), so with the identity mapping
+    // every XCD fetches the halo rows its neighbours already hold.  p.xcd != 0: XCD k takes a CONTIGUOUS run of pixel tiles
+    // (and all channel tiles of each), so halo rows and the second channel tile's B tile are L2 hits.
+    int bx = blockIdx.x, by_ = blockIdx.y;
+    if (p.xcd) {
+        const int gxx = gridDim.x, gyy = gridDim.y;
+        const int b = bx + gxx * by_;
+        const int k = b & 7, j = b >> 3;
+        bx = k * (gxx >> 3) + j / gyy;
+        by_ = j - (j / gyy) * gyy;
+    }
+    const int m0 = by_ * BM, p0 = bx * BN;
     const int Cs = p.C0 + p.C1, HW = p.Hs * p.Ws;
     // grid.z > 1: the reduction is split over workgroups (few, deep tiles — D's 256->512 k4 data gradient is 128 tiles x 512
     // stages); partial results meet in the zero-filled destination through atomics (no bias / activation in that mode)
@@ -829,7 +842,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     // scalar registers and written once at the end: 6 stamps per stage = loop top | reads issued | MFMA block 1 issued |
     // lgkmcnt(0) | barrier passed | MFMA block 2 issued
     long long ts[4][6];
-    const bool probe = p.tl != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool probe = p.tl != nullptr && bx == 0 && by_ == 0;
 #ifdef NEMAR_TIMELINE      /* the probe's s_memtime + waits perturb the loop's wait counts: compiled in on demand only */
 #define WS2_STAMP(i_)                                                     \
     if (probe && ks >= 40 && ks < 44) {                                       \
@@ -981,6 +994,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
+static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup -> tile mapping in the wave-specialised igemm
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
 static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise
                                  // reproducible backward pass), 0 = fp32 atomics in the weight / bias gradients (round-1 scheme)
@@ -1063,6 +1077,9 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     bool vec = false;
     if (route_ws2(p, &vec)) {
         int mt = g_ws2_mt ? g_ws2_mt : 4;
+        IgemmParams q = p;
+        q.xcd = (g_xcd_map && nemar_cdiv(p.P, 128) % 8 == 0) ? 1 : 0;
+        const IgemmParams& p = q;
         if (mt == 4 && !vec && g_nl4_scalar)          // gathered (non-VEC) B tile: 4 loader waves share the 32 4-byte loads
             hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128), p.ksplit),
                                dim3(8 * 64), g_lds_pad, st, p);
@@ -1582,7 +1599,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.zero = p.wp + packed_core_floats(K, C * R * S);
     p.dbg = g_dbg; p.tl = g_tl;
     p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
-    p.rf = 0; p.rf_row = nullptr; p.rf_col = nullptr;
+    p.rf = 0; p.rf_row = nullptr; p.rf_col = nullptr; p.xcd = 0;
     p.bias = bias;
     p.dst0 = y; p.dst1 = nullptr; p.M0 = K;
     p.OH = OH; p.OW = OW; p.OHf = OH; p.OWf = OW; p.osy = 1; p.ooy = 0; p.osx = 1; p.oox = 0;
@@ -1662,7 +1679,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             p.sy = 1; p.sx = 1; p.border = BORDER_ZERO; p.act = act; p.slope = slope;
             p.pad = pad;
             p.ring_p = 0; p.ring_H = 0; p.ring_W = 0; p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
-            p.rf = 0; p.rf_row = nullptr; p.rf_col = nullptr;
+            p.rf = 0; p.rf_row = nullptr; p.rf_col = nullptr; p.xcd = 0;
             p.fd_ohw = make_fastdiv(OHc * OWc); p.fd_ow = make_fastdiv(OWc); p.fd_cs = make_fastdiv(K);
             float* wp = wsf + pack_stride * (size_t)cls;
             p.wp = wp;
@@ -1862,6 +1879,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 6) { g_min_blocks = value > 0 ? value : 384; return NEMAR_OK; }
     if (key == 14) { g_deterministic = value != 0; return NEMAR_OK; }
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
+    if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
     if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }

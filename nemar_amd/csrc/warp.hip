@@ -380,7 +380,9 @@ struct GatherWs {
     float* gpart;                 // [N][tiles][6] per-workgroup sums of the affine grid gradient
 };
 
-template <int MODE>
+// GG: the pass also computes d loss / d grid for the tile's own pixels (needs the 4-corner gathers of `in`); !GG: grid
+// gradient left to grid_sample_bwd_kernel<MODE, false>, this pass only streams gsrc + gout and writes grad_input.
+template <int MODE, bool GG>
 __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ gsrc,
                                                                     const float* __restrict__ gout,
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     // Local arrays are only ever indexed by unrolled constants (a run-time channel index would put them in scratch memory).
     // ---- stage 1: the tile's own pixels (4 per thread, independent iterations: their loads overlap): geometry + gout -> LDS,
     //      d loss / d grid -> global, far pixels -> list ------------------------------------------------------------------------
-    constexpr int OWN_PT = GT_W * GT_H / GT_THREADS;
+    constexpr int OWN_PT = GG ? GT_W * GT_H / GT_THREADS : 0;
 #pragma unroll
     for (int i = 0; i < OWN_PT; ++i) {
         const int t = tid + i * GT_THREADS;
@@ -470,10 +472,15 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
         for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
     }
     // ---- stage 2: the halo ring (pixels within GT_R of the tile that belong to neighbouring tiles): geometry + gout only -----
-    constexpr int HALO_N = GT_NP - GT_W * GT_H;                 // top / bottom bands of GT_R rows, then GT_R columns left / right
+    //      (!GG: every pixel of the region, own ones included — those also feed the far list and max |gout|)
+    constexpr int HALO_N = GG ? GT_NP - GT_W * GT_H : GT_NP;    // top / bottom bands of GT_R rows, then GT_R columns left / right
+#pragma unroll 2
     for (int e = tid; e < HALO_N; e += GT_THREADS) {
         int ry, rx;
-        if (e < 2 * GT_R * GT_RW) {
+        if (!GG) {
+            ry = e / GT_RW;
+            rx = e - ry * GT_RW;
+        } else if (e < 2 * GT_R * GT_RW) {
             const int r = e / GT_RW;
             rx = e - r * GT_RW;
             ry = r < GT_R ? r : GT_H + r;
@@ -495,12 +502,18 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             const bool anyx = (unsigned)s.x0 < (unsigned)W || (unsigned)(s.x0 + 1) < (unsigned)W;
             const bool anyy = (unsigned)s.y0 < (unsigned)H || (unsigned)(s.y0 + 1) < (unsigned)H;
             const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;
-            if (anyx && anyy && near) {
-                key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+            const bool own = !GG && ry >= GT_R && ry < GT_R + GT_H && rx >= GT_R && rx < GT_R + GT_W;
+            if (anyx && anyy && (near || own)) {
                 const size_t it = (size_t)h * W + w;
 #pragma unroll
                 for (int c = 0; c < GT_CH; ++c)
                     if (c < C) g[c] = goN[(size_t)c * plane + it];
+                if (near) key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+                else s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w);
+                if (own) {
+#pragma unroll
+                    for (int c = 0; c < GT_CH; ++c) gmax = fmaxf(gmax, fabsf(g[c]));
+                }
             }
         }
         s_key[idx] = key;
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     __syncthreads();
     // far pixels of this tile -> global list (slots claimed with one atomic per workgroup; list order is irrelevant)
     if (tid == 0 && s_nfar) s_base = atomicAdd(ws.count, s_nfar);
-    if (MODE == GRID_AFFINE) {
+    if (MODE == GRID_AFFINE && GG) {
         const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -672,6 +685,7 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
 // ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
 // near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
 int g_tiled_scatter = 0;
+int g_gather_fused = 0;     // nemar_grid_sample_tune(8): grid gradient fused into the gather pass (A/B; default: two passes)
 
 struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
 GatherLayout gather_layout(int N, int C, int H, int W) {
@@ -712,13 +726,25 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
         ws.far_list = (unsigned*)(wsb + L.list_off); ws.gpart = (float*)(wsb + L.gpart_off);
         (void)hipMemsetAsync(ws.count, 0, 8, st);
         const dim3 tg(L.tiles_x, L.tiles_y, N);
-        hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE>), tg, dim3(GT_THREADS), 0, st, in, gsrc, gout, gin, accum_gin,
-                           ggrid, accum_ggrid, C, H, W, ws);
+        if (g_gather_fused) {
+            hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true>), tg, dim3(GT_THREADS), 0, st, in, gsrc, gout, gin,
+                               accum_gin, ggrid, accum_ggrid, C, H, W, ws);
+            if (MODE == GRID_AFFINE)
+                hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)ws.gpart, ggrid,
+                                   L.tiles_x * L.tiles_y, accum_ggrid);
+        } else {
+            // two streaming passes: d loss / d grid (4-corner gathers of `in`, every CU full of independent loads), then the
+            // gather pass over gsrc + gout only — measured faster than the fused pass, whose workgroups alternate between a
+            // dependent-load phase and an LDS phase at 3 workgroups per CU (warp.hip header, profiles/)
+            hipLaunchKernelGGL((grid_sample_bwd_kernel<MODE, false>), grid, block, 0, st, in, gsrc, gout, nullptr, ggrid,
+                               accum_ggrid, C, H, W, Ho, Wo, gpart);
+            if (MODE == GRID_AFFINE)
+                hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)gpart, ggrid, gx, accum_ggrid);
+            hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, false>), tg, dim3(GT_THREADS), 0, st, in, gsrc, gout, gin,
+                               accum_gin, ggrid, accum_ggrid, C, H, W, ws);
+        }
         hipLaunchKernelGGL((far_scatter_kernel<MODE>), dim3(1024), dim3(256), 0, st, gsrc, gout, C, H, W, ws);
         hipLaunchKernelGGL(far_fold_kernel, tg, dim3(256), 0, st, gin, C, H, W, ws);
-        if (MODE == GRID_AFFINE)
-            hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)ws.gpart, ggrid,
-                               L.tiles_x * L.tiles_y, accum_ggrid);
         return 0;
     }
     // legacy scatter kernels: grad_input through fp32 atomics into the zero-filled (or accumulated) buffer
@@ -743,8 +769,9 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 
 }  // namespace
 
-NEMAR_API int nemar_grid_sample_tune(int tiled_scatter) {
-    g_tiled_scatter = tiled_scatter;
+NEMAR_API int nemar_grid_sample_tune(int variant) {
+    g_gather_fused = (variant & 8) ? 1 : 0;
+    g_tiled_scatter = variant & ~8;
     return NEMAR_OK;
 }
 

@@ -46,6 +46,12 @@ def test_grid_sample_bwd_gather_and_fixed_point_paths(be):
     """Default grad_input path on several 64x16 destination tiles: near pixels (gather in LDS, halo across tile borders),
     far pixels (64-bit fixed-point atomics + fold), a mix of both, every grid mode, accumulate, tile tails; each case runs
     twice on one workspace and must be bitwise identical with the accumulator returned all-zero (kernel_cases)."""
+    be.lib.grid_sample_tune(8)                  # grid gradient fused into the gather pass (A/B variant)
+    try:
+        K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.02)
+        K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=3, H=36, W=70, Ho=36, Wo=70, scale=0.02, accumulate=True)
+    finally:
+        be.lib.grid_sample_tune(0)
     K.case_grid_sample(be, K.GRID_UNET, N=1, C=2, H=40, W=150, Ho=40, Wo=150, scale=0.0)       # the linspace zoom only: all near
     K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.02)      # ~1.5 px noise: near + a few far
     K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.5)       # every pixel far (and many OOB)
@@ -144,6 +150,7 @@ def test_conv_ws2_vector_loads(be, mt):
         K.case_conv_fwd(be, 3, 32, 0, 5, 4, 33, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)      # OW = 4
         K.case_conv_fwd(be, 1, 16, 16, 9, 12, 70, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)   # concat, P = 108 (tail)
         K.case_conv_fwd(be, 2, 16, 0, 3, 16, 20, 1, 1, 0, K.PAD_ZERO)                       # 1x1
+        K.case_conv_fwd(be, 2, 16, 0, 16, 32, 130, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_RELU) # 8 pixel tiles x 2 channel tiles: XCD-aware mapping
         K.case_conv_bwd_data(be, 2, 24, 0, 7, 8, 32, 3, 1, 1, K.PAD_REFLECT)                # ring + vector main pass
         K.case_conv_bwd_data(be, 2, 24, 0, 7, 8, 16, 3, 1, 1, K.PAD_ZERO)
         K.case_conv_transpose_fwd(be, 2, 16, 40, 5, 8, 3, 1)                                # parity classes, dx in {0, 1}
