@@ -600,13 +600,20 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 // v_cndmask per stage on the two border lanes of a row.  8 wave-instructions per stage instead of 32.
 // SPB = stages per barrier.  1: 3-deep stage ring, one workgroup barrier per 16 reduction rows.  2: 4 stage slots used as
 // two 32-row halves — the loaders fill one half while the MFMA waves consume the other, one barrier per 32 rows.
-template <int MT, bool VEC, int SPB = 1, int NL = 2>   // NL = loader waves (4 only with VEC)
+// ADIR = the A operand (packed weights) bypasses LDS.  A wave's A fragments are private to it (wave w owns channel rows
+// 32w..32w+31 of the tile; only the pixel tile B is shared by the four MFMA waves), and the packed layout IS the fragment
+// layout — lane (m, kslot) needs one 16-byte word per 8 reduction rows — so each MFMA wave fetches its own two words per stage
+// straight from global memory (L2-resident: the whole packed tensor is 2.4 MB) into registers, one stage ahead, in the
+// issue shadow of its MFMAs.  The loader waves then move HALF the bytes per stage (the B tile only): they are the critical path
+// of this kernel, and global->LDS DMA throughput per CU is what bounds them.
+template <int MT, bool VEC, int SPB = 1, int NL = 2, bool ADIR = false>   // NL = loader waves (4 only with VEC)
 __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p) {
     static_assert(NL == 2 || NL == 4, "loader split");
+    static_assert(!ADIR || SPB == 1, "direct A operands: one-stage barrier variant only");
     constexpr int W2_NBUF = SPB == 1 ? 3 : 4;
     constexpr int BM = 32 * MT, BN = 128, LDB = VEC ? BN : BN + 4;
-    constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * LDB;
-    constexpr int A_PER_LOADER = BK * BM / 256 / NL;         // 1 KiB wave-instructions of A per loader per stage
+    constexpr int A_FLOATS = ADIR ? 0 : BK * BM, B_FLOATS = BK * LDB;
+    constexpr int A_PER_LOADER = ADIR ? 0 : BK * BM / 256 / NL;   // 1 KiB wave-instructions of A per loader per stage
     constexpr int B_PER_LOADER = VEC ? BK / 2 / NL : BK / (NL / 2);   // VEC: 2 rows x 128 px per instruction; else 1 row x 64 px
     constexpr int LOADS_PER_STAGE = A_PER_LOADER + B_PER_LOADER;
     static_assert(BK == 16, "a stage is two 8-row fragment groups");
@@ -657,8 +664,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         const int rofs = VEC ? ldr * (BK / NL) + (lane >> 5) : row0;  // first reduction row (channel offset in the stage) of this lane
         const float* s0n = p.src0 + ((size_t)n * p.C0 + rofs) * HW;
         const float* s1n = p.C1 ? p.src1 + ((size_t)n * p.C1 + rofs) * HW : s0n;
-        const float* wsrc[A_PER_LOADER];
-        int a_lds[A_PER_LOADER];
+        const float* wsrc[A_PER_LOADER > 0 ? A_PER_LOADER : 1];
+        int a_lds[A_PER_LOADER > 0 ? A_PER_LOADER : 1];
 #pragma unroll
         for (int q = 0; q < A_PER_LOADER; ++q) {
             const int inst = ldr * A_PER_LOADER + q;
@@ -809,9 +816,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
 
 #define WS2_READ(buf_, kg_, A_, B_)                                                                        \
     {                                                                                                          \
-        const float* sa = As0 + (buf_) * A_FLOATS + (kg_) * (2 * BM * 4) + a_off;                              \
         const float* sb = Bs0 + (buf_) * B_FLOATS + (kg_) * (8 * LDB) + b_off;                                 \
-        A_ = *reinterpret_cast<const f32x4*>(sa);                                                              \
+        if (!ADIR) A_ = *reinterpret_cast<const f32x4*>(As0 + (buf_) * A_FLOATS + (kg_) * (2 * BM * 4) + a_off); \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) B_[s] = *reinterpret_cast<const f32x4*>(sb + 2 * s * LDB); \
     }
 #define WS2_MFMA(A_, B_)                                                                                   \
@@ -895,8 +901,25 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         }
 #undef WS2_STAGE_FLAGS
     } else {
+    // ADIR: this lane's A words of the two 8-row groups of a stage: gA + stage * (4 * Mpad * 4) + {0, 2 * Mpad * 4} floats
+    const float* gA = p.wp + ((size_t)(ks0 * 4 + lhi) * p.Mpad + m0 + wid * 32 + l31) * 4;
+    const size_t gA_kg = (size_t)2 * p.Mpad * 4, gA_stage = (size_t)4 * p.Mpad * 4;
+    f32x4 na0, na1, a1n;
+    if (ADIR) {
+        na0 = *reinterpret_cast<const f32x4*>(gA);
+        na1 = *reinterpret_cast<const f32x4*>(gA + gA_kg);
+        gA += gA_stage;
+    }
     __builtin_amdgcn_s_barrier();                     // stage 0 is in LDS
     WS2_READ(0, 0, a0, b0);
+    if (ADIR) {
+        a0 = na0; a1n = na1;
+        if (nk > 1) {
+            na0 = *reinterpret_cast<const f32x4*>(gA);
+            na1 = *reinterpret_cast<const f32x4*>(gA + gA_kg);
+            gA += gA_stage;
+        }
+    }
     int buf = 0;
     for (int ks = 0; ks < nk; ++ks) {
         // the tap of this stage decides which border groups need patching (wave-uniform, from registers: a table
@@ -909,6 +932,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         }
         WS2_STAMP(0)
         WS2_READ(buf, 1, a1, b1);
+        if (ADIR) a1 = a1n;
         __builtin_amdgcn_sched_barrier(0);
         WS2_STAMP(1)
         WS2_MFMA(a0, b0);
@@ -919,7 +943,17 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         __builtin_amdgcn_s_barrier();                 // stage ks+1 has landed; buffer `buf` goes back to the loaders
         WS2_STAMP(4)
         buf = buf + 1 == W2_NBUF ? 0 : buf + 1;
-        if (ks + 1 < nk) WS2_READ(buf, 0, a0, b0);
+        if (ks + 1 < nk) {
+            WS2_READ(buf, 0, a0, b0);
+            if (ADIR) {                               // next stage's A words (fetched a stage ago); fetch the one after
+                a0 = na0; a1n = na1;
+                if (ks + 2 < nk) {
+                    na0 = *reinterpret_cast<const f32x4*>(gA);
+                    na1 = *reinterpret_cast<const f32x4*>(gA + gA_kg);
+                    gA += gA_stage;
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         WS2_MFMA(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -994,6 +1028,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
+static int g_adir = 1;           // tuning switch (key 16): MFMA waves fetch their A fragments straight from global memory (1) / through LDS (0)
 static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup -> tile mapping in the wave-specialised igemm
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
 static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise
@@ -1024,7 +1059,8 @@ void launch_igemm_cfg(const IgemmParams& p, bool fast, hipStream_t st) {
 template <int MT>
 void launch_ws2(const IgemmParams& p, bool vec, hipStream_t st) {
     dim3 grid(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 32 * MT), p.ring_p ? 1 : p.ksplit), block((MT + 2) * 64);
-    if (vec) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true>), grid, block, g_lds_pad, st, p);
+    if (vec && g_adir) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true, 1, 2, true>), grid, block, g_lds_pad, st, p);
+    else if (vec) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true>), grid, block, g_lds_pad, st, p);
     else hipLaunchKernelGGL((igemm_ws2_kernel<MT, false>), grid, block, g_lds_pad, st, p);
 }
 
@@ -1080,7 +1116,10 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         IgemmParams q = p;
         q.xcd = (g_xcd_map && nemar_cdiv(p.P, 128) % 8 == 0) ? 1 : 0;
         const IgemmParams& p = q;
-        if (mt == 4 && !vec && g_nl4_scalar)          // gathered (non-VEC) B tile: 4 loader waves share the 32 4-byte loads
+        if (mt == 4 && !vec && g_nl4_scalar && g_adir)     // gathered (non-VEC) B tile: 4 loader waves share the 32 4-byte loads
+            hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4, true>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128), p.ksplit),
+                               dim3(8 * 64), g_lds_pad, st, p);
+        else if (mt == 4 && !vec && g_nl4_scalar)
             hipLaunchKernelGGL((igemm_ws2_kernel<4, false, 1, 4>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128), p.ksplit),
                                dim3(8 * 64), g_lds_pad, st, p);
         else if (mt == 4 && vec && g_cfg128 == 7)     // experiment: 4 loader waves
@@ -1880,6 +1919,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 14) { g_deterministic = value != 0; return NEMAR_OK; }
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
+    if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
     if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }

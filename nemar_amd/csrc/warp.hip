@@ -367,7 +367,8 @@ __global__ __launch_bounds__(TL_THREADS) void grid_sample_bwd_tiled_kernel(const
 // well: contributions are scaled by 2^(40 - e), e = exponent of max |gout| (found by the first pass), i.e. 40 bits below the
 // largest gradient, and far_fold_kernel adds the converted sums to grad_input and returns the accumulator to all-zero.
 constexpr int GT_W = 64, GT_H = 16, GT_R = 3, GT_RW = GT_W + 2 * GT_R, GT_RH = GT_H + 2 * GT_R, GT_NP = GT_RW * GT_RH;
-constexpr int GT_THREADS = 256, GT_CH = 4;
+constexpr int GT_THREADS = 512, GT_CH = 4;     // 8 waves per tile: 3 tiles per CU (LDS) x 8 = 24 waves keep enough loads in flight
+constexpr int GT_TPT = GT_W * GT_H / GT_THREADS;   // vertically adjacent texels per thread in the gather phase
 constexpr int GT_KEY_NONE = 0x7fff7fff;
 constexpr int FIX_BITS = 40;
 
@@ -537,24 +538,24 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     }
     __syncthreads();
     for (unsigned i = tid; i < s_nfar; i += GT_THREADS) ws.far_list[s_base + i] = s_far[i];
-    // ---- gather: a thread owns 4 vertically adjacent texels (column lx, rows 4*rg .. 4*rg+3) and walks the 10 x 7 staged
-    //      pixels around them once, in a fixed order; a pixel whose corner base is (ky, kx) touches texel rows ky, ky+1 and
-    //      columns kx, kx+1 with the bilinear weights of grid_sample ------------------------------------------------------------
+    // ---- gather: a thread owns GT_TPT vertically adjacent texels (column lx, rows TPT*rg ..) and walks the (TPT + 2R) x (2R + 1)
+    //      staged pixels around them once, in a fixed order; a pixel whose corner base is (ky, kx) touches texel rows ky, ky+1
+    //      and columns kx, kx+1 with the bilinear weights of grid_sample ---------------------------------------------------------
     const int lx = tid & 63, rg = tid >> 6;
-    const int xt = lx + 2 * GT_R, yt0 = 4 * rg + 2 * GT_R;
-    float sum[4][GT_CH];
+    const int xt = lx + 2 * GT_R, yt0 = GT_TPT * rg + 2 * GT_R;
+    float sum[GT_TPT][GT_CH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < GT_TPT; ++i)
 #pragma unroll
         for (int c = 0; c < GT_CH; ++c) sum[i][c] = 0.f;
-    for (int rr = 0; rr < 4 + 2 * GT_R; ++rr) {
-        const int rowbase = (4 * rg + rr) * GT_RW + lx;
+    for (int rr = 0; rr < GT_TPT + 2 * GT_R; ++rr) {
+        const int rowbase = (GT_TPT * rg + rr) * GT_RW + lx;
 #pragma unroll
         for (int dx = 0; dx <= 2 * GT_R; ++dx) {
             const int k = s_key[rowbase + dx];
             const int ex = xt - (int)(short)(k & 0xffff);       // 0: the texel column is the pixel's left corner, 1: its right one
             const int a = (k >> 16) - yt0;                      // texel a is the pixel's top corner row, a + 1 its bottom one
-            if ((unsigned)ex <= 1u && a >= -1 && a <= 3) {
+            if ((unsigned)ex <= 1u && a >= -1 && a <= GT_TPT - 1) {
                 const float ftx = s_tx[rowbase + dx], fty = s_ty[rowbase + dx];
                 const float wx = ex ? ftx : 1.f - ftx;
                 const float wtop = wx * (1.f - fty), wbot = wx * fty;   // == ex*ey / tx*ey / ex*ty / tx*ty of the scatter form
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
 #pragma unroll
                 for (int c = 0; c < GT_CH; ++c) g[c] = s_g[c][rowbase + dx];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < GT_TPT; ++i) {
                     const float wgt = (i == a) ? wtop : wbot;
                     if (i == a || i == a + 1) {
 #pragma unroll
@@ -575,8 +576,8 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     float* ginN = gin + (size_t)n * C * plane;
     const int x = tx0 + lx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = ty0 + 4 * rg + i;
+    for (int i = 0; i < GT_TPT; ++i) {
+        const int y = ty0 + GT_TPT * rg + i;
         if (y < H && x < W) {
 #pragma unroll
             for (int c = 0; c < GT_CH; ++c) {
@@ -685,7 +686,7 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
 // ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
 // near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
 int g_tiled_scatter = 0;
-int g_gather_fused = 0;     // nemar_grid_sample_tune(8): grid gradient fused into the gather pass (A/B; default: two passes)
+int g_gather_fused = 1;     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
 
 struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
 GatherLayout gather_layout(int N, int C, int H, int W) {
@@ -733,9 +734,8 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
                 hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)ws.gpart, ggrid,
                                    L.tiles_x * L.tiles_y, accum_ggrid);
         } else {
-            // two streaming passes: d loss / d grid (4-corner gathers of `in`, every CU full of independent loads), then the
-            // gather pass over gsrc + gout only — measured faster than the fused pass, whose workgroups alternate between a
-            // dependent-load phase and an LDS phase at 3 workgroups per CU (warp.hip header, profiles/)
+            // A/B variant: two streaming passes — d loss / d grid (grid_sample_bwd_kernel without grad_input), then the gather
+            // pass over gsrc + gout only.  Measured 5-10 % SLOWER than the fused pass (profiles/r2_microbench.jsonl).
             hipLaunchKernelGGL((grid_sample_bwd_kernel<MODE, false>), grid, block, 0, st, in, gsrc, gout, nullptr, ggrid,
                                accum_ggrid, C, H, W, Ho, Wo, gpart);
             if (MODE == GRID_AFFINE)
@@ -770,7 +770,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 }  // namespace
 
 NEMAR_API int nemar_grid_sample_tune(int variant) {
-    g_gather_fused = (variant & 8) ? 1 : 0;
+    g_gather_fused = (variant & 8) ? 0 : 1;
     g_tiled_scatter = variant & ~8;
     return NEMAR_OK;
 }

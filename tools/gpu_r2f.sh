@@ -12,7 +12,7 @@ for l in open('$O/microbench.jsonl'):
     if d['op'].startswith('grid_sample') and 'gather' in d.get('variant',''):
         print('%-20s %-32s %-18s sigma=%-10s %8.1f us %7.0f GB/s' % (d['op'], d.get('variant',''), d['shape'], d['sigma'], d['us'], d['GBps']))
 PY
-for kv in "15 1" "15 0"; do echo "== tune $kv"; python tools/microbench_conv.py --iters 30 --tune $kv 2>/dev/null | python -c "
+for kv in "16 1" "16 0"; do echo "== tune $kv"; python tools/microbench_conv.py --iters 30 --tune $kv 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)
