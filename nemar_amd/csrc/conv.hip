@@ -1028,7 +1028,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
-static int g_adir = 1;           // tuning switch (key 16): MFMA waves fetch their A fragments straight from global memory (1) / through LDS (0)
+static int g_adir = 0;           // tuning switch (key 16): MFMA waves fetch their A fragments straight from global memory (1; measured 3 %
+                                 // SLOWER: 370.8 vs 358.4 us on the 256->256 3x3 layer, gpurun_out/r2g) / through LDS (0, default)
 static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup -> tile mapping in the wave-specialised igemm
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
 static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise

@@ -367,8 +367,7 @@ __global__ __launch_bounds__(TL_THREADS) void grid_sample_bwd_tiled_kernel(const
 // well: contributions are scaled by 2^(40 - e), e = exponent of max |gout| (found by the first pass), i.e. 40 bits below the
 // largest gradient, and far_fold_kernel adds the converted sums to grad_input and returns the accumulator to all-zero.
 constexpr int GT_W = 64, GT_H = 16, GT_R = 3, GT_RW = GT_W + 2 * GT_R, GT_RH = GT_H + 2 * GT_R, GT_NP = GT_RW * GT_RH;
-constexpr int GT_THREADS = 512, GT_CH = 4;     // 8 waves per tile: 3 tiles per CU (LDS) x 8 = 24 waves keep enough loads in flight
-constexpr int GT_TPT = GT_W * GT_H / GT_THREADS;   // vertically adjacent texels per thread in the gather phase
+constexpr int GT_CH = 4;
 constexpr int GT_KEY_NONE = 0x7fff7fff;
 constexpr int FIX_BITS = 40;
 
@@ -383,7 +382,7 @@ struct GatherWs {
 
 // GG: the pass also computes d loss / d grid for the tile's own pixels (needs the 4-corner gathers of `in`); !GG: grid
 // gradient left to grid_sample_bwd_kernel<MODE, false>, this pass only streams gsrc + gout and writes grad_input.
-template <int MODE, bool GG>
+template <int MODE, bool GG, int GT_THREADS>
 __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ gsrc,
                                                                     const float* __restrict__ gout,
@@ -396,6 +395,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     __shared__ float red[16];
     __shared__ unsigned s_far[GT_W * GT_H];
     __shared__ unsigned s_nfar, s_base;
+    constexpr int GT_TPT = GT_W * GT_H / GT_THREADS;   // vertically adjacent texels per thread in the gather phase
     const int n = blockIdx.z;
     const int tx0 = blockIdx.x * GT_W, ty0 = blockIdx.y * GT_H;
     const int tid = threadIdx.x;
@@ -523,11 +523,23 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
 #pragma unroll
         for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
     }
-    gmax = wave_max(gmax);
-    if ((tid & 63) == 0 && gmax > 0.f) atomicMax(ws.maxbits, __float_as_uint(gmax));   // positive floats order like their bits
     __syncthreads();
-    // far pixels of this tile -> global list (slots claimed with one atomic per workgroup; list order is irrelevant)
-    if (tid == 0 && s_nfar) s_base = atomicAdd(ws.count, s_nfar);
+    // far pixels of this tile -> global list (slots claimed with one atomic per workgroup; list order is irrelevant), and the
+    // tile's max |gout| -> the scale of the fixed-point scatter.  Only tiles that HAVE far pixels touch the two global words
+    // (one word takes ~90 atomics per microsecond: 8 waves x 8192 tiles on it cost more than the whole pass), and the max is
+    // only sent when it would raise the current value.
+    if (s_nfar) {
+        gmax = wave_max(gmax);
+        if ((tid & 63) == 0) red[tid >> 6] = gmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = red[0];
+            for (int i = 1; i < GT_THREADS / 64; ++i) m = fmaxf(m, red[i]);
+            const unsigned bits = __float_as_uint(m);                   // positive floats order like their bit patterns
+            if (bits > *(volatile unsigned*)ws.maxbits) atomicMax(ws.maxbits, bits);
+            s_base = atomicAdd(ws.count, s_nfar);
+        }
+    }
     if (MODE == GRID_AFFINE && GG) {
         const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
 #pragma unroll
@@ -686,6 +698,7 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
 // ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
 // near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
 int g_tiled_scatter = 0;
+int g_gather_512 = 0;       // nemar_grid_sample_tune(16): 512-thread workgroups in the gather pass (A/B)
 int g_gather_fused = 1;     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
 
 struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
@@ -728,8 +741,12 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
         (void)hipMemsetAsync(ws.count, 0, 8, st);
         const dim3 tg(L.tiles_x, L.tiles_y, N);
         if (g_gather_fused) {
-            hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true>), tg, dim3(GT_THREADS), 0, st, in, gsrc, gout, gin,
-                               accum_gin, ggrid, accum_ggrid, C, H, W, ws);
+            if (g_gather_512)
+                hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true, 512>), tg, dim3(512), 0, st, in, gsrc, gout, gin,
+                                   accum_gin, ggrid, accum_ggrid, C, H, W, ws);
+            else
+                hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true, 256>), tg, dim3(256), 0, st, in, gsrc, gout, gin,
+                                   accum_gin, ggrid, accum_ggrid, C, H, W, ws);
             if (MODE == GRID_AFFINE)
                 hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)ws.gpart, ggrid,
                                    L.tiles_x * L.tiles_y, accum_ggrid);
@@ -740,7 +757,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
                                accum_ggrid, C, H, W, Ho, Wo, gpart);
             if (MODE == GRID_AFFINE)
                 hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)gpart, ggrid, gx, accum_ggrid);
-            hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, false>), tg, dim3(GT_THREADS), 0, st, in, gsrc, gout, gin,
+            hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, false, 256>), tg, dim3(256), 0, st, in, gsrc, gout, gin,
                                accum_gin, ggrid, accum_ggrid, C, H, W, ws);
         }
         hipLaunchKernelGGL((far_scatter_kernel<MODE>), dim3(1024), dim3(256), 0, st, gsrc, gout, C, H, W, ws);
@@ -771,7 +788,8 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 
 NEMAR_API int nemar_grid_sample_tune(int variant) {
     g_gather_fused = (variant & 8) ? 0 : 1;
-    g_tiled_scatter = variant & ~8;
+    g_gather_512 = (variant & 16) ? 1 : 0;
+    g_tiled_scatter = variant & ~24;
     return NEMAR_OK;
 }
 

@@ -46,6 +46,11 @@ def test_grid_sample_bwd_gather_and_fixed_point_paths(be):
     """Default grad_input path on several 64x16 destination tiles: near pixels (gather in LDS, halo across tile borders),
     far pixels (64-bit fixed-point atomics + fold), a mix of both, every grid mode, accumulate, tile tails; each case runs
     twice on one workspace and must be bitwise identical with the accumulator returned all-zero (kernel_cases)."""
+    be.lib.grid_sample_tune(16)                 # A/B variant: 512-thread workgroups
+    try:
+        K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.02)
+    finally:
+        be.lib.grid_sample_tune(0)
     be.lib.grid_sample_tune(8)                  # A/B variant: grid gradient in its own pass
     try:
         K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.02)
@@ -141,11 +146,11 @@ def test_conv_forced_128_tiles(be, cfg):
 
 
 @pytest.mark.parametrize("mt", [4, 2])
-def test_conv_ws2_weights_through_lds_variant(be, mt):
-    """nemar_tune(16, 0): the A operand staged through LDS by the loader waves (the round-1 scheme), kept for A/B timing;
-    the default lets every MFMA wave fetch its own A fragments from global memory."""
+def test_conv_ws2_direct_weight_fragments_variant(be, mt):
+    """nemar_tune(16, 1): every MFMA wave fetches its own A fragments (packed weights) straight from global memory instead of
+    through LDS — an A/B variant (measured slower on MI355X), kept correct."""
     be.lib.tune(7, mt)
-    be.lib.tune(16, 0)
+    be.lib.tune(16, 1)
     try:
         K.case_conv_fwd(be, 2, 16, 0, 6, 8, 40, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_RELU)
         K.case_conv_fwd(be, 1, 16, 16, 9, 12, 70, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)
@@ -153,7 +158,7 @@ def test_conv_ws2_weights_through_lds_variant(be, mt):
         K.case_conv_bwd_data(be, 2, 24, 0, 7, 8, 32, 3, 1, 1, K.PAD_REFLECT)
     finally:
         be.lib.tune(7, 0)
-        be.lib.tune(16, 1)
+        be.lib.tune(16, 0)
 
 
 @pytest.mark.parametrize("mt", [1, 2, 4])
