@@ -372,9 +372,10 @@ constexpr int GT_KEY_NONE = 0x7fff7fff;
 constexpr int FIX_BITS = 40;
 
 struct GatherWs {
-    unsigned* count;              // [1]  number of far pixels            } zeroed by the entry point before every call
-    unsigned* maxbits;            // [1]  bit pattern of max |gout|       }
-    unsigned* far_list;           // [N*H*W] packed (n * H + h) * W + w of far pixels (order irrelevant)
+    unsigned* count;              // [1]  != 0: some tile has far pixels      } zeroed by the entry point before every call
+    unsigned* maxbits;            // [1]  bit pattern of max |gout|           }
+    unsigned* wg_count;           // [N*tiles] far pixels of each tile (written by every tile of the gather pass)
+    unsigned* far_list;           // [N*tiles][GT_W*GT_H] packed (n * H + h) * W + w of each tile's far pixels
     long long* acc;               // [N*C*H*W] fixed-point accumulator — ALL-ZERO between calls (far_fold_kernel restores it)
     unsigned* dirty;              // [N*tiles] tile touched by the far scatter — all-zero between calls
     float* gpart;                 // [N][tiles][6] per-workgroup sums of the affine grid gradient
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     __shared__ float s_g[GT_CH][GT_NP];
     __shared__ float red[16];
     __shared__ unsigned s_far[GT_W * GT_H];
-    __shared__ unsigned s_nfar, s_base;
+    __shared__ unsigned s_nfar;
     constexpr int GT_TPT = GT_W * GT_H / GT_THREADS;   // vertically adjacent texels per thread in the gather phase
     const int n = blockIdx.z;
     const int tx0 = blockIdx.x * GT_W, ty0 = blockIdx.y * GT_H;
@@ -524,10 +525,11 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
         for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
     }
     __syncthreads();
-    // far pixels of this tile -> global list (slots claimed with one atomic per workgroup; list order is irrelevant), and the
-    // tile's max |gout| -> the scale of the fixed-point scatter.  Only tiles that HAVE far pixels touch the two global words
-    // (one word takes ~90 atomics per microsecond: 8 waves x 8192 tiles on it cost more than the whole pass), and the max is
-    // only sent when it would raise the current value.
+    // far pixels of this tile -> the tile's own list segment (no global counter), and the tile's max |gout| -> the scale of the
+    // fixed-point scatter.  Only tiles that HAVE far pixels touch the two global words, and only when that would change them
+    // (one word takes ~90 atomics per microsecond: 8 waves x 8192 tiles on it cost more than the whole pass).
+    const size_t wgid = ((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0) ws.wg_count[wgid] = s_nfar;
     if (s_nfar) {
         gmax = wave_max(gmax);
         if ((tid & 63) == 0) red[tid >> 6] = gmax;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             for (int i = 1; i < GT_THREADS / 64; ++i) m = fmaxf(m, red[i]);
             const unsigned bits = __float_as_uint(m);                   // positive floats order like their bit patterns
             if (bits > *(volatile unsigned*)ws.maxbits) atomicMax(ws.maxbits, bits);
-            s_base = atomicAdd(ws.count, s_nfar);
+            if (*(volatile unsigned*)ws.count == 0u) *(volatile unsigned*)ws.count = 1u;
         }
     }
     if (MODE == GRID_AFFINE && GG) {
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
         }
     }
     __syncthreads();
-    for (unsigned i = tid; i < s_nfar; i += GT_THREADS) ws.far_list[s_base + i] = s_far[i];
+    for (unsigned i = tid; i < s_nfar; i += GT_THREADS) ws.far_list[wgid * (GT_W * GT_H) + i] = s_far[i];
     // ---- gather: a thread owns GT_TPT vertically adjacent texels (column lx, rows TPT*rg ..) and walks the (TPT + 2R) x (2R + 1)
     //      staged pixels around them once, in a fixed order; a pixel whose corner base is (ky, kx) touches texel rows ky, ky+1
     //      and columns kx, kx+1 with the bilinear weights of grid_sample ---------------------------------------------------------
@@ -602,19 +604,22 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     }
 }
 
-// one thread per far pixel: corners scattered with 64-bit fixed-point atomics (associative => reproducible)
+// one workgroup per tile, one thread per far pixel of it: corners scattered with 64-bit fixed-point atomics (associative =>
+// reproducible)
 template <int MODE>
 __global__ __launch_bounds__(256) void far_scatter_kernel(const float* __restrict__ gsrc, const float* __restrict__ gout, int C,
                                                           int H, int W, GatherWs ws) {
-    const unsigned count = *ws.count;
+    if (*ws.count == 0u) return;
+    const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned count = ws.wg_count[wgid];
     if (count == 0u) return;
     const unsigned mb = *ws.maxbits;
     const int e = max((int)((mb >> 23) & 255u) - 126, -80);       // max |g| < 2^e (clamped: 2^(FIX_BITS - e) must be a float)
     const float scale = __uint_as_float((unsigned)(127 + FIX_BITS - e) << 23);   // 2^(FIX_BITS - e): products stay exact
     const size_t plane = (size_t)H * W;
     const int tiles_x = (W + GT_W - 1) / GT_W, tiles_y = (H + GT_H - 1) / GT_H;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const unsigned pid = ws.far_list[i];
+    for (unsigned i = threadIdx.x; i < count; i += blockDim.x) {
+        const unsigned pid = ws.far_list[wgid * (GT_W * GT_H) + i];
         const int w = (int)(pid % (unsigned)W);
         const unsigned t = pid / (unsigned)W;
         const int h = (int)(t % (unsigned)H), n = (int)(t / (unsigned)H);
@@ -698,10 +703,10 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
 // ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
 // near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
 int g_tiled_scatter = 0;
-int g_gather_512 = 0;       // nemar_grid_sample_tune(16): 512-thread workgroups in the gather pass (A/B)
+int g_gather_512 = 1;       // 512-thread workgroups in the gather pass (default: 170 vs 249 us at 8x3x1024^2); nemar_grid_sample_tune(16): 256
 int g_gather_fused = 1;     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
 
-struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
+struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, wgc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
 GatherLayout gather_layout(int N, int C, int H, int W) {
     GatherLayout L;
     L.tiles_x = nemar_cdiv(W, GT_W); L.tiles_y = nemar_cdiv(H, GT_H);
@@ -711,7 +716,9 @@ GatherLayout gather_layout(int N, int C, int H, int W) {
     o = (o + 15) & ~(size_t)15;
     L.zero_bytes = o;
     L.misc_off = o; o += 16;
-    L.list_off = o; o += sizeof(unsigned) * (size_t)N * H * W;
+    L.wgc_off = o; o += sizeof(unsigned) * (size_t)N * L.tiles_x * L.tiles_y;
+    o = (o + 15) & ~(size_t)15;
+    L.list_off = o; o += sizeof(unsigned) * (size_t)N * L.tiles_x * L.tiles_y * GT_W * GT_H;
     o = (o + 15) & ~(size_t)15;
     const int nogin_blocks = nemar_cdiv((long long)H * W, 256);     // per-block sums of the affine kernels (either of them)
     const int nwg = L.tiles_x * L.tiles_y > nogin_blocks ? L.tiles_x * L.tiles_y : nogin_blocks;
@@ -738,6 +745,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
         ws.acc = (long long*)(wsb + L.acc_off); ws.dirty = (unsigned*)(wsb + L.dirty_off);
         ws.count = (unsigned*)(wsb + L.misc_off); ws.maxbits = ws.count + 1;
         ws.far_list = (unsigned*)(wsb + L.list_off); ws.gpart = (float*)(wsb + L.gpart_off);
+        ws.wg_count = (unsigned*)(wsb + L.wgc_off);
         (void)hipMemsetAsync(ws.count, 0, 8, st);
         const dim3 tg(L.tiles_x, L.tiles_y, N);
         if (g_gather_fused) {
@@ -760,7 +768,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
             hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, false, 256>), tg, dim3(256), 0, st, in, gsrc, gout, gin,
                                accum_gin, ggrid, accum_ggrid, C, H, W, ws);
         }
-        hipLaunchKernelGGL((far_scatter_kernel<MODE>), dim3(1024), dim3(256), 0, st, gsrc, gout, C, H, W, ws);
+        hipLaunchKernelGGL((far_scatter_kernel<MODE>), tg, dim3(256), 0, st, gsrc, gout, C, H, W, ws);
         hipLaunchKernelGGL(far_fold_kernel, tg, dim3(256), 0, st, gin, C, H, W, ws);
         return 0;
     }
@@ -788,7 +796,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 
 NEMAR_API int nemar_grid_sample_tune(int variant) {
     g_gather_fused = (variant & 8) ? 0 : 1;
-    g_gather_512 = (variant & 16) ? 1 : 0;
+    g_gather_512 = (variant & 16) ? 0 : 1;
     g_tiled_scatter = variant & ~24;
     return NEMAR_OK;
 }

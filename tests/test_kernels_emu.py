@@ -46,7 +46,7 @@ def test_grid_sample_bwd_gather_and_fixed_point_paths(be):
     """Default grad_input path on several 64x16 destination tiles: near pixels (gather in LDS, halo across tile borders),
     far pixels (64-bit fixed-point atomics + fold), a mix of both, every grid mode, accumulate, tile tails; each case runs
     twice on one workspace and must be bitwise identical with the accumulator returned all-zero (kernel_cases)."""
-    be.lib.grid_sample_tune(16)                 # A/B variant: 512-thread workgroups
+    be.lib.grid_sample_tune(16)                 # A/B variant: 256-thread workgroups
     try:
         K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.02)
     finally:

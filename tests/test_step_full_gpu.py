@@ -10,14 +10,16 @@ the fp32 rounding floor of the quantity's class, written below.  Two refinements
 run (gpurun_out/r2a/full_rows.txt: every loss / image / weight-gradient row inside the bound, the build's gradient errors
 statistically equal to the reference's own fp32 gaps — R net median 6e-4 vs 1.7e-3):
   * one tensor's own |f32 - f64| is a single draw of a heavy-tailed quantity, so a gradient row uses
-    max(own gap, upper-quartile relative gap of its network) — otherwise a tensor whose reference run happened to land close
+    max(own gap, 90th-percentile relative gap of its network) — otherwise a tensor whose reference run happened to land close
     (R's 2-element output bias: 6e-4 where its weight shows 1.8e-3) gets a bound tighter than its conditioning;
   * post-Adam checksums: the first Adam step moves every element by lr * sign(g), so an element whose gradient is at
     rounding distance of zero moves by 2 lr = 4e-4 between ANY two fp32 implementations; three such elements are
     allowed per tensor on top of the relative bound, and biases in front of an InstanceNorm (true gradient exactly zero,
     i.e. pure rounding noise with a random sign) are not compared.
-The 1024x1024 config has no fp64 run (it does not fit
-the build container); its gap per quantity class is taken from the 512x512 config's measured relative gaps."""
+The 1024x1024 config has no fp64 run (one fp64 step of the reference needs > 60 GB: it was tried, tests/golden/make_golden.py
+died in a 26 GB allocation), so there the build is compared with the reference's FP32 run — both sides carry rounding error —
+with the gap per quantity class taken from the 512x512 config's measured relative gaps (90th percentile of the class), doubled
+for the gradient classes: the registration net of that config is two levels deeper and sees 4x the pixels."""
 import os
 
 import numpy as np
@@ -36,7 +38,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 BASE = {
     'loss': (1e-4, 1e-6), 'reg': (1e-4, 1e-7), 'mean': (0.0, 2e-5), 'absmean': (2e-5, 2e-6), 'proj': (0.0, 2e-4),
     'crop0': (0.0, 5e-5), 'cropc': (0.0, 5e-5), 'offsets': (2e-5, 2e-6),
-    'gradnorm': (2e-3, 0.0), 'gradproj': (2e-3, 0.0), 'gradmax': (1e-2, 0.0), 'psum': (5e-5, 0.0), 'pabs': (5e-5, 0.0),
+    'gradnorm': (3e-3, 0.0), 'gradproj': (3e-3, 0.0), 'gradmax': (1e-2, 0.0), 'psum': (5e-5, 0.0), 'pabs': (5e-5, 0.0),
 }
 
 
@@ -66,11 +68,11 @@ def _rel_gaps_by_class(g):
 
 
 def _net_grad_gap(g, net):
-    """upper quartile over the weight tensors of one network of |gradnorm_f32 - gradnorm_f64| / gradnorm_f64"""
+    """90th percentile over the weight tensors of one network of |gradnorm_f32 - gradnorm_f64| / gradnorm_f64"""
     pre = 'f64/gradnorm/%s/' % net
     rel = [abs(float(g['f32/' + k[4:]]) - float(g[k])) / max(float(g[k]), 1e-30)
            for k in g.files if k.startswith(pre) and k.endswith('weight')]
-    return float(np.quantile(rel, 0.75)) if rel else 0.0
+    return float(np.quantile(rel, 0.9)) if rel else 0.0
 
 
 LR = 2e-4
@@ -131,6 +133,8 @@ def compare(name, rec, report=None):
                 gap = max(gap, _net_grad_gap(g, tail.split('/')[0]) * scale)
         else:
             gap = class_gap.get(cls, 0.0) * max(scale, 1.0 if cls in ('loss', 'crop0', 'cropc', 'mean', 'proj') else 0.0)
+            if cls.startswith('grad'):     # a projection / max of a tiny tensor moves as much as its norm does
+                gap = 2.0 * scale * max(class_gap.get(c, 0.0) for c in ('gradnorm', 'gradproj', 'gradmax'))
         tol = rel * scale + ab + 4.0 * gap
         err = float(np.abs(got - want).max())
         rows.append((q, err, tol, err <= tol))

@@ -54,7 +54,7 @@ def main():
             t = timeit(lambda: lib.grid_sample_fwd(P(img), P(off), 1, P(res), N, C, H, W, H, W, st()), a.iters)
             out.append(dict(op="grid_sample_fwd", shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
                             GBps=px * 4 * (2 * C + 2) / t / 1e9))
-            for variant, name in ((0, "gather fused (default)"), (16, "gather fused 512 threads"), (8, "gather 2-pass"), (2, "global fp32 atomics (round 1)"), (1, "LDS-tile fp32 atomics")):
+            for variant, name in ((0, "gather fused (default)"), (16, "gather fused 256 threads"), (8, "gather 2-pass"), (2, "global fp32 atomics (round 1)"), (1, "LDS-tile fp32 atomics")):
                 lib.grid_sample_tune(variant)
                 t = timeit(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), P(gin), 0, P(gd), 0, N, C, H, W, H, W, P(gws), wsb, st()), a.iters)
                 out.append(dict(op="grid_sample_bwd+gin", variant=name, shape=[N, C, H, W], sigma=sigma, us=t * 1e6,
