@@ -136,8 +136,9 @@ class NEMARModel(BaseModel):
         d_params = itertools.chain(self.netD.parameters(), *[x.parameters() for x in self.netD_multiresolution])
         self.optimizer_D = ops.FlatAdam(d_params, lr=opt.lr, betas=betas)
         self.optimizers += [self.optimizer_T, self.optimizer_D, self.optimizer_R]
-        # identical replicas on every rank before the first step
+        # identical replicas on every rank before the first step; bucketed gradient averaging overlapped with backward
         dist.broadcast_parameters(self.optimizers)
+        self.sync_T, self.sync_D, self.sync_R = dist.grad_sync_for([self.optimizer_T, self.optimizer_D, self.optimizer_R])
 
     def set_input(self, input):
         AtoB = self.opt.direction == 'AtoB'
@@ -259,16 +260,20 @@ class NEMARModel(BaseModel):
         # D step
         self.set_requires_grad([self.netT, self.netR], False)
         self.optimizer_D.zero_grad()
+        self.sync_D.begin(expected=1 if self._batched else 3)     # real, fake_TR, fake_RT passes through every discriminator
         self.backward_D()
-        dist.all_reduce_gradients([self.optimizer_D])
+        self.sync_D.finish()
         self.optimizer_D.step()
         self.set_requires_grad([self.netT, self.netR], True)
         # T + R step (sees the updated D)
         self.set_requires_grad([self.netD, *self.netD_multiresolution], False)
         self.optimizer_R.zero_grad()
         self.optimizer_T.zero_grad()
+        self.sync_T.begin(expected=1 if self._batched else 2)     # T(a) and T(R(a))
+        self.sync_R.begin(expected=1)
         self.backward_T_and_R()
-        dist.all_reduce_gradients([self.optimizer_R, self.optimizer_T])
+        self.sync_R.finish()
+        self.sync_T.finish()
         self.optimizer_R.step()
         self.optimizer_T.step()
         self.set_requires_grad([self.netD, *self.netD_multiresolution], True)

@@ -126,6 +126,14 @@ def _packed(weight, kind, nbytes):
     return buf, 0
 
 
+def grad_ready(param):
+    """A gradient contribution of `param` has been launched (weight / bias gradient kernels accumulate straight into
+    param.grad): lets nemar_amd.distributed.GradSync start the all-reduce of a bucket as soon as it is complete."""
+    gs = getattr(param, '_grad_sync', None)
+    if gs is not None:
+        gs.ready(param)
+
+
 def _grad_buffer(param):
     """param.grad as an accumulation target (allocated zero-filled on first use)."""
     if param.grad is None:
@@ -199,8 +207,12 @@ class _Conv2d(Function):
             wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
             L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
                                 R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st)
+            grad_ready(ctx.weight)
+            if want_b:
+                grad_ready(ctx.bias)
         elif want_b:
             _bias_grad(g, _grad_buffer(ctx.bias), N, K, OH * OW, st)
+            grad_ready(ctx.bias)
         return gx, gx2, None, None, None, None, None, None, None, None
 
 
@@ -263,8 +275,10 @@ class _ConvTranspose2d(Function):
             wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
             L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
                                 S, stride, pad, PAD_ZERO, _p(_workspace(wsb, g.device)), wsb, st)
+            grad_ready(ctx.weight)
         if ctx.needs_input_grad[2] and ctx.bias is not None:
             _bias_grad(g, _grad_buffer(ctx.bias), N, Co, Ho * Wo, st)
+            grad_ready(ctx.bias)
         return gx, None, None, None, None, None, None, None
 
 

@@ -67,6 +67,65 @@ def test_gloo_world_size_2():
     assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
 
 
+def _sync_worker(rank, world, port, out):
+    """Real ops.FlatAdam buffers (CPU tensors: construction, views and zero_grad are plain torch) driven through GradSync the way
+    the conv backward does: gradients written into the flat buffer's views, ops.grad_ready() per contribution."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from nemar_amd import distributed as dist
+    from nemar_amd import ops
+    dist.init_from_env(backend="gloo")
+    torch.manual_seed(0)                                               # same initial parameters on both ranks
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (128,), (3, 64, 7, 7), (3,), (5,)]
+    params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    opt = ops.FlatAdam(params)
+    dist.broadcast_parameters([opt])
+    sync = dist.GradSync(opt, bucket_bytes=16 << 10)
+    assert len(sync.buckets) >= 3 and sync.buckets[0][1] == opt.flat_numel and sync.buckets[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(sync.buckets, sync.buckets[1:]))          # contiguous, walked from the end
+    g = torch.Generator().manual_seed(1000 + rank)
+    contrib = [[torch.randn(s, generator=g) for s in shapes] for _ in range(2)]      # two passes (T is applied twice)
+    opt.zero_grad()
+    sync.begin(expected=2)
+    launched_at = {}
+    for pas in range(2):
+        for i in range(len(params) - 1, -1, -1):                       # backward order: last layer first
+            params[i].grad.add_(contrib[pas][i])                       # the kernels accumulate into the flat buffer's views
+            ops.grad_ready(params[i])
+            for b in sync.launched:
+                launched_at.setdefault(b, (pas, i))
+    # buckets go out in order, the first one as soon as ITS parameters are final — long before the backward pass ends
+    assert sync.launched == sorted(sync.launched) and launched_at[0][0] == 1 and launched_at[0][1] > 0
+    assert len(sync.launched) == len(sync.buckets)
+    sync.finish()
+    local = [contrib[0][i] + contrib[1][i] for i in range(len(shapes))]
+    gathered = [None] * world
+    td = torch.distributed
+    td.all_gather_object(gathered, [t.numpy() for t in local])
+    for i, p in enumerate(params):
+        mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        assert torch.allclose(p.grad, mean, atol=1e-6), i
+    with pytest.raises(RuntimeError):                                  # a third contribution after the bucket went out
+        sync.begin(expected=1)
+        ops.grad_ready(params[-1])
+        ops.grad_ready(params[-1])
+    out.put(rank)
+    td.destroy_process_group()
+
+
+def test_bucketed_overlapped_gradient_sync_on_flat_adam_buffers():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 def test_single_process_is_a_noop():
     from nemar_amd import distributed as dist
     o = _FakeOpt(10, 0)
