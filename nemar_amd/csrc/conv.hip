@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
+static int g_mt8 = 0;            // tuning switch (key 17): 256x128 tiles in the wave-specialised kernel: 0 off, 1 = 2 loader waves, 2 = 4 loader waves
 static int g_adir = 0;           // tuning switch (key 16): MFMA waves fetch their A fragments straight from global memory (1; measured 3 %
                                  // SLOWER: 370.8 vs 358.4 us on the 256->256 3x3 layer, gpurun_out/r2g) / through LDS (0, default)
 static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup -> tile mapping in the wave-specialised igemm
@@ -1129,6 +1130,13 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
         else if (mt == 4 && vec && g_cfg128 == 6)     // experiment: one barrier per 32 reduction rows
             hipLaunchKernelGGL((igemm_ws2_kernel<4, true, 2>), dim3(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 128)), dim3(6 * 64),
                                g_lds_pad, st, p);
+        else if (mt == 4 && vec && g_mt8 && p.M > 128 && p.ksplit == 1) {
+            // 256 channels x 128 pixels per workgroup (8 MFMA waves): one workgroup per CU, the B tile staged once per pixel
+            // tile instead of once per 128-channel half, 24 instead of 32 KiB of global->LDS traffic per 2 x 16 reduction rows
+            const dim3 g8(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 256));
+            if (g_mt8 == 2) hipLaunchKernelGGL((igemm_ws2_kernel<8, true, 1, 4>), g8, dim3(12 * 64), g_lds_pad, st, p);
+            else hipLaunchKernelGGL((igemm_ws2_kernel<8, true, 1, 2>), g8, dim3(10 * 64), g_lds_pad, st, p);
+        }
         else if (mt == 4) launch_ws2<4>(p, vec, st);
         else if (mt == 2) launch_ws2<2>(p, vec, st);
         else launch_ws2<1>(p, vec, st);
@@ -1814,6 +1822,28 @@ void legacy_wgrad_plan(int K, int J, int P, int* splits_out, int* pix_per_split_
     *splits_out = nemar_cdiv(P, *pix_per_split_out);
 }
 constexpr int BIAS_CHUNK = 4096;
+
+// Layers whose gy planes are not a multiple of 4 floats (the discriminator's 31x31 / 15x15 maps) cannot be read in aligned
+// 16-byte chunks; instead of the first-generation VGPR-staged kernel (62 TF on the 256->512 k4 layer) gy is copied once into
+// planes of OHv >= OH rows with (OHv * OW) % 4 == 0, zero-filled below row OH, and the wave-specialised kernel runs on the
+// virtual OHv x OW map: the extra rows multiply whatever source texel they address by zero.
+int padded_rows(int OH, int OW) {
+    int ohv = OH;
+    while ((ohv * OW) % 4) ++ohv;
+    return ohv;
+}
+__global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int plane,
+                                                         int plane_padded, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pl = idx / plane_padded;
+        const int r = (int)(idx - pl * plane_padded);
+        dst[idx] = r < plane ? src[pl * plane + r] : 0.f;
+    }
+}
+bool wgrad_pad_route(int K, int OH, int OW, int pad_mode) {
+    return K > 4 && (OH * OW) % 4 != 0 && pad_mode == BORDER_ZERO && g_wgrad != 1;
+}
 }  // namespace
 
 // Scratch of the weight / bias gradient: per-split slabs of the fixed-order reduction (max over the kernels the shape can
@@ -1829,6 +1859,12 @@ NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, i
     legacy_wgrad_plan(K, J, P, &splits, &pps);
     const size_t f2 = (size_t)splits * ((size_t)K * J + K);
     if (f2 > fl) fl = f2;
+    if ((OH * OW) % 4 != 0 && K > 4) {          // padded-gy route: slabs of the virtual map + the padded copy of gy
+        const int ohv = padded_rows(OH, OW);
+        nemar_wgrad2_plan(K, J, N * ohv * OW, g_wgrad_blocks, &splits, &pps);
+        const size_t f4 = (size_t)splits * ((size_t)K * J + K) + 4 + (size_t)N * K * ohv * OW;
+        if (f4 > fl) fl = f4;
+    }
     if (K <= 4) {
         const size_t f3 = (size_t)nemar_narrow_wgrad_splits(N, C, OH, OW) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
         if (f3 > fl) fl = f3;
@@ -1880,6 +1916,20 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide)");
         return NEMAR_OK;
     }
+    if (part && wgrad_pad_route(K, OH, OW, pad_mode)) {
+        const int ohv = padded_rows(OH, OW);
+        int splits, pps;
+        nemar_wgrad2_plan(K, J, N * ohv * OW, g_wgrad_blocks, &splits, &pps);
+        float* gyp = part + (((size_t)splits * ((size_t)K * J + K) + 3) & ~(size_t)3);       // 16-byte aligned, behind the slabs
+        const long long total = (long long)N * K * ohv * OW;
+        hipLaunchKernelGGL(pad_planes_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, gy, gyp, OH * OW, ohv * OW, total);
+        if (nemar_wgrad2_eligible(K, ohv, OW, gyp)) {
+            nemar_wgrad2_launch(x0, C0, x1, C1, gyp, gw, gb, N, H, W, K, ohv, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
+                                g_wgrad != 2, g_dbg, part, st);
+            NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide, padded gy)");
+            return NEMAR_OK;
+        }
+    }
     WgradParams p;
     p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1; p.Hs = H; p.Ws = W;
     p.gy = gy; p.K = K; p.OH = OH; p.OW = OW;
@@ -1921,6 +1971,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
+    if (key == 17) { g_mt8 = value; return NEMAR_OK; }
     if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
     if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }

@@ -227,6 +227,11 @@ WGRAD_WIDE_CASES = [
     (1, 3, 3, 8, 8, 24, 3, 1, 1, PAD_ZERO),          # STN first conv: 3+3 channels -> J = 54
     (2, 32, 0, 4, 16, 32, 1, 1, 0, PAD_ZERO),        # 1x1
     (2, 24, 0, 6, 32, 64, 3, 1, 1, PAD_REFLECT),     # 64-row tile, vector loads, 2 column tiles
+    # odd output planes (OH*OW % 4 != 0: the discriminator's 31x31 / 15x15 maps): gy copied into zero-padded planes
+    (2, 16, 0, 8, 8, 40, 4, 1, 1, PAD_ZERO),         # 7x7 outputs -> 8 virtual rows
+    (3, 8, 0, 6, 7, 150, 4, 1, 1, PAD_ZERO),         # 5x6 = 30 -> 6 virtual rows (36), 2 channel tiles
+    (2, 12, 0, 11, 11, 20, 3, 2, 1, PAD_ZERO),       # stride 2 -> 6x6 (fine) ; K <= 32 tile
+    (1, 8, 0, 9, 9, 70, 3, 1, 0, PAD_ZERO),          # 7x7 outputs, no padding
 ]
 
 

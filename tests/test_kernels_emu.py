@@ -161,6 +161,20 @@ def test_conv_ws2_direct_weight_fragments_variant(be, mt):
         be.lib.tune(16, 0)
 
 
+@pytest.mark.parametrize("nl", [1, 2])
+def test_conv_ws2_256_channel_tiles(be, nl):
+    """nemar_tune(17, .): 256 channels x 128 pixels per workgroup (8 MFMA waves + 2 / 4 loader waves)."""
+    be.lib.tune(7, 4)
+    be.lib.tune(17, nl)
+    try:
+        K.case_conv_fwd(be, 2, 16, 0, 8, 16, 200, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_RELU)      # ragged M = 200, 2 pixel tiles
+        K.case_conv_fwd(be, 1, 16, 16, 9, 12, 260, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)       # 2 channel tiles (260), concat
+        K.case_conv_bwd_data(be, 2, 136, 0, 7, 8, 32, 3, 1, 1, K.PAD_REFLECT)                    # folded reflect border
+    finally:
+        be.lib.tune(7, 0)
+        be.lib.tune(17, 0)
+
+
 @pytest.mark.parametrize("mt", [1, 2, 4])
 def test_conv_ws2_vector_loads(be, mt):
     """Wave-specialised igemm with 16-byte B loads (stride 1, OW % 4 == 0, |dx| <= 1): clamped border groups are patched

@@ -14,6 +14,7 @@ rows = []
 for line in open(sys.argv[1]):
     d = json.loads(line)
     op, C0, C1, K, R, s, p, pm, H, W, N = (d[k] for k in ("op", "C0", "C1", "K", "R", "stride", "pad", "pad_mode", "H", "W", "N"))
+    act = d.get("act", 1)
     C = C0 + C1
     OH, OW = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
     x0 = torch.randn(N, C0, H, W, device=dev); x1 = torch.randn(N, C1, H, W, device=dev) if C1 else None
@@ -24,7 +25,7 @@ for line in open(sys.argv[1]):
     wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, W, K, R, R, s, p, pm))
     ws = torch.empty(wsb // 4 + 16, device=dev)
     if op == "fwd":
-        f = lambda pre: lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, W, K, R, R, s, p, pm, 1, 0.2, P(ws), wsb, pre, st())
+        f = lambda pre: lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, W, K, R, R, s, p, pm, act, 0.2, P(ws), wsb, pre, st())
     elif op == "dgrad":
         f = lambda pre: lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx0), C0, P(gx1), C1, N, H, W, K, OH, OW, R, R, s, p, pm, P(ws), wsb, pre, st())
     else:

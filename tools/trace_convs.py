@@ -13,17 +13,17 @@ _f, _d, _w = L.conv2d_fwd, L.conv2d_bwd_data, L.conv2d_bwd_weight
 
 
 def fwd(x0, C0, x1, C1, w, b, y, N, H, W, K, R, S, stride, pad, pm, *rest):
-    calls[("fwd", C0, C1, K, R, stride, pad, pm, H, W, N)] += 1
+    calls[("fwd", C0, C1, K, R, stride, pad, pm, H, W, N, rest[0])] += 1
     return _f(x0, C0, x1, C1, w, b, y, N, H, W, K, R, S, stride, pad, pm, *rest)
 
 
 def dgrad(gy, w, b, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pm, *rest):
-    calls[("dgrad", C0, C1, K, R, stride, pad, pm, H, W, N)] += 1
+    calls[("dgrad", C0, C1, K, R, stride, pad, pm, H, W, N, act)] += 1
     return _d(gy, w, b, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pm, *rest)
 
 
 def wgrad(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pm, *rest):
-    calls[("wgrad", C0, C1, K, R, stride, pad, pm, H, W, N)] += 1
+    calls[("wgrad", C0, C1, K, R, stride, pad, pm, H, W, N, 0)] += 1
     return _w(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pm, *rest)
 
 
@@ -38,4 +38,4 @@ calls.clear()
 model.set_input(data); model.optimize_parameters()
 torch.cuda.synchronize()
 for k, c in sorted(calls.items(), key=lambda kv: (kv[0][0], -kv[0][8], kv[0][1])):
-    print(json.dumps(dict(zip(("op", "C0", "C1", "K", "R", "stride", "pad", "pad_mode", "H", "W", "N"), k), count=c)))
+    print(json.dumps(dict(zip(("op", "C0", "C1", "K", "R", "stride", "pad", "pad_mode", "H", "W", "N", "act"), k), count=c)))
