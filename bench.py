@@ -11,7 +11,8 @@ N GPUs = N independent batch shards (weak scaling) + gradient all-reduce(avg) ov
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline            dominant kernel = the fp32-MFMA implicit-GEMM conv (the 256->256 3x3 reflect layer of the
                       translation net's residual blocks, 36 launches/step fwd): algorithmic FLOP / launch duration
-                      measured with HIP events on the launch stream inside the timed region, vs the 157.3 TF fp32 peak
+                      measured with HIP events on the launch stream in two extra steps right after the timed region, vs
+                      the 157.3 TF fp32 peak
   roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
   cpu_baseline        the CPU oracle (oracle/torch_ref.py, a proven-equal restatement of the reference's step) timed
                       on this box's host cores on a bounded sample (config-2 shape at batch 1)
@@ -69,31 +70,42 @@ class KernelTimer:
         return {tag: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e-3) for tag, v in self.spans.items()}
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle's step (CPU, fp32) on config-2 shape at batch 1: images/sec on this box's host cores."""
+def _cpu_steps(stn_type, n_blocks, size, seconds_budget, max_steps):
+    """oracle/torch_ref.py steps (CPU, fp32, batch 1) -> (images/sec, steps timed)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import json as _json
     import seeded
     from oracle import torch_ref as R
     from nemar_amd.models import networks, stn
-    opt = build_opt(1, 256, ['--no_dropout'])
+    opt = build_opt(1, size, ['--no_dropout', '--stn_type', stn_type])
     torch.manual_seed(0)
-    netT = networks.define_G(3, 3, 64, 'resnet_9blocks', 'instance', False, 'normal', 0.02, [])
-    netR = stn.define_stn(argparse.Namespace(**{**vars(opt), 'gpu_ids': []}), 'unet')
+    netT = networks.define_G(3, 3, 64, 'resnet_%dblocks' % n_blocks, 'instance', False, 'normal', 0.02, [])
+    netR = stn.define_stn(argparse.Namespace(**{**vars(opt), 'gpu_ids': []}), stn_type)
     netD = networks.define_D(6, 64, 'basic', 3, 'instance', 'normal', 0.02, [])
     sd = lambda n: {k: v.detach().clone() for k, v in n.state_dict().items()}
-    m = R.RefModel(sd(netT), sd(netR), sd(netD), n_blocks=9, stn_type='unet', lambda_smooth=10.0)
-    A, B = seeded.seeded_images(1, 3, 256, 256, 1)
+    m = R.RefModel(sd(netT), sd(netR), sd(netD), n_blocks=n_blocks, stn_type=stn_type, lambda_smooth=10.0)
+    A, B = seeded.seeded_images(1, 3, size, size, 1)
     A, B = torch.from_numpy(A), torch.from_numpy(B)
     m.optimize_parameters(A, B)          # warm-up
     t0, n = time.time(), 0
-    while n < 3 or (time.time() - t0 < seconds_budget and n < 8):
+    while n < 2 or (time.time() - t0 < seconds_budget and n < max_steps):
         m.optimize_parameters(A, B)
         n += 1
-    dt = (time.time() - t0) / n
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return n / (time.time() - t0), n
+
+
+def cpu_baseline():
+    """The CPU oracle (a restatement of the reference's step proven equal to it by tests/test_oracle_golden.py) timed on this
+    box's host cores, as SURVEY.md §8d asks: BASELINE config 1 (the reference's own CPU-runnable case: affine STN,
+    resnet_6blocks, 128x128, batch 1) always, and the config-2 shape (the GPU workload) at batch 1.  Both without dropout
+    (the oracle draws no masks; dropout is a negligible share of CPU time) against the GPU's batch 8 with dropout on — the
+    CPU path does not get faster per image with a larger batch (measured 0.23 img/s at batch 1 and at batch 2 in round 1)."""
+    c2, n2 = _cpu_steps('unet', 9, 256, 16.0, 6)
+    c1, n1 = _cpu_steps('affine', 6, 128, 6.0, 12)
+    return {"value": c2, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d steps of the config-2 shape (unet cfg A, resnet_9blocks, 256x256) at batch 1, no dropout, "
-                      "oracle/torch_ref.py on torch CPU fp32; host has %d logical cores" % (n, os.cpu_count())}
+                      "oracle/torch_ref.py on torch CPU fp32; host has %d logical cores" % (n2, os.cpu_count()),
+            "config1": {"value": c1, "unit": "images/sec",
+                        "sample": "%d steps of BASELINE config 1 (affine STN, resnet_6blocks, 128x128, batch 1, no dropout)" % n1}}
 
 
 def main():
@@ -147,13 +159,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    timer.enabled = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # per-launch durations of the roofline kernels: HIP events on the launch stream in a SEPARATE pass of two steps, after
+    # the timed region (the event records would otherwise sit inside it)
+    timer.enabled = True
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     timer.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -172,7 +189,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: --stn_type unet --stn_cfg A, resnet_9blocks T, basic PatchGAN D, "
                                "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32%s"
                                % (a.size, a.size, a.batch, (" + " + " ".join(a.opt)) if a.opt else ""),
-                   "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                   "global_batch": a.batch * world, "parallelism": "dp%d" % world, "stn_cfg": opt.stn_cfg,
                    "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"},
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
     }

@@ -174,6 +174,13 @@ int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, int W, int
 int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned offset,
                   void* stream);
 
+/* Input pipeline, on the GPU: random crop + horizontal flip + ToTensor/Normalize(0.5, 0.5) of a pool of images resident in
+ * HBM — reference data/base_dataset.py:63-78 (get_params: ONE crop position / flip per A-B pair) and :81-112
+ * (get_transform; Normalize :111).  pool [M,C,H,W] with values in [0, 1/scale]; params [B,4] int32 device array
+ * (pool index, y0, x0, flip), 16-byte aligned; y [B,C,Hc,Wc] = (pool[...] * scale - 0.5) / 0.5. */
+int nemar_crop_flip_normalize(const float* pool, const int* params, float* y, int M, int B, int C, int H, int W,
+                              int Hc, int Wc, float scale, void* stream);
+
 /* ---- K13: losses (already multiplied by their lambda `weight`; optionally accumulated into a device scalar) ------
  * l1:  torch.nn.L1Loss — reference models/nemar_model.py:68,179,195; b == NULL gives mean|a|
  *      (affine STN regulariser, reference models/stn/affine_stn.py:136-138).

@@ -57,6 +57,7 @@ SIGNATURES = {
     "nemar_maxpool2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "nemar_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nemar_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nemar_crop_flip_normalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _fl, _vp]),
     "nemar_dropout": (_i, [_vp, _vp, _ll, _fl, _u64, _u32, _vp]),
     "nemar_loss_workspace": (_sz, []),
     "nemar_l1_loss_fwd": (_i, [_vp, _vp, _ll, _fl, _vp, _i, _vp, _sz, _vp]),

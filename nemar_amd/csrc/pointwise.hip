@@ -267,6 +267,27 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+// ---- input pipeline: crop + horizontal flip + Normalize(0.5, 0.5) of a resident image pool, one launch per batch -------------
+// y[b][c][h][w] = (pool[idx[b]][c][y0[b] + h][flip[b] ? x0[b] + Wc - 1 - w : x0[b] + w] * scale - 0.5) / 0.5
+// params = int4 per sample (pool index, y0, x0, flip): the reference draws one crop position / flip per A-B pair
+// (data/base_dataset.py get_params :63-78) and applies it to both images (get_transform :81-112, Normalize :111).
+__global__ __launch_bounds__(256) void crop_flip_normalize_kernel(const float* __restrict__ pool, const int* __restrict__ params,
+                                                                  float* __restrict__ y, int C, int H, int W, int Hc, int Wc,
+                                                                  float scale, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(idx % Wc);
+        long long t = idx / Wc;
+        const int h = (int)(t % Hc); t /= Hc;
+        const int c = (int)(t % C);
+        const int b = (int)(t / C);
+        const int4 pr = reinterpret_cast<const int4*>(params)[b];
+        const int sx = pr.w ? pr.z + Wc - 1 - w : pr.z + w;
+        const float v = pool[(((size_t)pr.x * C + c) * H + (pr.y + h)) * W + sx];
+        y[idx] = (v * scale - 0.5f) / 0.5f;
+    }
+}
+
 }  // namespace
 
 NEMAR_API int nemar_act_bwd(const float* gy, const float* y, float* gx, long long n, int act, float slope, void* stream) {
@@ -361,5 +382,20 @@ NEMAR_API int nemar_dropout(const float* x, float* y, long long n, float p, unsi
     hipLaunchKernelGGL(dropout_kernel, dim3(nemar_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n,
                        thresh, 1.f / (1.f - p), (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset);
     NEMAR_CHECK_LAUNCH("dropout");
+    return NEMAR_OK;
+}
+
+// On-GPU augmentation of the input pipeline (reference data/base_dataset.py:63-112: crop, flip, ToTensor, Normalize).
+// pool [M,C,H,W] (values in [0, 1/scale]), params [B,4] int32 (pool index, y0, x0, flip) -> y [B,C,Hc,Wc] in [-1,1].
+NEMAR_API int nemar_crop_flip_normalize(const float* pool, const int* params, float* y, int M, int B, int C, int H, int W,
+                                        int Hc, int Wc, float scale, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(pool && params && y && M > 0 && B > 0 && C > 0 && Hc > 0 && Wc > 0 && Hc <= H && Wc <= W,
+                  "crop_flip_normalize: bad arguments");
+    NEMAR_REQUIRE((((uintptr_t)params) & 15) == 0, "crop_flip_normalize: params must be 16-byte aligned");
+    const long long total = (long long)B * C * Hc * Wc;
+    hipLaunchKernelGGL(crop_flip_normalize_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, pool,
+                       params, y, C, H, W, Hc, Wc, scale, total);
+    NEMAR_CHECK_LAUNCH("crop_flip_normalize");
     return NEMAR_OK;
 }

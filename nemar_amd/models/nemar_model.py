@@ -80,8 +80,6 @@ class NEMARModel(BaseModel):
         BaseModel.__init__(self, opt)
         self.train_stn = True
         self.setup_visualizers()
-        if self.isTrain and getattr(opt, 'enable_tbvis', False):
-            print('TensorBoard visualisation is outside the MI355X hot path (SURVEY.md §2): --enable_tbvis ignored')
         self.tb_visualizer = None
         # NEMAR_BATCHED_PASSES=1: T's two applications and D's 3 + 2 applications per step run as single batches (valid
         # without cross-sample ops, i.e. not with BatchNorm).  Measured on MI355X, config 2: 78.15 vs 78.00 ms/step —
@@ -94,6 +92,11 @@ class NEMARModel(BaseModel):
             self.criterionGAN = networks.GANLoss(opt.gan_mode)
             self.criterionL1 = ops.l1_loss
             self.setup_optimizers()
+            if getattr(opt, 'enable_tbvis', False):
+                # scalars the reference's TensorboardVisualizer reports (util/tb_visualizer.py:53-92): losses and the mean
+                # deformation offsets, the latter reduced on the device (nemar_amd/util/visualizer.py)
+                from ..util.visualizer import TrainingMonitor
+                self.tb_visualizer = TrainingMonitor(self, opt)
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
             self._lam_smooth = torch.full((), float(opt.lambda_smooth), dtype=torch.float32, device=self.device)
 
@@ -171,6 +174,9 @@ class NEMARModel(BaseModel):
             self.fake_RT_B = self.netR.warp(field, [self.fake_B])[0]
             self.stn_reg_term = self.netR.regularization(field, self.registered_real_A)
         self._resized = {}
+        if self.tb_visualizer is not None:
+            # the reference runs netR a second time here (get_grid, :172-173); the field of the pass above is the same tensor
+            self.deformation_field_A_to_B = getattr(self.netR, 'last_offsets', None)
 
     def _half(self, name, tensor, level):
         """tensor bilinearly resized to 1/2^level resolution (reference :185-188 etc.).  Only the step's INPUTS (real_A,
@@ -277,3 +283,5 @@ class NEMARModel(BaseModel):
         self.optimizer_R.step()
         self.optimizer_T.step()
         self.set_requires_grad([self.netD, *self.netD_multiresolution], True)
+        if self.tb_visualizer is not None:
+            self.tb_visualizer.iteration_step()

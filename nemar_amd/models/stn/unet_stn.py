@@ -111,6 +111,7 @@ class UnetSTN(nn.Module):
             d_up = ops.resize_bilinear(d, self.oh, self.ow)
         else:
             d_up = d
+        self.last_offsets = d_up.detach()          # for the offset statistics (util/visualizer.OffsetMeter); no copy
         return d, d_up
 
     def get_grid(self, img_a, img_b, return_offsets_only=False):

@@ -15,6 +15,9 @@ class EmuBackend:
     def dev(self, a):
         return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
+    def dev_i32(self, a):
+        return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
     def zeros(self, *shape):
         return np.zeros(shape, dtype=np.float32)
 
@@ -49,6 +52,9 @@ class HipBackend:
 
     def dev(self, a):
         return self.torch.tensor(np.asarray(a, dtype=np.float32), device=self.device).contiguous()
+
+    def dev_i32(self, a):
+        return self.torch.tensor(np.asarray(a, dtype=np.int32), device=self.device).contiguous()
 
     def zeros(self, *shape):
         return self.torch.zeros(shape, dtype=self.torch.float32, device=self.device)

@@ -381,3 +381,22 @@ def case_adam(be, n=3001, steps=3, seed=0):
     # g spans six decades, so m = lerp(m, g) cancels: fp32 rounding is relative to the larger operand
     _assert_close(be.np(d_m), m64, atol=1e-7 * np.abs(m64).max(), rtol=1e-6, what="adam m")
     _assert_close(be.np(d_v), v64, atol=1e-7 * np.abs(v64).max(), rtol=1e-6, what="adam v")
+
+
+def case_crop_flip_normalize(be, seed=0):
+    """Input-pipeline augmentation: crop + flip + Normalize(0.5, 0.5) of a resident pool (numpy restatement of the reference's
+    get_transform chain, data/base_dataset.py:81-112)."""
+    rng = np.random.default_rng(seed)
+    M, C, H, W, Hc, Wc, B = 5, 3, 11, 14, 8, 9, 4
+    pool = rng.uniform(0, 1, (M, C, H, W)).astype(np.float32)
+    params = np.array([[3, 0, 0, 0], [0, 3, 5, 1], [4, 2, 1, 1], [1, 1, 4, 0]], dtype=np.int32)
+    want = np.zeros((B, C, Hc, Wc))
+    for b, (i, y0, x0, flip) in enumerate(params):
+        crop = pool[i, :, y0:y0 + Hc, x0:x0 + Wc].astype(np.float64)
+        if flip:
+            crop = crop[:, :, ::-1]
+        want[b] = (crop - 0.5) / 0.5
+    d_pool, d_par = be.dev(pool), be.dev_i32(params)
+    d_y = be.full((B, C, Hc, Wc), np.nan)
+    be.lib.crop_flip_normalize(be.ptr(d_pool), be.ptr(d_par), be.ptr(d_y), M, B, C, H, W, Hc, Wc, 1.0, be.stream)
+    _assert_close(be.np(d_y), want, atol=1e-6, what="crop_flip_normalize")

@@ -254,6 +254,10 @@ def test_pointwise(be):
     K.case_pointwise(be)
 
 
+def test_crop_flip_normalize(be):
+    K.case_crop_flip_normalize(be)
+
+
 def test_dropout(be):
     K.case_dropout(be)
 

@@ -12,6 +12,8 @@ st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 rows = []
 for line in open(sys.argv[1]):
+    if not line.startswith('{'):
+        continue
     d = json.loads(line)
     op, C0, C1, K, R, s, p, pm, H, W, N = (d[k] for k in ("op", "C0", "C1", "K", "R", "stride", "pad", "pad_mode", "H", "W", "N"))
     act = d.get("act", 1)
