@@ -606,11 +606,14 @@ __global__ __launch_bounds__(WS_NT) void igemm_ws_kernel(IgemmParams p) {
 // straight from global memory (L2-resident: the whole packed tensor is 2.4 MB) into registers, one stage ahead, in the
 // issue shadow of its MFMAs.  The loader waves then move HALF the bytes per stage (the B tile only): they are the critical path
 // of this kernel, and global->LDS DMA throughput per CU is what bounds them.
-template <int MT, bool VEC, int SPB = 1, int NL = 2, bool ADIR = false>   // NL = loader waves (4 only with VEC)
+// RING = LDS ring depth of the one-stage-per-barrier variant: the loaders run RING - 1 stages ahead of the MFMA waves (3: two
+// stage times = ~1.7 us for a global->LDS copy to land; 4 / 5 trade LDS (16 KiB per stage) for more latency tolerance).
+template <int MT, bool VEC, int SPB = 1, int NL = 2, bool ADIR = false, int RING = 3>   // NL = loader waves (4 only with VEC)
 __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p) {
     static_assert(NL == 2 || NL == 4, "loader split");
     static_assert(!ADIR || SPB == 1, "direct A operands: one-stage barrier variant only");
-    constexpr int W2_NBUF = SPB == 1 ? 3 : 4;
+    static_assert(RING >= 3 && RING <= 5, "ring depth");
+    constexpr int W2_NBUF = SPB == 1 ? RING : 4;
     constexpr int BM = 32 * MT, BN = 128, LDB = VEC ? BN : BN + 4;
     constexpr int A_FLOATS = ADIR ? 0 : BK * BM, B_FLOATS = BK * LDB;
     constexpr int A_PER_LOADER = ADIR ? 0 : BK * BM / 256 / NL;   // 1 KiB wave-instructions of A per loader per stage
@@ -761,22 +764,29 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             }
             return;
         }
-        WS2_ISSUE(0);
-        if (nk > 1) {
-            WS2_ISSUE(1);
-            WS2_WAIT_ONE_IN_FLIGHT();
-        } else {
-            wait_vmem();
+        // RING - 1 stages are issued before anything is consumed; the barrier of iteration ks needs stage ks + 1 landed, the
+        // (up to RING - 2) stages issued after it may stay in flight (counted s_waitcnt: loads retire in issue order)
+#define WS2_WAIT_IN_FLIGHT(n_)                                                                                        \
+        {                                                                                                            \
+            const int ns_ = (n_);                                                                                    \
+            if (ns_ <= 0) wait_vmem();                                                                               \
+            else if (ns_ == 1) WS2_WAIT_ONE_IN_FLIGHT();                                                             \
+            else if (ns_ == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * LOADS_PER_STAGE) & 15) | (((2 * LOADS_PER_STAGE) >> 4) << 14)); \
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | ((3 * LOADS_PER_STAGE) & 15) | (((3 * LOADS_PER_STAGE) >> 4) << 14)); \
         }
+        static_assert(3 * LOADS_PER_STAGE < 64, "vmcnt is a 6-bit counter");
+        int issued = 0;
+        for (; issued < W2_NBUF - 1 && issued < nk; ++issued) WS2_ISSUE(issued);
+        WS2_WAIT_IN_FLIGHT(issued - 1);
         __builtin_amdgcn_s_barrier();                 // stage 0 is in LDS
-        if (nk > 2) WS2_ISSUE(2);
+        if (issued < nk) { WS2_ISSUE(issued); ++issued; }
         for (int ks = 0; ks < nk; ++ks) {
-            // the barrier of iteration ks needs stage ks+1 landed; stage ks+2 (if any) may stay in flight
-            if (ks + 2 < nk) WS2_WAIT_ONE_IN_FLIGHT();
-            else wait_vmem();
+            // stages ks + 2 .. issued - 1 may stay in flight; stage ks + 1 must have landed
+            WS2_WAIT_IN_FLIGHT(issued - (ks + 2));
             __builtin_amdgcn_s_barrier();             // also: every MFMA wave has finished reading buffer ks % NBUF
-            if (ks + 3 < nk) WS2_ISSUE(ks + 3);
+            if (issued < nk) { WS2_ISSUE(issued); ++issued; }
         }
+#undef WS2_WAIT_IN_FLIGHT
 #undef WS2_ISSUE
 #undef WS2_ISSUE_NEXT
 #undef WS2_ENTER_TAP
@@ -1028,6 +1038,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     }
 }
 
+static int g_ring = 3;           // tuning switch (key 18): LDS ring depth of the wave-specialised 16-byte-load kernel (3, 4, 5)
 static int g_mt8 = 0;            // tuning switch (key 17): 256x128 tiles in the wave-specialised kernel: 0 off, 1 = 2 loader waves, 2 = 4 loader waves
 static int g_adir = 0;           // tuning switch (key 16): MFMA waves fetch their A fragments straight from global memory (1; measured 3 %
                                  // SLOWER: 370.8 vs 358.4 us on the 256->256 3x3 layer, gpurun_out/r2g) / through LDS (0, default)
@@ -1062,6 +1073,8 @@ template <int MT>
 void launch_ws2(const IgemmParams& p, bool vec, hipStream_t st) {
     dim3 grid(nemar_cdiv(p.P, 128), nemar_cdiv(p.M, 32 * MT), p.ring_p ? 1 : p.ksplit), block((MT + 2) * 64);
     if (vec && g_adir) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true, 1, 2, true>), grid, block, g_lds_pad, st, p);
+    else if (vec && g_ring == 4) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true, 1, 2, false, 4>), grid, block, g_lds_pad, st, p);
+    else if (vec && g_ring == 5) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true, 1, 2, false, 5>), grid, block, g_lds_pad, st, p);
     else if (vec) hipLaunchKernelGGL((igemm_ws2_kernel<MT, true>), grid, block, g_lds_pad, st, p);
     else hipLaunchKernelGGL((igemm_ws2_kernel<MT, false>), grid, block, g_lds_pad, st, p);
 }
@@ -1972,6 +1985,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
+    if (key == 18) { g_ring = (value == 4 || value == 5) ? value : 3; return NEMAR_OK; }
     if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }
     if (key == 10) { g_deep64 = value != 0; return NEMAR_OK; }

@@ -156,6 +156,24 @@ def test_conv_ws2_direct_weight_fragments_variant(be, mt):
         be.lib.tune(16, 0)
 
 
+@pytest.mark.parametrize("ring", [4, 5])
+def test_conv_ws2_deeper_lds_ring(be, ring):
+    """nemar_tune(18, .): loaders 3 / 4 stages ahead of the MFMA waves (counted waits over 2 / 3 stages in flight), incl.
+    reductions shorter than the ring."""
+    be.lib.tune(7, 4)
+    be.lib.tune(18, ring)
+    try:
+        K.case_conv_fwd(be, 2, 16, 0, 6, 8, 40, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_RELU)       # 9 stages
+        K.case_conv_fwd(be, 2, 16, 0, 3, 16, 20, 1, 1, 0, K.PAD_ZERO)                           # 1 stage
+        K.case_conv_fwd(be, 1, 32, 0, 4, 8, 130, 1, 1, 0, K.PAD_ZERO)                           # 2 stages
+        K.case_conv_fwd(be, 1, 48, 0, 4, 8, 130, 1, 1, 0, K.PAD_ZERO)                           # 3 stages
+        K.case_conv_fwd(be, 1, 16, 0, 4, 8, 70, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)         # 9 stages, M tail
+        K.case_conv_bwd_data(be, 2, 24, 0, 7, 8, 32, 3, 1, 1, K.PAD_REFLECT)
+    finally:
+        be.lib.tune(7, 0)
+        be.lib.tune(18, 3)
+
+
 @pytest.mark.parametrize("nl", [1, 2])
 def test_conv_ws2_256_channel_tiles(be, nl):
     """nemar_tune(17, .): 256 channels x 128 pixels per workgroup (8 MFMA waves + 2 / 4 loader waves)."""
