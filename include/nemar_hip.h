@@ -87,7 +87,8 @@ int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, 
  * w [K,C0+C1,R,S] (torch layout), bias [K] or NULL.  pad_mode: NEMAR_PAD_ZERO | NEMAR_PAD_REFLECT
  * (reflect == nn.ReflectionPad2d(pad) followed by an unpadded conv).  act is applied in the epilogue:
  * NEMAR_ACT_NONE | RELU | LRELU(slope) | TANH.  y [N,K,OH,OW], OH = (H + 2 pad - R) / stride + 1.
- * workspace: packed weights (nemar_conv2d_fwd_workspace bytes).  prepacked != 0: the workspace already holds this
+ * workspace: packed weights, then the slabs of a split reduction (tiny, deep layers; summed in a fixed order, so the forward
+ * pass stays bitwise reproducible) — nemar_conv2d_fwd_workspace bytes.  prepacked != 0: the workspace already holds this
  * weight tensor's packed image from an earlier call with the same (w values, shape, stride, pad): the pack launch is
  * skipped (the caller caches one workspace per weight tensor and invalidates it when the optimizer steps). */
 #define NEMAR_PAD_ZERO 0
@@ -96,7 +97,7 @@ int nemar_smoothness_bwd(const float* d, const float* img, int Ci, float alpha, 
 #define NEMAR_ACT_RELU 1
 #define NEMAR_ACT_LRELU 2
 #define NEMAR_ACT_TANH 3
-size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S);
+size_t nemar_conv2d_fwd_workspace(int N, int H, int W, int K, int C, int R, int S, int stride, int pad);
 int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
                      float* y, int N, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode,
                      int act, float slope, void* workspace, size_t ws_bytes, int prepacked, void* stream);

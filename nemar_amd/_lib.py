@@ -36,7 +36,7 @@ SIGNATURES = {
     "nemar_smoothness_workspace": (_sz, [_i, _i, _i]),
     "nemar_smoothness_fwd": (_i, [_vp, _vp, _i, _fl, _fl, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "nemar_smoothness_bwd": (_i, [_vp, _vp, _i, _fl, _vp, _fl, _vp, _i, _i, _i, _i, _vp]),
-    "nemar_conv2d_fwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "nemar_conv2d_fwd_workspace": (_sz, [_i] * 9),
     "nemar_conv2d_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _vp, _sz, _i, _vp]),
     "nemar_conv2d_bwd_data_workspace": (_sz, [_i] * 10),
     "nemar_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _fl, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.M) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[m];
+                    if (p.bias && blockIdx.z == 0) v += p.bias[m];       // split reductions: slab 0 carries the bias
                     v = apply_act(v, p.act, p.slope);
                     if (m < p.M0) {
                         if (d0) d0[((size_t)n * p.M0 + m) * oplane + sp] = v;
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (m < p.M) {
-                const float bv = p.bias ? p.bias[m] : 0.f;
+                const float bv = (p.bias && blockIdx.z == 0) ? p.bias[m] : 0.f;   // split reductions: slab 0 carries the bias
                 f32x4 v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = apply_act(acc[t][r] + bv, p.act, p.slope);
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             const int m = m0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (m < p.M) {
                 float v = acc[t][r];
-                if (p.bias) v += p.bias[m];
+                if (p.bias && blockIdx.z == 0) v += p.bias[m];
                 v = apply_act(v, p.act, p.slope);
                 if (m < p.M0) {
                     if (d0) d0[((size_t)n * p.M0 + m) * oplane + sp] = v;
@@ -1568,8 +1568,8 @@ int normalize_ksplit(int Kred, int ksplit) {
 //   [packed weights x stride^2 parity classes][padded-domain scratch (strided reflect)][flipped weights (C <= 4)]
 //   [compact border-ring gradient (stride-1 reflect)][ksplit slabs of the gradient (split reductions)]
 struct DgradLayout {
-    size_t pack_stride, padded_off, w2_off, ring_off, slab_off, aux_rows_off, aux_cols_off, total;
-    int ring_len, ksplit;
+    size_t pack_stride, padded_off, w2_off, ring_off, ring_slab_off, slab_off, aux_rows_off, aux_cols_off, total;
+    int ring_len, ksplit, ring_ksplit;
     bool ring, fold;
 };
 DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
@@ -1586,6 +1586,17 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     L.ring_off = o;
     L.ring_len = L.ring ? 2 * pad * (W + 2 * pad) + 2 * pad * H : 0;
     o += (size_t)N * C * L.ring_len;
+    // a ring tile is a few pixels deep in a full-length reduction, and a lone workgroup per CU walks it at memory latency:
+    // the reduction is split until ~1.5 workgroups per CU exist (each split = one slab, summed in order)
+    L.ring_ksplit = 1;
+    L.ring_slab_off = o;
+    if (L.ring) {
+        const int tiles = nemar_cdiv(N * L.ring_len, 64) * nemar_cdiv(C, 64), stages = nemar_cdiv(K * R * S, BK);
+        int ks = nemar_cdiv(384, tiles);
+        if (ks > nemar_cdiv(stages, 8)) ks = nemar_cdiv(stages, 8);
+        L.ring_ksplit = normalize_ksplit(K * R * S, ks < 1 ? 1 : ks);
+        if (L.ring_ksplit > 1) o += (size_t)L.ring_ksplit * N * C * L.ring_len;
+    }
     // split reductions (stride 1, single destination, no bias / activation — the operator re-checks those): few, deep
     // 128x128 tiles (D's 256->512 k4 layer: 128 tiles x 512 stages) get one workgroup per CU; tiny deep problems on the
     // generic kernels (the 2x2 .. 32x32-pixel layers of the registration net) ~256 workgroups of >= 4 stages
@@ -1614,12 +1625,27 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     return L;
 }
 
+// Workspace of nemar_conv2d_fwd (floats): [packed weights][slabs of a split reduction].  Tiny, deep layers (the 2x2 .. 32x32
+// maps of the registration net: a 2x2-pixel 128->128 3x3 layer is 72 serial stages in two workgroups) split their reduction
+// like the data gradients do; per-split slabs summed in order keep the forward pass bitwise reproducible.
+struct FwdLayout { size_t pack, slab_off, total; int ksplit; };
+FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
+    FwdLayout L;
+    L.pack = packed_floats(K, C * R * S);
+    L.ksplit = 1;
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    if (g_ksplit && OH > 0 && OW > 0 && K > 4) L.ksplit = normalize_ksplit(C * R * S, small_problem_split(K, N * OH * OW, C * R * S));
+    L.slab_off = (L.pack + 3) & ~(size_t)3;
+    L.total = L.slab_off + (L.ksplit > 1 ? (size_t)L.ksplit * N * K * OH * OW : 0);
+    return L;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
-NEMAR_API size_t nemar_conv2d_fwd_workspace(int K, int C, int R, int S) {
-    if (K <= 0 || C <= 0 || R <= 0 || S <= 0) return 0;
-    return sizeof(float) * packed_floats(K, C * R * S);
+NEMAR_API size_t nemar_conv2d_fwd_workspace(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0 || R <= 0 || S <= 0 || stride < 1) return 0;
+    return sizeof(float) * fwd_layout(N, H, W, K, C, R, S, stride, pad).total;
 }
 
 NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
@@ -1638,7 +1664,8 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     NEMAR_REQUIRE((long long)N * OH * OW < (1ll << 31) && (long long)C * H * W < (1ll << 31) &&
                       (long long)C * R * S < (1 << 20),
                   "conv2d_fwd: problem too large for 32-bit tile indexing");
-    const size_t need = nemar_conv2d_fwd_workspace(K, C, R, S);
+    const FwdLayout FL = fwd_layout(N, H, W, K, C, R, S, stride, pad);
+    const size_t need = sizeof(float) * FL.total;
     if (ws_bytes < need) {
         nemar_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
         return NEMAR_EWORKSPACE;
@@ -1667,7 +1694,13 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.N = N; p.P = N * OH * OW;
     p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope; p.pad = pad;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
-    launch_igemm(p, st);       // forward convolutions never split their reduction
+    if (FL.ksplit > 1 && act == ACT_NONE) {      // slab 0 carries the bias; an activation would have to follow the sum
+        p.ksplit = FL.ksplit;
+        p.part = (float*)workspace + FL.slab_off;
+        p.part_stride = (long long)N * K * OH * OW;
+    }
+    launch_igemm(p, st);
+    if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, y, p.part_stride, false, st);
     NEMAR_CHECK_LAUNCH("conv2d_fwd");
     return NEMAR_OK;
 }
@@ -1791,12 +1824,15 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 dgrad_taps(p.taps, R, S, 0, 1, 0, 0);
                 const int ring_len = L.ring_len;
                 p.ring_p = pad; p.ring_H = H; p.ring_W = W;
-                p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
+                p.ksplit = L.ring_ksplit;
+                p.part = L.ring_ksplit > 1 ? wsf + L.ring_slab_off : nullptr;
+                p.part_stride = (long long)N * Mc * ring_len;
                 p.OH = 1; p.OW = ring_len; p.P = N * ring_len;
                 p.fd_ohw = make_fastdiv(ring_len); p.fd_ow = make_fastdiv(ring_len);
                 float* ring_buf = wsf + L.ring_off;
                 p.dst0 = ring_buf; p.dst1 = nullptr; p.M0 = Mc;
                 launch_igemm(p, st);
+                if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, ring_buf, p.part_stride, false, st);
                 RingBand band;
                 band.nrows = band.ncols = 0;
                 for (int t = 0; t < H; ++t)

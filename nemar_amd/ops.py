@@ -156,8 +156,8 @@ class _Conv2d(Function):
         OH = (H + 2 * pad - R) // stride + 1
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
-        wsb = L.conv2d_fwd_workspace(K, C, R, S)
-        ws, hit = _packed(weight, ('fwd', stride, pad), wsb)
+        wsb = L.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
+        ws, hit = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
             L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
@@ -267,8 +267,8 @@ class _ConvTranspose2d(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            wsb = L.conv2d_fwd_workspace(Ci, Co, R, S)
-            ws, hit = _packed(ctx.weight, ('convT_bwd', stride, pad), wsb)
+            wsb = L.conv2d_fwd_workspace(N, Ho, Wo, Ci, Co, R, S, stride, pad)
+            ws, hit = _packed(ctx.weight, ('convT_bwd', stride, pad, N, Ho, Wo), wsb)
             L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
                          0.0, _p(ws), wsb, hit, st)
         if ctx.needs_input_grad[1]:

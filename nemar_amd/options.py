@@ -57,6 +57,14 @@ class BaseOptions:
         parser = self.initialize(parser)
         opt, _ = parser.parse_known_args(argv)
         parser = models.get_option_setter(opt.model)(parser, self.isTrain)
+        # dataset-specific flags (reference options/base_options.py:80-82); the modes of the reference itself ('unaligned',
+        # ...) are not part of this build and add none
+        opt, _ = parser.parse_known_args(argv)
+        try:
+            from . import data
+            parser = data.get_option_setter(opt.dataset_mode)(parser, self.isTrain)
+        except ModuleNotFoundError:
+            pass
         self.parser = parser
         return parser.parse_args(argv)
 

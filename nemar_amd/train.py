@@ -7,18 +7,13 @@ console + loss_log.txt line.  Out of scope by SURVEY.md §2: visdom / HTML image
 """
 import time
 
-from .data import create_dataset, get_option_setter
+from .data import create_dataset
 from .models import create_model
 from .options import TrainOptions
 from .util.visualizer import LossLogger
 
 
-class _Options(TrainOptions):
-    def gather_options(self, argv=None):
-        opt = super().gather_options(argv)
-        parser = get_option_setter(opt.dataset_mode)(self.parser, self.isTrain)      # dataset flags (reference base_options.py:80-82)
-        self.parser = parser
-        return parser.parse_args(argv)
+_Options = TrainOptions
 
 
 def main(argv=None):

@@ -137,7 +137,7 @@ def case_conv_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NO
     d_x1 = be.dev(x[:, C0:]) if C1 else None
     d_w, d_b = be.dev(w), (be.dev(b) if bias else None)
     d_y = be.full((N, K, OH, OW), np.nan)
-    ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(K, C, R, R))
+    ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, R, R, stride, pad))
     be.lib.conv2d_fwd(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_w), be.ptr(d_b), be.ptr(d_y), N, H, W, K, R, R,
                       stride, pad, pad_mode, act, 0.2, be.ptr(ws), wsb, 0, be.stream)
     _assert_close(be.np(d_y), want, atol=2e-5, rtol=2e-5, what="conv2d_fwd")

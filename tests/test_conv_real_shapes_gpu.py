@@ -93,7 +93,7 @@ def test_conv_real_shape(be, shape):
 
     # ---- forward ---------------------------------------------------------------------------------------------
     d_y = be.full((N, K, OH, OW), np.nan)
-    wsb = lib.conv2d_fwd_workspace(K, C, R, R)
+    wsb = lib.conv2d_fwd_workspace(N, H, W, K, C, R, R, stride, pad)
     ws = be.bytes_buf(wsb)
     lib.conv2d_fwd(P(d_x0), C0, P(d_x1), C1, P(d_w), P(d_b), P(d_y), N, H, W, K, R, R, stride, pad, pm, 0, 0.2, P(ws),
                    wsb, 0, be.stream)

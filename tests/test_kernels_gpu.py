@@ -206,6 +206,15 @@ def test_conv_ws2_vector_loads(be, mt):
         be.lib.tune(7, 0)
 
 
+def test_conv_fwd_split_reduction(be):
+    """Tiny, deep forward layers (the registration net's 2x2 .. 8x8 maps) split their reduction over grid.z: per-split slabs
+    behind the packed weights, summed in split order (bias in slab 0); layers with a fused activation do not split."""
+    K.case_conv_fwd(be, 1, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE)    # STN bottleneck layer, 72 stages
+    K.case_conv_fwd(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE, bias=False)
+    K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)        # decoder conv with activation
+    K.case_conv_bwd_data(be, 2, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT)                  # main pass split + ring split
+
+
 def test_conv_bwd_data_split_reduction(be):
     """Few, deep tiles (256 stages): the wave-specialised data gradient splits the reduction over grid.z; every split stores
     its partial gradient to its own slab and the slabs are summed in split order."""

@@ -55,7 +55,7 @@ def main():
         gx0 = torch.empty(N, C0, H, H, device=dev) if not C1 else torch.empty(N, C0, H, H, device=dev)
         gx1 = torch.empty(N, C1, H, H, device=dev) if C1 else None
         gw = torch.zeros_like(w)
-        wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm))
+        wsb = max(lib.conv2d_fwd_workspace(N, H, H, K, C, R, R, s, p), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm))
         ws = torch.empty(wsb // 4 + 16, device=dev)
         ws2 = torch.empty(wsb // 4 + 16, device=dev)
         # weights are packed once per optimizer step in the real path: time the steady state (prepacked = 1)

@@ -24,7 +24,7 @@ for line in open(sys.argv[1]):
     y = torch.empty(N, K, OH, OW, device=dev); gy = torch.randn(N, K, OH, OW, device=dev)
     gx0 = torch.empty(N, C0, H, W, device=dev); gx1 = torch.empty(N, C1, H, W, device=dev) if C1 else None
     gw = torch.zeros_like(w)
-    wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, W, K, R, R, s, p, pm))
+    wsb = max(lib.conv2d_fwd_workspace(N, H, W, K, C, R, R, s, p), lib.conv2d_bwd_data_workspace(N, C, H, W, K, R, R, s, p, pm))
     ws = torch.empty(wsb // 4 + 16, device=dev)
     if op == "fwd":
         f = lambda pre: lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, W, K, R, R, s, p, pm, act, 0.2, P(ws), wsb, pre, st())

@@ -13,7 +13,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 N, C, K, H, R, s, p, pm = 8, 256, 256, 64, 3, 1, 1, 1
 x = torch.randn(N, C, H, H, device=dev); w = torch.randn(K, C, R, R, device=dev) * 0.05; b = torch.randn(K, device=dev)
 y = torch.empty(N, K, H, H, device=dev); gy = torch.randn(N, K, H, H, device=dev); gx = torch.empty_like(x); gw = torch.zeros_like(w)
-wsb = max(lib.conv2d_fwd_workspace(K, C, R, R), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm)); ws = torch.empty(wsb // 4 + 16, device=dev)
+wsb = max(lib.conv2d_fwd_workspace(N, H, H, K, C, R, R, s, p), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm)); ws = torch.empty(wsb // 4 + 16, device=dev)
 wwb = lib.conv2d_bwd_weight_workspace(N, C, H, H, K, H, H, R, R, s, p); ws3 = torch.empty(wwb // 4 + 16, device=dev)
 for _ in range(iters):
     if which == 'fwd':

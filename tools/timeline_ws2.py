@@ -13,7 +13,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 N, C, K, H, R, s, p, pm = 8, 256, 256, 64, 3, 1, 1, 1
 x = torch.randn(N, C, H, H, device=dev); w = torch.randn(K, C, R, R, device=dev) * 0.05; b = torch.randn(K, device=dev)
 y = torch.empty(N, K, H, H, device=dev)
-wsb = lib.conv2d_fwd_workspace(K, C, R, R); ws = torch.empty(wsb // 4 + 16, device=dev)
+wsb = lib.conv2d_fwd_workspace(N, H, H, K, C, R, R, 1, 1); ws = torch.empty(wsb // 4 + 16, device=dev)
 tl = torch.zeros(4 * 24, dtype=torch.int64, device=dev)
 call = lambda pre: lib.conv2d_fwd(P(x), C, None, 0, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, 1, 0.2, P(ws), wsb, pre, st())
 call(0)
