@@ -700,7 +700,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
             inb = pvalid;                                                                                            \
             if (p.border == BORDER_REFLECT) y = reflect(y, p.Hs);                                                    \
             else inb = inb && (unsigned)y < (unsigned)p.Hs;                                                          \
-            if (VEC) x = min(max(x, 0), p.Ws - 4);                                                                   \
+            if (VEC) x = (p.dbg & 2048) ? (min(max(x, 0), p.Ws - 4) & ~3) : min(max(x, 0), p.Ws - 4);  /* 2048: aligned-B ablation */ \
             else if (p.border == BORDER_REFLECT) x = reflect(x, p.Ws);                                               \
             else inb = inb && (unsigned)x < (unsigned)p.Ws;                                                          \
             sp_off = inb ? y * p.Ws + x : 0;                                                                         \
@@ -725,11 +725,15 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         if (ch0 >= p.C0 && p.C1) lp = inb ? s1n + sp_off + (size_t)(ch0 - p.C0) * HW : p.zero;
 #define WS2_ISSUE_NEXT()                                                                                             \
         {                                                                                                            \
-            _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q) {                                               \
-                glds_b128(wsrc[q], As0 + a_buf * A_FLOATS + a_lds[q]);                                               \
-                wsrc[q] += (size_t)BK * p.Mpad;                                                                      \
+            /* ablations (nemar_tune key 2): 1024 = no A loads, 512 = no B loads (results are garbage; timing only) */       \
+            if (!(p.dbg & 1024)) {                                                                                   \
+                _Pragma("unroll") for (int q = 0; q < A_PER_LOADER; ++q) {                                           \
+                    glds_b128(wsrc[q], As0 + a_buf * A_FLOATS + a_lds[q]);                                           \
+                    wsrc[q] += (size_t)BK * p.Mpad;                                                                  \
+                }                                                                                                    \
             }                                                                                                        \
-            if (VEC) {                                                                                               \
+            if (p.dbg & 512) {                                                                                       \
+            } else if (VEC) {                                                                                        \
                 _Pragma("unroll") for (int i = 0; i < B_PER_LOADER; ++i)                                             \
                     glds_b128(lp + (size_t)(2 * i) * lstride, Bs0 + a_buf * B_FLOATS + (ldr * B_PER_LOADER + i) * 256); \
             } else {                                                                                                 \
@@ -768,7 +772,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         // (up to RING - 2) stages issued after it may stay in flight (counted s_waitcnt: loads retire in issue order)
 #define WS2_WAIT_IN_FLIGHT(n_)                                                                                        \
         {                                                                                                            \
-            const int ns_ = (n_);                                                                                    \
+            const int ns_ = (p.dbg & (512 | 1024)) ? 0 : (n_);     /* ablated loads: the counts below would be wrong */ \
             if (ns_ <= 0) wait_vmem();                                                                               \
             else if (ns_ == 1) WS2_WAIT_ONE_IN_FLIGHT();                                                             \
             else if (ns_ == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * LOADS_PER_STAGE) & 15) | (((2 * LOADS_PER_STAGE) >> 4) << 14)); \
@@ -780,12 +784,31 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         WS2_WAIT_IN_FLIGHT(issued - 1);
         __builtin_amdgcn_s_barrier();                 // stage 0 is in LDS
         if (issued < nk) { WS2_ISSUE(issued); ++issued; }
+#ifdef NEMAR_TIMELINE
+        long long lts[4][4];
+        const bool lprobe = p.tl != nullptr && bx == 0 && by_ == 0;
+#define WS2_LSTAMP(i_) if (lprobe && ks >= 40 && ks < 44) lts[ks - 40][i_] = clock64();
+#else
+#define WS2_LSTAMP(i_)
+#endif
         for (int ks = 0; ks < nk; ++ks) {
             // stages ks + 2 .. issued - 1 may stay in flight; stage ks + 1 must have landed
+            WS2_LSTAMP(0)
             WS2_WAIT_IN_FLIGHT(issued - (ks + 2));
-            __builtin_amdgcn_s_barrier();             // also: every MFMA wave has finished reading buffer ks % NBUF
+            WS2_LSTAMP(1)
+            if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();   // also: every MFMA wave has finished reading buffer ks % NBUF
+            WS2_LSTAMP(2)
             if (issued < nk) { WS2_ISSUE(issued); ++issued; }
+            WS2_LSTAMP(3)
         }
+#ifdef NEMAR_TIMELINE
+        if (lprobe && lane == 0 && nk >= 44) {
+            long long* o = p.tl + (MT + ldr) * 24;          // behind the MFMA waves' 4 x 6 stamps per stage
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) o[i * 6 + j] = lts[i][j];
+        }
+#endif
+#undef WS2_LSTAMP
 #undef WS2_WAIT_IN_FLIGHT
 #undef WS2_ISSUE
 #undef WS2_ISSUE_NEXT
@@ -825,7 +848,8 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
     f32x4 a0, a1, b0[4], b1[4];
 
 #define WS2_READ(buf_, kg_, A_, B_)                                                                        \
-    {                                                                                                          \
+    {   /* (an ablation switch around these reads makes hipcc count the LDS waits of the MFMA blocks conservatively: measured \
+           once — MFMA-only skeleton 302 us vs 370 us for the full kernel, gpurun_out/abl2 — and removed again) */  \
         const float* sb = Bs0 + (buf_) * B_FLOATS + (kg_) * (8 * LDB) + b_off;                                 \
         if (!ADIR) A_ = *reinterpret_cast<const f32x4*>(As0 + (buf_) * A_FLOATS + (kg_) * (2 * BM * 4) + a_off); \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) B_[s] = *reinterpret_cast<const f32x4*>(sb + 2 * s * LDB); \
@@ -950,7 +974,7 @@ __global__ __launch_bounds__((MT + NL) * 64) void igemm_ws2_kernel(IgemmParams p
         WS2_STAMP(2)
         __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): this wave is done reading buffer `buf`
         WS2_STAMP(3)
-        __builtin_amdgcn_s_barrier();                 // stage ks+1 has landed; buffer `buf` goes back to the loaders
+        if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();   // stage ks+1 has landed; buffer `buf` goes back to the loaders (ablation 4: none)
         WS2_STAMP(4)
         buf = buf + 1 == W2_NBUF ? 0 : buf + 1;
         if (ks + 1 < nk) {
