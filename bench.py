@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PMC_FILE = "profiles/r1_pmc_traffic.json"
+PMC_FILE = "profiles/r2_pmc_traffic.json"
 
 
 def build_opt(batch, size, extra=()):

@@ -29,6 +29,8 @@ def timeit(fn, iters=50, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--size", type=int, default=0, help="only the shape with this image size (PMC passes)")
+    ap.add_argument("--sigma0", action="store_true", help="only the sigma = 0 regime (what the training step starts in)")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -36,6 +38,8 @@ def main():
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     out = []
     for (N, C, H, W) in ((8, 3, 256, 256), (16, 3, 512, 512), (8, 3, 1024, 1024)):
+        if a.size and H != a.size:
+            continue
         torch.manual_seed(0)
         img = torch.rand(N, C, H, W, device=dev) * 2 - 1
         go = torch.randn(N, C, H, W, device=dev)
@@ -43,7 +47,7 @@ def main():
         gin = torch.empty_like(img)
         wsb = lib.grid_sample_bwd_workspace(N, C, H, W)
         gws = torch.zeros(wsb // 4 + 16, device=dev)
-        for sigma in (0.0, 2.0 / W, 0.1, 'smooth3px'):
+        for sigma in ((0.0,) if a.sigma0 else (0.0, 2.0 / W, 0.1, 'smooth3px')):
             if sigma == 'smooth3px':      # low-frequency field of ~3 pixels amplitude (what a trained registration net emits)
                 off = torch.nn.functional.interpolate(torch.randn(N, 2, H // 32, W // 32, device=dev), size=(H, W), mode='bilinear',
                                                       align_corners=False) * (6.0 / W)
