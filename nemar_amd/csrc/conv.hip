@@ -2045,6 +2045,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
+    if (key == 19) { extern int g_narrow_fwd4; g_narrow_fwd4 = value != 0; return NEMAR_OK; }
     if (key == 18) { g_ring = (value == 4 || value == 5) ? value : 3; return NEMAR_OK; }
     if (key == 12) { g_ksplit = value != 0; return NEMAR_OK; }
     if (key == 11) { g_nl4_scalar = value != 0; return NEMAR_OK; }

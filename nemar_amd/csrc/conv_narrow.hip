@@ -107,6 +107,88 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(NarrowParams p) {
     }
 }
 
+// ---- register-tiled forward for wide images (OW >= 64): 4 horizontally adjacent output pixels per lane ------------------------
+// narrow_fwd_kernel reads one LDS value per M multiply-adds (LDS-issue bound: 26 TF-equivalent on the 7x7 RGB head).  Here a
+// lane owns pixels 4*lx .. 4*lx+3 of one row: per (channel, filter row) it reads the 4 + R - 1 source values of that row ONCE
+// (16-byte LDS reads, pitch padded to 16 bytes) and spends R * M * 4 multiply-adds on them with scalar-loaded weights — 84
+// FMAs per 3 LDS reads for the 64->3 7x7 layer.  Workgroup = 128 x 8 output pixels, 4 channels of halo tile per round.
+constexpr int T2W = 128, T2H = 8, CH2 = 4, PX2 = 4;
+template <int M, int R>
+__global__ __launch_bounds__(256) void narrow_fwd4_kernel(NarrowParams p) {
+    constexpr int LH = T2H + R - 1, LWP = (T2W + R - 1 + 3) / 4 * 4;       // LDS row pitch: multiple of 4 floats
+    constexpr int NV = (PX2 + R - 1 + 3) / 4;                              // 16-byte reads per (channel, filter row)
+    __shared__ __attribute__((aligned(16))) float tile[CH2 * LH * LWP + 8];
+    const int lx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.z / p.csplit, cs = blockIdx.z - n * p.csplit;
+    const int cper = ((p.C + p.csplit - 1) / p.csplit + CH - 1) / CH * CH;
+    const int cbeg = cs * cper, cend = min(p.C, cbeg + cper);
+    const int oy0 = blockIdx.y * T2H, ox0 = blockIdx.x * T2W;
+    const int HW = p.H * p.W;
+    const float* xn = p.x + (size_t)n * p.C * HW;
+    float acc[M][PX2];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int j = 0; j < PX2; ++j) acc[m][j] = (p.bias && cs == 0) ? p.bias[m] : 0.f;
+    const int CRS = p.C * R * R;
+    for (int c0 = cbeg; c0 < cend; c0 += CH2) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < CH2 * LH * LWP; idx += 256) {
+            const int ch = idx / (LH * LWP);
+            const int rem = idx - ch * (LH * LWP);
+            const int ly = rem / LWP, lxx = rem - ly * LWP;
+            int iy = oy0 - p.pad + ly, ix = ox0 - p.pad + lxx;
+            float v = 0.f;
+            if (c0 + ch < cend && lxx < T2W + R - 1) {
+                if (p.border == BORDER_REFLECT) {
+                    iy = min(max(reflect_idx(iy, p.H), 0), p.H - 1);
+                    ix = min(max(reflect_idx(ix, p.W), 0), p.W - 1);
+                    v = xn[(size_t)(c0 + ch) * HW + iy * p.W + ix];
+                } else if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                    v = xn[(size_t)(c0 + ch) * HW + iy * p.W + ix];
+                }
+            }
+            tile[idx] = v;
+        }
+        __syncthreads();
+        const int nch = min(CH2, cend - c0);
+        for (int ch = 0; ch < nch; ++ch) {
+            const float* wc = p.w + (size_t)(c0 + ch) * R * R;              // wave-uniform => scalar loads
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float v[NV * 4];
+                const float4* row = reinterpret_cast<const float4*>(tile + (ch * LH + ty + r) * LWP + PX2 * lx);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const float4 t = row[q];
+                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                }
+#pragma unroll
+                for (int s = 0; s < R; ++s)
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const float w = wc[(size_t)m * CRS + r * R + s];
+#pragma unroll
+                        for (int j = 0; j < PX2; ++j) acc[m][j] += w * v[j + s];
+                    }
+            }
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + PX2 * lx;
+    if (oy < p.OH) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int j = 0; j < PX2; ++j) {
+                if (ox + j < p.OW) {
+                    const size_t o = (((size_t)n * M + m) * p.OH + oy) * p.OW + ox + j;
+                    if (p.csplit > 1) p.part[(size_t)cs * ((size_t)p.N * M * p.OH * p.OW) + o] = acc[m][j];
+                    else p.y[o] = act_apply(acc[m][j], p.act, p.slope);
+                }
+            }
+    }
+}
+
 // gw[k][c][r][s] += sum_pixels gy[k][p] * x[c][p + (r,s) - pad].  blockIdx.y = channel chunk; blockIdx.x strides over
 // output tiles, accumulating in registers; each thread owns up to PAIRS (channel, tap) columns x K rows.
 template <int K, int R>
@@ -173,6 +255,97 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowParams p) {
     }
 }
 
+// ---- register-tiled weight gradient: a thread owns one (channel, filter row) and its R taps x K output channels --------------
+// narrow_wgrad_kernel spends one LDS read per K multiply-adds (15-18 TF-equivalent on the 64->3 7x7 head).  Here thread (ch, r)
+// keeps R * K accumulators and walks the 32 x 8 tile four pixels at a time: per group it reads the 4 + R - 1 source values of
+// row py + r once (16-byte reads) and the K x 4 gy values (same address in every lane: LDS broadcast), and spends R * K * 4
+// multiply-adds on them.  32 channels x R rows = 224 of 256 threads busy for R = 7.
+constexpr int WCH = 32;
+template <int K, int R>
+__global__ __launch_bounds__(256) void narrow_wgrad4_kernel(NarrowParams p) {
+    constexpr int LH = TH + R - 1, LWP = (TW + R - 1 + 3) / 4 * 4;
+    constexpr int NV = (4 + R - 1 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[WCH * LH * LWP];
+    __shared__ __attribute__((aligned(16))) float gyt[K * TH * TW];
+    const int c0 = blockIdx.y * WCH;
+    const int ch = threadIdx.x / R, r = threadIdx.x - ch * R;
+    const bool active = ch < WCH && c0 + ch < p.C;
+    float acc[R][K];
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[s][k] = 0.f;
+    const int HW = p.H * p.W;
+    for (int tl = blockIdx.x; tl < p.tiles_total; tl += gridDim.x) {
+        const int n = tl / (p.tiles_x * p.tiles_y);
+        const int rem = tl - n * (p.tiles_x * p.tiles_y);
+        const int tyi = rem / p.tiles_x, txi = rem - tyi * p.tiles_x;
+        const int oy0 = tyi * TH, ox0 = txi * TW;
+        const float* xn = p.x + (size_t)n * p.C * HW;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < WCH * LH * LWP; idx += 256) {
+            const int cc = idx / (LH * LWP);
+            const int rm = idx - cc * (LH * LWP);
+            const int ly = rm / LWP, lxx = rm - ly * LWP;
+            int iy = oy0 - p.pad + ly, ix = ox0 - p.pad + lxx;
+            float v = 0.f;
+            if (c0 + cc < p.C && lxx < TW + R - 1) {
+                if (p.border == BORDER_REFLECT) {
+                    iy = min(max(reflect_idx(iy, p.H), 0), p.H - 1);
+                    ix = min(max(reflect_idx(ix, p.W), 0), p.W - 1);
+                    v = xn[(size_t)(c0 + cc) * HW + iy * p.W + ix];
+                } else if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                    v = xn[(size_t)(c0 + cc) * HW + iy * p.W + ix];
+                }
+            }
+            tile[idx] = v;
+        }
+        for (int idx = threadIdx.x; idx < K * TH * TW; idx += 256) {
+            const int k = idx / (TH * TW), r2 = idx - k * (TH * TW);
+            const int oy = oy0 + r2 / TW, ox = ox0 + (r2 - (r2 / TW) * TW);
+            gyt[idx] = (oy < p.OH && ox < p.OW) ? p.gy[(((size_t)n * K + k) * p.OH + oy) * p.OW + ox] : 0.f;
+        }
+        __syncthreads();
+        if (active) {
+            for (int py = 0; py < TH; ++py) {
+                const float4* row = reinterpret_cast<const float4*>(tile + (ch * LH + py + r) * LWP);
+#pragma unroll 2
+                for (int g4 = 0; g4 < TW / 4; ++g4) {
+                    float v[NV * 4];
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) {
+                        const float4 t = row[g4 + q];
+                        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                    }
+                    float g[K][4];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float4 t = *reinterpret_cast<const float4*>(gyt + k * (TH * TW) + py * TW + 4 * g4);   // broadcast
+                        g[k][0] = t.x; g[k][1] = t.y; g[k][2] = t.z; g[k][3] = t.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < R; ++s)
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[s][k] += g[k][j] * v[j + s];
+                }
+            }
+        }
+    }
+    if (active) {
+        const int CRS = p.C * R * R;
+#pragma unroll
+        for (int s = 0; s < R; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const size_t o = (size_t)k * CRS + (size_t)(c0 + ch) * R * R + r * R + s;
+                if (p.part) p.part[(size_t)blockIdx.x * ((size_t)K * CRS) + o] = acc[s][k];
+                else atomicAdd(p.gw + o, acc[s][k]);
+            }
+    }
+}
+
 template <int R>
 void launch_fwd_r(const NarrowParams& p, int M, dim3 grid, hipStream_t st) {
     switch (M) {
@@ -180,6 +353,24 @@ void launch_fwd_r(const NarrowParams& p, int M, dim3 grid, hipStream_t st) {
         case 2: hipLaunchKernelGGL((narrow_fwd_kernel<2, R>), grid, dim3(256), 0, st, p); break;
         case 3: hipLaunchKernelGGL((narrow_fwd_kernel<3, R>), grid, dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL((narrow_fwd_kernel<4, R>), grid, dim3(256), 0, st, p); break;
+    }
+}
+template <int R>
+void launch_wgrad4_r(const NarrowParams& p, int K, dim3 grid, hipStream_t st) {
+    switch (K) {
+        case 1: hipLaunchKernelGGL((narrow_wgrad4_kernel<1, R>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((narrow_wgrad4_kernel<2, R>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((narrow_wgrad4_kernel<3, R>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((narrow_wgrad4_kernel<4, R>), grid, dim3(256), 0, st, p); break;
+    }
+}
+template <int R>
+void launch_fwd4_r(const NarrowParams& p, int M, dim3 grid, hipStream_t st) {
+    switch (M) {
+        case 1: hipLaunchKernelGGL((narrow_fwd4_kernel<1, R>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((narrow_fwd4_kernel<2, R>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((narrow_fwd4_kernel<3, R>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((narrow_fwd4_kernel<4, R>), grid, dim3(256), 0, st, p); break;
     }
 }
 template <int R>
@@ -202,6 +393,7 @@ bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int O
 
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st);
+int g_narrow_fwd4 = 1;      // nemar_tune(19): register-tiled narrow forward for wide images (1, default) / one pixel per lane (0)
 
 // channel ranges of the forward split mode: few output tiles and many channels (no activation) — so the launch fills the chip
 static int narrow_fwd_csplit(int N, int C, int OH, int OW, int act) {
@@ -232,18 +424,27 @@ int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y
         const int cper = nemar_cdiv(nemar_cdiv(C, p.csplit), CH) * CH;
         p.csplit = nemar_cdiv(C, cper);
     }
-    dim3 grid(p.tiles_x, p.tiles_y, N * p.csplit);
-    if (R == 3) launch_fwd_r<3>(p, K, grid, st);
-    else if (R == 4) launch_fwd_r<4>(p, K, grid, st);
-    else launch_fwd_r<7>(p, K, grid, st);
+    if (p.OW >= 64 && g_narrow_fwd4) {           // wide images: register-tiled kernel, 128 x 8 output tiles
+        dim3 grid4(nemar_cdiv(p.OW, T2W), nemar_cdiv(p.OH, T2H), N * p.csplit);
+        if (R == 3) launch_fwd4_r<3>(p, K, grid4, st);
+        else if (R == 4) launch_fwd4_r<4>(p, K, grid4, st);
+        else launch_fwd4_r<7>(p, K, grid4, st);
+    } else {
+        dim3 grid(p.tiles_x, p.tiles_y, N * p.csplit);
+        if (R == 3) launch_fwd_r<3>(p, K, grid, st);
+        else if (R == 4) launch_fwd_r<4>(p, K, grid, st);
+        else launch_fwd_r<7>(p, K, grid, st);
+    }
     if (p.csplit > 1) nemar_sum_partials(part, (long long)out_floats, p.csplit, y, (long long)out_floats, false, st);
     return 0;
 }
 
 // workgroups along x of the narrow weight gradient = number of slabs of its fixed-order reduction
+static bool narrow_wgrad_tiled(int C, int OW) { return g_narrow_fwd4 && OW >= 32 && C >= 16; }
+
 int nemar_narrow_wgrad_splits(int N, int C, int OH, int OW) {
     const int tiles_total = nemar_cdiv(OW, TW) * nemar_cdiv(OH, TH) * N;
-    const int chunks = nemar_cdiv(C, CH);
+    const int chunks = nemar_cdiv(C, narrow_wgrad_tiled(C, OW) ? WCH : CH);
     int gx = nemar_cdiv(1024, chunks);           // ~4 workgroups per CU in total
     if (gx > tiles_total) gx = tiles_total;
     return gx < 1 ? 1 : gx;
@@ -256,10 +457,15 @@ int nemar_narrow_wgrad(const float* x, const float* gy, float* gw, int N, int C,
     p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - R + 1; p.OW = W + 2 * pad - R + 1;
     p.pad = pad; p.border = border; p.act = 0; p.slope = 0.f; p.csplit = 1;
     p.tiles_x = nemar_cdiv(p.OW, TW); p.tiles_y = nemar_cdiv(p.OH, TH); p.tiles_total = p.tiles_x * p.tiles_y * N;
-    const int chunks = nemar_cdiv(C, CH);
+    const bool tiled = narrow_wgrad_tiled(C, p.OW);
+    const int chunks = nemar_cdiv(C, tiled ? WCH : CH);
     const int gx = nemar_narrow_wgrad_splits(N, C, p.OH, p.OW);
     dim3 grid(gx, chunks);
-    if (R == 3) launch_wgrad_r<3>(p, K, grid, st);
+    if (tiled) {
+        if (R == 3) launch_wgrad4_r<3>(p, K, grid, st);
+        else if (R == 4) launch_wgrad4_r<4>(p, K, grid, st);
+        else launch_wgrad4_r<7>(p, K, grid, st);
+    } else if (R == 3) launch_wgrad_r<3>(p, K, grid, st);
     else if (R == 4) launch_wgrad_r<4>(p, K, grid, st);
     else launch_wgrad_r<7>(p, K, grid, st);
     if (part) {

@@ -254,6 +254,33 @@ def test_conv_bwd_data_narrow_inputs(be):
     K.case_conv_bwd_data(be, 1, 1, 0, 8, 8, 33, 3, 1, 0, K.PAD_ZERO)        # no padding: gradient padding R-1
 
 
+def test_conv_narrow_register_tiled_forward(be):
+    """Wide images (OW >= 64) take the 4-pixels-per-lane narrow forward: tile tails in x and y, every filter size, reflect and
+    zero borders, the channel-split mode, and the data gradient of <= 4-input-channel layers that runs on it."""
+    K.case_conv_fwd(be, 1, 18, 0, 9, 70, 3, 7, 1, 3, K.PAD_REFLECT, act=K.O.ACT_TANH)       # T head shape, 5 channel rounds
+    K.case_conv_fwd(be, 2, 9, 0, 10, 130, 2, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)          # STN offset head, 2 tiles in x
+    K.case_conv_fwd(be, 1, 40, 0, 6, 66, 1, 4, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)           # k4: output one narrower; split mode
+    K.case_conv_fwd(be, 1, 5, 0, 5, 64, 4, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_LRELU)
+    K.case_conv_bwd_data(be, 1, 3, 0, 9, 70, 16, 7, 1, 3, K.PAD_REFLECT)                     # T stem data gradient
+    be.lib.tune(19, 0)
+    try:
+        K.case_conv_fwd(be, 1, 18, 0, 9, 70, 3, 7, 1, 3, K.PAD_REFLECT, act=K.O.ACT_TANH)   # the one-pixel-per-lane kernel
+    finally:
+        be.lib.tune(19, 1)
+
+
+def test_conv_narrow_register_tiled_weight_gradient(be):
+    """<= 4-output-channel weight gradients on images at least 32 wide: thread = (channel, filter row), 4 pixels per step."""
+    K.case_conv_bwd_weight(be, 1, 18, 0, 9, 40, 3, 7, 1, 3, K.PAD_REFLECT)       # T head shape: ragged channel chunk, 2 tiles in x/y
+    K.case_conv_bwd_weight(be, 2, 40, 0, 6, 36, 1, 4, 1, 1, K.PAD_ZERO)          # D logits shape, 2 channel chunks
+    K.case_conv_bwd_weight(be, 1, 33, 0, 10, 34, 2, 3, 1, 1, K.PAD_ZERO)         # STN offset head
+    be.lib.tune(19, 0)
+    try:
+        K.case_conv_bwd_weight(be, 1, 18, 0, 9, 40, 3, 7, 1, 3, K.PAD_REFLECT)   # first-generation kernel, same shape
+    finally:
+        be.lib.tune(19, 1)
+
+
 def test_conv_narrow_channel_split(be):
     """Narrow forward with few output tiles and no activation: channel ranges meet in y through atomics."""
     K.case_conv_fwd(be, 2, 40, 0, 9, 10, 1, 4, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE)              # D logit conv, 3 ranges
