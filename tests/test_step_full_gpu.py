@@ -18,7 +18,7 @@ statistically equal to the reference's own fp32 gaps — R net median 6e-4 vs 1.
     i.e. pure rounding noise with a random sign) are not compared.
 The 1024x1024 config has no fp64 run (one fp64 step of the reference needs > 60 GB: it was tried, tests/golden/make_golden.py
 died in a 26 GB allocation), so there the build is compared with the reference's FP32 run — both sides carry rounding error —
-with the gap per quantity class taken from the 512x512 config's measured relative gaps (90th percentile of the class), doubled
+with the gap per quantity class taken from the 512x512 config's measured relative gaps (90th percentile of the class), tripled
 for the gradient classes: the registration net of that config is two levels deeper and sees 4x the pixels."""
 import os
 
@@ -134,7 +134,7 @@ def compare(name, rec, report=None):
         else:
             gap = class_gap.get(cls, 0.0) * max(scale, 1.0 if cls in ('loss', 'crop0', 'cropc', 'mean', 'proj') else 0.0)
             if cls.startswith('grad'):     # a projection / max of a tiny tensor moves as much as its norm does
-                gap = 2.0 * scale * max(class_gap.get(c, 0.0) for c in ('gradnorm', 'gradproj', 'gradmax'))
+                gap = 3.0 * scale * max(class_gap.get(c, 0.0) for c in ('gradnorm', 'gradproj', 'gradmax'))
         tol = rel * scale + ab + 4.0 * gap
         err = float(np.abs(got - want).max())
         rows.append((q, err, tol, err <= tol))
