@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void narrow_fwd4_kernel(NarrowParams p) {
                     for (int m = 0; m < M; ++m) {
                         const float w = wc[(size_t)m * CRS + r * R + s];
 #pragma unroll
-                        for (int j = 0; j < PX2; ++j) acc[m][j] += w * v[j + s];
+                        for (int j = 0; j < PX2; ++j) acc[m][j] = fmaf(w, v[j + s], acc[m][j]);   // fused: half the VALU instructions
                     }
             }
         }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void narrow_wgrad4_kernel(NarrowParams p) {
 #pragma unroll
                         for (int k = 0; k < K; ++k)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[s][k] += g[k][j] * v[j + s];
+                            for (int j = 0; j < 4; ++j) acc[s][k] = fmaf(g[k][j], v[j + s], acc[s][k]);
                 }
             }
         }
