@@ -107,6 +107,22 @@ class Library:
         if SIGNATURES[full][0] is not _i or full == "nemar_version":
             return fn
 
+        if os.environ.get("NEMAR_DEBUG_SYNC"):
+            # debugging aid: name + integer arguments of every call on stderr, device synchronised after each one, so that a
+            # GPU memory fault is attributed to the launch that caused it
+            def checked(*a):
+                import sys
+                sys.stderr.write("[nemar] %s %s\n" % (full, [x for x in a if isinstance(x, (int, float))]))
+                sys.stderr.flush()
+                rc = fn(*a)
+                torch.cuda.synchronize()
+                if rc != 0:
+                    raise NemarHipError("%s failed (%d): %s" % (full, rc, self.last_error()))
+                return rc
+            checked.__name__ = full
+            self.__dict__[name] = checked
+            return checked
+
         def checked(*a):
             rc = fn(*a)
             if rc != 0:

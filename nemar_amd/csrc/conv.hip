@@ -1152,6 +1152,7 @@ void launch_igemm(const IgemmParams& p, hipStream_t st) {
     bool vec = false;
     if (route_ws2(p, &vec)) {
         int mt = g_ws2_mt ? g_ws2_mt : 4;
+        if (32 * mt > p.Mpad) mt = p.Mpad / 32;       // a forced tile must not read past the packed rows (M <= 32 packs 32 rows)
         IgemmParams q = p;
         q.xcd = (g_xcd_map && nemar_cdiv(p.P, 128) % 8 == 0) ? 1 : 0;
         const IgemmParams& p = q;
