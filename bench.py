@@ -154,8 +154,10 @@ def main():
     for _ in range(a.warmup):
         step()
 
+    multi = dist.is_distributed()        # world > 1 (or the one-rank RCCL smoke configuration, NEMAR_DIST_SINGLE=1)
+
     def barrier():
-        if world > 1:
+        if multi:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +174,7 @@ def main():
         step()
     torch.cuda.synchronize()
     timer.enabled = False
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -193,6 +195,9 @@ def main():
                    "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"},
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
     }
+    if os.environ.get("NEMAR_BENCH_DUMP_LOSSES"):       # tests: the losses of the last step + how many gradient buckets went out
+        out["losses"] = {k: float(v) for k, v in losses.items()}
+        out["dist_buckets_launched"] = sum(len(getattr(model, n).launched) for n in ("sync_T", "sync_D", "sync_R"))
     C = 256
     hw = (a.size // 4) ** 2
     # HBM traffic comes from separate rocprofv3 --pmc passes over the same kernels (tools/profile_round.sh); it is

@@ -24,8 +24,14 @@ import torch
 import torch.distributed as td
 
 
+def _forced():
+    # NEMAR_DIST_SINGLE=1: run the whole data-parallel machinery (RCCL communicator, bucketed side-stream collectives, parameter
+    # broadcast) with a world of ONE rank — lets a one-GPU box exercise every torch.distributed / RCCL call of the N > 1 path
+    return os.environ.get("NEMAR_DIST_SINGLE", "0") == "1"
+
+
 def is_distributed():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _forced())
 
 
 def rank():
@@ -42,7 +48,7 @@ def init_from_env(backend=None):
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not td.is_initialized():
+    if (ws > 1 or _forced()) and not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

@@ -54,6 +54,20 @@ class _LazyLoss:
         return 'LazyLoss(%g)' % float(self)
 
 
+def _loss_property(name):
+    """`model.loss_<name>` is a 0-dim TENSOR, as in the reference (models/nemar_model.py:179-261) — arithmetic, .item(),
+    SummaryWriter.add_scalar all work — but it is only FORMED when somebody reads it: the step itself back-propagates from the
+    list of weighted terms and runs no scalar arithmetic kernels."""
+    key = '_lazy_loss_' + name
+
+    def get(self):
+        return self.__dict__[key].value()
+
+    def put(self, parts):
+        self.__dict__[key] = parts if isinstance(parts, _LazyLoss) else _LazyLoss([(parts, 1.0)])
+    return property(get, put)
+
+
 class NEMARModel(BaseModel):
     """netT: translation A->B; netR: registration (STN) A~>B; netD: PatchGAN on (A, B) pairs."""
 
@@ -99,6 +113,15 @@ class NEMARModel(BaseModel):
                 self.tb_visualizer = TrainingMonitor(self, opt)
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
             self._lam_smooth = torch.full((), float(opt.lambda_smooth), dtype=torch.float32, device=self.device)
+
+    loss_L1_TR = _loss_property('L1_TR')
+    loss_GAN_TR = _loss_property('GAN_TR')
+    loss_L1_RT = _loss_property('L1_RT')
+    loss_GAN_RT = _loss_property('GAN_RT')
+    loss_smoothness = _loss_property('smoothness')
+    loss_D_fake_TR = _loss_property('D_fake_TR')
+    loss_D_fake_RT = _loss_property('D_fake_RT')
+    loss_D = _loss_property('D')
 
     def setup_visualizers(self):
         # <loss>_TR: registration-first branch T(R(a)); <loss>_RT: translation-first branch R(T(a))
@@ -234,7 +257,7 @@ class NEMARModel(BaseModel):
         terms = real + fake_tr + fake_rt
         self.loss_D = _LazyLoss([(t, 1.0) for t in terms])
         torch.autograd.backward(terms, [self._one] * len(terms))
-        return self.loss_D
+        return self.__dict__['_lazy_loss_D']
 
     # ---- translation + registration step ----------------------------------------------------------------------
     def backward_T_and_R(self):

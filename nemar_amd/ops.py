@@ -135,7 +135,18 @@ def grad_ready(param):
 
 
 def _grad_buffer(param):
-    """param.grad as an accumulation target (allocated zero-filled on first use)."""
+    """param.grad as an accumulation target.  Parameters owned by a FlatAdam accumulate into their view of the optimizer's
+    flat gradient buffer: if user code re-seated or cleared `.grad` (`p.grad = None`, `zero_grad(set_to_none=True)` of some
+    wrapper), the view is put back — the kernels must never write into a tensor the optimizer and the all-reduce do not see.
+    Stand-alone parameters get a zero-filled tensor on first use."""
+    view = getattr(param, '_flat_grad', None)
+    if view is not None:
+        g = param.grad
+        if g is None or g.data_ptr() != view.data_ptr():
+            if g is not None:
+                view.add_(g)                 # keep whatever was accumulated outside (normally nothing)
+            param.grad = view
+        return view
     if param.grad is None:
         param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
     return param.grad
@@ -633,6 +644,7 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+                p._flat_grad = p.grad
         self.offsets = offs
 
     def zero_grad(self, set_to_none=False):

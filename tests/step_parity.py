@@ -184,6 +184,23 @@ def run(name, report=None, check=True):
                     worst = (c, k)
             add(pre + 'grad/%s 1-cos(whole net)' % nm, 1.0 - dot / (np.sqrt(na * nb) + 1e-300), 1e-3)
             add(pre + 'grad/%s 1-cos(worst tensor %s)' % (nm, worst[1]), 1.0 - worst[0], 1e-2)
+            # ELEMENTWISE: max |g_build - g_fp64| per tensor, relative to the tensor's max, against the fp32 oracle's own
+            # elementwise gap to fp64 (how far two correct fp32 evaluations of this tensor are apart: ReLU / max-pool / floor()
+            # decisions upstream) — base 2e-3 + 4 x that gap; reported for the worst tensor of the net
+            g32 = {'T': ref.grads_T, 'R': ref.grads_R, 'D': ref.grads_D}[nm]
+            worst_e = (0.0, None, 0.0)
+            for k, v in g64.items():
+                b = v.numpy()
+                vmax = float(np.abs(b).max())
+                if vmax < 1e-5 * gmax:
+                    continue
+                e = _maxabs(mine[k], b) / vmax
+                cond = _maxabs(g32[k].numpy(), b) / vmax
+                ratio = e / (2e-3 + 4 * cond)
+                if ratio > worst_e[0]:
+                    worst_e = (ratio, k, e)
+            add(pre + 'grad/%s elementwise, worst tensor %s (err %.2e) / (2e-3 + 4 x fp32-oracle gap)' % (nm, worst_e[1], worst_e[2]),
+                worst_e[0], 1.0)
         # post-Adam weights vs the fp64 oracle: elements whose update differs by more than half a step
         for nm, net, p32, p64 in (('T', hip.netT, ref.T, ref64.T), ('R', hip.netR, ref.R, ref64.R),
                                   ('D', hip.netD, ref.D, ref64.D)):

@@ -74,3 +74,49 @@ def test_update_learning_rate_steps_the_schedulers():
     lr0 = m.optimizers[0].param_groups[0]['lr']
     m.update_learning_rate()
     assert m.optimizers[0].param_groups[0]['lr'] <= lr0
+
+
+def test_loss_attributes_are_tensors_and_grads_stay_in_the_flat_buffer():
+    """`model.loss_<name>` are 0-dim tensors like the reference's (arithmetic / .item() / add_scalar work); a parameter
+    whose .grad was cleared or re-seated by user code goes back to its view of the optimizer's flat gradient buffer."""
+    cfg = STEP_CONFIGS["affine128"]
+    m = step_parity.build_hip_model("affine128")
+    m.set_input(_inputs(cfg))
+    m.optimize_parameters()
+    for name in m.loss_names:
+        v = getattr(m, 'loss_' + name)
+        assert isinstance(v, torch.Tensor) and v.dim() == 0 and v.is_cuda, name
+    total = m.loss_L1_TR + m.loss_L1_RT + 0.5 * m.loss_GAN_TR
+    assert abs(total.item() - (float(m.loss_L1_TR) + float(m.loss_L1_RT) + 0.5 * float(m.loss_GAN_TR))) < 1e-4
+    assert abs(float(m.loss_D) - m.get_current_losses()['D']) < 1e-6
+    # re-seated gradients
+    p = next(m.netD.parameters())
+    view_ptr = p.grad.data_ptr()
+    p.grad = None
+    q = list(m.netD.parameters())[2]
+    q.grad = torch.zeros_like(q)
+    m.set_input(_inputs(cfg))
+    m.optimize_parameters()
+    assert p.grad is not None and p.grad.data_ptr() == view_ptr and float(p.grad.abs().sum()) > 0
+    assert q.grad.data_ptr() == q._flat_grad.data_ptr()
+
+
+def test_dropout_masks_follow_the_torch_seed_and_are_regenerated_in_backward():
+    """the Philox stream is seeded from torch.initial_seed() + rank in NEMARModel.__init__ (different per rank /
+    per torch.manual_seed), and the backward pass regenerates exactly the forward mask."""
+    from nemar_amd import ops
+    x = torch.ones(1, 4, 64, 64, device='cuda', requires_grad=True)
+    masks = []
+    for seed in (11, 11, 12):
+        ops.manual_seed(seed)
+        y = ops.dropout(x, 0.5, True)
+        g, = torch.autograd.grad(y.sum(), x)
+        assert torch.equal(g, (y != 0).float() * 2.0)          # same mask, same 1/(1-p) scale
+        masks.append((y != 0).cpu())
+    assert torch.equal(masks[0], masks[1]) and not torch.equal(masks[0], masks[2])
+    torch.manual_seed(123)
+    m1 = step_parity.build_hip_model("affine128")
+    s1 = ops._dropout_state["seed"]
+    torch.manual_seed(124)
+    m2 = step_parity.build_hip_model("affine128")
+    assert ops._dropout_state["seed"] != s1 and s1 == (123 & 0xFFFFFFFFFFFFFFFF)

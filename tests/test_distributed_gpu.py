@@ -91,3 +91,27 @@ def test_two_ranks_equal_one_process_on_the_full_batch():
     for i, (g2, g1) in enumerate(zip(got[0]['flat_g'], want['flat_g'])):
         scale = np.abs(g1).max()
         assert np.abs(g2 - g1).max() <= (2e-3 if i == 1 else 1e-2) * scale, (i, np.abs(g2 - g1).max(), scale)
+
+
+def test_rccl_code_path_with_a_world_of_one_rank():
+    """Every torch.distributed / RCCL call of the N > 1 path — init_process_group("nccl"), the parameter broadcast, the
+    bucketed all-reduce(AVG) on the side stream behind an event, the stream-level waits, bench.py's barrier and MAX reduction
+    — executed on ONE GPU with a one-rank communicator (NEMAR_DIST_SINGLE=1).  No bytes cross xGMI here; what this pins is that
+    the calls are accepted by RCCL and ordered correctly: the step must produce the same losses as the plain single-process run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for forced in ("1", "0"):
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                   NEMAR_DIST_SINGLE=forced, NEMAR_BENCH_DUMP_LOSSES="1")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--batch", "2", "--opt=--no_dropout"], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    assert a["n_gpus"] == 1 and a["losses_finite"] and a["dist_buckets_launched"] > 0 and b["dist_buckets_launched"] == 0
+    for k, v in a["losses"].items():
+        assert abs(v - b["losses"][k]) <= 1e-6 * max(1.0, abs(v)), (k, v, b["losses"][k])
