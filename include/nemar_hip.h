@@ -9,7 +9,7 @@
  *     tensors are contiguous NCHW float32.  The library never allocates, frees or synchronises.
  *   - every launch goes on `stream` (a hipStream_t passed as void*; NULL = the null stream), so the caller's
  *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream.  The only process-global
- *     state are the nemar_tune* measurement switches below (defaults = the product configuration).
+ *     state are the nemar_tune* measurement switches and the scratch arena registered with nemar_set_scratch (below).
  *   - return value: 0 on success, negative on error (NEMAR_EINVAL bad shape/pointer/unsupported,
  *     NEMAR_ELAUNCH HIP launch error, NEMAR_EWORKSPACE workspace too small); nemar_last_error() returns the
  *     message of the calling thread's last failure.  Python glue raises on non-zero.
@@ -136,9 +136,21 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   10 4-deep LDS ring for every 64x64 launch
  *   11 four loader waves for gathered B tiles (on)                   12 reduction splits in data gradients (on)
  *   14 fixed-order split reductions (1, default) / fp32 atomics in the weight + bias gradients (0)
- *   15 XCD-aware workgroup -> tile mapping of the wave-specialised kernels (1, default) */
+ *   15 XCD-aware workgroup -> tile mapping of the wave-specialised kernels (1, default)
+ *   16..19 loader / tile / ring-depth / narrow-kernel variants
+ *   20 3x3 stride-1 layers with >= 128 output channels on the bf16 matrix pipe with three-way split operands (1, default;
+ *      needs the scratch arena below; 0 = exact-fp32 MFMA kernels).  Packed weight images are per setting. */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
+/* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data.  The wide 3x3 stride-1 layers (the ResnetBlock
+ * convolutions, reference models/networks.py:418-439) run on the bf16 matrix pipe at fp32-equivalent accuracy: each fp32
+ * operand is split exactly into three bf16 terms and six partial products are accumulated in fp32 (csrc/conv_bf6.hip).  The
+ * split copy of the source tensor lives in this arena for the duration of the call.  nemar_conv2d_scratch -> bytes the layer
+ * wants (0: never uses it); nemar_set_scratch registers a caller-owned device buffer (process-global like the tune switches:
+ * one stream at a time may run operators that use it; bytes = 0 unregisters).  A layer whose need exceeds the registered
+ * arena, or with no arena at all, runs on the exact-fp32 MFMA kernels instead — same results within fp32 rounding. */
+size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad);
+int nemar_set_scratch(void* scratch, size_t bytes);
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient; two fixed-order stages through `workspace`). */
 size_t nemar_bias_grad_workspace(int N, int C, int HW);
 int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* workspace, size_t ws_bytes, void* stream);

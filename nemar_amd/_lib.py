@@ -44,6 +44,8 @@ SIGNATURES = {
     "nemar_conv2d_bwd_weight_workspace": (_sz, [_i] * 11),
     "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz,
                                      _vp]),
+    "nemar_conv2d_scratch": (_sz, [_i] * 9),
+    "nemar_set_scratch": (_i, [_vp, _sz]),
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "nemar_tune": (_i, [_i, _i]),

@@ -29,6 +29,7 @@
 // the (huge) pixel reduction split across workgroups and fp32 atomics into the caller's gradient buffer:
 // conv_wgrad.hip (wave-specialised) for everything whose gy planes are 16-byte chunkable, wgrad_kernel below for the rest.
 #include "common.h"
+#include "conv_bf6.h"
 
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
 bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW);
@@ -1067,6 +1068,11 @@ static int g_mt8 = 0;            // tuning switch (key 17): 256x128 tiles in the
 static int g_adir = 0;           // tuning switch (key 16): MFMA waves fetch their A fragments straight from global memory (1; measured 3 %
                                  // SLOWER: 370.8 vs 358.4 us on the 256->256 3x3 layer, gpurun_out/r2g) / through LDS (0, default)
 static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup -> tile mapping in the wave-specialised igemm
+// key 20: 3x3 / stride-1 layers with >= 128 output channels run on the bf16 matrix pipe with three-way split operands
+// (conv_bf6.hip) whenever the caller has registered a scratch arena large enough for the split source planes
+static int g_bf6 = 1;
+static void* g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
 static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise
                                  // reproducible backward pass), 0 = fp32 atomics in the weight / bias gradients (round-1 scheme)
@@ -1603,6 +1609,10 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     L.ring = refl && stride == 1;
     L.fold = refl && !L.ring;
     L.pack_stride = packed_floats(C, K * R * S);             // upper bound over parity classes and channel skips
+    if (nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, BF6_ZERO)) {     // room for either packed image
+        const size_t b = (nemar_bf6_pack_bytes(C, K) + 3) / 4;
+        if (b > L.pack_stride) L.pack_stride = b;
+    }
     size_t o = L.pack_stride * (size_t)(stride * stride);
     L.padded_off = o;
     if (L.fold) o += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
@@ -1657,6 +1667,10 @@ struct FwdLayout { size_t pack, slab_off, total; int ksplit; };
 FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
     FwdLayout L;
     L.pack = packed_floats(K, C * R * S);
+    if (nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, BF6_ZERO)) {     // room for either packed image
+        const size_t b = (nemar_bf6_pack_bytes(K, C) + 3) / 4;
+        if (b > L.pack) L.pack = b;
+    }
     L.ksplit = 1;
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (g_ksplit && OH > 0 && OW > 0 && K > 4) L.ksplit = normalize_ksplit(C * R * S, small_problem_split(K, N * OH * OW, C * R * S));
@@ -1703,6 +1717,16 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
                          g_deterministic ? (float*)workspace : nullptr, ws_bytes / sizeof(float), st);
         NEMAR_CHECK_LAUNCH("conv2d_fwd (narrow)");
         return NEMAR_OK;
+    }
+    {
+        const int mode = pad_mode == BORDER_REFLECT ? BF6_REFLECT : BF6_ZERO;
+        if (g_bf6 && C1 == 0 && act == ACT_NONE && nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, mode) &&
+            g_scratch && g_scratch_bytes >= nemar_bf6_scratch_bytes(N, C, H, W)) {
+            if (!prepacked) nemar_bf6_pack(w, workspace, K, C, 0, st);
+            nemar_bf6_conv(x0, workspace, bias, y, N, H, W, K, C, mode, g_scratch, g_xcd_map, st);
+            NEMAR_CHECK_LAUNCH("conv2d_fwd (bf16 x 6)");
+            return NEMAR_OK;
+        }
     }
     IgemmParams p;
     fwd_taps(p.taps, R, S, pad);
@@ -1766,6 +1790,17 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                   "conv2d_bwd_data: problem too large for 32-bit tile indexing");
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)workspace;
+    {
+        // 3x3 stride-1 layers: the data gradient is the same convolution with flipped, transposed weights (conv_bf6.hip)
+        const int mode = refl ? BF6_DGRAD_REFLECT : BF6_ZERO;
+        if (g_bf6 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, mode) &&
+            g_scratch && g_scratch_bytes >= nemar_bf6_scratch_bytes(N, K, H, W)) {
+            if (!prepacked) nemar_bf6_pack(w, workspace, K, C, 1, st);
+            nemar_bf6_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, mode, g_scratch, g_xcd_map, st);
+            NEMAR_CHECK_LAUNCH("conv2d_bwd_data (bf16 x 6)");
+            return NEMAR_OK;
+        }
+    }
     const size_t pack_stride = L.pack_stride;
     // Reflect padding.  The gradient w.r.t. the PADDED input splits into the image interior — exactly the zero-padded
     // data gradient, computed on the unpadded domain — and the border ring, whose texels are mirrors of in-image
@@ -2044,6 +2079,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 14) { g_deterministic = value != 0; return NEMAR_OK; }
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
+    if (key == 20) { g_bf6 = value != 0; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
     if (key == 19) { extern int g_narrow_fwd4; g_narrow_fwd4 = value != 0; return NEMAR_OK; }
@@ -2055,6 +2091,26 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 5) { g_wgrad_blocks = value > 0 ? value : 512; return NEMAR_OK; }
     nemar_set_error("nemar_tune: unknown key %d", key);
     return NEMAR_EINVAL;
+}
+
+// Transient scratch arena shared by the operators of one stream (split source planes of the bf16 x 6 convolutions).  The
+// caller owns it and keeps it alive while calls that may use it are in flight; bytes == 0 unregisters.
+NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
+    g_scratch = bytes ? scratch : nullptr;
+    g_scratch_bytes = scratch ? bytes : 0;
+    return NEMAR_OK;
+}
+
+// Scratch bytes nemar_conv2d_fwd / nemar_conv2d_bwd_data want for this layer (0: the layer never uses the arena)
+NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return 0;
+    size_t b = 0;
+    if (nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, BF6_ZERO)) b = nemar_bf6_scratch_bytes(N, C, H, W);
+    if (nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, BF6_ZERO)) {
+        const size_t d = nemar_bf6_scratch_bytes(N, K, H, W);
+        if (d > b) b = d;
+    }
+    return b;
 }
 
 NEMAR_API size_t nemar_bias_grad_workspace(int N, int C, int HW) {

@@ -1,0 +1,403 @@
+// nemar_amd — 3x3 / stride-1 / pad-1 convolutions of the wide layers (the translation net's 256-channel residual blocks:
+// reference models/networks.py:418-439, 18 convolutions per pass) on the BF16 matrix pipe, at fp32-equivalent accuracy.
+//
+// gfx950 has no TF32-like mode and its fp32 MFMA runs at the vector rate (157 TFLOP/s); the bf16 MFMA runs 16x faster.
+// Every fp32 operand is split EXACTLY into three bf16 terms  v = b0 + b1 + b2  (b0 = RN(v), b1 = RN(v - b0), b2 = v - b0 - b1:
+// 3 x 8 significant bits cover fp32's 24), and a product a*c is accumulated in fp32 from the six partial products of weight
+// 2^-16 and above:  a0c0 + (a0c1 + a1c0) + (a0c2 + a1c1 + a2c0).  Each bf16 x bf16 product is exact in fp32; the three dropped terms
+// (a1c2, a2c1, a2c2) are <= 2^-23 |a c| together, the size of the rounding error the fp32 MFMA commits on the product itself —
+// so the result carries fp32-class error (tests/test_conv_real_shapes_gpu.py measures both paths against fp64 on the same
+// inputs) at 6/16 of the fp32-MFMA issue time.
+//
+// Data flow of one convolution (all inside nemar_conv2d_fwd / nemar_conv2d_bwd_data):
+//   1. split_planes_kernel: source [N,C,H,W] fp32 -> three bf16 planes, CHANNEL-BLOCKED and PADDED:
+//         plane[t][n][c/8][row 0..H+3][slot 0..W+3][8 channels]      (16 bytes per (pixel, channel group))
+//      rows 1..H / slots 1..W hold the image, row 0 / H+1 and slot 0 / W+1 the padding ALREADY MATERIALISED (zeros, or the
+//      mirrored texels of nn.ReflectionPad2d(1)), rows H+2, H+3 and slots W+2, W+3 the pre-folded border sums the reflect DATA
+//      gradient needs (below).  One lane's MFMA operand (8 consecutive reduction channels of one pixel) is one 16-byte word,
+//      and a tile's halo (its rows + 2, full padded width) is ONE contiguous run per (plane, channel group).
+//   2. igemm_bf6_kernel: implicit GEMM, workgroup tile = 128 output channels x 256 pixels (whole image rows), 4 MFMA waves
+//      (128 channels x 64 pixels each: 8 accumulators of 32x32) + 2 loader waves.  Per 16-channel chunk of the reduction the
+//      loaders DMA the tile's halo once (global_load_lds, 16 bytes per lane, no VGPRs) into a double-buffered LDS region and all
+//      nine taps read it at shifted addresses — the source is fetched once per chunk instead of once per tap — plus one 12 KiB
+//      stage of packed weights per tap into a ring.  One workgroup barrier per tap (48 MFMAs per wave).
+//   3. the reflect data gradient  dx = Pad^T(Conv^T(gy))  folds the padded border back: output row 1 receives the gradient of
+//      padded row 0, which only the first filter row produces, i.e. for that (row, tap) pair the source row is gy[0] + gy[2]
+//      instead of gy[2]; same for row H-2, columns 1 and W-2, and the four corners.  The split kernel writes those sums once
+//      (rows H+2 / H+3, slots W+2 / W+3) and the MFMA waves select them by address: no ring launch, no extra taps.
+// Weights are split and re-ordered once per optimizer step (bf6_pack_kernel) into [chunk][tap][128-row block][plane][k group]
+// [128][8]: a stage is one contiguous 12 KiB run.
+#include "common.h"
+#include "conv_bf6.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rn(float v) {
+    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// v == b0 + b1 + b2 exactly (both subtractions are exact in fp32: Sterbenz-type cancellation of the leading bits)
+__device__ __forceinline__ void split3(float v, unsigned short& b0, unsigned short& b1, unsigned short& b2) {
+    b0 = bf16_rn(v);
+    const float r1 = v - bf16_val(b0);
+    b1 = bf16_rn(r1);
+    const float r2 = r1 - bf16_val(b1);
+    b2 = bf16_rn(r2);
+}
+
+__device__ __forceinline__ int mirror(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// value of plane position (row, slot) of one channel image xc [H, W]
+__device__ __forceinline__ float plane_value(const float* xc, int row, int slot, int H, int W, int mode) {
+    if (mode != BF6_DGRAD_REFLECT) {
+        if (row > H + 1 || slot > W + 1) return 0.f;
+        int y = row - 1, x = slot - 1;
+        if (mode == BF6_REFLECT) {
+            y = mirror(y, H);
+            x = mirror(x, W);
+        } else if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) {
+            return 0.f;
+        }
+        return xc[y * W + x];
+    }
+    int ya, yb = -1, xa, xb = -1;
+    if (row >= 1 && row <= H) ya = row - 1;
+    else if (row == H + 2) { ya = 0; yb = 2; }
+    else if (row == H + 3) { ya = H - 3; yb = H - 1; }
+    else return 0.f;
+    if (slot >= 1 && slot <= W) xa = slot - 1;
+    else if (slot == W + 2) { xa = 0; xb = 2; }
+    else if (slot == W + 3) { xa = W - 3; xb = W - 1; }
+    else return 0.f;
+    float v = xc[ya * W + xa];
+    if (yb >= 0) v += xc[yb * W + xa];
+    if (xb >= 0) {
+        float u = xc[ya * W + xb];
+        if (yb >= 0) u += xc[yb * W + xb];
+        v += u;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32x4 pack8(const unsigned short* b) {
+    u32x4 o;
+    o[0] = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    o[1] = (unsigned)b[2] | ((unsigned)b[3] << 16);
+    o[2] = (unsigned)b[4] | ((unsigned)b[5] << 16);
+    o[3] = (unsigned)b[6] | ((unsigned)b[7] << 16);
+    return o;
+}
+
+// one thread = one (n, channel group, row, slot): 8 strided reads (coalesced across the slots of a row), 3 x 16-byte writes
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C,
+                                                           int H, int W, int mode, long long total) {
+    const int Hp = H + 4, Ws = W + 4, CG = C >> 3;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int slot = (int)(t % Ws);
+        long long q = t / Ws;
+        const int row = (int)(q % Hp);
+        q /= Hp;
+        const int cg = (int)(q % CG), n = (int)(q / CG);
+        const float* xc = x + ((size_t)n * C + (size_t)cg * 8) * H * W;
+        unsigned short b0[8], b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(plane_value(xc + (size_t)j * H * W, row, slot, H, W, mode), b0[j], b1[j], b2[j]);
+        out[t] = pack8(b0);
+        out[total + t] = pack8(b1);
+        out[2 * total + t] = pack8(b2);
+    }
+}
+
+// packed weights: 16-byte word index (((chunk * 9 + tap) * mblks + mblk) * 3 + plane) * 256 + kgroup * 128 + m
+__global__ __launch_bounds__(256) void bf6_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int M, int Cred,
+                                                       int dgrad) {
+    const int mblks = M >> 7;
+    const long long total = (long long)(Cred >> 4) * 9 * mblks * 256;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(t & 127), kg = (int)((t >> 7) & 1);
+        long long q = t >> 8;
+        const int mblk = (int)(q % mblks);
+        q /= mblks;
+        const int tap = (int)(q % 9), chunk = (int)(q / 9);
+        const int mg = mblk * 128 + m;
+        unsigned short b0[8], b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cr = chunk * 16 + kg * 8 + j;
+            // forward: w[K = M][C = Cred][3][3];  data gradient: w[K = Cred][C = M][3][3] with the taps flipped
+            const float v = dgrad ? w[((size_t)cr * M + mg) * 9 + (8 - tap)] : w[((size_t)mg * Cred + cr) * 9 + tap];
+            split3(v, b0[j], b1[j], b2[j]);
+        }
+        u32x4* o = out + (((size_t)(chunk * 9 + tap) * mblks + mblk) * 3) * 256 + kg * 128 + m;
+        o[0] = pack8(b0);
+        o[256] = pack8(b1);
+        o[512] = pack8(b2);
+    }
+}
+
+struct Bf6Params {
+    const u32x4* planes;       // split source, see split_planes_kernel
+    const u32x4* wp;           // packed weights
+    const float* bias;         // [M] or null
+    float* dst;                // [N, M, H, W]
+    int N, H, W, M, Cred;
+    int Ws, HpWs;              // slots per plane row, 16-byte words per (plane, n, channel group) image
+    int wshift, RT;            // log2 W, output rows per tile (256 / W)
+    int tiles_per_img, mblks;
+    int halo_instr, aux_instr; // 1 KiB DMA instructions per (plane, k group) for the halo rows / the two folded rows
+    int fold;                  // reflect data gradient: select the folded rows / slots
+    int xcd;                   // workgroup -> tile mapping keeps neighbouring tiles on one XCD
+    long long plane16;         // 16-byte words per plane
+};
+
+__device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// REGION_KB = KiB of LDS per (plane, k group) halo region = DMA instructions per region; RING = weight-stage ring depth
+template <int REGION_KB, int RING>
+__global__ __launch_bounds__(384) void igemm_bf6_kernel(Bf6Params p) {
+    constexpr int REGION16 = REGION_KB * 64;             // 16-byte words per region
+    constexpr int BBUF16 = 6 * REGION16;                 // 3 planes x 2 k groups
+    constexpr int ASTAGE16 = 6 * 128;                    // 3 planes x 2 k groups x 128 rows
+    constexpr int NBL = 3 * REGION_KB;                   // halo instructions per loader per chunk (loader = k group)
+    constexpr int WINDOW = 10 - RING;                    // stages (taps RING-1 .. 8) that carry the next chunk's halo
+    constexpr int NB = (NBL + WINDOW - 1) / WINDOW;      // halo instruction slots per stage
+    constexpr int PER = 6 + NB;                          // DMA instructions per loader per stage (constant: counted waits)
+    static_assert((RING - 1) * PER < 64, "vmcnt is a 6-bit counter");
+    static_assert((2 * BBUF16 + RING * ASTAGE16) * 16 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * BBUF16 + RING * ASTAGE16];
+    u32x4* const Bs = smem;
+    u32x4* const As = smem + 2 * BBUF16;
+
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    // consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous run of tiles, and both channel halves of a
+    // pixel tile (same halo) to the same one
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
+    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int CG = p.Cred >> 3;
+
+    if (wid >= 4) {
+        // ================================ loader waves: wave 4 = k group 0, wave 5 = k group 1 ================================
+        const int kg = wid - 4;
+        const int ipr = p.halo_instr + p.aux_instr;                      // <= REGION_KB
+        const int nbl = 3 * ipr;
+        const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + kg * 384 + lane;
+        const size_t wstage = (size_t)p.mblks * 768;
+        // source of this loader's halo words of chunk c, plane t: planes + t * plane16 + ((n * CG + 2c + kg) * HpWs) + ...
+        const u32x4* const bsrc0 = p.planes + ((size_t)n * CG + kg) * p.HpWs + lane;
+        const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
+        int islot = 0, ci = 0, ti = 0;        // ring slot / chunk / tap of the next stage to issue
+        int bpl = 0, bin = 0, bcnt = nbl;      // halo stream of chunk ci + 1: plane, instruction within the region, issued count
+        const u32x4* asrc = wsrc0;
+
+#define BF6_HALO_ONE(chunk_, pl_, in_)                                                                                  \
+        {                                                                                                               \
+            const u32x4* g_ = bsrc0 + (size_t)(pl_) * p.plane16 + (size_t)(2 * (chunk_)) * p.HpWs +                     \
+                              ((in_) < p.halo_instr ? halo_off + (in_) * 64 : aux_off + ((in_) - p.halo_instr) * 64);   \
+            glds16(g_, Bs + ((chunk_) & 1) * BBUF16 + ((pl_) * 2 + kg) * REGION16 + (in_) * 64);                        \
+        }
+#define BF6_ISSUE()                                                                                                     \
+        {                                                                                                               \
+            u32x4* const ad_ = As + islot * ASTAGE16 + kg * 384;                                                        \
+            _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(asrc + q * 64, ad_ + q * 64);                          \
+            if (ti == RING - 1) { bpl = 0; bin = 0; bcnt = (ci + 1 < nchunks) ? 0 : nbl; }                              \
+            _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                            \
+                if (bcnt < nbl) {                                                                                       \
+                    BF6_HALO_ONE(ci + 1, bpl, bin);                                                                     \
+                    ++bcnt;                                                                                             \
+                    if (++bin == ipr) { bin = 0; ++bpl; }                                                               \
+                } else {                                                                                                \
+                    glds16(asrc, ad_);             /* filler: keeps the per-stage instruction count constant */          \
+                }                                                                                                       \
+            }                                                                                                           \
+            asrc += wstage;                                                                                             \
+            islot = islot + 1 == RING ? 0 : islot + 1;                                                                  \
+            if (++ti == 9) { ti = 0; ++ci; }                                                                            \
+        }
+#define BF6_WAIT_IN_FLIGHT(n_)                                                                                          \
+        {                                                                                                               \
+            const int ns_ = (n_);                                                                                       \
+            if (ns_ <= 0) wait_vmem();                                                                                  \
+            else if (ns_ == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER & 15) | ((PER >> 4) << 14));                    \
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 15) | (((2 * PER) >> 4) << 14));                      \
+        }
+        static_assert(RING <= 4, "two stages in flight at most");
+        // halo of chunk 0, then RING - 1 weight stages, before anything is consumed
+        for (int pl = 0; pl < 3; ++pl)
+            for (int in = 0; in < ipr; ++in) BF6_HALO_ONE(0, pl, in);
+        int issued = 0;
+        for (; issued < RING - 1 && issued < nstage; ++issued) BF6_ISSUE();
+        BF6_WAIT_IN_FLIGHT(issued - 1);
+        __builtin_amdgcn_s_barrier();                 // stage 0 (and the first halo) are in LDS
+        if (issued < nstage) { BF6_ISSUE(); ++issued; }
+        for (int ks = 0; ks < nstage; ++ks) {
+            BF6_WAIT_IN_FLIGHT(issued - (ks + 2));    // stage ks + 1 has landed (with everything issued before it)
+            __builtin_amdgcn_s_barrier();             // every MFMA wave has finished reading ring slot ks % RING
+            if (issued < nstage) { BF6_ISSUE(); ++issued; }
+        }
+#undef BF6_WAIT_IN_FLIGHT
+#undef BF6_ISSUE
+#undef BF6_HALO_ONE
+        return;
+    }
+
+    // ================================ MFMA waves: 128 channels x 64 pixels each ================================
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int row[2], col[2];
+    bool top[2], bot[2], lft[2], rgt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int px = 64 * wid + 32 * nt + l31;
+        row[nt] = px >> p.wshift;
+        col[nt] = px & (p.W - 1);
+        const int y = y0 + row[nt];
+        top[nt] = p.fold && y == 1;
+        bot[nt] = p.fold && y == p.H - 2;
+        lft[nt] = p.fold && col[nt] == 1;
+        rgt[nt] = p.fold && col[nt] == p.W - 2;
+    }
+    const int auxoff = p.halo_instr * 64;             // the two folded rows sit behind the halo rows of a region
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    __builtin_amdgcn_s_barrier();                     // stage 0 is in LDS
+    int slot = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const u32x4* const Bb = Bs + (chunk & 1) * BBUF16 + lhi * REGION16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, sx = tap - 3 * (tap / 3);
+            u32x4 bf[2][3], af[4][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                int ra = (row[nt] + r) * p.Ws;
+                if (r == 2) ra = top[nt] ? auxoff : ra;
+                if (r == 0) ra = bot[nt] ? auxoff + p.Ws : ra;
+                int sl = col[nt] + sx;
+                if (sx == 2) sl = lft[nt] ? p.W + 2 : sl;
+                if (sx == 0) sl = rgt[nt] ? p.W + 3 : sl;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = Bb[pl * 2 * REGION16 + ra + sl];
+            }
+            const u32x4* const Ab = As + slot * ASTAGE16 + lhi * 128 + l31;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[mt][pl] = Ab[pl * 256 + mt * 32];
+            // six partial products, smallest first; consecutive MFMAs go to different accumulators
+#define BF6_TERM(pa_, pb_)                                                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                        \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][pa_]),      \
+                                                                          __builtin_bit_cast(bf16x8, bf[nt][pb_]),      \
+                                                                          acc[mt][nt], 0, 0, 0);
+            BF6_TERM(2, 0)
+            BF6_TERM(1, 1)
+            BF6_TERM(0, 2)
+            BF6_TERM(1, 0)
+            BF6_TERM(0, 1)
+            BF6_TERM(0, 0)
+#undef BF6_TERM
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): this wave is done reading the stage
+            __builtin_amdgcn_s_barrier();             // the next stage has landed; this ring slot goes back to the loaders
+            slot = slot + 1 == RING ? 0 : slot + 1;
+        }
+    }
+
+    // epilogue: D register r of lane l = channel (r & 3) + 8 (r >> 2) + 4 (l >> 5), pixel l & 31 of the 32 x 32 tile
+    const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[mt][nt][r];
+                if (p.bias) v += p.bias[m];
+                d0[(size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
+int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+}  // namespace
+
+bool nemar_bf6_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode) {
+    if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
+    if (M % 128 != 0 || Cred % 16 != 0 || M <= 0 || Cred <= 0) return false;
+    if (!(W == 32 || W == 64 || W == 128)) return false;
+    const int RT = 256 / W;
+    if (H % RT != 0 || H < 4) return false;
+    if (W == 128 && mode == BF6_DGRAD_REFLECT) return false;      // halo + folded rows of two buffers exceed the LDS
+    if ((long long)N * Cred * (H + 4) * (W + 4) >= (1ll << 31)) return false;
+    return true;
+}
+
+size_t nemar_bf6_scratch_bytes(int N, int Cred, int H, int W) {
+    return (size_t)3 * N * (Cred / 8) * (H + 4) * (W + 4) * 16 + 16384;     // + slack for whole-KiB halo reads
+}
+
+size_t nemar_bf6_pack_bytes(int M, int Cred) { return (size_t)(Cred / 16) * 9 * (M / 128) * 768 * 16 + 16384; }
+
+void nemar_bf6_pack(const float* w, void* packed, int K, int C, int dgrad, hipStream_t st) {
+    const int M = dgrad ? C : K, Cred = dgrad ? K : C;
+    const long long total = (long long)(Cred / 16) * 9 * (M / 128) * 256;
+    hipLaunchKernelGGL(bf6_pack_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad);
+}
+
+void nemar_bf6_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
+                    int mode, void* scratch, int xcd_map, hipStream_t st) {
+    const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
+                       mode, total);
+    Bf6Params p;
+    p.planes = (const u32x4*)scratch;
+    p.wp = (const u32x4*)packed;
+    p.bias = bias;
+    p.dst = dst;
+    p.N = N; p.H = H; p.W = W; p.M = M; p.Cred = Cred;
+    p.Ws = W + 4;
+    p.HpWs = (H + 4) * (W + 4);
+    p.wshift = ilog2(W);
+    p.RT = 256 / W;
+    p.tiles_per_img = H / p.RT;
+    p.mblks = M / 128;
+    p.halo_instr = nemar_cdiv((long long)(p.RT + 2) * p.Ws * 16, 1024);
+    p.fold = mode == BF6_DGRAD_REFLECT;
+    p.aux_instr = p.fold ? nemar_cdiv((long long)2 * p.Ws * 16, 1024) : 0;
+    p.plane16 = total;
+    const int grid = N * p.tiles_per_img * p.mblks;
+    p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
+    const int region = p.halo_instr + p.aux_instr;
+    const dim3 g(grid), b(384);
+    if (region <= 6) hipLaunchKernelGGL((igemm_bf6_kernel<6, 4>), g, b, 0, st, p);
+    else if (region == 7) hipLaunchKernelGGL((igemm_bf6_kernel<7, 4>), g, b, 0, st, p);
+    else if (region == 8) hipLaunchKernelGGL((igemm_bf6_kernel<8, 4>), g, b, 0, st, p);
+    else if (region == 9) hipLaunchKernelGGL((igemm_bf6_kernel<9, 4>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((igemm_bf6_kernel<10, 3>), g, b, 0, st, p);
+}

@@ -73,6 +73,26 @@ def _workspace(nbytes, device):
     return buf
 
 
+_arena = {}            # device -> tensor registered with nemar_set_scratch
+_arena_live = [None]   # (data_ptr, bytes) the library currently holds
+
+
+def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
+    """Make sure the library's transient scratch arena (split source planes of the wide 3x3 layers, csrc/conv_bf6.hip) covers
+    this layer.  Grow-only per device; stream-ordered like _workspace."""
+    need = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
+    if not need:
+        return
+    buf = _arena.get(device)
+    if buf is None or buf.numel() * 4 < need:
+        buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
+        _arena[device] = buf
+    live = (buf.data_ptr(), buf.numel() * 4)
+    if _arena_live[0] != live:
+        L.set_scratch(_p(buf), live[1])
+        _arena_live[0] = live
+
+
 _zero_ws_cache = {}
 
 
@@ -108,6 +128,12 @@ _pack_cache = {}
 
 def invalidate_packed_weights():
     _param_epoch.n += 1
+
+
+def tune(key, value):
+    """nemar_tune through the packed-weight cache: several switches (tile family, split-bf16 route) change the packed image."""
+    L.tune(key, value)
+    invalidate_packed_weights()
 
 
 def _packed(weight, kind, nbytes):
@@ -169,6 +195,7 @@ class _Conv2d(Function):
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
         ws, hit = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
+        _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device)
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
             L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
@@ -208,6 +235,7 @@ class _Conv2d(Function):
                 raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
             # the packed image depends on which source halves are differentiated (channel skip) and on the geometry
             ws, hit = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, N, H, W), wsb)
+            _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
             L.conv2d_bwd_data(_p(g), _p(w), None, ACT_NONE, 0.0, _p(gx), C0, _p(gx2), C1, N, H, W, K, OH, OW, R, S,
                               stride, pad, pad_mode, _p(ws), wsb, hit, st)
             if not need_x2:

@@ -33,11 +33,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tune", type=int, nargs=2, action='append', default=[], help="nemar_tune key value")
     ap.add_argument("--only", type=str, default=None)
+    ap.add_argument("--arena", action='store_true', help="register a scratch arena (split-bf16 kernels for the wide 3x3 layers); "
+                                                         "forward is then timed without the fused activation, as the resblocks run it")
     a = ap.parse_args()
     lib = _lib.load()
     for k, v in a.tune:
         lib.tune(k, v)
     dev = torch.device("cuda:0")
+    act = 0 if a.arena else 1
+    arena = None
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     N = a.batch
@@ -55,16 +59,23 @@ def main():
         gx0 = torch.empty(N, C0, H, H, device=dev) if not C1 else torch.empty(N, C0, H, H, device=dev)
         gx1 = torch.empty(N, C1, H, H, device=dev) if C1 else None
         gw = torch.zeros_like(w)
+        if a.arena:
+            need = lib.conv2d_scratch(N, H, H, K, C, R, R, s, p)
+            if need:
+                arena = torch.empty(need // 4 + 16, device=dev)
+                lib.set_scratch(P(arena), need)
+            else:
+                lib.set_scratch(None, 0)
         wsb = max(lib.conv2d_fwd_workspace(N, H, H, K, C, R, R, s, p), lib.conv2d_bwd_data_workspace(N, C, H, H, K, R, R, s, p, pm))
         ws = torch.empty(wsb // 4 + 16, device=dev)
         ws2 = torch.empty(wsb // 4 + 16, device=dev)
         # weights are packed once per optimizer step in the real path: time the steady state (prepacked = 1)
-        lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, 1, 0.2, P(ws), wsb, 0, st())
+        lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, act, 0.2, P(ws), wsb, 0, st())
         if not (pm == 1 and C1):
             lib.conv2d_bwd_data(P(gy), P(w), None, 0, 0.0, P(gx0), C0, P(gx1), C1, N, H, H, K, OH, OH, R, R, s, p, pm,
                                 P(ws2), wsb, 0, st())
         flop = 2.0 * N * K * OH * OH * C * R * R
-        t_f = timeit(lambda: lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, 1, 0.2,
+        t_f = timeit(lambda: lib.conv2d_fwd(P(x0), C0, P(x1), C1, P(w), P(b), P(y), N, H, H, K, R, R, s, p, pm, act, 0.2,
                                             P(ws), wsb, 1, st()), a.iters, 2)
         if pm == 1 and C1:
             t_d = float('nan')
