@@ -179,6 +179,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     losses = model.get_current_losses()
+    if multi:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
 
@@ -237,7 +240,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         with contextlib.redirect_stdout(sys.stderr):     # the net constructors print; stdout carries the JSON line only
             out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

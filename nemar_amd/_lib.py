@@ -146,4 +146,9 @@ def load(path=None):
         return Library(path)
     if _default is None:
         _default = Library(DEFAULT_PATH)
+        # measurement hook: NEMAR_TUNE="21=1,15=0" applies nemar_tune switches once at load (tools/, A/B runs of bench.py)
+        for kv in os.environ.get("NEMAR_TUNE", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=")
+                _default.tune(int(k), int(v))
     return _default

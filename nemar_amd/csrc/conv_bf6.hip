@@ -152,9 +152,11 @@ struct Bf6Params {
     int wshift, RT;            // log2 W, output rows per tile (256 / W)
     int tiles_per_img, mblks;
     int halo_instr, aux_instr; // 1 KiB DMA instructions per (plane, k group) for the halo rows / the two folded rows
+    int halo16, aux16;         // exact 16-byte words of those two runs (second-generation kernel: exact-sized LDS regions)
     int fold;                  // reflect data gradient: select the folded rows / slots
     int xcd;                   // workgroup -> tile mapping keeps neighbouring tiles on one XCD
     long long plane16;         // 16-byte words per plane
+    int dbg;                   // ablation bits (nemar_tune key 2): 0x10000 no MFMAs, 0x20000 no LDS fragment reads, 0x40000 no global->LDS copies
 };
 
 __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
@@ -339,6 +341,232 @@ __global__ __launch_bounds__(384) void igemm_bf6_kernel(Bf6Params p) {
     }
 }
 
+// ---- second generation: same data flow, MFMA waves software-pipelined -------------------------------------------------
+// First generation above: per tap every MFMA wave reads its 18 fragments, waits for them, then issues 48 MFMAs — LDS latency and
+// the workgroup barrier sit exposed between two MFMA blocks (measured: 2.2x the pure MFMA time).  Here every fragment is fetched
+// one 12-MFMA block ahead of its use: the A fragments of channel tile mt + 1 while the MFMAs of tile mt issue (two tiles' worth
+// of registers instead of four), tile 0 of tap T + 1 during the last block of tap T, the B fragments of tap T + 1 during the
+// second half of tap T (pixel tile 1 into spare registers, pixel tile 0 into the registers its predecessor vacates after the
+// first half of the last block).  For that the loaders keep one more stage landed: barrier j certifies stage j + 2 (a stage
+// is issued RING - 2 taps before it is needed).  LDS regions are exact-sized (the last 1 KiB copy of a run is lane-masked) so
+// that the reflect data gradient fits a 4-slot ring too.  hipcc's scheduler undoes the interleaving (it sinks every read to the
+// end of the tap and the MFMAs below the barrier): the groups are pinned with sched_barrier.
+template <int NB, int ABL = 0>      // ABL: timing ablations (results are garbage): 1 no MFMAs, 2 no LDS fragment reads
+__global__ __launch_bounds__(384) void igemm_bf6p_kernel(Bf6Params p) {
+    constexpr int RING = 4, ASTAGE16 = 768, PER = 6 + NB;
+    constexpr int WINDOW_FIRST = RING - 2;               // taps WINDOW_FIRST .. 8 of a chunk carry the next chunk's halo copies
+    constexpr int SMEM16 = 9728;                          // 152 KiB: ring 48 KiB + two halo buffers of <= 52 KiB
+    static_assert(2 * PER < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM16];
+    u32x4* const As = smem;
+    u32x4* const Bs = smem + RING * ASTAGE16;
+    const int region16 = p.halo16 + p.aux16, bbuf16 = 6 * region16;
+
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
+    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int CG = p.Cred >> 3;
+
+    if (wid >= 4) {
+        // ================================ loader waves ================================
+        const int kg = wid - 4;
+        const int hi = (p.halo16 + 63) >> 6, ai = (p.aux16 + 63) >> 6, ipr = hi + ai, nbl = 3 * ipr;
+        const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + kg * 384 + lane;
+        const size_t wstage = (size_t)p.mblks * 768;
+        const u32x4* const bsrc0 = p.planes + ((size_t)n * CG + kg) * p.HpWs;
+        const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
+        const bool off = (p.dbg & 0x40000) != 0;
+        int islot = 0, ci = 0, ti = 0;
+        int bpl = 0, bin = 0, bcnt = nbl;
+        const u32x4* asrc = wsrc0;
+#define BF6P_HALO_ONE(chunk_, pl_, in_)                                                                                 \
+        {                                                                                                               \
+            const bool aux_ = (in_) >= hi;                                                                              \
+            const int j_ = aux_ ? (in_) - hi : (in_);                                                                   \
+            const int w_ = j_ * 64 + lane;                                                                              \
+            if (w_ < (aux_ ? p.aux16 : p.halo16) && !off)                                                               \
+                glds16(bsrc0 + (size_t)(pl_) * p.plane16 + (size_t)(2 * (chunk_)) * p.HpWs + (aux_ ? aux_off : halo_off) + w_, \
+                       Bs + ((chunk_) & 1) * bbuf16 + ((pl_) * 2 + kg) * region16 + (aux_ ? p.halo16 : 0) + j_ * 64);   \
+        }
+#define BF6P_ISSUE()                                                                                                    \
+        {                                                                                                               \
+            u32x4* const ad_ = As + islot * ASTAGE16 + kg * 384;                                                        \
+            if (!off) { _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(asrc + q * 64, ad_ + q * 64); }            \
+            if (ti == WINDOW_FIRST) { bpl = 0; bin = 0; bcnt = (ci + 1 < nchunks) ? 0 : nbl; }                          \
+            _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                            \
+                if (bcnt < nbl) {                                                                                       \
+                    BF6P_HALO_ONE(ci + 1, bpl, bin);                                                                    \
+                    ++bcnt;                                                                                             \
+                    if (++bin == ipr) { bin = 0; ++bpl; }                                                               \
+                } else if (!off) {                                                                                      \
+                    glds16(asrc, ad_);             /* filler: keeps the per-stage instruction count constant */          \
+                }                                                                                                       \
+            }                                                                                                           \
+            asrc += wstage;                                                                                             \
+            islot = (islot + 1) & (RING - 1);                                                                           \
+            if (++ti == 9) { ti = 0; ++ci; }                                                                            \
+        }
+#define BF6P_WAIT_IN_FLIGHT(n_)                                                                                         \
+        {                                                                                                               \
+            const int ns_ = off ? 0 : (n_);                                                                             \
+            if (ns_ <= 0) wait_vmem();                                                                                  \
+            else if (ns_ == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER & 15) | ((PER >> 4) << 14));                    \
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 15) | (((2 * PER) >> 4) << 14));                      \
+        }
+        for (int pl = 0; pl < 3; ++pl)
+            for (int in = 0; in < ipr; ++in) BF6P_HALO_ONE(0, pl, in);
+        int issued = 0;
+        for (; issued < RING && issued < nstage; ++issued) BF6P_ISSUE();
+        BF6P_WAIT_IN_FLIGHT(issued - 2);              // stages 0 and 1 (and the first halo) have landed
+        __builtin_amdgcn_s_barrier();                 // B_-1
+        for (int j = 0; j < nstage; ++j) {
+            BF6P_WAIT_IN_FLIGHT(issued - (j + 3));    // stage j + 2 has landed
+            __builtin_amdgcn_s_barrier();             // B_j: the MFMA waves have finished reading stage j
+            if (issued < nstage) { BF6P_ISSUE(); ++issued; }
+        }
+#undef BF6P_WAIT_IN_FLIGHT
+#undef BF6P_ISSUE
+#undef BF6P_HALO_ONE
+        return;
+    }
+
+    // ================================ MFMA waves ================================
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int row[2], col[2];
+    bool top[2], bot[2], lft[2], rgt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int px = 64 * wid + 32 * nt + l31;
+        row[nt] = px >> p.wshift;
+        col[nt] = px & (p.W - 1);
+        const int y = y0 + row[nt];
+        top[nt] = p.fold && y == 1;
+        bot[nt] = p.fold && y == p.H - 2;
+        lft[nt] = p.fold && col[nt] == 1;
+        rgt[nt] = p.fold && col[nt] == p.W - 2;
+    }
+    const int auxoff = p.halo16;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    constexpr bool noread = (ABL & 2) != 0, nomfma = (ABL & 1) != 0;
+
+    // B fragments of pixel tile nt_ for tap (r, sx) from halo buffer `hb_`
+#define BF6P_READ_B(dst_, nt_, hb_, r_, sx_)                                                                            \
+    if constexpr (!noread) {                                                                                                      \
+        const u32x4* const Bb_ = Bs + (hb_) * bbuf16 + lhi * region16;                                                  \
+        int ra_ = (row[nt_] + (r_)) * p.Ws;                                                                             \
+        if ((r_) == 2) ra_ = top[nt_] ? auxoff : ra_;                                                                   \
+        if ((r_) == 0) ra_ = bot[nt_] ? auxoff + p.Ws : ra_;                                                            \
+        int sl_ = col[nt_] + (sx_);                                                                                     \
+        if ((sx_) == 2) sl_ = lft[nt_] ? p.W + 2 : sl_;                                                                 \
+        if ((sx_) == 0) sl_ = rgt[nt_] ? p.W + 3 : sl_;                                                                 \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) dst_[pl] = Bb_[pl * 2 * region16 + ra_ + sl_];                 \
+    }
+#define BF6P_READ_A(dst_, slot_, mt_)                                                                                   \
+    if constexpr (!noread) {                                                                                                      \
+        const u32x4* const Ab_ = As + (slot_) * ASTAGE16 + lhi * 128 + l31 + (mt_) * 32;                                \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) dst_[pl] = Ab_[pl * 256];                                      \
+    }
+#define BF6P_MFMA1(mt_, nt_, A_, B_, q_)                                                                               \
+    acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_[PA[q_]]),                     \
+                                                            __builtin_bit_cast(bf16x8, B_[PB[q_]]), acc[mt_][nt_], 0, 0, 0);
+    // six partial products, smallest first; consecutive MFMAs alternate between the two pixel tiles' accumulators
+#define BF6P_MFMA(mt_, A_)                                                                                              \
+    if constexpr (!nomfma) {                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                                                 \
+            BF6P_MFMA1(mt_, 0, A_, b0, q)                                                                               \
+            BF6P_MFMA1(mt_, 1, A_, b1, q)                                                                               \
+        }                                                                                                               \
+    }
+#define BF6P_MFMA_NT(mt_, nt_, A_, B_)                                                                                  \
+    if constexpr (!nomfma) {                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) BF6P_MFMA1(mt_, nt_, A_, B_, q)                                   \
+    }
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    const u32x4 one8 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    u32x4 a0[3], a1[3], a2[3], a3[3], b0[3], b1[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) a0[pl] = a1[pl] = a2[pl] = a3[pl] = b0[pl] = b1[pl] = one8;
+
+    __builtin_amdgcn_s_barrier();                     // B_-1: stages 0, 1 and the first halo are in LDS
+    BF6P_READ_B(b0, 0, 0, 0, 0)
+    BF6P_READ_B(b1, 1, 0, 0, 0)
+    BF6P_READ_A(a0, 0, 0)
+    int slot = 0;
+#define BF6P_PIN() __builtin_amdgcn_sched_barrier(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int hb = chunk & 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // tap T + 1 (after the last tap: harmless reads of stale LDS)
+            const int ntap = tap == 8 ? 0 : tap + 1;
+            const int nr = ntap / 3, nsx = ntap - 3 * (ntap / 3);
+            const int nhb = tap == 8 ? hb ^ 1 : hb;
+            const int nslot = (slot + 1) & (RING - 1);
+            u32x4 m1[3];
+            BF6P_PIN()
+            BF6P_READ_A(a1, slot, 1)
+            BF6P_PIN()
+            BF6P_MFMA(0, a0)
+            BF6P_PIN()
+            BF6P_READ_A(a2, slot, 2)
+            BF6P_PIN()
+            BF6P_MFMA(1, a1)
+            BF6P_PIN()
+            BF6P_READ_A(a3, slot, 3)
+            BF6P_READ_B(m1, 1, nhb, nr, nsx)
+            BF6P_PIN()
+            BF6P_MFMA(2, a2)
+            BF6P_PIN()
+            BF6P_READ_A(a0, nslot, 0)
+            BF6P_PIN()
+            BF6P_MFMA_NT(3, 0, a3, b0)
+            BF6P_PIN()
+            BF6P_READ_B(b0, 0, nhb, nr, nsx)
+            BF6P_PIN()
+            BF6P_MFMA_NT(3, 1, a3, b1)
+            BF6P_PIN()
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): this wave is done with stage T (and holds tile 0 of T + 1)
+            __builtin_amdgcn_s_barrier();             // B_T: stage T + 2 has landed, the slot of stage T goes back to the loaders
+            if constexpr (!noread) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b1[pl] = m1[pl];
+            }
+            slot = nslot;
+        }
+    }
+#undef BF6P_PIN
+#undef BF6P_MFMA_NT
+#undef BF6P_MFMA
+#undef BF6P_MFMA1
+#undef BF6P_READ_A
+#undef BF6P_READ_B
+
+    const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[mt][nt][r];
+                if (p.bias) v += p.bias[m];
+                d0[(size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
 int ilog2(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -371,7 +599,7 @@ void nemar_bf6_pack(const float* w, void* packed, int K, int C, int dgrad, hipSt
 }
 
 void nemar_bf6_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
-                    int mode, void* scratch, int xcd_map, hipStream_t st) {
+                    int mode, void* scratch, int xcd_map, int dbg, int variant, hipStream_t st) {
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     hipLaunchKernelGGL(split_planes_kernel, dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
                        mode, total);
@@ -391,10 +619,25 @@ void nemar_bf6_conv(const float* src, const void* packed, const float* bias, flo
     p.fold = mode == BF6_DGRAD_REFLECT;
     p.aux_instr = p.fold ? nemar_cdiv((long long)2 * p.Ws * 16, 1024) : 0;
     p.plane16 = total;
+    p.dbg = dbg;
+    p.halo16 = (p.RT + 2) * p.Ws;
+    p.aux16 = p.fold ? 2 * p.Ws : 0;
     const int grid = N * p.tiles_per_img * p.mblks;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
     const dim3 g(grid), b(384);
+    if (variant == 1 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
+        const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
+        const int nb = nemar_cdiv(3 * ipr, 7);
+        const int abl = (dbg >> 16) & 3;
+        if (abl == 1 && nb == 4) hipLaunchKernelGGL((igemm_bf6p_kernel<4, 1>), g, b, 0, st, p);
+        else if (abl == 2 && nb == 4) hipLaunchKernelGGL((igemm_bf6p_kernel<4, 2>), g, b, 0, st, p);
+        else if (abl == 3 && nb == 4) hipLaunchKernelGGL((igemm_bf6p_kernel<4, 3>), g, b, 0, st, p);
+        else if (nb <= 3) hipLaunchKernelGGL((igemm_bf6p_kernel<3>), g, b, 0, st, p);
+        else if (nb == 4) hipLaunchKernelGGL((igemm_bf6p_kernel<4>), g, b, 0, st, p);
+        else hipLaunchKernelGGL((igemm_bf6p_kernel<5>), g, b, 0, st, p);
+        return;
+    }
     if (region <= 6) hipLaunchKernelGGL((igemm_bf6_kernel<6, 4>), g, b, 0, st, p);
     else if (region == 7) hipLaunchKernelGGL((igemm_bf6_kernel<7, 4>), g, b, 0, st, p);
     else if (region == 8) hipLaunchKernelGGL((igemm_bf6_kernel<8, 4>), g, b, 0, st, p);

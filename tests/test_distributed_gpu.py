@@ -110,7 +110,9 @@ def test_rccl_code_path_with_a_world_of_one_rank():
                             "--no-cpu-baseline", "--batch", "2", "--opt=--no_dropout"], env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        assert lines, (r.stdout[-1500:], r.stderr[-1500:])
+        outs.append(json.loads(lines[-1]))
     a, b = outs
     assert a["n_gpus"] == 1 and a["losses_finite"] and a["dist_buckets_launched"] > 0 and b["dist_buckets_launched"] == 0
     for k, v in a["losses"].items():

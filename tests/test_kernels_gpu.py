@@ -317,20 +317,31 @@ def test_adam(be):
     K.case_adam(be, n=100003)
 
 
-def test_conv_split_bf16_matrix_pipe(be):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_conv_split_bf16_matrix_pipe(be, variant):
     """3x3 stride-1 layers with >= 128 output channels on the bf16 MFMA with three-way split operands (conv_bf6.hip): padded,
     channel-blocked split planes; halo staged once per 16-channel chunk; weight-stage ring; zero and reflect padding; one and
     several row tiles per image, both 128-channel halves, 32- and 64-pixel rows."""
-    K.case_conv_bf6(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
-    K.case_conv_bf6(be, 1, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False)
-    K.case_conv_bf6(be, 1, 16, 8, 64, 128, K.PAD_REFLECT, dgrad=False)
+    be.lib.tune(21, variant)         # 0 first generation, 1 software-pipelined MFMA waves + exact-sized LDS regions
+    try:
+        K.case_conv_bf6(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
+        K.case_conv_bf6(be, 1, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False)
+        K.case_conv_bf6(be, 1, 16, 8, 64, 128, K.PAD_REFLECT, dgrad=False)
+        K.case_conv_bf6(be, 1, 48, 4, 128, 128, K.PAD_REFLECT, dgrad=False)      # 128-pixel rows: two rows per tile, 3 chunks
+    finally:
+        be.lib.tune(21, 0)
 
 
-def test_conv_split_bf16_reflect_data_gradient(be):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_conv_split_bf16_reflect_data_gradient(be, variant):
     """Data gradient of a reflect-padded 3x3 layer on the split-bf16 kernel: the folded border rows / slots written by the split
     pass are selected by address for (row 1, last filter row), (row H-2, first filter row) and the same in x; tiles that hold
     both special rows, only one, or none; and the zero-padded data gradient."""
-    K.case_conv_bf6(be, 1, 128, 8, 32, 16, K.PAD_REFLECT, dgrad=True)
-    K.case_conv_bf6(be, 2, 128, 16, 32, 32, K.PAD_REFLECT, dgrad=True)
-    K.case_conv_bf6(be, 1, 128, 12, 64, 16, K.PAD_REFLECT, dgrad=True)
-    K.case_conv_bf6(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
+    be.lib.tune(21, variant)
+    try:
+        K.case_conv_bf6(be, 1, 128, 8, 32, 16, K.PAD_REFLECT, dgrad=True)
+        K.case_conv_bf6(be, 2, 128, 16, 32, 32, K.PAD_REFLECT, dgrad=True)
+        K.case_conv_bf6(be, 1, 128, 12, 64, 16, K.PAD_REFLECT, dgrad=True)
+        K.case_conv_bf6(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
+    finally:
+        be.lib.tune(21, 0)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# split-bf16 kernel generations A/B + ablations of the pipelined one, then the full suite and bench on the faster one
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$1; mkdir -p $O
+cd $R
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "split_bf16" --tb=short 2>&1 | tail -5
+fmt='
+import sys, json
+for l in sys.stdin:
+    try: d = json.loads(l)
+    except Exception: continue
+    print("%-34s fwd %7.1f us %5.1f TF | dgrad %7.1f us %5.1f TF" % (d["layer"], d["fwd_us"], d["fwd_TF"], d["dgrad_us"], d["dgrad_TF"]))
+'
+for t in "21 0" "21 1" "21 1 --tune 2 65536" "21 1 --tune 2 131072" "21 1 --tune 2 196608" "21 1 --tune 2 262144" "21 1 --tune 15 0"; do
+  echo "== tune $t"; timeout 200 python tools/microbench_conv.py --iters 30 --only T.resblock --arena --tune $t 2>/dev/null | python -c "$fmt"
+done | tee $O/microbench.txt
+NEMAR_TUNE="21=1" NEMAR_BF6_REPORT=$O/bf6_accuracy_v2.txt timeout 600 python -m pytest tests/test_conv_real_shapes_gpu.py -q -k "split_bf16" --tb=short 2>&1 | tail -5; cat $O/bf6_accuracy_v2.txt
+for v in 0 1; do
+NEMAR_TUNE="21=$v" python bench.py --no-cpu-baseline > $O/bench_v$v.json 2> $O/bench.err; python -c "
+import json; d = json.load(open('$O/bench_v$v.json')); print('bench variant $v: %.2f img/s  %.2f ms/step  roofline %.1f TF (%.0f us)' % (d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_us']))"
+done
+NEMAR_TUNE="21=1" NEMAR_FULL_REPORT=$O/full_rows.txt timeout 1500 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | tail -30 > $O/pytest_gpu.txt
+tail -6 $O/pytest_gpu.txt
