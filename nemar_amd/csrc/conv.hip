@@ -1071,6 +1071,7 @@ static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup 
 // key 20: 3x3 / stride-1 layers with >= 128 output channels run on the bf16 matrix pipe with three-way split operands
 // (conv_bf6.hip) whenever the caller has registered a scratch arena large enough for the split source planes
 static int g_bf6 = 1;
+static int g_bf6_rot = 0;       // key 22: chunk-order rotation groups of the second-generation kernel
 static int g_bf6_variant = 0;   // key 21: 0 first generation, 1 software-pipelined MFMA waves
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
@@ -1724,7 +1725,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         if (g_bf6 && C1 == 0 && act == ACT_NONE && nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, mode) &&
             g_scratch && g_scratch_bytes >= nemar_bf6_scratch_bytes(N, C, H, W)) {
             if (!prepacked) nemar_bf6_pack(w, workspace, K, C, 0, st);
-            nemar_bf6_conv(x0, workspace, bias, y, N, H, W, K, C, mode, g_scratch, g_xcd_map, g_dbg, g_bf6_variant, st);
+            nemar_bf6_conv(x0, workspace, bias, y, N, H, W, K, C, mode, g_scratch, g_xcd_map, g_dbg, g_bf6_variant, g_bf6_rot, g_tl, st);
             NEMAR_CHECK_LAUNCH("conv2d_fwd (bf16 x 6)");
             return NEMAR_OK;
         }
@@ -1797,7 +1798,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         if (g_bf6 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, mode) &&
             g_scratch && g_scratch_bytes >= nemar_bf6_scratch_bytes(N, K, H, W)) {
             if (!prepacked) nemar_bf6_pack(w, workspace, K, C, 1, st);
-            nemar_bf6_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, mode, g_scratch, g_xcd_map, g_dbg, g_bf6_variant, st);
+            nemar_bf6_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, mode, g_scratch, g_xcd_map, g_dbg, g_bf6_variant, g_bf6_rot, g_tl, st);
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (bf16 x 6)");
             return NEMAR_OK;
         }
@@ -2081,7 +2082,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 20) { g_bf6 = value != 0; return NEMAR_OK; }
-    if (key == 21) { g_bf6_variant = value; return NEMAR_OK; }      // packed images made under the other setting are stale
+    if (key == 21) { g_bf6_variant = value; return NEMAR_OK; }
+    if (key == 22) { g_bf6_rot = value; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
     if (key == 19) { extern int g_narrow_fwd4; g_narrow_fwd4 = value != 0; return NEMAR_OK; }

@@ -14,4 +14,5 @@ size_t nemar_bf6_pack_bytes(int M, int Cred);                       // split, ti
 void nemar_bf6_pack(const float* w, void* packed, int K, int C, int dgrad, hipStream_t st);
 // src [N, Cred, H, W] fp32 -> dst [N, M, H, W] fp32 (+ bias[M] when non-null); `scratch` >= nemar_bf6_scratch_bytes
 void nemar_bf6_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M,
-                    int Cred, int mode, void* scratch, int xcd_map, int dbg, int variant, hipStream_t st);
+                    int Cred, int mode, void* scratch, int xcd_map, int dbg, int variant, int rot, long long* tl,
+                    hipStream_t st);

@@ -156,12 +156,19 @@ struct Bf6Params {
     int fold;                  // reflect data gradient: select the folded rows / slots
     int xcd;                   // workgroup -> tile mapping keeps neighbouring tiles on one XCD
     long long plane16;         // 16-byte words per plane
+    long long* tl;             // NEMAR_TIMELINE builds: cycle stamps of workgroup 0 (tools/timeline_bf6.py)
+    int rot;                   // > 1: chunk order rotated per tile in `rot` groups (second-generation kernel)
     int dbg;                   // ablation bits (nemar_tune key 2): 0x10000 no MFMAs, 0x20000 no LDS fragment reads, 0x40000 no global->LDS copies
 };
 
 __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// scalar (wave-uniform) base + per-lane byte offset: hipcc selects the SGPR-base form of global_load_lds for it
+__device__ __forceinline__ void glds16u(const u32x4* ubase, unsigned lane_bytes, u32x4* lds) {
+    glds16(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + lane_bytes), lds);
 }
 
 // REGION_KB = KiB of LDS per (plane, k group) halo region = DMA instructions per region; RING = weight-stage ring depth
@@ -362,7 +369,9 @@ __global__ __launch_bounds__(384) void igemm_bf6p_kernel(Bf6Params p) {
     u32x4* const Bs = smem + RING * ASTAGE16;
     const int region16 = p.halo16 + p.aux16, bbuf16 = 6 * region16;
 
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    // wave id as a SCALAR: everything the loaders derive from it (k group, global bases, LDS bases) then lives in SGPRs and the
+    // copies use the scalar-base + lane-offset address form — no address VGPR is rewritten between two copies in flight
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int t = blockIdx.x;
     if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
     const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
@@ -374,41 +383,69 @@ __global__ __launch_bounds__(384) void igemm_bf6p_kernel(Bf6Params p) {
         // ================================ loader waves ================================
         const int kg = wid - 4;
         const int hi = (p.halo16 + 63) >> 6, ai = (p.aux16 + 63) >> 6, ipr = hi + ai, nbl = 3 * ipr;
-        const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + kg * 384 + lane;
+        const unsigned lane16 = (unsigned)lane * 16u;                    // this lane's byte offset inside a 1 KiB copy
+        const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + kg * 384;
         const size_t wstage = (size_t)p.mblks * 768;
         const u32x4* const bsrc0 = p.planes + ((size_t)n * CG + kg) * p.HpWs;
         const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
-        const bool off = (p.dbg & 0x40000) != 0;
+        const bool offA = (p.dbg & (0x40000 | 0x80000)) != 0, offB = (p.dbg & (0x40000 | 0x100000)) != 0, off = offA || offB;
+        // Every workgroup walks the same packed weights; started together they would all ask the same few L2 channels for
+        // the same 12 KiB stage at the same moment.  p.rot > 1: workgroups start the reduction at different 16-channel chunks
+        // (chunk order rotated by tile index; the summation order of a tile is still fixed, run to run).
+        const int rot = p.rot > 1 ? (ptile % p.rot) * (nchunks / p.rot) : 0;
         int islot = 0, ci = 0, ti = 0;
+        int ce = rot;                          // reduction chunk that sequence position ci maps to
+        int ce1 = rot + 1 == nchunks ? 0 : rot + 1;
         int bpl = 0, bin = 0, bcnt = nbl;
-        const u32x4* asrc = wsrc0;
-#define BF6P_HALO_ONE(chunk_, pl_, in_)                                                                                 \
+        const u32x4* asrc = wsrc0 + (size_t)rot * 9 * wstage;
+#define BF6P_HALO_ONE(seq_, chunk_, pl_, in_)             /* seq_ = position in this workgroup's chunk order */        \
         {                                                                                                               \
             const bool aux_ = (in_) >= hi;                                                                              \
             const int j_ = aux_ ? (in_) - hi : (in_);                                                                   \
             const int w_ = j_ * 64 + lane;                                                                              \
-            if (w_ < (aux_ ? p.aux16 : p.halo16) && !off)                                                               \
-                glds16(bsrc0 + (size_t)(pl_) * p.plane16 + (size_t)(2 * (chunk_)) * p.HpWs + (aux_ ? aux_off : halo_off) + w_, \
-                       Bs + ((chunk_) & 1) * bbuf16 + ((pl_) * 2 + kg) * region16 + (aux_ ? p.halo16 : 0) + j_ * 64);   \
+            if (w_ < (aux_ ? p.aux16 : p.halo16) && !offB)                                                              \
+                glds16u(bsrc0 + (size_t)(pl_) * p.plane16 + (size_t)(2 * (chunk_)) * p.HpWs + (aux_ ? aux_off : halo_off) + j_ * 64, lane16, \
+                       Bs + ((seq_) & 1) * bbuf16 + ((pl_) * 2 + kg) * region16 + (aux_ ? p.halo16 : 0) + j_ * 64);     \
         }
 #define BF6P_ISSUE()                                                                                                    \
         {                                                                                                               \
             u32x4* const ad_ = As + islot * ASTAGE16 + kg * 384;                                                        \
-            if (!off) { _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(asrc + q * 64, ad_ + q * 64); }            \
+            if (!offA) {                                                                                                \
+                /* all six addresses first, in six DIFFERENT register pairs: rewriting the address VGPRs of a copy that is   \
+                   still in flight stalls the wave until that copy completes (measured: 290 cycles per copy, L2 latency) */   \
+                const u32x4* a_[6];                                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 6; ++q)                                                           \
+                    a_[q] = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(asrc + q * 64) + lane16);      \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(a_[q], ad_ + q * 64);                              \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+            }                                                                                                           \
+            BF6P_ASTAMP()                                                                                               \
             if (ti == WINDOW_FIRST) { bpl = 0; bin = 0; bcnt = (ci + 1 < nchunks) ? 0 : nbl; }                          \
             _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                            \
                 if (bcnt < nbl) {                                                                                       \
-                    BF6P_HALO_ONE(ci + 1, bpl, bin);                                                                    \
+                    BF6P_HALO_ONE(ci + 1, ce1, bpl, bin);                                                               \
                     ++bcnt;                                                                                             \
                     if (++bin == ipr) { bin = 0; ++bpl; }                                                               \
-                } else if (!off) {                                                                                      \
-                    glds16(asrc, ad_);             /* filler: keeps the per-stage instruction count constant */          \
+                } else if (!offA) {                                                                                     \
+                    glds16u(asrc, lane16, ad_);    /* filler: keeps the per-stage instruction count constant */          \
                 }                                                                                                       \
             }                                                                                                           \
             asrc += wstage;                                                                                             \
             islot = (islot + 1) & (RING - 1);                                                                           \
-            if (++ti == 9) { ti = 0; ++ci; }                                                                            \
+            if (++ti == 9) {                                                                                            \
+                ti = 0; ++ci;                                                                                           \
+                ce = ce1;                                                                                               \
+                ce1 = ce1 + 1 == nchunks ? 0 : ce1 + 1;                                                                 \
+                if (ce == 0) asrc = wsrc0;                 /* wrapped around the end of the packed weights */           \
+            }                                                                                                           \
         }
+#ifdef NEMAR_TIMELINE
+        long long astamp = 0;
+#define BF6P_ASTAMP() astamp = clock64();
+#else
+#define BF6P_ASTAMP()
+#endif
 #define BF6P_WAIT_IN_FLIGHT(n_)                                                                                         \
         {                                                                                                               \
             const int ns_ = off ? 0 : (n_);                                                                             \
@@ -417,16 +454,28 @@ __global__ __launch_bounds__(384) void igemm_bf6p_kernel(Bf6Params p) {
             else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 15) | (((2 * PER) >> 4) << 14));                      \
         }
         for (int pl = 0; pl < 3; ++pl)
-            for (int in = 0; in < ipr; ++in) BF6P_HALO_ONE(0, pl, in);
+            for (int in = 0; in < ipr; ++in) BF6P_HALO_ONE(0, rot, pl, in);
         int issued = 0;
         for (; issued < RING && issued < nstage; ++issued) BF6P_ISSUE();
         BF6P_WAIT_IN_FLIGHT(issued - 2);              // stages 0 and 1 (and the first halo) have landed
         __builtin_amdgcn_s_barrier();                 // B_-1
+#ifdef NEMAR_TIMELINE
+        const bool lprobe = p.tl != nullptr && blockIdx.x == 0 && lane == 0;
+#define BF6P_LSTAMP(i_) if (lprobe && j >= 40 && j < 48) p.tl[(wid * 8 + (j - 40)) * 4 + (i_)] = ((i_) == 3 ? astamp : clock64());
+#else
+#define BF6P_LSTAMP(i_)
+#endif
         for (int j = 0; j < nstage; ++j) {
+            BF6P_LSTAMP(0)
             BF6P_WAIT_IN_FLIGHT(issued - (j + 3));    // stage j + 2 has landed
+            BF6P_LSTAMP(1)
             __builtin_amdgcn_s_barrier();             // B_j: the MFMA waves have finished reading stage j
+            BF6P_LSTAMP(2)
             if (issued < nstage) { BF6P_ISSUE(); ++issued; }
+            BF6P_LSTAMP(3)                            // (the stamp taken after the six weight copies of this issue)
         }
+#undef BF6P_LSTAMP
+#undef BF6P_ASTAMP
 #undef BF6P_WAIT_IN_FLIGHT
 #undef BF6P_ISSUE
 #undef BF6P_HALO_ONE
@@ -534,8 +583,19 @@ __global__ __launch_bounds__(384) void igemm_bf6p_kernel(Bf6Params p) {
             BF6P_PIN()
             BF6P_MFMA_NT(3, 1, a3, b1)
             BF6P_PIN()
+#ifdef NEMAR_TIMELINE
+            const int T_ = chunk * 9 + tap;
+            const bool mprobe = p.tl != nullptr && blockIdx.x == 0 && lane == 0 && T_ >= 40 && T_ < 48;
+            if (mprobe) p.tl[(wid * 8 + (T_ - 40)) * 4 + 0] = clock64();
+#endif
             __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): this wave is done with stage T (and holds tile 0 of T + 1)
+#ifdef NEMAR_TIMELINE
+            if (mprobe) p.tl[(wid * 8 + (T_ - 40)) * 4 + 1] = clock64();
+#endif
             __builtin_amdgcn_s_barrier();             // B_T: stage T + 2 has landed, the slot of stage T goes back to the loaders
+#ifdef NEMAR_TIMELINE
+            if (mprobe) p.tl[(wid * 8 + (T_ - 40)) * 4 + 2] = clock64();
+#endif
             if constexpr (!noread) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) b1[pl] = m1[pl];
@@ -549,6 +609,228 @@ __global__ __launch_bounds__(384) void igemm_bf6p_kernel(Bf6Params p) {
 #undef BF6P_MFMA1
 #undef BF6P_READ_A
 #undef BF6P_READ_B
+
+    const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[mt][nt][r];
+                if (p.bias) v += p.bias[m];
+                d0[(size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
+// ---- third generation: no loader waves ---------------------------------------------------------------------------------
+// Measured on the second generation (tools/timeline_bf6.py, tools/probes/dma_probe2.hip): a wave that streams MFMAs back to back
+// monopolises the instruction issue of its SIMD.  The loader waves share SIMDs 0 and 1 with MFMA waves 0 and 1 and got ONE
+// instruction issued per ~8 MFMAs (a six-copy burst that takes 120 cycles on a quiet SIMD took 1750, s_setprio makes no
+// difference), so every tap ended with the MFMA waves parked at the barrier while the loaders finished issuing: tap time =
+// MFMA block + loader tail, 2900 cycles instead of 1750.  Here the four MFMA waves issue the copies themselves, a few per 12-MFMA
+// block, in the issue shadow of their own MFMAs: wave w moves a quarter of every weight stage (3 x 1 KiB) and every fourth halo
+// copy, waits for ITS copies of stage T + 2 (counted vmcnt) before barrier T, and the barrier makes all four quarters visible.
+// Four waves per workgroup = one per SIMD = the whole 512-register file for each.
+template <int NBW>       // halo copy slots per wave per tap (taps 2..8 of a chunk carry the next chunk's halo)
+__global__ __launch_bounds__(256) void igemm_bf6m_kernel(Bf6Params p) {
+    constexpr int RING = 4, ASTAGE16 = 768, PER = 3 + NBW;
+    constexpr int SMEM16 = 9728;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM16];
+    u32x4* const As = smem;
+    u32x4* const Bs = smem + RING * ASTAGE16;
+    const int region16 = p.halo16 + p.aux16, bbuf16 = 6 * region16;
+
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
+    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int CG = p.Cred >> 3;
+
+    // ---- this wave's share of the copies ----
+    const int hi = (p.halo16 + 63) >> 6, ai = (p.aux16 + 63) >> 6, ipr = hi + ai, ncopies = 6 * ipr;
+    const u32x4* asrc = p.wp + (size_t)mblk * 768 + wid * 192 + lane;        // + stage * mblks * 768
+    const size_t wstage = (size_t)p.mblks * 768;
+    const u32x4* const bsrc0 = p.planes + (size_t)n * CG * p.HpWs + lane;
+    const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
+    int bi = ncopies, breg = 0, bin = 0;           // halo stream of the chunk being fetched: linear copy index, region, copy in region
+    int bchunk = 0;                                // ... and that chunk
+    // one halo copy (or, when this wave's share of the chunk is done, a re-issue of its first weight copy: the per-tap copy count
+    // stays constant, which is what the counted waits rely on)
+#define BF6M_COPY_B(aslot_)                                                                                             \
+    {                                                                                                                   \
+        if (bi < ncopies) {                                                                                             \
+            const bool aux_ = bin >= hi;                                                                                \
+            const int j_ = aux_ ? bin - hi : bin;                                                                       \
+            const int pl_ = breg >> 1, kg_ = breg & 1;                                                                  \
+            if (j_ * 64 + lane < (aux_ ? p.aux16 : p.halo16))                                                           \
+                glds16(bsrc0 + (size_t)pl_ * p.plane16 + (size_t)(2 * bchunk + kg_) * p.HpWs + (aux_ ? aux_off : halo_off) + j_ * 64, \
+                       Bs + (bchunk & 1) * bbuf16 + breg * region16 + (aux_ ? p.halo16 : 0) + j_ * 64);                 \
+            bi += 4;                                                                                                    \
+            bin += 4;                                                                                                   \
+            while (bin >= ipr) { bin -= ipr; ++breg; }                                                                  \
+        } else {                                                                                                        \
+            glds16(asrc - wstage, As + (aslot_) * ASTAGE16 + wid * 192);                                                \
+        }                                                                                                               \
+    }
+#define BF6M_HALO_BEGIN(chunk_)                                                                                         \
+    {                                                                                                                   \
+        bchunk = (chunk_);                                                                                              \
+        bi = bchunk < nchunks ? wid : ncopies;                                                                          \
+        breg = 0;                                                                                                       \
+        bin = wid;                                                                                                      \
+        while (bin >= ipr) { bin -= ipr; ++breg; }                                                                      \
+    }
+    // weight copy q (0..2) of the stage being issued into ring slot aslot_
+#define BF6M_COPY_A(aslot_, q_) glds16(asrc + (q_) * 64, As + (aslot_) * ASTAGE16 + wid * 192 + (q_) * 64);
+    // a whole stage at once (prologue): ti_ = its tap
+#define BF6M_ISSUE_STAGE(aslot_, ci_, ti_)                                                                              \
+    {                                                                                                                   \
+        BF6M_COPY_A(aslot_, 0) BF6M_COPY_A(aslot_, 1) BF6M_COPY_A(aslot_, 2)                                            \
+        asrc += wstage;                                                                                                 \
+        if ((ti_) == 2) BF6M_HALO_BEGIN((ci_) + 1)                                                                      \
+        _Pragma("unroll") for (int q = 0; q < NBW; ++q) BF6M_COPY_B(aslot_)                                             \
+    }
+#define BF6M_WAIT_OWN(n_)      /* at most n_ stages' worth of this wave's copies still in flight */                     \
+    {                                                                                                                   \
+        if ((n_) <= 0) wait_vmem();                                                                                     \
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | (PER & 15) | ((PER >> 4) << 14));                                      \
+    }
+    static_assert(PER < 16, "one stage of copies per wave");
+
+    // ---- MFMA side ----
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int row[2], col[2];
+    bool top[2], bot[2], lft[2], rgt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int px = 64 * wid + 32 * nt + l31;
+        row[nt] = px >> p.wshift;
+        col[nt] = px & (p.W - 1);
+        const int y = y0 + row[nt];
+        top[nt] = p.fold && y == 1;
+        bot[nt] = p.fold && y == p.H - 2;
+        lft[nt] = p.fold && col[nt] == 1;
+        rgt[nt] = p.fold && col[nt] == p.W - 2;
+    }
+    const int auxoff = p.halo16;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#define BF6M_READ_B(dst_, nt_, hb_, r_, sx_)                                                                            \
+    {                                                                                                                   \
+        const u32x4* const Bb_ = Bs + (hb_) * bbuf16 + lhi * region16;                                                  \
+        int ra_ = (row[nt_] + (r_)) * p.Ws;                                                                             \
+        if ((r_) == 2) ra_ = top[nt_] ? auxoff : ra_;                                                                   \
+        if ((r_) == 0) ra_ = bot[nt_] ? auxoff + p.Ws : ra_;                                                            \
+        int sl_ = col[nt_] + (sx_);                                                                                     \
+        if ((sx_) == 2) sl_ = lft[nt_] ? p.W + 2 : sl_;                                                                 \
+        if ((sx_) == 0) sl_ = rgt[nt_] ? p.W + 3 : sl_;                                                                 \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) dst_[pl] = Bb_[pl * 2 * region16 + ra_ + sl_];                 \
+    }
+#define BF6M_READ_A(dst_, slot_, mt_)                                                                                   \
+    {                                                                                                                   \
+        const u32x4* const Ab_ = As + (slot_) * ASTAGE16 + lhi * 128 + l31 + (mt_) * 32;                                \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) dst_[pl] = Ab_[pl * 256];                                      \
+    }
+#define BF6M_MFMA1(mt_, nt_, A_, B_, q_)                                                                               \
+    acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_[PA[q_]]),                     \
+                                                            __builtin_bit_cast(bf16x8, B_[PB[q_]]), acc[mt_][nt_], 0, 0, 0);
+#define BF6M_MFMA(mt_, A_)                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                                                     \
+        BF6M_MFMA1(mt_, 0, A_, b0, q)                                                                                   \
+        BF6M_MFMA1(mt_, 1, A_, b1, q)                                                                                   \
+    }
+#define BF6M_MFMA_NT(mt_, nt_, A_, B_) _Pragma("unroll") for (int q = 0; q < 6; ++q) BF6M_MFMA1(mt_, nt_, A_, B_, q)
+#define BF6M_PIN() __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    u32x4 a0[3], a1[3], a2[3], a3[3], b0[3], b1[3];
+
+    // ---- prologue: this wave's quarter of the first halo and of stages 0, 1, 2 ----
+    BF6M_HALO_BEGIN(0)
+    while (bi < ncopies) BF6M_COPY_B(0)
+    BF6M_ISSUE_STAGE(0, 0, 0)
+    BF6M_ISSUE_STAGE(1, 0, 1)
+    BF6M_ISSUE_STAGE(2, 0, 2)
+    BF6M_WAIT_OWN(1)                                  // everything but stage 2
+    __builtin_amdgcn_s_barrier();                     // B_-1: stages 0, 1 and the first halo are in LDS, all four quarters
+    BF6M_READ_B(b0, 0, 0, 0, 0)
+    BF6M_READ_B(b1, 1, 0, 0, 0)
+    BF6M_READ_A(a0, 0, 0)
+    int slot = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int hb = chunk & 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ntap = tap == 8 ? 0 : tap + 1;
+            const int nr = ntap / 3, nsx = ntap - 3 * (ntap / 3);
+            const int nhb = tap == 8 ? hb ^ 1 : hb;
+            const int nslot = (slot + 1) & (RING - 1);
+            // the stage issued during this tap: T + 3, into the slot stage T - 1 vacated at the last barrier
+            const int iti = tap + 3 >= 9 ? tap + 3 - 9 : tap + 3;
+            const int ici = tap + 3 >= 9 ? chunk + 1 : chunk;
+            const int islot = (slot + 3) & (RING - 1);
+            const bool issue = ici < nchunks;
+            u32x4 m1[3];
+            BF6M_PIN()
+            BF6M_READ_A(a1, slot, 1)
+            BF6M_PIN()
+            BF6M_MFMA(0, a0)
+            BF6M_PIN()
+            if (issue) { BF6M_COPY_A(islot, 0) BF6M_COPY_A(islot, 1) }
+            BF6M_READ_A(a2, slot, 2)
+            BF6M_PIN()
+            BF6M_MFMA(1, a1)
+            BF6M_PIN()
+            if (issue) {
+                BF6M_COPY_A(islot, 2)
+                asrc += wstage;
+                if (iti == 2) BF6M_HALO_BEGIN(ici + 1)
+#pragma unroll
+                for (int q = 0; q < NBW; ++q) BF6M_COPY_B(islot)
+            }
+            BF6M_READ_A(a3, slot, 3)
+            BF6M_READ_B(m1, 1, nhb, nr, nsx)
+            BF6M_PIN()
+            BF6M_MFMA(2, a2)
+            BF6M_PIN()
+            BF6M_READ_A(a0, nslot, 0)
+            BF6M_PIN()
+            BF6M_MFMA_NT(3, 0, a3, b0)
+            BF6M_PIN()
+            BF6M_READ_B(b0, 0, nhb, nr, nsx)
+            BF6M_PIN()
+            BF6M_MFMA_NT(3, 1, a3, b1)
+            BF6M_PIN()
+            BF6M_WAIT_OWN(issue ? 1 : 0)              // this wave's copies of stage T + 2 have landed
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): done reading stage T (tile 0 of T + 1 is in registers)
+            __builtin_amdgcn_s_barrier();             // B_T: stage T + 2 complete for everyone; slot of stage T is free
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b1[pl] = m1[pl];
+            slot = nslot;
+        }
+    }
+#undef BF6M_PIN
+#undef BF6M_MFMA_NT
+#undef BF6M_MFMA
+#undef BF6M_MFMA1
+#undef BF6M_READ_A
+#undef BF6M_READ_B
+#undef BF6M_WAIT_OWN
+#undef BF6M_ISSUE_STAGE
+#undef BF6M_COPY_A
+#undef BF6M_HALO_BEGIN
+#undef BF6M_COPY_B
 
     const size_t HW = (size_t)p.H * p.W;
 #pragma unroll
@@ -599,7 +881,7 @@ void nemar_bf6_pack(const float* w, void* packed, int K, int C, int dgrad, hipSt
 }
 
 void nemar_bf6_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
-                    int mode, void* scratch, int xcd_map, int dbg, int variant, hipStream_t st) {
+                    int mode, void* scratch, int xcd_map, int dbg, int variant, int rot, long long* tl, hipStream_t st) {
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     hipLaunchKernelGGL(split_planes_kernel, dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
                        mode, total);
@@ -620,12 +902,21 @@ void nemar_bf6_conv(const float* src, const void* packed, const float* bias, flo
     p.aux_instr = p.fold ? nemar_cdiv((long long)2 * p.Ws * 16, 1024) : 0;
     p.plane16 = total;
     p.dbg = dbg;
+    p.tl = tl;
+    p.rot = (rot > 1 && (Cred / 16) % rot == 0) ? rot : 0;
     p.halo16 = (p.RT + 2) * p.Ws;
     p.aux16 = p.fold ? 2 * p.Ws : 0;
     const int grid = N * p.tiles_per_img * p.mblks;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
     const dim3 g(grid), b(384);
+    if (variant == 2 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
+        const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
+        const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), 7);
+        if (nbw <= 2) hipLaunchKernelGGL((igemm_bf6m_kernel<2>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_bf6m_kernel<3>), g, dim3(256), 0, st, p);
+        return;
+    }
     if (variant == 1 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nb = nemar_cdiv(3 * ipr, 7);

@@ -324,12 +324,15 @@ def test_adam(be):
     K.case_adam(be)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_conv_split_bf16_matrix_pipe(be, variant):
     """3x3 stride-1 layers with >= 128 output channels on the bf16 MFMA with three-way split operands (conv_bf6.hip): padded,
     channel-blocked split planes; halo staged once per 16-channel chunk; weight-stage ring; zero and reflect padding; one and
     several row tiles per image, both 128-channel halves, 32- and 64-pixel rows."""
-    be.lib.tune(21, variant)         # 0 first generation, 1 software-pipelined MFMA waves + exact-sized LDS regions
+    # 0 first generation, 1 software-pipelined MFMA waves + exact-sized LDS regions, 2 no loader waves (the MFMA waves issue the
+    # copies), 3 = 1 with the chunk order rotated per tile (two groups)
+    be.lib.tune(21, 1 if variant == 3 else variant)
+    be.lib.tune(22, 2 if variant == 3 else 0)
     try:
         K.case_conv_bf6(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
         K.case_conv_bf6(be, 1, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False)
@@ -337,14 +340,16 @@ def test_conv_split_bf16_matrix_pipe(be, variant):
         K.case_conv_bf6(be, 1, 48, 4, 128, 128, K.PAD_REFLECT, dgrad=False)      # 128-pixel rows: two rows per tile, 3 chunks
     finally:
         be.lib.tune(21, 0)
+        be.lib.tune(22, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_conv_split_bf16_reflect_data_gradient(be, variant):
     """Data gradient of a reflect-padded 3x3 layer on the split-bf16 kernel: the folded border rows / slots written by the split
     pass are selected by address for (row 1, last filter row), (row H-2, first filter row) and the same in x; tiles that hold
     both special rows, only one, or none; and the zero-padded data gradient."""
-    be.lib.tune(21, variant)
+    be.lib.tune(21, 1 if variant == 3 else variant)
+    be.lib.tune(22, 2 if variant == 3 else 0)
     try:
         K.case_conv_bf6(be, 1, 128, 8, 32, 16, K.PAD_REFLECT, dgrad=True)
         K.case_conv_bf6(be, 2, 128, 16, 32, 32, K.PAD_REFLECT, dgrad=True)
@@ -352,3 +357,4 @@ def test_conv_split_bf16_reflect_data_gradient(be, variant):
         K.case_conv_bf6(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
     finally:
         be.lib.tune(21, 0)
+        be.lib.tune(22, 0)
