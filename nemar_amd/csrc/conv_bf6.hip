@@ -782,12 +782,22 @@ __global__ __launch_bounds__(256) void igemm_bf6m_kernel(Bf6Params p) {
             const int islot = (slot + 3) & (RING - 1);
             const bool issue = ici < nchunks;
             u32x4 m1[3];
+#ifdef NEMAR_TIMELINE
+            const int T_ = chunk * 9 + tap;
+            const bool mprobe = p.tl != nullptr && blockIdx.x == 0 && lane == 0 && T_ >= 40 && T_ < 48;
+#define BF6M_STAMP(i_) if (mprobe) p.tl[(wid * 8 + (T_ - 40)) * 8 + (i_)] = clock64();
+#else
+#define BF6M_STAMP(i_)
+#endif
+            BF6M_STAMP(0)
             BF6M_PIN()
             BF6M_READ_A(a1, slot, 1)
             BF6M_PIN()
             BF6M_MFMA(0, a0)
             BF6M_PIN()
+            BF6M_STAMP(1)
             if (issue) { BF6M_COPY_A(islot, 0) BF6M_COPY_A(islot, 1) }
+            BF6M_STAMP(2)
             BF6M_READ_A(a2, slot, 2)
             BF6M_PIN()
             BF6M_MFMA(1, a1)
@@ -799,6 +809,7 @@ __global__ __launch_bounds__(256) void igemm_bf6m_kernel(Bf6Params p) {
 #pragma unroll
                 for (int q = 0; q < NBW; ++q) BF6M_COPY_B(islot)
             }
+            BF6M_STAMP(3)
             BF6M_READ_A(a3, slot, 3)
             BF6M_READ_B(m1, 1, nhb, nr, nsx)
             BF6M_PIN()
@@ -812,9 +823,14 @@ __global__ __launch_bounds__(256) void igemm_bf6m_kernel(Bf6Params p) {
             BF6M_PIN()
             BF6M_MFMA_NT(3, 1, a3, b1)
             BF6M_PIN()
+            BF6M_STAMP(4)
             BF6M_WAIT_OWN(issue ? 1 : 0)              // this wave's copies of stage T + 2 have landed
+            BF6M_STAMP(5)
             __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): done reading stage T (tile 0 of T + 1 is in registers)
+            BF6M_STAMP(6)
             __builtin_amdgcn_s_barrier();             // B_T: stage T + 2 complete for everyone; slot of stage T is free
+            BF6M_STAMP(7)
+#undef BF6M_STAMP
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) b1[pl] = m1[pl];
             slot = nslot;
@@ -831,6 +847,277 @@ __global__ __launch_bounds__(256) void igemm_bf6m_kernel(Bf6Params p) {
 #undef BF6M_COPY_A
 #undef BF6M_HALO_BEGIN
 #undef BF6M_COPY_B
+
+    const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[mt][nt][r];
+                if (p.bias) v += p.bias[m];
+                d0[(size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
+// ---- fourth generation: the third, rebuilt around what its timeline showed ------------------------------------------------
+// (tools/timeline_bf6.py, gpurun_out/timeline_bf6_v3.txt: a 12-MFMA block takes 384 cycles of matrix pipe but 520-700 in the
+// kernel, the two halo copies of a tap with their address arithmetic and branches 500, and the six-deep dependent MFMA chains of
+// the last block 40+ cycles per MFMA.)  Same data flow and protocol, but
+//   * every fragment of tap T + 1 is read during tap T into a second register set (one wave per SIMD = 512 registers), so all 48
+//     MFMAs of a tap are independent of this tap's LDS reads and rotate over the eight accumulators;
+//   * the tap body is branch-free: the halo copies of a chunk are described once per wave (source offset, LDS offset, lane limit)
+//     in registers indexed by the unrolled tap position, the tail re-issues harmless copies instead of skipping, and the per-tap
+//     copy count is a compile-time function of the tap, so the counted vmcnt waits need no filler copies outside the window;
+//   * with A(T + 1) fully in registers at barrier T - 1... the weight stage for tap T + 4 is issued during tap T (two taps of lead);
+//   * sched_group_barrier prescribes the interleaving (one LDS read or one copy and a couple of scalar/vector ALU instructions per
+//     MFMA), instead of 12-MFMA blocks separated by everything else.
+// Two chunks (18 taps) per loop iteration, so that the register-set parity is a compile-time constant of the tap position.
+template <int NBW>       // halo copy slots per wave per tap on taps 3..8 of a chunk (they carry the next chunk's halo)
+__global__ __launch_bounds__(256) void igemm_bf6x_kernel(Bf6Params p) {
+    constexpr int RING = 4, ASTAGE16 = 768, KB = 6 * NBW;
+    constexpr int SMEM16 = 9728;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM16];
+    u32x4* const As = smem;
+    u32x4* const Bs = smem + RING * ASTAGE16;
+    const int region16 = p.halo16 + p.aux16, bbuf16 = 6 * region16;
+
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
+    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int CG = p.Cred >> 3;
+
+    // ---- this wave's copies: weights = words [192 wid, 192 wid + 192) of every 768-word stage; halo = every fourth 1 KiB copy ----
+    const int hi = (p.halo16 + 63) >> 6, ai = (p.aux16 + 63) >> 6, ipr = hi + ai, ncopies = 6 * ipr;
+    const size_t wstage = (size_t)p.mblks * 768;
+    const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + wid * 192;
+    const u32x4* const bsrc0 = p.planes + (size_t)n * CG * p.HpWs;
+    const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
+    unsigned goff[KB], blds[KB];      // per halo copy of this wave: source word offset from the chunk's images (+ lane), LDS word offset
+    int blim[KB];                     // ... and the number of lanes that take part
+    int share = 0;
+    {
+        int breg = 0, bin = wid;
+        while (bin >= ipr) { bin -= ipr; ++breg; }
+        unsigned g = 0, l = 0;
+        int lim = 0;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (wid + 4 * k < ncopies) {
+                const bool aux = bin >= hi;
+                const int j = aux ? bin - hi : bin;
+                const int pl = breg >> 1, kg = breg & 1;
+                g = (unsigned)((size_t)pl * p.plane16 + (size_t)kg * p.HpWs + (aux ? aux_off : halo_off) + j * 64);
+                l = (unsigned)(breg * region16 + (aux ? p.halo16 : 0) + j * 64);
+                lim = (aux ? p.aux16 : p.halo16) - j * 64;
+                share = k + 1;
+                bin += 4;
+                while (bin >= ipr) { bin -= ipr; ++breg; }
+            }
+            goff[k] = g + lane;       // (slots beyond the share repeat the last copy)
+            blds[k] = l;
+            blim[k] = lim;
+        }
+    }
+    // copies of one stage: COUNT(ti) = 3 + (ti >= 3 ? NBW : 0) wave-instructions, in this order
+#define BF6X_COPIES(stage_, ti_, ci_)                                                                                   \
+    {                                                                                                                   \
+        const int st_ = min((stage_), nstage - 1);                   /* tail: harmless re-copies of the last stage */   \
+        const u32x4* const a_ = wsrc0 + (size_t)st_ * wstage + lane;                                                    \
+        u32x4* const ad_ = As + ((stage_) & (RING - 1)) * ASTAGE16 + wid * 192;                                         \
+        glds16(a_, ad_);                                                                                                \
+        glds16(a_ + 64, ad_ + 64);                                                                                      \
+        glds16(a_ + 128, ad_ + 128);                                                                                    \
+        if ((ti_) >= 3) {                                                                                               \
+            const int hc_ = min((ci_) + 1, nchunks - 1);             /* chunk whose halo travels with this stage */     \
+            const u32x4* const bb_ = bsrc0 + (size_t)(2 * hc_) * p.HpWs;                                                \
+            u32x4* const bd_ = Bs + (((ci_) + 1) & 1) * bbuf16;                                                         \
+            _Pragma("unroll") for (int q = 0; q < NBW; ++q) {                                                           \
+                const int k_ = ((ti_) - 3) * NBW + q;                                                                   \
+                if (lane < blim[k_]) glds16(bb_ + goff[k_], bd_ + blds[k_]);                                            \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+#define BF6X_COUNT(ti_) (3 + ((ti_) >= 3 ? NBW : 0))
+#define BF6X_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14));
+
+    // ---- MFMA side ----
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int row[2], col[2];
+    bool top[2], bot[2], lft[2], rgt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int px = 64 * wid + 32 * nt + l31;
+        row[nt] = px >> p.wshift;
+        col[nt] = px & (p.W - 1);
+        const int y = y0 + row[nt];
+        top[nt] = p.fold && y == 1;
+        bot[nt] = p.fold && y == p.H - 2;
+        lft[nt] = p.fold && col[nt] == 1;
+        rgt[nt] = p.fold && col[nt] == p.W - 2;
+    }
+    const int auxoff = p.halo16;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    u32x4 af[2][4][3], bf[2][2][3];
+    // all fragments of tap (r_, sx_) of the chunk in halo buffer hb_, weights in ring slot slot_, into register set set_
+#define BF6X_READ(set_, slot_, hb_, r_, sx_)                                                                            \
+    {                                                                                                                   \
+        const u32x4* const Bb_ = Bs + (hb_) * bbuf16 + lhi * region16;                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                              \
+            int ra_ = (row[nt] + (r_) + z) * p.Ws;       /* z: see the loop head */                                     \
+            if ((r_) == 2) ra_ = top[nt] ? auxoff : ra_;                                                                \
+            if ((r_) == 0) ra_ = bot[nt] ? auxoff + p.Ws : ra_;                                                         \
+            int sl_ = col[nt] + (sx_);                                                                                  \
+            if ((sx_) == 2) sl_ = lft[nt] ? p.W + 2 : sl_;                                                              \
+            if ((sx_) == 0) sl_ = rgt[nt] ? p.W + 3 : sl_;                                                              \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) bf[set_][nt][pl] = Bb_[pl * 2 * region16 + ra_ + sl_];     \
+        }                                                                                                               \
+        const u32x4* const Ab_ = As + (slot_) * ASTAGE16 + lhi * 128 + l31;                                             \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) af[set_][mt][pl] = Ab_[pl * 256 + mt * 32];                \
+    }
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+
+    // ---- prologue: this wave's share of the first halo and of stages 0..3 ----
+    {
+        const u32x4* const bb = bsrc0;
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < share && lane < blim[k]) glds16(bb + goff[k], Bs + blds[k]);
+    }
+    BF6X_COPIES(0, 0, 0)
+    BF6X_COPIES(1, 1, 0)
+    BF6X_COPIES(2, 2, 0)
+    BF6X_COPIES(3, 3, 0)
+    BF6X_VMCNT(6 + NBW)                               // (stages 2 and 3 may be in flight) the first halo and stages 0, 1 have landed
+    __builtin_amdgcn_s_barrier();                     // ... for all four waves
+    int z = 0;
+    BF6X_READ(0, 0, 0, 0, 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                     // every wave holds the fragments of tap 0: slot 0 may be refilled (tap 0 does)
+    for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {
+        // an opaque zero per iteration: keeps hipcc from hoisting the 18 taps' fragment addresses out of the loop (that costs
+        // more registers than the file has: 512 + spills) — they are three VALU instructions each to recompute
+#ifndef NEMAR_HOST_EMULATION
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+#endif
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int chunk = chunk0 + half;
+            if (half == 1 && chunk >= nchunks) break;
+            const int hb = half;                      // = chunk & 1
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int cur = (tap + half) & 1, nxt = cur ^ 1;          // = T & 1 with T = 9 chunk + tap
+                const int T = chunk * 9 + tap;
+                // tap T + 1: every fragment into the other register set (after the last tap: a harmless read of stale LDS);
+                // stage T + 4 into the slot of stage T (read during tap T - 1): two full taps ahead of its first use.
+                // 23 + NBW slots of [<= 1 memory instruction + its scalar / vector arithmetic][2 MFMAs], pinned: hipcc otherwise
+                // clumps the reads and copies, and every clump longer than an MFMA's 32-cycle shadow idles the matrix pipe
+#ifdef NEMAR_TIMELINE
+                const bool xprobe = p.tl != nullptr && blockIdx.x == 0 && lane == 0 && T >= 40 && T < 48;
+#define BF6X_STAMP(i_) if (xprobe) p.tl[(wid * 8 + (T - 40)) * 8 + (i_)] = clock64();
+#else
+#define BF6X_STAMP(i_)
+#endif
+                BF6X_STAMP(0)
+                const int ntap = tap == 8 ? 0 : tap + 1;
+                const int nhb = tap == 8 ? hb ^ 1 : hb;
+                const int nr = ntap / 3, nsx = ntap % 3;
+                const int iti = tap + 4 >= 9 ? tap + 4 - 9 : tap + 4;
+                const int ici = tap + 4 >= 9 ? chunk + 1 : chunk;
+#define BF6X_MFMAS(beg_, n_)                                                                                            \
+                _Pragma("unroll") for (int m_ = (beg_); m_ < (beg_) + (n_) && m_ < 48; ++m_) {                           \
+                    const int q_ = m_ >> 3, mt_ = (m_ & 7) >> 1, nt_ = m_ & 1;                                          \
+                    acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cur][mt_][PA[q_]]), \
+                                                                            __builtin_bit_cast(bf16x8, bf[cur][nt_][PB[q_]]), \
+                                                                            acc[mt_][nt_], 0, 0, 0);                    \
+                }                                                                                                       \
+                __builtin_amdgcn_sched_barrier(0);
+                int baddr[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    int ra_ = (row[nt] + nr + z) * p.Ws;
+                    if (nr == 2) ra_ = top[nt] ? auxoff : ra_;
+                    if (nr == 0) ra_ = bot[nt] ? auxoff + p.Ws : ra_;
+                    int sl_ = col[nt] + nsx;
+                    if (nsx == 2) sl_ = lft[nt] ? p.W + 2 : sl_;
+                    if (nsx == 0) sl_ = rgt[nt] ? p.W + 3 : sl_;
+                    baddr[nt] = ra_ + sl_;
+                }
+                const u32x4* const Bn_ = Bs + nhb * bbuf16 + lhi * region16;
+                const u32x4* const An_ = As + ((T + 1) & (RING - 1)) * ASTAGE16 + lhi * 128 + l31;
+                BF6X_MFMAS(0, 2)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {                 // slots 1..6: the B fragments
+                    bf[nxt][i / 3][i % 3] = Bn_[(i % 3) * 2 * region16 + baddr[i / 3]];
+                    BF6X_MFMAS(2 + 2 * i, 2)
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {                // slots 7..18: the A fragments
+                    af[nxt][i / 3][i % 3] = An_[(i % 3) * 256 + (i / 3) * 32];
+                    BF6X_MFMAS(14 + 2 * i, 2)
+                }
+                {                                             // slots 19..: the copies of stage T + 4
+                    const int st_ = min(T + 4, nstage - 1);   // (tail: harmless re-copies of the last stage)
+                    const u32x4* const a_ = wsrc0 + (size_t)st_ * wstage + lane;
+                    u32x4* const ad_ = As + (T & (RING - 1)) * ASTAGE16 + wid * 192;
+                    glds16(a_, ad_);
+                    BF6X_MFMAS(38, 2)
+                    glds16(a_ + 64, ad_ + 64);
+                    BF6X_MFMAS(40, 2)
+                    glds16(a_ + 128, ad_ + 128);
+                    BF6X_MFMAS(42, 2)
+                    if (iti >= 3) {
+                        const int hc_ = min(ici + 1, nchunks - 1);
+                        const u32x4* const bb_ = bsrc0 + (size_t)(2 * hc_) * p.HpWs;
+                        u32x4* const bd_ = Bs + ((ici + 1) & 1) * bbuf16;
+#pragma unroll
+                        for (int q = 0; q < NBW; ++q) {
+                            const int k_ = (iti - 3) * NBW + q;
+                            if (lane < blim[k_]) glds16(bb_ + goff[k_], bd_ + blds[k_]);
+                            BF6X_MFMAS(44 + 2 * q, q == NBW - 1 ? 48 : 2)
+                        }
+                    } else {
+                        BF6X_MFMAS(44, 48)
+                    }
+                }
+#undef BF6X_MFMAS
+                // this wave's copies of stage T + 2 have landed; those of T + 3 and T + 4 may still be in flight
+                const int t3 = tap + 3 >= 9 ? tap + 3 - 9 : tap + 3;
+                const int nfl = BF6X_COUNT(t3) + BF6X_COUNT(iti);     // compile-time after unrolling: one of three values
+                BF6X_STAMP(1)
+                if (nfl == 6) BF6X_VMCNT(6)
+                else if (nfl == 6 + NBW) BF6X_VMCNT(6 + NBW)
+                else BF6X_VMCNT(6 + 2 * NBW)
+                BF6X_STAMP(2)
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every fragment of tap T + 1 is in registers
+                BF6X_STAMP(3)
+                __builtin_amdgcn_s_barrier();         // B_T: stage T + 2 complete for all waves; slot of stage T + 1 is free
+                BF6X_STAMP(4)
+#undef BF6X_STAMP
+            }
+        }
+    }
+    wait_vmem();                                      // (the tail's re-copies)
+#undef BF6X_READ
+#undef BF6X_VMCNT
+#undef BF6X_COUNT
+#undef BF6X_COPIES
 
     const size_t HW = (size_t)p.H * p.W;
 #pragma unroll
@@ -910,6 +1197,13 @@ void nemar_bf6_conv(const float* src, const void* packed, const float* bias, flo
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
     const dim3 g(grid), b(384);
+    if (variant == 3 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
+        const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
+        const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), 6);
+        if (nbw <= 2) hipLaunchKernelGGL((igemm_bf6x_kernel<2>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_bf6x_kernel<3>), g, dim3(256), 0, st, p);
+        return;
+    }
     if (variant == 2 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), 7);

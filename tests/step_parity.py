@@ -199,8 +199,9 @@ def run(name, report=None, check=True):
                     continue
                 e = np.abs(np.asarray(mine[k], dtype=np.float64) - b).ravel() / vmax
                 cond = np.abs(g32[k].numpy().astype(np.float64) - b).ravel() / vmax
-                ratio = max(float(np.quantile(e, 0.99)) / (2e-3 + 4 * float(np.quantile(cond, 0.99))),
-                            float(e.max()) / (2e-2 + 4 * float(cond.max())))
+                ratio = float(e.max()) / (2e-2 + 4 * float(cond.max()))
+                if e.size >= 1000:           # (a bias vector's 99th percentile IS its worst element)
+                    ratio = max(ratio, float(np.quantile(e, 0.99)) / (2e-3 + 4 * float(np.quantile(cond, 0.99))))
                 if ratio > worst_e[0]:
                     worst_e = (ratio, k, float(e.max()))
             add(pre + 'grad/%s elementwise, worst tensor %s (max err %.2e of the tensor max)' % (nm, worst_e[1], worst_e[2]),

@@ -317,14 +317,15 @@ def test_adam(be):
     K.case_adam(be, n=100003)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_conv_split_bf16_matrix_pipe(be, variant):
     """3x3 stride-1 layers with >= 128 output channels on the bf16 MFMA with three-way split operands (conv_bf6.hip): padded,
     channel-blocked split planes; halo staged once per 16-channel chunk; weight-stage ring; zero and reflect padding; one and
     several row tiles per image, both 128-channel halves, 32- and 64-pixel rows."""
     # 0 first generation, 1 software-pipelined MFMA waves + exact-sized LDS regions, 2 no loader waves (the MFMA waves issue the
-    # copies), 3 = 1 with the chunk order rotated per tile (two groups)
-    be.lib.tune(21, 1 if variant == 3 else variant)
+    # copies), 3 = 1 with the chunk order rotated per tile (two groups), 4 = fourth generation (2 + full fragment double buffering,
+    # branch-free copy descriptors)
+    be.lib.tune(21, {0: 0, 1: 1, 2: 2, 3: 1, 4: 3}[variant])
     be.lib.tune(22, 2 if variant == 3 else 0)
     try:
         K.case_conv_bf6(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
@@ -336,12 +337,12 @@ def test_conv_split_bf16_matrix_pipe(be, variant):
         be.lib.tune(22, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_conv_split_bf16_reflect_data_gradient(be, variant):
     """Data gradient of a reflect-padded 3x3 layer on the split-bf16 kernel: the folded border rows / slots written by the split
     pass are selected by address for (row 1, last filter row), (row H-2, first filter row) and the same in x; tiles that hold
     both special rows, only one, or none; and the zero-padded data gradient."""
-    be.lib.tune(21, 1 if variant == 3 else variant)
+    be.lib.tune(21, {0: 0, 1: 1, 2: 2, 3: 1, 4: 3}[variant])
     be.lib.tune(22, 2 if variant == 3 else 0)
     try:
         K.case_conv_bf6(be, 1, 128, 8, 32, 16, K.PAD_REFLECT, dgrad=True)
