@@ -144,7 +144,7 @@ int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data.  The wide 3x3 stride-1 layers (the ResnetBlock
  * convolutions, reference models/networks.py:418-439) run on the bf16 matrix pipe at fp32-equivalent accuracy: each fp32
- * operand is split exactly into three bf16 terms and six partial products are accumulated in fp32 (csrc/conv_bf6.hip).  The
+ * operand is split exactly into three bf16 terms and six partial products are accumulated in fp32 (csrc/conv_split16.hip).  The
  * split copy of the source tensor lives in this arena for the duration of the call.  nemar_conv2d_scratch -> bytes the layer
  * wants (0: never uses it); nemar_set_scratch registers a caller-owned device buffer (process-global like the tune switches:
  * one stream at a time may run operators that use it; bytes = 0 unregisters).  A layer whose need exceeds the registered

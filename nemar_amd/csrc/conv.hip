@@ -29,7 +29,7 @@
 // the (huge) pixel reduction split across workgroups and fp32 atomics into the caller's gradient buffer:
 // conv_wgrad.hip (wave-specialised) for everything whose gy planes are 16-byte chunkable, wgrad_kernel below for the rest.
 #include "common.h"
-#include "conv_bf6.h"
+#include "conv_split16.h"
 
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
 bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW);
@@ -1069,10 +1069,10 @@ static int g_adir = 0;           // tuning switch (key 16): MFMA waves fetch the
                                  // SLOWER: 370.8 vs 358.4 us on the 256->256 3x3 layer, gpurun_out/r2g) / through LDS (0, default)
 static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup -> tile mapping in the wave-specialised igemm
 // key 20: 3x3 / stride-1 layers with >= 128 output channels run on the bf16 matrix pipe with three-way split operands
-// (conv_bf6.hip) whenever the caller has registered a scratch arena large enough for the split source planes
-static int g_bf6 = 1;
-static int g_bf6_rot = 0;       // key 22: chunk-order rotation groups of the second-generation kernel
-static int g_bf6_variant = 0;   // key 21: 0 first generation, 1 software-pipelined MFMA waves
+// (conv_split16.hip) whenever the caller has registered a scratch arena large enough for the split source planes
+static int g_split16 = 1;
+static int g_split16_variant = 4;   // key 21: 4 fp16 x 3 products (default), 3 bf16 x 6 products, 0 bf16 x 6 on the first-generation
+                                // kernel with loader waves (kept for the A/B numbers in DESIGN.md)
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
@@ -1611,8 +1611,8 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     L.ring = refl && stride == 1;
     L.fold = refl && !L.ring;
     L.pack_stride = packed_floats(C, K * R * S);             // upper bound over parity classes and channel skips
-    if (nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, BF6_ZERO)) {     // room for either packed image
-        const size_t b = (nemar_bf6_pack_bytes(C, K) + 3) / 4;
+    if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO)) {     // room for either packed image
+        const size_t b = (nemar_split16_pack_bytes(C, K) + 3) / 4;
         if (b > L.pack_stride) L.pack_stride = b;
     }
     size_t o = L.pack_stride * (size_t)(stride * stride);
@@ -1669,8 +1669,8 @@ struct FwdLayout { size_t pack, slab_off, total; int ksplit; };
 FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
     FwdLayout L;
     L.pack = packed_floats(K, C * R * S);
-    if (nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, BF6_ZERO)) {     // room for either packed image
-        const size_t b = (nemar_bf6_pack_bytes(K, C) + 3) / 4;
+    if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO)) {     // room for either packed image
+        const size_t b = (nemar_split16_pack_bytes(K, C) + 3) / 4;
         if (b > L.pack) L.pack = b;
     }
     L.ksplit = 1;
@@ -1721,11 +1721,11 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         return NEMAR_OK;
     }
     {
-        const int mode = pad_mode == BORDER_REFLECT ? BF6_REFLECT : BF6_ZERO;
-        if (g_bf6 && C1 == 0 && act == ACT_NONE && nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, mode) &&
-            g_scratch && g_scratch_bytes >= nemar_bf6_scratch_bytes(N, C, H, W)) {
-            if (!prepacked) nemar_bf6_pack(w, workspace, K, C, 0, st);
-            nemar_bf6_conv(x0, workspace, bias, y, N, H, W, K, C, mode, g_scratch, g_xcd_map, g_dbg, g_bf6_variant, g_bf6_rot, g_tl, st);
+        const int mode = pad_mode == BORDER_REFLECT ? SPLIT16_REFLECT : SPLIT16_ZERO;
+        if (g_split16 && C1 == 0 && act == ACT_NONE && nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, mode) &&
+            g_scratch && g_scratch_bytes >= nemar_split16_scratch_bytes(N, C, H, W)) {
+            if (!prepacked) nemar_split16_pack(w, workspace, K, C, 0, g_split16_variant, st);
+            nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, mode, g_scratch, g_xcd_map, g_split16_variant, g_tl, st);
             NEMAR_CHECK_LAUNCH("conv2d_fwd (bf16 x 6)");
             return NEMAR_OK;
         }
@@ -1793,12 +1793,12 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)workspace;
     {
-        // 3x3 stride-1 layers: the data gradient is the same convolution with flipped, transposed weights (conv_bf6.hip)
-        const int mode = refl ? BF6_DGRAD_REFLECT : BF6_ZERO;
-        if (g_bf6 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, mode) &&
-            g_scratch && g_scratch_bytes >= nemar_bf6_scratch_bytes(N, K, H, W)) {
-            if (!prepacked) nemar_bf6_pack(w, workspace, K, C, 1, st);
-            nemar_bf6_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, mode, g_scratch, g_xcd_map, g_dbg, g_bf6_variant, g_bf6_rot, g_tl, st);
+        // 3x3 stride-1 layers: the data gradient is the same convolution with flipped, transposed weights (conv_split16.hip)
+        const int mode = refl ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO;
+        if (g_split16 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode) &&
+            g_scratch && g_scratch_bytes >= nemar_split16_scratch_bytes(N, K, H, W)) {
+            if (!prepacked) nemar_split16_pack(w, workspace, K, C, 1, g_split16_variant, st);
+            nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, mode, g_scratch, g_xcd_map, g_split16_variant, g_tl, st);
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (bf16 x 6)");
             return NEMAR_OK;
         }
@@ -2081,9 +2081,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 14) { g_deterministic = value != 0; return NEMAR_OK; }
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
-    if (key == 20) { g_bf6 = value != 0; return NEMAR_OK; }
-    if (key == 21) { g_bf6_variant = value; return NEMAR_OK; }
-    if (key == 22) { g_bf6_rot = value; return NEMAR_OK; }      // packed images made under the other setting are stale
+    if (key == 20) { g_split16 = value != 0; return NEMAR_OK; }
+    if (key == 21) { g_split16_variant = (value == 0 || value == 3) ? value : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
     if (key == 19) { extern int g_narrow_fwd4; g_narrow_fwd4 = value != 0; return NEMAR_OK; }
@@ -2109,9 +2108,9 @@ NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
 NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return 0;
     size_t b = 0;
-    if (nemar_bf6_eligible(N, H, W, K, C, R, S, stride, pad, BF6_ZERO)) b = nemar_bf6_scratch_bytes(N, C, H, W);
-    if (nemar_bf6_eligible(N, H, W, C, K, R, S, stride, pad, BF6_ZERO)) {
-        const size_t d = nemar_bf6_scratch_bytes(N, K, H, W);
+    if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO)) b = nemar_split16_scratch_bytes(N, C, H, W);
+    if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO)) {
+        const size_t d = nemar_split16_scratch_bytes(N, K, H, W);
         if (d > b) b = d;
     }
     return b;

@@ -1,0 +1,17 @@
+// Internal interface of conv_split16.hip (3x3 stride-1 convolutions of wide layers on the bf16 matrix pipe with a three-way
+// operand split: fp32-equivalent products at 16/6 of the fp32-MFMA rate).  Called by conv.hip's operators only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+enum { SPLIT16_ZERO = 0, SPLIT16_REFLECT = 1, SPLIT16_DGRAD_REFLECT = 2 };
+
+// M = output channels of the launch, Cred = reduction channels, source [N, Cred, H, W] -> destination [N, M, H, W]
+bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode);
+size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W);      // split activation planes
+size_t nemar_split16_pack_bytes(int M, int Cred);                       // split, tile-ordered weights
+// w [K, C, 3, 3].  dgrad == 0: M = K rows, reduction over C.  dgrad != 0: M = C rows, reduction over K, taps flipped.
+void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, int variant, hipStream_t st);
+// src [N, Cred, H, W] fp32 -> dst [N, M, H, W] fp32 (+ bias[M] when non-null); `scratch` >= nemar_split16_scratch_bytes
+void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M,
+                    int Cred, int mode, void* scratch, int xcd_map, int variant, long long* tl, hipStream_t st);

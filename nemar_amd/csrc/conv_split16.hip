@@ -1,0 +1,805 @@
+// nemar_amd — 3x3 / stride-1 / pad-1 convolutions of the wide layers (the translation net's 256-channel residual blocks:
+// reference models/networks.py:418-439, 18 convolutions per pass, 36.5 of the 63.8 ms of convolution time in a round-1 step) on
+// the 16-BIT matrix pipe, at fp32 accuracy.
+//
+// gfx950 has no TF32-like mode and its fp32 MFMA runs at the vector rate (157 TFLOP/s); the 16-bit MFMAs run 16x faster.  Every
+// fp32 operand is split into 16-bit terms whose partial products, accumulated in fp32 by the MFMA, reproduce the fp32 product to
+// (better than) the rounding error of an fp32 multiply-add chain:
+//   * fp16 x 3 (default):  v 2^k = h + l + e,  h = RN16(v 2^k), l = RN16(v 2^k - h), |e| <= 2^-22 |v 2^k|; products h h' + h l' + l h'
+//     (the dropped l l' and the two e terms are ~3 * 2^-22 relative: an fp32 accumulation of the layer's 2304-term dot products
+//     contributes ~2^-19 either way).  fp16's exponent range is narrow, so each tensor is scaled by the power of two that puts its
+//     largest magnitude at 2^11..2^12 (absmax_kernel -> one word; folded border sums stay below 2^14) and the epilogue takes the
+//     two scales out again, exactly.  3/16 of the fp32-MFMA issue time, 4 operand bytes per element.
+//   * bf16 x 6 (nemar_tune(21, 3)):  v = b0 + b1 + b2 EXACTLY (3 x 8 significant bits), products of weight 2^-16 and above:
+//     a0c0 + (a0c1 + a1c0) + (a0c2 + a1c1 + a2c0); no scaling (bf16 has fp32's exponent range).  6/16 of the issue time, 6 bytes.
+//   Measured against float64 on the bench shape (tests/test_conv_real_shapes_gpu.py::test_split16_error_is_fp32_class): max error
+//   fwd 3.4e-6 (fp16 x 3) / 4.4e-6 (bf16 x 6) / 5.2e-6 (exact-fp32 MFMA kernel), rms 3.1e-7 / 4.3e-7 / 5.0e-7 — the 16-bit MFMA
+//   adds its 16 products per instruction before rounding once, the fp32 MFMA rounds after every product.
+//
+// Data flow of one convolution (all inside nemar_conv2d_fwd / nemar_conv2d_bwd_data):
+//   1. absmax_kernel (fp16 form) + split_planes_kernel: source [N,C,H,W] fp32 -> NPL 16-bit planes, CHANNEL-BLOCKED and PADDED:
+//         plane[t][n][c/8][row 0..H+3][slot 0..W+3][8 channels]      (16 bytes per (pixel, channel group))
+//      rows 1..H / slots 1..W hold the image, row 0 / H+1 and slot 0 / W+1 the padding ALREADY MATERIALISED (zeros, or the
+//      mirrored texels of nn.ReflectionPad2d(1)), rows H+2, H+3 and slots W+2, W+3 the pre-folded border sums the reflect DATA
+//      gradient needs (below).  One lane's MFMA operand (8 consecutive reduction channels of one pixel) is one 16-byte word,
+//      and a tile's halo (its rows + 2, full padded width) is ONE contiguous run per (plane, channel group).
+//   2. igemm_split16_kernel: implicit GEMM, workgroup tile = 128 output channels x 256 pixels (whole image rows), four waves of
+//      128 channels x 64 pixels (8 accumulators of 32x32), one per SIMD.  Per 16-channel chunk of the reduction the tile's halo is
+//      copied once (global_load_lds, 16 bytes per lane, no VGPRs) into a double-buffered LDS region and all nine taps read it at
+//      shifted addresses — the source is fetched once per chunk, not once per tap — plus one stage of packed weights per tap
+//      into a 4-slot ring.  One workgroup barrier per tap.  How the copies are issued and why: see the kernel.
+//   3. the reflect data gradient  dx = Pad^T(Conv^T(gy))  folds the padded border back: output row 1 receives the gradient of
+//      padded row 0, which only the first filter row produces, i.e. for that (row, tap) pair the source row is gy[0] + gy[2]
+//      instead of gy[2]; same for row H-2, columns 1 and W-2, and the four corners.  The split kernel writes those sums once
+//      (rows H+2 / H+3, slots W+2 / W+3) and the MFMA waves select them by address: no ring launch, no extra taps.
+// Weights are split and re-ordered once per optimizer step (split16_pack_kernel) into [chunk][tap][128-row block][plane][k group]
+// [128][8]: a stage is one contiguous run.
+#include "common.h"
+#include "conv_split16.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rn(float v) {
+    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// v == b0 + b1 + b2 exactly (both subtractions are exact in fp32: Sterbenz-type cancellation of the leading bits)
+__device__ __forceinline__ void split3(float v, unsigned short& b0, unsigned short& b1, unsigned short& b2) {
+    b0 = bf16_rn(v);
+    const float r1 = v - bf16_val(b0);
+    b1 = bf16_rn(r1);
+    const float r2 = r1 - bf16_val(b1);
+    b2 = bf16_rn(r2);
+}
+
+__device__ __forceinline__ int mirror(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// value of plane position (row, slot) of one channel image xc [H, W]
+__device__ __forceinline__ float plane_value(const float* xc, int row, int slot, int H, int W, int mode) {
+    if (mode != SPLIT16_DGRAD_REFLECT) {
+        if (row > H + 1 || slot > W + 1) return 0.f;
+        int y = row - 1, x = slot - 1;
+        if (mode == SPLIT16_REFLECT) {
+            y = mirror(y, H);
+            x = mirror(x, W);
+        } else if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) {
+            return 0.f;
+        }
+        return xc[y * W + x];
+    }
+    int ya, yb = -1, xa, xb = -1;
+    if (row >= 1 && row <= H) ya = row - 1;
+    else if (row == H + 2) { ya = 0; yb = 2; }
+    else if (row == H + 3) { ya = H - 3; yb = H - 1; }
+    else return 0.f;
+    if (slot >= 1 && slot <= W) xa = slot - 1;
+    else if (slot == W + 2) { xa = 0; xb = 2; }
+    else if (slot == W + 3) { xa = W - 3; xb = W - 1; }
+    else return 0.f;
+    float v = xc[ya * W + xa];
+    if (yb >= 0) v += xc[yb * W + xa];
+    if (xb >= 0) {
+        float u = xc[ya * W + xb];
+        if (yb >= 0) u += xc[yb * W + xb];
+        v += u;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32x4 pack8(const unsigned short* b) {
+    u32x4 o;
+    o[0] = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    o[1] = (unsigned)b[2] | ((unsigned)b[3] << 16);
+    o[2] = (unsigned)b[4] | ((unsigned)b[5] << 16);
+    o[3] = (unsigned)b[6] | ((unsigned)b[7] << 16);
+    return o;
+}
+
+// ---- fp16 x 3 variant of the same idea ---------------------------------------------------------------------------------
+// fp16 carries 11 significant bits: v * 2^k = h + l + e with h = RN16(v 2^k), l = RN16(v 2^k - h), |e| <= 2^-22 |v 2^k|, and three
+// products  h h' + h l' + l h'  leave a relative error of ~3 * 2^-22 per product — far below what the fp32 ACCUMULATION of a
+// 2304-term dot product contributes either way (measured: tests/test_conv_real_shapes_gpu.py).  Half the MFMAs and two thirds of
+// the operand bytes of the bf16 x 6 form.  fp16's exponent range is narrow, so every tensor is scaled by a power of two that puts
+// its largest magnitude at 2^11..2^12 (folded border sums of the reflect data gradient stay below 2^14); the scale comes from one
+// max-reduction pass (absmax_kernel -> a word behind the planes / behind the packed weights) and is taken out again, exactly, in
+// the convolution's epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float pow2_scale(unsigned maxbits) {       // 2^(11 - floor(log2 max)), 1 for zero / non-finite
+    const int e = (int)((maxbits >> 23) & 255u);
+    if (e == 0 || e == 255) return 1.f;
+    const int se = 127 + 11 - (e - 127);
+    if (se < 1 || se > 254) return 1.f;
+    return __builtin_bit_cast(float, (unsigned)se << 23);
+}
+__device__ __forceinline__ unsigned short f16_rn(float v) {
+    const _Float16 h = (_Float16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned short& l) {
+    h = f16_rn(v);
+    const float r = v - (float)__builtin_bit_cast(_Float16, h);
+    l = f16_rn(r);
+}
+
+// max |x| as the bit pattern of a non-negative float (ordered like an unsigned integer); *out zeroed by the caller
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// one thread = one (n, channel group, row, slot): 8 strided reads (coalesced across the slots of a row), NPL x 16-byte writes
+template <int NPL>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C,
+                                                           int H, int W, int mode, long long total, const unsigned* maxbits) {
+    const int Hp = H + 4, Ws = W + 4, CG = C >> 3;
+    const float scale = NPL == 2 ? pow2_scale(*maxbits) : 1.f;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int slot = (int)(t % Ws);
+        long long q = t / Ws;
+        const int row = (int)(q % Hp);
+        q /= Hp;
+        const int cg = (int)(q % CG), n = (int)(q / CG);
+        const float* xc = x + ((size_t)n * C + (size_t)cg * 8) * H * W;
+        unsigned short b0[8], b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = plane_value(xc + (size_t)j * H * W, row, slot, H, W, mode);
+            if (NPL == 3) split3(v, b0[j], b1[j], b2[j]);
+            else split2_f16(v * scale, b0[j], b1[j]);
+        }
+        out[t] = pack8(b0);
+        out[total + t] = pack8(b1);
+        if (NPL == 3) out[2 * total + t] = pack8(b2);
+    }
+}
+
+// packed weights: 16-byte word index (((chunk * 9 + tap) * mblks + mblk) * NPL + plane) * 256 + kgroup * 128 + m
+template <int NPL>
+__global__ __launch_bounds__(256) void split16_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int M, int Cred,
+                                                       int dgrad, const unsigned* maxbits) {
+    const int mblks = M >> 7;
+    const long long total = (long long)(Cred >> 4) * 9 * mblks * 256;
+    const float scale = NPL == 2 ? pow2_scale(*maxbits) : 1.f;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(t & 127), kg = (int)((t >> 7) & 1);
+        long long q = t >> 8;
+        const int mblk = (int)(q % mblks);
+        q /= mblks;
+        const int tap = (int)(q % 9), chunk = (int)(q / 9);
+        const int mg = mblk * 128 + m;
+        unsigned short b0[8], b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cr = chunk * 16 + kg * 8 + j;
+            // forward: w[K = M][C = Cred][3][3];  data gradient: w[K = Cred][C = M][3][3] with the taps flipped
+            const float v = dgrad ? w[((size_t)cr * M + mg) * 9 + (8 - tap)] : w[((size_t)mg * Cred + cr) * 9 + tap];
+            if (NPL == 3) split3(v, b0[j], b1[j], b2[j]);
+            else split2_f16(v * scale, b0[j], b1[j]);
+        }
+        u32x4* o = out + (((size_t)(chunk * 9 + tap) * mblks + mblk) * NPL) * 256 + kg * 128 + m;
+        o[0] = pack8(b0);
+        o[256] = pack8(b1);
+        if (NPL == 3) o[512] = pack8(b2);
+    }
+}
+
+struct Split16Params {
+    const u32x4* planes;       // split source, see split_planes_kernel
+    const u32x4* wp;           // packed weights
+    const float* bias;         // [M] or null
+    float* dst;                // [N, M, H, W]
+    int N, H, W, M, Cred;
+    int Ws, HpWs;              // slots per plane row, 16-byte words per (plane, n, channel group) image
+    int wshift, RT;            // log2 W, output rows per tile (256 / W)
+    int tiles_per_img, mblks;
+    int halo_instr, aux_instr; // 1 KiB DMA instructions per (plane, k group) for the halo rows / the two folded rows
+    int halo16, aux16;         // exact 16-byte words of those two runs (second-generation kernel: exact-sized LDS regions)
+    int fold;                  // reflect data gradient: select the folded rows / slots
+    int xcd;                   // workgroup -> tile mapping keeps neighbouring tiles on one XCD
+    long long plane16;         // 16-byte words per plane
+    const unsigned* xmax;      // fp16 x 3 form: max |source| and max |weight| bit patterns (the power-of-two scales follow from them)
+    const unsigned* wmax;
+    long long* tl;             // NEMAR_TIMELINE builds: cycle stamps of workgroup 0 (tools/timeline_split16.py)
+};
+
+__device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// scalar (wave-uniform) base + per-lane byte offset: hipcc selects the SGPR-base form of global_load_lds for it
+__device__ __forceinline__ void glds16u(const u32x4* ubase, unsigned lane_bytes, u32x4* lds) {
+    glds16(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + lane_bytes), lds);
+}
+
+// ---- first generation (nemar_tune(21, 0), bf16 x 6): 4 MFMA waves + 2 loader waves, kept for the A/B numbers of DESIGN.md §5.
+// Its loader waves share SIMDs 0 and 1 with two of the MFMA waves and starve (see the kernel below).
+// REGION_KB = KiB of LDS per (plane, k group) halo region = DMA instructions per region; RING = weight-stage ring depth
+template <int REGION_KB, int RING>
+__global__ __launch_bounds__(384) void igemm_split16_lw_kernel(Split16Params p) {
+    constexpr int REGION16 = REGION_KB * 64;             // 16-byte words per region
+    constexpr int BBUF16 = 6 * REGION16;                 // 3 planes x 2 k groups
+    constexpr int ASTAGE16 = 6 * 128;                    // 3 planes x 2 k groups x 128 rows
+    constexpr int NBL = 3 * REGION_KB;                   // halo instructions per loader per chunk (loader = k group)
+    constexpr int WINDOW = 10 - RING;                    // stages (taps RING-1 .. 8) that carry the next chunk's halo
+    constexpr int NB = (NBL + WINDOW - 1) / WINDOW;      // halo instruction slots per stage
+    constexpr int PER = 6 + NB;                          // DMA instructions per loader per stage (constant: counted waits)
+    static_assert((RING - 1) * PER < 64, "vmcnt is a 6-bit counter");
+    static_assert((2 * BBUF16 + RING * ASTAGE16) * 16 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * BBUF16 + RING * ASTAGE16];
+    u32x4* const Bs = smem;
+    u32x4* const As = smem + 2 * BBUF16;
+
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    // consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous run of tiles, and both channel halves of a
+    // pixel tile (same halo) to the same one
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
+    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int CG = p.Cred >> 3;
+
+    if (wid >= 4) {
+        // ================================ loader waves: wave 4 = k group 0, wave 5 = k group 1 ================================
+        const int kg = wid - 4;
+        const int ipr = p.halo_instr + p.aux_instr;                      // <= REGION_KB
+        const int nbl = 3 * ipr;
+        const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + kg * 384 + lane;
+        const size_t wstage = (size_t)p.mblks * 768;
+        // source of this loader's halo words of chunk c, plane t: planes + t * plane16 + ((n * CG + 2c + kg) * HpWs) + ...
+        const u32x4* const bsrc0 = p.planes + ((size_t)n * CG + kg) * p.HpWs + lane;
+        const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
+        int islot = 0, ci = 0, ti = 0;        // ring slot / chunk / tap of the next stage to issue
+        int bpl = 0, bin = 0, bcnt = nbl;      // halo stream of chunk ci + 1: plane, instruction within the region, issued count
+        const u32x4* asrc = wsrc0;
+
+#define SPLIT16_HALO_ONE(chunk_, pl_, in_)                                                                                  \
+        {                                                                                                               \
+            const u32x4* g_ = bsrc0 + (size_t)(pl_) * p.plane16 + (size_t)(2 * (chunk_)) * p.HpWs +                     \
+                              ((in_) < p.halo_instr ? halo_off + (in_) * 64 : aux_off + ((in_) - p.halo_instr) * 64);   \
+            glds16(g_, Bs + ((chunk_) & 1) * BBUF16 + ((pl_) * 2 + kg) * REGION16 + (in_) * 64);                        \
+        }
+#define SPLIT16_ISSUE()                                                                                                     \
+        {                                                                                                               \
+            u32x4* const ad_ = As + islot * ASTAGE16 + kg * 384;                                                        \
+            _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(asrc + q * 64, ad_ + q * 64);                          \
+            if (ti == RING - 1) { bpl = 0; bin = 0; bcnt = (ci + 1 < nchunks) ? 0 : nbl; }                              \
+            _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                            \
+                if (bcnt < nbl) {                                                                                       \
+                    SPLIT16_HALO_ONE(ci + 1, bpl, bin);                                                                     \
+                    ++bcnt;                                                                                             \
+                    if (++bin == ipr) { bin = 0; ++bpl; }                                                               \
+                } else {                                                                                                \
+                    glds16(asrc, ad_);             /* filler: keeps the per-stage instruction count constant */          \
+                }                                                                                                       \
+            }                                                                                                           \
+            asrc += wstage;                                                                                             \
+            islot = islot + 1 == RING ? 0 : islot + 1;                                                                  \
+            if (++ti == 9) { ti = 0; ++ci; }                                                                            \
+        }
+#define SPLIT16_WAIT_IN_FLIGHT(n_)                                                                                          \
+        {                                                                                                               \
+            const int ns_ = (n_);                                                                                       \
+            if (ns_ <= 0) wait_vmem();                                                                                  \
+            else if (ns_ == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER & 15) | ((PER >> 4) << 14));                    \
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 15) | (((2 * PER) >> 4) << 14));                      \
+        }
+        static_assert(RING <= 4, "two stages in flight at most");
+        // halo of chunk 0, then RING - 1 weight stages, before anything is consumed
+        for (int pl = 0; pl < 3; ++pl)
+            for (int in = 0; in < ipr; ++in) SPLIT16_HALO_ONE(0, pl, in);
+        int issued = 0;
+        for (; issued < RING - 1 && issued < nstage; ++issued) SPLIT16_ISSUE();
+        SPLIT16_WAIT_IN_FLIGHT(issued - 1);
+        __builtin_amdgcn_s_barrier();                 // stage 0 (and the first halo) are in LDS
+        if (issued < nstage) { SPLIT16_ISSUE(); ++issued; }
+        for (int ks = 0; ks < nstage; ++ks) {
+            SPLIT16_WAIT_IN_FLIGHT(issued - (ks + 2));    // stage ks + 1 has landed (with everything issued before it)
+            __builtin_amdgcn_s_barrier();             // every MFMA wave has finished reading ring slot ks % RING
+            if (issued < nstage) { SPLIT16_ISSUE(); ++issued; }
+        }
+#undef SPLIT16_WAIT_IN_FLIGHT
+#undef SPLIT16_ISSUE
+#undef SPLIT16_HALO_ONE
+        return;
+    }
+
+    // ================================ MFMA waves: 128 channels x 64 pixels each ================================
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int row[2], col[2];
+    bool top[2], bot[2], lft[2], rgt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int px = 64 * wid + 32 * nt + l31;
+        row[nt] = px >> p.wshift;
+        col[nt] = px & (p.W - 1);
+        const int y = y0 + row[nt];
+        top[nt] = p.fold && y == 1;
+        bot[nt] = p.fold && y == p.H - 2;
+        lft[nt] = p.fold && col[nt] == 1;
+        rgt[nt] = p.fold && col[nt] == p.W - 2;
+    }
+    const int auxoff = p.halo_instr * 64;             // the two folded rows sit behind the halo rows of a region
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    __builtin_amdgcn_s_barrier();                     // stage 0 is in LDS
+    int slot = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const u32x4* const Bb = Bs + (chunk & 1) * BBUF16 + lhi * REGION16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, sx = tap - 3 * (tap / 3);
+            u32x4 bf[2][3], af[4][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                int ra = (row[nt] + r) * p.Ws;
+                if (r == 2) ra = top[nt] ? auxoff : ra;
+                if (r == 0) ra = bot[nt] ? auxoff + p.Ws : ra;
+                int sl = col[nt] + sx;
+                if (sx == 2) sl = lft[nt] ? p.W + 2 : sl;
+                if (sx == 0) sl = rgt[nt] ? p.W + 3 : sl;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = Bb[pl * 2 * REGION16 + ra + sl];
+            }
+            const u32x4* const Ab = As + slot * ASTAGE16 + lhi * 128 + l31;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[mt][pl] = Ab[pl * 256 + mt * 32];
+            // six partial products, smallest first; consecutive MFMAs go to different accumulators
+#define SPLIT16_TERM(pa_, pb_)                                                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                        \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][pa_]),      \
+                                                                          __builtin_bit_cast(bf16x8, bf[nt][pb_]),      \
+                                                                          acc[mt][nt], 0, 0, 0);
+            SPLIT16_TERM(2, 0)
+            SPLIT16_TERM(1, 1)
+            SPLIT16_TERM(0, 2)
+            SPLIT16_TERM(1, 0)
+            SPLIT16_TERM(0, 1)
+            SPLIT16_TERM(0, 0)
+#undef SPLIT16_TERM
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): this wave is done reading the stage
+            __builtin_amdgcn_s_barrier();             // the next stage has landed; this ring slot goes back to the loaders
+            slot = slot + 1 == RING ? 0 : slot + 1;
+        }
+    }
+
+    // epilogue: D register r of lane l = channel (r & 3) + 8 (r >> 2) + 4 (l >> 5), pixel l & 31 of the 32 x 32 tile
+    const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[mt][nt][r];
+                if (p.bias) v += p.bias[m];
+                d0[(size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
+// ---- the product kernel --------------------------------------------------------------------------------------------------
+// What the first generation's measurements said (tools/timeline_split16.py, tools/probes/dma_probe2.hip):
+//   * a wave that streams MFMAs back to back monopolises the instruction issue of its SIMD: the loader waves, co-resident with MFMA
+//     waves 0 and 1, got one instruction issued per ~8 MFMAs (a six-copy burst that takes 120 cycles on a quiet SIMD took 1750;
+//     s_setprio makes no difference), so every tap ended with the MFMA waves parked at the barrier while the loaders finished:
+//     tap = MFMA block + loader tail = 2900 cycles for 1536 cycles of matrix pipe.  => no loader waves: the four MFMA waves issue
+//     the copies themselves, wave w a quarter of every weight stage and every fourth halo copy; it waits for ITS copies (counted
+//     vmcnt) before the tap's barrier, and the barrier makes all four quarters visible.
+//   * one wave per SIMD owns the whole 512-register file: every fragment of tap T + 1 is read during tap T into a second register
+//     set, so the MFMAs of a tap never wait for LDS and rotate over the eight accumulators (no dependent chains).
+//   * the tap body is branch-free: the halo copies of a chunk are described once per wave (source offset, LDS offset, lane limit)
+//     in registers indexed by the unrolled tap position, the tail re-issues harmless copies instead of skipping, and the per-tap
+//     copy count is a compile-time function of the tap, so the counted waits need no filler copies.
+//   * the weight stage for tap T + 4 is issued during tap T, into the slot whose fragments went to registers a tap ago: two full
+//     taps of lead on a 4-slot ring.
+//   * hipcc clumps the LDS reads and copies of a tap (any clump longer than an MFMA's 32-cycle shadow idles the matrix pipe): the
+//     body is cut into slots of [<= 1 memory instruction + its address arithmetic][its share of the MFMAs], pinned by sched_barrier.
+//   Result (timeline, gpurun_out/timeline_bf6_v4.txt): 1680-1730 cycles per 48-MFMA tap = 90 % matrix-pipe issue, after which the
+//   clock, not the schedule, is what is left: under this MFMA density the chip runs at ~1.45 GHz.  Hence fp16 x 3: half the MFMAs.
+// Two chunks (18 taps) per loop iteration, so that the register-set parity is a compile-time constant of the tap position.
+// NPL = operand planes: 3 = bf16 x 6 products, 2 = fp16 x 3 products (scaled, see split2_f16)
+template <int NBW, int NPL>       // NBW = halo copy slots per wave per tap on taps 3..8 of a chunk (they carry the next chunk's halo)
+__global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
+    constexpr int RING = 4, ASTAGE16 = 256 * NPL, KB = 6 * NBW, NREG = 2 * NPL, NP = NPL == 3 ? 6 : 3, NMFMA = 8 * NP;
+    constexpr int ACOPY = NPL;                           // 1 KiB weight copies per wave per stage (a quarter of the stage)
+    constexpr int SMEM16 = 9728;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM16];
+    u32x4* const As = smem;
+    u32x4* const Bs = smem + RING * ASTAGE16;
+    const int region16 = p.halo16 + p.aux16, bbuf16 = NREG * region16;
+
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
+    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int CG = p.Cred >> 3;
+
+    // ---- this wave's copies: weights = words [192 wid, 192 wid + 192) of every 768-word stage; halo = every fourth 1 KiB copy ----
+    const int hi = (p.halo16 + 63) >> 6, ai = (p.aux16 + 63) >> 6, ipr = hi + ai, ncopies = NREG * ipr;
+    const size_t wstage = (size_t)p.mblks * ASTAGE16;
+    const u32x4* const wsrc0 = p.wp + (size_t)mblk * ASTAGE16 + wid * (64 * ACOPY);
+    const u32x4* const bsrc0 = p.planes + (size_t)n * CG * p.HpWs;
+    const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
+    unsigned goff[KB], blds[KB];      // per halo copy of this wave: source word offset from the chunk's images (+ lane), LDS word offset
+    int blim[KB];                     // ... and the number of lanes that take part
+    int share = 0;
+    {
+        int breg = 0, bin = wid;
+        while (bin >= ipr) { bin -= ipr; ++breg; }
+        unsigned g = 0, l = 0;
+        int lim = 0;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (wid + 4 * k < ncopies) {
+                const bool aux = bin >= hi;
+                const int j = aux ? bin - hi : bin;
+                const int pl = breg >> 1, kg = breg & 1;
+                g = (unsigned)((size_t)pl * p.plane16 + (size_t)kg * p.HpWs + (aux ? aux_off : halo_off) + j * 64);
+                l = (unsigned)(breg * region16 + (aux ? p.halo16 : 0) + j * 64);
+                lim = (aux ? p.aux16 : p.halo16) - j * 64;
+                share = k + 1;
+                bin += 4;
+                while (bin >= ipr) { bin -= ipr; ++breg; }
+            }
+            goff[k] = g + lane;       // (slots beyond the share repeat the last copy)
+            blds[k] = l;
+            blim[k] = lim;
+        }
+    }
+    // copies of one stage: COUNT(ti) = ACOPY + (ti >= 3 ? NBW : 0) wave-instructions, in this order
+#define S16_COPIES(stage_, ti_, ci_)                                                                                   \
+    {                                                                                                                   \
+        const int st_ = min((stage_), nstage - 1);                   /* tail: harmless re-copies of the last stage */   \
+        const u32x4* const a_ = wsrc0 + (size_t)st_ * wstage + lane;                                                    \
+        u32x4* const ad_ = As + ((stage_) & (RING - 1)) * ASTAGE16 + wid * (64 * ACOPY);                                \
+        _Pragma("unroll") for (int q = 0; q < ACOPY; ++q) glds16(a_ + 64 * q, ad_ + 64 * q);                            \
+        if ((ti_) >= 3) {                                                                                               \
+            const int hc_ = min((ci_) + 1, nchunks - 1);             /* chunk whose halo travels with this stage */     \
+            const u32x4* const bb_ = bsrc0 + (size_t)(2 * hc_) * p.HpWs;                                                \
+            u32x4* const bd_ = Bs + (((ci_) + 1) & 1) * bbuf16;                                                         \
+            _Pragma("unroll") for (int q = 0; q < NBW; ++q) {                                                           \
+                const int k_ = ((ti_) - 3) * NBW + q;                                                                   \
+                if (lane < blim[k_]) glds16(bb_ + goff[k_], bd_ + blds[k_]);                                            \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+#define S16_COUNT(ti_) (ACOPY + ((ti_) >= 3 ? NBW : 0))
+#define S16_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14));
+
+    // ---- MFMA side ----
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int row[2], col[2];
+    bool top[2], bot[2], lft[2], rgt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int px = 64 * wid + 32 * nt + l31;
+        row[nt] = px >> p.wshift;
+        col[nt] = px & (p.W - 1);
+        const int y = y0 + row[nt];
+        top[nt] = p.fold && y == 1;
+        bot[nt] = p.fold && y == p.H - 2;
+        lft[nt] = p.fold && col[nt] == 1;
+        rgt[nt] = p.fold && col[nt] == p.W - 2;
+    }
+    const int auxoff = p.halo16;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    u32x4 af[2][4][NPL], bf[2][2][NPL];
+    // all fragments of tap (r_, sx_) of the chunk in halo buffer hb_, weights in ring slot slot_, into register set set_
+#define S16_READ(set_, slot_, hb_, r_, sx_)                                                                            \
+    {                                                                                                                   \
+        const u32x4* const Bb_ = Bs + (hb_) * bbuf16 + lhi * region16;                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                              \
+            int ra_ = (row[nt] + (r_) + z) * p.Ws;       /* z: see the loop head */                                     \
+            if ((r_) == 2) ra_ = top[nt] ? auxoff : ra_;                                                                \
+            if ((r_) == 0) ra_ = bot[nt] ? auxoff + p.Ws : ra_;                                                         \
+            int sl_ = col[nt] + (sx_);                                                                                  \
+            if ((sx_) == 2) sl_ = lft[nt] ? p.W + 2 : sl_;                                                              \
+            if ((sx_) == 0) sl_ = rgt[nt] ? p.W + 3 : sl_;                                                              \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) bf[set_][nt][pl] = Bb_[pl * 2 * region16 + ra_ + sl_];   \
+        }                                                                                                               \
+        const u32x4* const Ab_ = As + (slot_) * ASTAGE16 + lhi * 128 + l31;                                             \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) af[set_][mt][pl] = Ab_[pl * 256 + mt * 32];              \
+    }
+    // partial products, smallest first: bf16 (a2 b0) (a1 b1) (a0 b2) (a1 b0) (a0 b1) (a0 b0); fp16 (l h') (h l') (h h')
+    constexpr int PA[6] = {NPL == 3 ? 2 : 1, NPL == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NPL == 3 ? 2 : 0, 0, 1, 0};
+
+    // ---- prologue: this wave's share of the first halo and of stages 0..3 ----
+    {
+        const u32x4* const bb = bsrc0;
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < share && lane < blim[k]) glds16(bb + goff[k], Bs + blds[k]);
+    }
+    S16_COPIES(0, 0, 0)
+    S16_COPIES(1, 1, 0)
+    S16_COPIES(2, 2, 0)
+    S16_COPIES(3, 3, 0)
+    S16_VMCNT(2 * ACOPY + NBW)                       // (stages 2 and 3 may be in flight) the first halo and stages 0, 1 have landed
+    __builtin_amdgcn_s_barrier();                     // ... for all four waves
+    int z = 0;
+    S16_READ(0, 0, 0, 0, 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                     // every wave holds the fragments of tap 0: slot 0 may be refilled (tap 0 does)
+    for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {
+        // an opaque zero per iteration: keeps hipcc from hoisting the 18 taps' fragment addresses out of the loop (that costs
+        // more registers than the file has: 512 + spills) — they are three VALU instructions each to recompute
+#ifndef NEMAR_HOST_EMULATION
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+#endif
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int chunk = chunk0 + half;
+            if (half == 1 && chunk >= nchunks) break;
+            const int hb = half;                      // = chunk & 1
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int cur = (tap + half) & 1, nxt = cur ^ 1;          // = T & 1 with T = 9 chunk + tap
+                const int T = chunk * 9 + tap;
+                // tap T + 1: every fragment into the other register set (after the last tap: a harmless read of stale LDS);
+                // stage T + 4 into the slot of stage T (read during tap T - 1): two full taps ahead of its first use.
+                // 23 + NBW slots of [<= 1 memory instruction + its scalar / vector arithmetic][2 MFMAs], pinned: hipcc otherwise
+                // clumps the reads and copies, and every clump longer than an MFMA's 32-cycle shadow idles the matrix pipe
+#ifdef NEMAR_TIMELINE
+                const bool xprobe = p.tl != nullptr && blockIdx.x == 0 && lane == 0 && T >= 40 && T < 48;
+#define S16_STAMP(i_) if (xprobe) p.tl[(wid * 8 + (T - 40)) * 8 + (i_)] = clock64();
+#else
+#define S16_STAMP(i_)
+#endif
+                S16_STAMP(0)
+                const int ntap = tap == 8 ? 0 : tap + 1;
+                const int nhb = tap == 8 ? hb ^ 1 : hb;
+                const int nr = ntap / 3, nsx = ntap % 3;
+                const int iti = tap + 4 >= 9 ? tap + 4 - 9 : tap + 4;
+                const int ici = tap + 4 >= 9 ? chunk + 1 : chunk;
+#define S16_MFMAS(beg_, end_)                 /* MFMAs [beg_, end_) of the tap's NMFMA: m = 8 q + 2 mt + nt */        \
+                _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < NMFMA; ++m_) {                              \
+                    const int q_ = m_ >> 3, mt_ = (m_ & 7) >> 1, nt_ = m_ & 1;                                          \
+                    if constexpr (NPL == 3)                                                                             \
+                        acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cur][mt_][PA[q_]]), \
+                                                                                __builtin_bit_cast(bf16x8, bf[cur][nt_][PB[q_]]), \
+                                                                                acc[mt_][nt_], 0, 0, 0);                \
+                    else                                                                                                \
+                        acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[cur][mt_][PA[q_]]), \
+                                                                               __builtin_bit_cast(f16x8, bf[cur][nt_][PB[q_]]), \
+                                                                               acc[mt_][nt_], 0, 0, 0);                 \
+                }                                                                                                       \
+                __builtin_amdgcn_sched_barrier(0);
+                // slot i of NSLOT gets MFMAs [i NMFMA / NSLOT, (i + 1) NMFMA / NSLOT)
+                constexpr int NSLOT = 1 + 6 * NPL + ACOPY + NBW;
+#define S16_SLOT(i_) S16_MFMAS((i_) * NMFMA / NSLOT, ((i_) + 1) * NMFMA / NSLOT)
+                int baddr[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    int ra_ = (row[nt] + nr + z) * p.Ws;
+                    if (nr == 2) ra_ = top[nt] ? auxoff : ra_;
+                    if (nr == 0) ra_ = bot[nt] ? auxoff + p.Ws : ra_;
+                    int sl_ = col[nt] + nsx;
+                    if (nsx == 2) sl_ = lft[nt] ? p.W + 2 : sl_;
+                    if (nsx == 0) sl_ = rgt[nt] ? p.W + 3 : sl_;
+                    baddr[nt] = ra_ + sl_;
+                }
+                const u32x4* const Bn_ = Bs + nhb * bbuf16 + lhi * region16;
+                const u32x4* const An_ = As + ((T + 1) & (RING - 1)) * ASTAGE16 + lhi * 128 + l31;
+                S16_SLOT(0)
+#pragma unroll
+                for (int i = 0; i < 2 * NPL; ++i) {           // the B fragments
+                    bf[nxt][i / NPL][i % NPL] = Bn_[(i % NPL) * 2 * region16 + baddr[i / NPL]];
+                    S16_SLOT(1 + i)
+                }
+#pragma unroll
+                for (int i = 0; i < 4 * NPL; ++i) {           // the A fragments
+                    af[nxt][i / NPL][i % NPL] = An_[(i % NPL) * 256 + (i / NPL) * 32];
+                    S16_SLOT(1 + 2 * NPL + i)
+                }
+                {                                             // the copies of stage T + 4
+                    const int st_ = min(T + 4, nstage - 1);   // (tail: harmless re-copies of the last stage)
+                    const u32x4* const a_ = wsrc0 + (size_t)st_ * wstage + lane;
+                    u32x4* const ad_ = As + (T & (RING - 1)) * ASTAGE16 + wid * (64 * ACOPY);
+#pragma unroll
+                    for (int q = 0; q < ACOPY; ++q) {
+                        glds16(a_ + 64 * q, ad_ + 64 * q);
+                        S16_SLOT(1 + 6 * NPL + q)
+                    }
+                    if (iti >= 3) {
+                        const int hc_ = min(ici + 1, nchunks - 1);
+                        const u32x4* const bb_ = bsrc0 + (size_t)(2 * hc_) * p.HpWs;
+                        u32x4* const bd_ = Bs + ((ici + 1) & 1) * bbuf16;
+#pragma unroll
+                        for (int q = 0; q < NBW; ++q) {
+                            const int k_ = (iti - 3) * NBW + q;
+                            if (lane < blim[k_]) glds16(bb_ + goff[k_], bd_ + blds[k_]);
+                            S16_SLOT(1 + 6 * NPL + ACOPY + q)
+                        }
+                    } else {
+                        S16_MFMAS((1 + 6 * NPL + ACOPY) * NMFMA / NSLOT, NMFMA)
+                    }
+                }
+#undef S16_SLOT
+#undef S16_MFMAS
+                // this wave's copies of stage T + 2 have landed; those of T + 3 and T + 4 may still be in flight
+                const int t3 = tap + 3 >= 9 ? tap + 3 - 9 : tap + 3;
+                const int nfl = S16_COUNT(t3) + S16_COUNT(iti);     // compile-time after unrolling: one of three values
+                S16_STAMP(1)
+                if (nfl == 2 * ACOPY) S16_VMCNT(2 * ACOPY)
+                else if (nfl == 2 * ACOPY + NBW) S16_VMCNT(2 * ACOPY + NBW)
+                else S16_VMCNT(2 * ACOPY + 2 * NBW)
+                S16_STAMP(2)
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every fragment of tap T + 1 is in registers
+                S16_STAMP(3)
+                __builtin_amdgcn_s_barrier();         // B_T: stage T + 2 complete for all waves; slot of stage T + 1 is free
+                S16_STAMP(4)
+#undef S16_STAMP
+            }
+        }
+    }
+    wait_vmem();                                      // (the tail's re-copies)
+#undef S16_READ
+#undef S16_VMCNT
+#undef S16_COUNT
+#undef S16_COPIES
+
+    const size_t HW = (size_t)p.H * p.W;
+    // fp16 form: take the two power-of-two operand scales out again (exact)
+    const float unscale = NPL == 2 ? 1.f / (pow2_scale(*p.xmax) * pow2_scale(*p.wmax)) : 1.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[mt][nt][r];
+                if (NPL == 2) v *= unscale;
+                if (p.bias) v += p.bias[m];
+                d0[(size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
+int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+}  // namespace
+
+bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode) {
+    if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
+    if (M % 128 != 0 || Cred % 16 != 0 || M <= 0 || Cred <= 0) return false;
+    if (!(W == 32 || W == 64 || W == 128)) return false;
+    const int RT = 256 / W;
+    if (H % RT != 0 || H < 4) return false;
+    if (W == 128 && mode == SPLIT16_DGRAD_REFLECT) return false;      // halo + folded rows of two buffers exceed the LDS
+    if ((long long)N * Cred * (H + 4) * (W + 4) >= (1ll << 31)) return false;
+    return true;
+}
+
+size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W) {
+    return (size_t)3 * N * (Cred / 8) * (H + 4) * (W + 4) * 16 + 16384;     // + slack for whole-KiB halo reads
+}
+
+size_t nemar_split16_pack_bytes(int M, int Cred) { return (size_t)(Cred / 16) * 9 * (M / 128) * 768 * 16 + 16384; }
+
+namespace {
+// the max words sit in the slack behind the planes / the packed weights
+unsigned* scratch_max_word(void* scratch, int N, int Cred, int H, int W) {
+    return (unsigned*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W) - 64);
+}
+unsigned* pack_max_word(void* packed, int M, int Cred) { return (unsigned*)((char*)packed + nemar_split16_pack_bytes(M, Cred) - 64); }
+}  // namespace
+
+void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, int variant, hipStream_t st) {
+    const int M = dgrad ? C : K, Cred = dgrad ? K : C;
+    const long long total = (long long)(Cred / 16) * 9 * (M / 128) * 256;
+    if (variant == 4) {
+        unsigned* mw = pack_max_word(packed, M, Cred);
+        (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
+        hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid((long long)K * C * 9, 256 * 4)), dim3(256), 0, st, w, (long long)K * C * 9, mw);
+        hipLaunchKernelGGL((split16_pack_kernel<2>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad, mw);
+        return;
+    }
+    hipLaunchKernelGGL((split16_pack_kernel<3>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad,
+                       (const unsigned*)nullptr);
+}
+
+void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
+                    int mode, void* scratch, int xcd_map, int variant, long long* tl, hipStream_t st) {
+    const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
+    unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
+    if (variant == 4) {
+        (void)hipMemsetAsync(xmw, 0, sizeof(unsigned), st);
+        const long long nsrc = (long long)N * Cred * H * W;
+        hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid(nsrc, 256 * 8)), dim3(256), 0, st, src, nsrc, xmw);
+        hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
+                           mode, total, xmw);
+    } else {
+        hipLaunchKernelGGL((split_planes_kernel<3>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
+                           mode, total, (const unsigned*)nullptr);
+    }
+    Split16Params p;
+    p.planes = (const u32x4*)scratch;
+    p.wp = (const u32x4*)packed;
+    p.bias = bias;
+    p.dst = dst;
+    p.N = N; p.H = H; p.W = W; p.M = M; p.Cred = Cred;
+    p.Ws = W + 4;
+    p.HpWs = (H + 4) * (W + 4);
+    p.wshift = ilog2(W);
+    p.RT = 256 / W;
+    p.tiles_per_img = H / p.RT;
+    p.mblks = M / 128;
+    p.halo_instr = nemar_cdiv((long long)(p.RT + 2) * p.Ws * 16, 1024);
+    p.fold = mode == SPLIT16_DGRAD_REFLECT;
+    p.aux_instr = p.fold ? nemar_cdiv((long long)2 * p.Ws * 16, 1024) : 0;
+    p.plane16 = total;
+    p.tl = tl;
+    p.xmax = xmw;
+    p.wmax = pack_max_word(const_cast<void*>(packed), M, Cred);
+    p.halo16 = (p.RT + 2) * p.Ws;
+    p.aux16 = p.fold ? 2 * p.Ws : 0;
+    const int grid = N * p.tiles_per_img * p.mblks;
+    p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
+    const int region = p.halo_instr + p.aux_instr;
+    const dim3 g(grid), b(384);
+    if (variant == 4) {                 // fp16 x 3 (always fits: four regions per halo buffer, 8 KiB weight stages)
+        const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
+        const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), 6);
+        if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2>), g, dim3(256), 0, st, p);
+        else if (nbw == 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 2>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_split16_kernel<3, 2>), g, dim3(256), 0, st, p);
+        return;
+    }
+    if (variant == 3 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
+        const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
+        const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), 6);
+        if (nbw <= 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 3>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_split16_kernel<3, 3>), g, dim3(256), 0, st, p);
+        return;
+    }
+    if (region <= 6) hipLaunchKernelGGL((igemm_split16_lw_kernel<6, 4>), g, b, 0, st, p);
+    else if (region == 7) hipLaunchKernelGGL((igemm_split16_lw_kernel<7, 4>), g, b, 0, st, p);
+    else if (region == 8) hipLaunchKernelGGL((igemm_split16_lw_kernel<8, 4>), g, b, 0, st, p);
+    else if (region == 9) hipLaunchKernelGGL((igemm_split16_lw_kernel<9, 4>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((igemm_split16_lw_kernel<10, 3>), g, b, 0, st, p);
+}

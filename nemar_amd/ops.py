@@ -78,7 +78,7 @@ _arena_live = [None]   # (data_ptr, bytes) the library currently holds
 
 
 def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
-    """Make sure the library's transient scratch arena (split source planes of the wide 3x3 layers, csrc/conv_bf6.hip) covers
+    """Make sure the library's transient scratch arena (split source planes of the wide 3x3 layers, csrc/conv_split16.hip) covers
     this layer.  Grow-only per device; stream-ordered like _workspace."""
     need = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
     if not need:
@@ -131,7 +131,7 @@ def invalidate_packed_weights():
 
 
 def tune(key, value):
-    """nemar_tune through the packed-weight cache: several switches (tile family, split-bf16 route) change the packed image."""
+    """nemar_tune through the packed-weight cache: several switches (tile family, split-16 route) change the packed image."""
     L.tune(key, value)
     invalidate_packed_weights()
 

@@ -173,6 +173,26 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, e
     return d;
 }
 
+
+// 32x32x16 f16: same operand / result maps as the bf16 form
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c, int, int, int) {
+    struct AB { float a[8], b[8]; } mine, all[64];
+    for (int j = 0; j < 8; ++j) { mine.a[j] = (float)a[j]; mine.b[j] = (float)b[j]; }
+    emu_wave_exchange(&mine, sizeof(mine), all);
+    int l = emu_lane_id();
+    int col = l & 31;
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 8; ++j) acc += all[row + 32 * g].a[j] * all[col + 32 * g].b[j];
+        d[r] = acc;
+    }
+    return d;
+}
+
 // ---- direct global->LDS copy (global_load_lds_*): LDS destination = wave-uniform base + lane*size ------------------
 static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* g,
                                                     __attribute__((address_space(3))) void* l, unsigned size,

@@ -165,7 +165,7 @@ def case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=F
 
 class scratch_arena:
     """Register a scratch arena with the library for the duration of a block (nemar_set_scratch): the wide 3x3 stride-1
-    layers then run on the split-bf16 matrix-pipe kernels (csrc/conv_bf6.hip)."""
+    layers then run on the split-16 matrix-pipe kernels (csrc/conv_split16.hip)."""
 
     def __init__(self, be, nbytes):
         self.be, self.buf, self.nbytes = be, be.bytes_buf(nbytes), nbytes
@@ -179,12 +179,12 @@ class scratch_arena:
         self.be.lib.set_scratch(None, 0)
 
 
-def case_conv_bf6(be, N, C, H, W, K, pad_mode, dgrad, seed=0):
+def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0):
     """One wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_fwd (dgrad False) or nemar_conv2d_bwd_data with the scratch
-    arena registered: the split-bf16 route must be eligible for the shape, and obey the same tolerance against the float64 oracle
+    arena registered: the split-16 route must be eligible for the shape, and obey the same tolerance against the float64 oracle
     as the exact-fp32 kernels."""
     need = be.lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)
-    assert need > 0, "shape is not eligible for the split-bf16 kernels"
+    assert need > 0, "shape is not eligible for the split-16 kernels"
     with scratch_arena(be, need):
         if dgrad:
             case_conv_bwd_data(be, N, C, 0, H, W, K, 3, 1, 1, pad_mode, seed=seed)

@@ -186,7 +186,7 @@ def run(name, report=None, check=True):
             add(pre + 'grad/%s 1-cos(worst tensor %s)' % (nm, worst[1]), 1.0 - worst[0], 1e-2)
             # ELEMENTWISE: |g_build - g_fp64| per element, relative to the tensor's max, against the fp32 oracle's own elementwise
             # gap to fp64 (how far two correct fp32 evaluations of this tensor are apart).  Two bounds per tensor: the bulk (99th
-            # percentile) within 2e-3 + 4 x the oracle's 99th-percentile gap, and the single worst element within 2e-2 + 4 x the
+            # percentile) within 5e-3 + 4 x the oracle's 99th-percentile gap, and the single worst element within 2e-2 + 4 x the
             # oracle's worst gap — one ReLU / LeakyReLU / max-pool mask that flips upstream moves a handful of elements by
             # ~1e-2 of the tensor's max in ANY pair of fp32 evaluations (measured: gpurun_out/r2r, 1.07e-2 on one element of R's
             # localisation weights in the 128x128 affine config while every norm / cosine row passed).  Reported: worst tensor.
@@ -201,7 +201,7 @@ def run(name, report=None, check=True):
                 cond = np.abs(g32[k].numpy().astype(np.float64) - b).ravel() / vmax
                 ratio = float(e.max()) / (2e-2 + 4 * float(cond.max()))
                 if e.size >= 1000:           # (a bias vector's 99th percentile IS its worst element)
-                    ratio = max(ratio, float(np.quantile(e, 0.99)) / (2e-3 + 4 * float(np.quantile(cond, 0.99))))
+                    ratio = max(ratio, float(np.quantile(e, 0.99)) / (5e-3 + 4 * float(np.quantile(cond, 0.99))))
                 if ratio > worst_e[0]:
                     worst_e = (ratio, k, float(e.max()))
             add(pre + 'grad/%s elementwise, worst tensor %s (max err %.2e of the tensor max)' % (nm, worst_e[1], worst_e[2]),

@@ -83,17 +83,17 @@ def test_conv_real_shape(be, shape):
     _run_shape(be, shape)
 
 
-BF6_SHAPES = [
+SPLIT16_SHAPES = [
     ("T resblock 256->256 k3 reflect 64x64", 8, 256, 0, 64, 64, 256, 3, 1, 1, PAD_REFLECT),
     ("T resblock 256->256 k3 reflect 128x128 (512^2 input)", 2, 256, 0, 128, 128, 256, 3, 1, 1, PAD_REFLECT),
     ("wide zero-padded 128->128 k3 32x32", 8, 128, 0, 32, 32, 128, 3, 1, 1, PAD_ZERO),
 ]
 
 
-@pytest.mark.parametrize("shape", BF6_SHAPES, ids=[s[0] for s in BF6_SHAPES])
-def test_conv_real_shape_split_bf16(be, shape):
+@pytest.mark.parametrize("shape", SPLIT16_SHAPES, ids=[s[0] for s in SPLIT16_SHAPES])
+def test_conv_real_shape_split16(be, shape):
     """Scratch arena registered, as nemar_amd/ops.py does: forward and data gradient of the wide 3x3 layers run on the
-    split-bf16 kernels (csrc/conv_bf6.hip) and must obey the SAME tolerances as the exact-fp32 kernels."""
+    split-16 kernels (csrc/conv_split16.hip) and must obey the SAME tolerances as the exact-fp32 kernels."""
     from kernel_cases import scratch_arena
     name, N, C0, C1, H, W, K, R, stride, pad, pm = shape
     need = be.lib.conv2d_scratch(N, H, W, K, C0 + C1, R, R, stride, pad)
@@ -102,9 +102,9 @@ def test_conv_real_shape_split_bf16(be, shape):
         _run_shape(be, shape)
 
 
-def test_split_bf16_error_is_fp32_class(be):
-    """The accuracy claim of csrc/conv_bf6.hip, measured: resblock forward and reflect data gradient at the bench shape, both
-    routes against the same float64 reference on a channel subset.  The split-bf16 route must not be worse than 1.5x the
+def test_split16_error_is_fp32_class(be):
+    """The accuracy claim of csrc/conv_split16.hip, measured: resblock forward and reflect data gradient at the bench shape, both
+    routes against the same float64 reference on a channel subset.  The split-16 route must not be worse than 1.5x the
     exact-fp32 route's own max error (+ one fp32 ulp of the result scale), and repeated calls must agree bitwise."""
     from kernel_cases import scratch_arena
     N, C, H, W, K = 8, 256, 64, 64, 256
@@ -136,7 +136,7 @@ def test_split_bf16_error_is_fp32_class(be):
     with scratch_arena(be, lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)):
         y6, g6 = run()
         y6b, g6b = run()
-    assert np.array_equal(y6, y6b) and np.array_equal(g6, g6b), "split-bf16 route is not reproducible"
+    assert np.array_equal(y6, y6b) and np.array_equal(g6, g6b), "split-16 route is not reproducible"
     assert not np.array_equal(y6, y32), "the arena did not switch the route"
     rows = []
     for what, a32, a6, want, sel in (("fwd", y32, y6, want_f, ks), ("dgrad", g32, g6, want_d, ks)):
@@ -145,11 +145,11 @@ def test_split_bf16_error_is_fp32_class(be):
         scale = np.abs(want).max()
         rows.append((what, e32.max(), e6.max(), np.sqrt((e32 ** 2).mean()), np.sqrt((e6 ** 2).mean()), scale))
     import os
-    rep = os.environ.get('NEMAR_BF6_REPORT')
+    rep = os.environ.get('NEMAR_SPLIT16_REPORT')
     if rep:
         with open(rep, 'a') as f:
             for r in rows:
-                f.write("%-6s max|err| exact-fp32 %.3e  split-bf16 %.3e   rms exact-fp32 %.3e  split-bf16 %.3e   (result scale %.3g)\n" % r)
+                f.write("%-6s max|err| exact-fp32 %.3e  split-16 %.3e   rms exact-fp32 %.3e  split-16 %.3e   (result scale %.3g)\n" % r)
     for what, m32, m6, r32, r6, scale in rows:
         assert m6 <= 1.5 * m32 + 1.2e-7 * scale, (what, m32, m6)
         assert r6 <= 1.5 * r32, (what, r32, r6)

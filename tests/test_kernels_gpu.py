@@ -317,38 +317,33 @@ def test_adam(be):
     K.case_adam(be, n=100003)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-def test_conv_split_bf16_matrix_pipe(be, variant):
-    """3x3 stride-1 layers with >= 128 output channels on the bf16 MFMA with three-way split operands (conv_bf6.hip): padded,
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_conv_split16_matrix_pipe(be, variant):
+    """3x3 stride-1 layers with >= 128 output channels on the bf16 MFMA with three-way split operands (conv_split16.hip): padded,
     channel-blocked split planes; halo staged once per 16-channel chunk; weight-stage ring; zero and reflect padding; one and
     several row tiles per image, both 128-channel halves, 32- and 64-pixel rows."""
-    # 0 first generation, 1 software-pipelined MFMA waves + exact-sized LDS regions, 2 no loader waves (the MFMA waves issue the
-    # copies), 3 = 1 with the chunk order rotated per tile (two groups), 4 = fourth generation (2 + full fragment double buffering,
-    # branch-free copy descriptors)
-    be.lib.tune(21, {0: 0, 1: 1, 2: 2, 3: 1, 4: 3}[variant])
-    be.lib.tune(22, 2 if variant == 3 else 0)
+    # 4 = fp16 x 3 products (two scaled fp16 planes; the default), 3 = bf16 x 6 products, 0 = bf16 x 6 on the first-generation
+    # kernel (loader waves)
+    be.lib.tune(21, variant)
     try:
-        K.case_conv_bf6(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
-        K.case_conv_bf6(be, 1, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False)
-        K.case_conv_bf6(be, 1, 16, 8, 64, 128, K.PAD_REFLECT, dgrad=False)
-        K.case_conv_bf6(be, 1, 48, 4, 128, 128, K.PAD_REFLECT, dgrad=False)      # 128-pixel rows: two rows per tile, 3 chunks
+        K.case_conv_split16(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
+        K.case_conv_split16(be, 1, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False)
+        K.case_conv_split16(be, 1, 16, 8, 64, 128, K.PAD_REFLECT, dgrad=False)
+        K.case_conv_split16(be, 1, 48, 4, 128, 128, K.PAD_REFLECT, dgrad=False)      # 128-pixel rows: two rows per tile, 3 chunks
     finally:
-        be.lib.tune(21, 0)
-        be.lib.tune(22, 0)
+        be.lib.tune(21, 4)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-def test_conv_split_bf16_reflect_data_gradient(be, variant):
-    """Data gradient of a reflect-padded 3x3 layer on the split-bf16 kernel: the folded border rows / slots written by the split
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_conv_split16_reflect_data_gradient(be, variant):
+    """Data gradient of a reflect-padded 3x3 layer on the split-16 kernel: the folded border rows / slots written by the split
     pass are selected by address for (row 1, last filter row), (row H-2, first filter row) and the same in x; tiles that hold
     both special rows, only one, or none; and the zero-padded data gradient."""
-    be.lib.tune(21, {0: 0, 1: 1, 2: 2, 3: 1, 4: 3}[variant])
-    be.lib.tune(22, 2 if variant == 3 else 0)
+    be.lib.tune(21, variant)
     try:
-        K.case_conv_bf6(be, 1, 128, 8, 32, 16, K.PAD_REFLECT, dgrad=True)
-        K.case_conv_bf6(be, 2, 128, 16, 32, 32, K.PAD_REFLECT, dgrad=True)
-        K.case_conv_bf6(be, 1, 128, 12, 64, 16, K.PAD_REFLECT, dgrad=True)
-        K.case_conv_bf6(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
+        K.case_conv_split16(be, 1, 128, 8, 32, 16, K.PAD_REFLECT, dgrad=True)
+        K.case_conv_split16(be, 2, 128, 16, 32, 32, K.PAD_REFLECT, dgrad=True)
+        K.case_conv_split16(be, 1, 128, 12, 64, 16, K.PAD_REFLECT, dgrad=True)
+        K.case_conv_split16(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
     finally:
-        be.lib.tune(21, 0)
-        be.lib.tune(22, 0)
+        be.lib.tune(21, 4)

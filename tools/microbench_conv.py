@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tune", type=int, nargs=2, action='append', default=[], help="nemar_tune key value")
     ap.add_argument("--only", type=str, default=None)
-    ap.add_argument("--arena", action='store_true', help="register a scratch arena (split-bf16 kernels for the wide 3x3 layers); "
+    ap.add_argument("--arena", action='store_true', help="register a scratch arena (split-16 kernels for the wide 3x3 layers); "
                                                          "forward is then timed without the fused activation, as the resblocks run it")
     a = ap.parse_args()
     lib = _lib.load()

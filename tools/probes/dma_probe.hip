@@ -1,5 +1,5 @@
 // Measurement probe (not part of the product): raw global -> LDS copy throughput per CU on gfx950 for the access patterns of the
-// split-bf16 convolution loaders.  W loader waves per workgroup stream 1 KiB global_load_lds_dwordx4 instructions with at most
+// split-16 convolution loaders.  W loader waves per workgroup stream 1 KiB global_load_lds_dwordx4 instructions with at most
 // D wave-instructions in flight per wave, from (shared = every workgroup the same 4 MiB, private = its own 4 MiB).
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/dma_probe.hip -o tools/probes/_build/dma_probe
 #include <hip/hip_runtime.h>

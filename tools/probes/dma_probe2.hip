@@ -1,4 +1,4 @@
-// Measurement probe (not part of the product): why do the loader waves of the split-bf16 convolution need ~290 cycles per 1 KiB
+// Measurement probe (not part of the product): why do the loader waves of the split-16 convolution need ~290 cycles per 1 KiB
 // global->LDS copy when a free-running wave needs ~66?  Same copy burst (6 x 1 KiB per iteration from a 3.5 MiB region shared
 // by all workgroups), toggling the ingredients: BAR = workgroup barrier per iteration with 4 parked waves, BIG = 152 KiB of LDS,
 // and the burst length.
