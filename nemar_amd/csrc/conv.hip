@@ -1980,6 +1980,10 @@ NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, i
         const size_t f3 = (size_t)nemar_narrow_wgrad_splits(N, C, OH, OW) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
         if (f3 > fl) fl = f3;
     }
+    if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {       // slabs of the split-16 route + bias partials
+        const size_t f5 = (size_t)nemar_split16_wgrad_splits(N, C, H, W, K) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
+        if (f5 > fl) fl = f5;
+    }
     return sizeof(float) * fl;
 }
 
@@ -2019,6 +2023,19 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
             }
         }
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
+        return NEMAR_OK;
+    }
+    if (g_split16 && g_split16_variant == 4 && part && C1 == 0 && nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
+        g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K)) {
+        // wide 3x3 stride-1 layers: fp16 x 3 on the 16-bit matrix pipe (conv_split16_wgrad.hip); bias gradient as its own reduction
+        nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map, st);
+        if (gb) {
+            const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
+            float* pb = part + (size_t)nemar_split16_wgrad_splits(N, C0, H, W, K) * K * J;
+            hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, pb, N, K, OH * OW, BIAS_CHUNK);
+            nemar_sum_partials(pb, K, N * chunks, gb, K, true, st);
+        }
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (split-16)");
         return NEMAR_OK;
     }
     if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
@@ -2111,6 +2128,10 @@ NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, 
     if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO)) b = nemar_split16_scratch_bytes(N, C, H, W);
     if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO)) {
         const size_t d = nemar_split16_scratch_bytes(N, K, H, W);
+        if (d > b) b = d;
+    }
+    if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {
+        const size_t d = nemar_split16_wgrad_scratch_bytes(N, C, H, W, K);
         if (d > b) b = d;
     }
     return b;

@@ -15,3 +15,12 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, i
 // src [N, Cred, H, W] fp32 -> dst [N, M, H, W] fp32 (+ bias[M] when non-null); `scratch` >= nemar_split16_scratch_bytes
 void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M,
                     int Cred, int mode, void* scratch, int xcd_map, int variant, long long* tl, hipStream_t st);
+
+// ---- weight gradient of the same layers (conv_split16_wgrad.hip) ----
+bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
+size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K);     // split gy (three shifts) and padded x planes
+int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K);               // slabs of K C 9 floats the caller provides
+// gw [K][C][3][3] += dW from x [N,C,H,W] and gy [N,K,H,W]; slabs summed in order (bitwise reproducible)
+void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int reflect, void* scratch,
+                         float* part, int xcd_map, hipStream_t st);
+void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);

@@ -1,0 +1,339 @@
+// nemar_amd — weight gradient of the wide 3x3 / stride-1 / pad-1 layers on the 16-bit matrix pipe (fp16 x 3 products at fp32
+// accuracy: the operand split, its scaling and its error analysis are those of conv_split16.hip).
+//
+//     dW[k][c][r][s] = sum over n, y, x of  gy[n][k][y][x] * xpad[n][c][y + r][x + s]          (reference: autograd of
+//     nn.Conv2d inside ResnetBlock, models/networks.py:418-439 — 36 of these per step, 13 of the 59 ms after the forward and data
+//     gradient moved to conv_split16.hip)
+//
+// The reduction runs over PIXELS, so an MFMA operand (8 consecutive reduction elements per lane) is 8 consecutive pixels of one
+// channel, and the tap's horizontal shift s would misalign every second operand read.  The split pass therefore writes
+//   G_s[n][k][y][x'] = gy[n][k][y][x' - s]   for s = 0, 1, 2 (zero where x' - s falls outside the row),   x' = 0 .. 8 CPR - 1
+//   X  [n][c][yp][x'] = xpad[n][c][yp][x']                    (padding materialised, zero beyond column W + 1)
+// with CPR = ceil((W + 2) / 8) 8-pixel chunks per row, so that   dW[k][c][r][s] = sum_{n,y,x'} G_s[k][y][x'] X[c][y + r][x']
+// reads BOTH operands at the same aligned chunk: flat chunk f = y CPR + q of G_s against flat chunk f + r CPR of X.  Both are
+// stored tile-ordered — [64-channel block][flat chunk][64 channels][8 pixels] fp16, high and low plane — so a stage of the
+// reduction is a run of contiguous 1 KiB copies and an LDS fragment read is conflict-free (32 lanes = 32 consecutive channels).
+//
+// wgrad_split16_kernel: workgroup = 64 k x 64 c x ALL NINE taps over RB image rows of one image (a slab of the pixel reduction;
+// slabs are summed in order by nemar_sum_partials: bitwise reproducible), four waves of 32 k x 32 c (nine accumulators each), one
+// per SIMD.  Same machinery as igemm_split16_kernel: no loader waves (each wave issues a quarter of every stage's copies in the
+// shadow of its MFMAs and waits for ITS copies before the step's barrier), 4-slot stage ring with the stage for step T + 4 issued
+// during step T, every fragment of step T + 1 read during step T into a second register set, the body cut into pinned slots.
+#include "common.h"
+#include "conv_split16.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pow2_scale(unsigned maxbits) {       // as in conv_split16.hip: 2^(11 - floor(log2 max))
+    const int e = (int)((maxbits >> 23) & 255u);
+    if (e == 0 || e == 255) return 1.f;
+    const int se = 127 + 11 - (e - 127);
+    if (se < 1 || se > 254) return 1.f;
+    return __builtin_bit_cast(float, (unsigned)se << 23);
+}
+__device__ __forceinline__ unsigned short f16_rn(float v) {
+    const _Float16 h = (_Float16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned short& l) {
+    h = f16_rn(v);
+    const float r = v - (float)__builtin_bit_cast(_Float16, h);
+    l = f16_rn(r);
+}
+__device__ __forceinline__ u32x4 pack8(const unsigned short* b) {
+    u32x4 o;
+    o[0] = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    o[1] = (unsigned)b[2] | ((unsigned)b[3] << 16);
+    o[2] = (unsigned)b[4] | ((unsigned)b[5] << 16);
+    o[3] = (unsigned)b[6] | ((unsigned)b[7] << 16);
+    return o;
+}
+__device__ __forceinline__ int mirror(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// G_s planes: word (((s * 2 + pl) * N + n) * KBLK + kblk) * F + f) * 64 + kk, F = H * CPR.  One thread = one (n, k, y, chunk):
+// reads the 10 texels x' - 2 .. x' + 7 of its row once, writes the three shifted versions, two planes each.
+__global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restrict__ gy, u32x4* __restrict__ out, int N, int K, int H,
+                                                            int W, int CPR, long long total, const unsigned* maxbits) {
+    const float scale = pow2_scale(*maxbits);
+    const int KBLK = K >> 6, F = H * CPR;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(t & 63);
+        long long q = t >> 6;
+        const int f = (int)(q % F);
+        q /= F;
+        const int kblk = (int)(q % KBLK), n = (int)(q / KBLK);
+        const int y = f / CPR, x0 = (f - y * CPR) * 8;
+        const float* row = gy + (((size_t)n * K + kblk * 64 + kk) * H + y) * W;
+        float v[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) {
+            const int x = x0 - 2 + e;
+            v[e] = (x >= 0 && x < W) ? row[x] * scale : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            unsigned short h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2_f16(v[e + 2 - s], h[e], l[e]);
+            out[(size_t)(s * 2) * total + t] = pack8(h);
+            out[(size_t)(s * 2 + 1) * total + t] = pack8(l);
+        }
+    }
+}
+
+// X planes: word ((pl * N + n) * CBLK + cblk) * FX + f) * 64 + cc, FX = (H + 2) * CPR; padding materialised
+__global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C, int H,
+                                                            int W, int CPR, int reflect, long long total, const unsigned* maxbits) {
+    const float scale = pow2_scale(*maxbits);
+    const int CBLK = C >> 6, FX = (H + 2) * CPR;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(t & 63);
+        long long q = t >> 6;
+        const int f = (int)(q % FX);
+        q /= FX;
+        const int cblk = (int)(q % CBLK), n = (int)(q / CBLK);
+        const int yp = f / CPR, x0 = (f - yp * CPR) * 8;
+        int y = yp - 1;
+        bool rowok = true;
+        if (reflect) y = mirror(y, H);
+        else rowok = (unsigned)y < (unsigned)H;
+        const float* row = x + (((size_t)n * C + cblk * 64 + cc) * H + (rowok ? y : 0)) * W;
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int xp = x0 + e;                   // padded column
+            int xs = xp - 1;
+            bool ok = rowok && xp < W + 2;
+            if (reflect) xs = mirror(xs, W);
+            else ok = ok && (unsigned)xs < (unsigned)W;
+            split2_f16(ok ? row[xs] * scale : 0.f, h[e], l[e]);
+        }
+        out[t] = pack8(h);
+        out[total + t] = pack8(l);
+    }
+}
+
+__global__ __launch_bounds__(256) void absmax2_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+struct WgParams {
+    const u32x4* G;            // [3 s][2 planes] blocks of gplane16 words
+    const u32x4* X;            // [2 planes] blocks of xplane16 words
+    float* part;               // slabs [splits][K][C][9]
+    int N, H, W, C, K;
+    int CPR, F, FX, RB, spi;   // chunks per row, flat chunks per image of G / X, rows per split, splits per image
+    int KBLK, CBLK;
+    long long gplane16, xplane16;
+    const unsigned* gmax;
+    const unsigned* xmax;
+    int xcd;
+};
+
+__global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
+    constexpr int RING = 4, STAGE16 = 1536;            // 12 G words-columns + 12 X: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
+    __shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles = p.KBLK * p.CBLK;
+    int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);      // the tiles of one pixel slab stay on one XCD (same sources)
+    const int split = t / tiles, tile = t - split * tiles;
+    const int kblk = tile / p.CBLK, cblk = tile - kblk * p.CBLK;
+    const int n = split / p.spi, y0 = (split - n * p.spi) * p.RB;
+    const int nsteps = p.RB * p.CPR / 2, f0 = y0 * p.CPR;
+
+    // ---- this wave's six copies of a stage: copy i = 6 wid + q of 24 (i < 12: G, [s][plane][chunk]; else X, [r][plane][chunk]) ----
+    const u32x4* csrc[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int i = 6 * wid + q;
+        if (i < 12) {
+            const int s = i >> 2, pl = (i >> 1) & 1, ch = i & 1;
+            csrc[q] = p.G + (size_t)(s * 2 + pl) * p.gplane16 + (((size_t)n * p.KBLK + kblk) * p.F + f0 + ch) * 64 + lane;
+        } else {
+            const int j = i - 12, r = j >> 2, pl = (j >> 1) & 1, ch = j & 1;
+            csrc[q] = p.X + (size_t)pl * p.xplane16 + (((size_t)n * p.CBLK + cblk) * p.FX + f0 + r * p.CPR + ch) * 64 + lane;
+        }
+    }
+#define WG_COPIES(stage_)                                                                                               \
+    {                                                                                                                   \
+        const int st_ = min((stage_), nsteps - 1);                   /* tail: harmless re-copies of the last stage */   \
+        u32x4* const d_ = smem + ((stage_) & (RING - 1)) * STAGE16 + wid * 384;                                         \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);                 \
+    }
+#define WG_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14));
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wk = wid >> 1, wc = wid & 1;
+    f32x16 acc[3][3];                                  // [s][r]
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][r][e] = 0.f;
+    u32x4 af[2][3][2], bf[2][3][2];                    // [register set][s | r][plane]
+    const int a_off = lhi * 64 + wk * 32 + l31, b_off = 768 + lhi * 64 + wc * 32 + l31;
+#define WG_READ(set_, slot_)                                                                                            \
+    {                                                                                                                   \
+        const u32x4* const S_ = smem + (slot_) * STAGE16;                                                               \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) af[set_][i >> 1][i & 1] = S_[a_off + i * 128];                    \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) bf[set_][i >> 1][i & 1] = S_[b_off + i * 128];                    \
+    }
+    // partial products, smallest first: (l h') (h l') (h h')
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+
+    WG_COPIES(0)
+    WG_COPIES(1)
+    WG_COPIES(2)
+    WG_COPIES(3)
+    WG_VMCNT(12)                                       // stages 0 and 1 have landed (2 and 3 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    WG_READ(0, 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                      // every wave holds the fragments of step 0: slot 0 may be refilled
+    for (int T0 = 0; T0 < nsteps; T0 += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int T = T0 + half, cur = half, nxt = half ^ 1;
+            // 18 slots of [<= 1 memory instruction][its share of the 27 MFMAs], pinned (see conv_split16.hip)
+#define WG_MFMAS(beg_, end_)                              /* m = 9 q + 3 s + r */                                           \
+            _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < 27; ++m_) {                                     \
+                const int q_ = m_ / 9, s_ = (m_ % 9) / 3, r_ = m_ % 3;                                                  \
+                acc[s_][r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[cur][s_][PA[q_]]),    \
+                                                                     __builtin_bit_cast(f16x8, bf[cur][r_][PB[q_]]),    \
+                                                                     acc[s_][r_], 0, 0, 0);                             \
+            }                                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);
+#define WG_SLOT(i_) WG_MFMAS((i_) * 27 / 18, ((i_) + 1) * 27 / 18)
+            const u32x4* const S_ = smem + ((T + 1) & (RING - 1)) * STAGE16;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                af[nxt][i >> 1][i & 1] = S_[a_off + i * 128];
+                WG_SLOT(i)
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                bf[nxt][i >> 1][i & 1] = S_[b_off + i * 128];
+                WG_SLOT(6 + i)
+            }
+            {
+                const int st_ = min(T + 4, nsteps - 1);
+                u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + wid * 384;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
+                    WG_SLOT(12 + q)
+                }
+            }
+#undef WG_SLOT
+#undef WG_MFMAS
+            WG_VMCNT(12)                               // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers
+            __builtin_amdgcn_s_barrier();              // stage T + 2 complete for all waves; slot of stage T + 1 is free
+        }
+    }
+    wait_vmem();                                       // (the tail's re-copies)
+#undef WG_READ
+#undef WG_VMCNT
+#undef WG_COPIES
+
+    // slab [split][k][c][tap = 3 r + s]; D register e of lane l = row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31
+    const float unscale = 1.f / (pow2_scale(*p.gmax) * pow2_scale(*p.xmax));
+    float* const slab = p.part + (size_t)split * p.K * p.C * 9;
+    const int c = cblk * 64 + wc * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = kblk * 64 + wk * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        float* const o = slab + ((size_t)k * p.C + c) * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) o[3 * r + s] = acc[s][r][e] * unscale;
+    }
+}
+
+int rows_per_split(int N, int H, int CPR, int tiles) {
+    // ~256 workgroups: splits per image = ceil(256 / (tiles N)), rounded to a divisor of H whose row block is a whole number of
+    // double steps (RB CPR % 4 == 0)
+    int want = (256 + tiles * N - 1) / (tiles * N);
+    if (want < 1) want = 1;
+    int best = 0;
+    for (int spi = 1; spi <= H; ++spi) {
+        if (H % spi) continue;
+        const int rb = H / spi;
+        if ((rb * CPR) % 4) continue;
+        if (best == 0 || spi <= want) best = spi;
+        if (spi >= want) break;
+    }
+    return best ? H / best : 0;
+}
+
+}  // namespace
+
+bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
+    if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
+    if (C % 64 || K % 64 || C < 128 || K < 128 || W % 8 || H < 4 || W < 8) return false;
+    const int CPR = (W + 2 + 7) / 8;
+    if (rows_per_split(N, H, CPR, (K / 64) * (C / 64)) == 0) return false;
+    if ((long long)N * (C > K ? C : K) * (H + 2) * CPR * 64 >= (1ll << 31)) return false;
+    return true;
+}
+
+size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K) {
+    const int CPR = (W + 2 + 7) / 8;
+    return ((size_t)6 * N * K * H * CPR + (size_t)2 * N * C * (H + 2) * CPR) * 16 + 16384;
+}
+
+int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K) {
+    const int CPR = (W + 2 + 7) / 8;
+    const int rb = rows_per_split(N, H, CPR, (K / 64) * (C / 64));
+    return rb ? N * (H / rb) : 0;
+}
+
+// gw [K][C][3][3] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C 9 floats
+void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int reflect, void* scratch,
+                         float* part, int xcd_map, hipStream_t st) {
+    const int CPR = (W + 2 + 7) / 8, KBLK = K / 64, CBLK = C / 64;
+    const long long gtotal = (long long)N * K * H * CPR, xtotal = (long long)N * C * (H + 2) * CPR;      // words per plane block
+    u32x4* const G = (u32x4*)scratch;
+    u32x4* const X = G + 6 * gtotal;
+    unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K) - 64);
+    (void)hipMemsetAsync(mw, 0, 2 * sizeof(unsigned), st);
+    const long long ng = (long long)N * K * H * W, nx = (long long)N * C * H * W;
+    hipLaunchKernelGGL(absmax2_kernel, dim3(nemar_stream_grid(ng, 256 * 8)), dim3(256), 0, st, gy, ng, mw);
+    hipLaunchKernelGGL(absmax2_kernel, dim3(nemar_stream_grid(nx, 256 * 8)), dim3(256), 0, st, x, nx, mw + 1);
+    hipLaunchKernelGGL(split_wgrad_g_kernel, dim3(nemar_cdiv(gtotal, 256)), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, mw);
+    hipLaunchKernelGGL(split_wgrad_x_kernel, dim3(nemar_cdiv(xtotal, 256)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal,
+                       mw + 1);
+    WgParams p;
+    p.G = G; p.X = X; p.part = part;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
+    p.CPR = CPR; p.F = H * CPR; p.FX = (H + 2) * CPR;
+    p.RB = rows_per_split(N, H, CPR, KBLK * CBLK);
+    p.spi = H / p.RB;
+    p.KBLK = KBLK; p.CBLK = CBLK;
+    p.gplane16 = gtotal; p.xplane16 = xtotal;
+    p.gmax = mw; p.xmax = mw + 1;
+    const int splits = N * p.spi, grid = splits * KBLK * CBLK;
+    p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(wgrad_split16_kernel, dim3(grid), dim3(256), 0, st, p);
+    nemar_sum_partials(part, (long long)K * C * 9, splits, gw, (long long)K * C * 9, true, st);
+}

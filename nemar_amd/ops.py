@@ -244,6 +244,7 @@ class _Conv2d(Function):
         if need_w:
             gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
             wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
+            _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
             L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
                                 R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st)
             grad_ready(ctx.weight)

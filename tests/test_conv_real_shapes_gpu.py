@@ -130,16 +130,29 @@ def test_split16_error_is_fp32_class(be):
         ws = be.bytes_buf(wsb)
         lib.conv2d_bwd_data(P(d_gy), P(d_w), None, 0, 0.0, P(d_g), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1, PAD_REFLECT,
                             P(ws), wsb, 0, be.stream)
-        return be.np(d_y), be.np(d_g)
+        d_gw = be.full((K, C, 3, 3), 0.0)
+        wsb = lib.conv2d_bwd_weight_workspace(N, C, H, W, K, H, W, 3, 3, 1, 1)
+        ws = be.bytes_buf(wsb)
+        lib.conv2d_bwd_weight(P(d_x), C, None, 0, P(d_gys), P(d_gw), None, N, H, W, K, H, W, 3, 3, 1, 1, PAD_REFLECT, P(ws), wsb,
+                              be.stream)
+        return be.np(d_y), be.np(d_g), be.np(d_gw)
 
-    y32, g32 = run()
+    gys = gy / np.sqrt(N * H * W)
+    d_gys = be.dev(gys.numpy())
+    wz = torch.zeros((len(ks), C, 3, 3), dtype=torch.float64, requires_grad=True)
+    _conv_cpu(x.double(), wz, None, 1, 1, PAD_REFLECT).backward(gys[:, ks].double())
+    want_w = wz.grad.numpy()
+    y32, g32, w32 = run()
     with scratch_arena(be, lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)):
-        y6, g6 = run()
-        y6b, g6b = run()
-    assert np.array_equal(y6, y6b) and np.array_equal(g6, g6b), "split-16 route is not reproducible"
-    assert not np.array_equal(y6, y32), "the arena did not switch the route"
+        y6, g6, w6 = run()
+        y6b, g6b, w6b = run()
+    assert np.array_equal(y6, y6b) and np.array_equal(g6, g6b) and np.array_equal(w6, w6b), "split-16 route is not reproducible"
+    assert not np.array_equal(y6, y32) and not np.array_equal(w6, w32), "the arena did not switch the route"
     rows = []
-    for what, a32, a6, want, sel in (("fwd", y32, y6, want_f, ks), ("dgrad", g32, g6, want_d, ks)):
+    for what, a32, a6, want, sel in (("fwd", y32, y6, want_f, ks), ("dgrad", g32, g6, want_d, ks), ("wgrad", w32, w6, want_w, None)):
+        if sel is None:
+            a32, a6 = a32[ks][None], a6[ks][None]
+            sel = slice(None)
         e32 = np.abs(a32[:, sel] - want)
         e6 = np.abs(a6[:, sel] - want)
         scale = np.abs(want).max()

@@ -347,3 +347,12 @@ def test_conv_split16_reflect_data_gradient(be, variant):
         K.case_conv_split16(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
     finally:
         be.lib.tune(21, 4)
+
+
+def test_conv_split16_weight_gradient(be):
+    """Weight gradient of the wide 3x3 layers on the 16-bit matrix pipe (conv_split16_wgrad.hip): three pre-shifted gy copies and
+    padded x planes in tile order, nine taps per workgroup, pixel slabs summed in order; reflect and zero padding, one and several
+    slabs per image, 2 and 3 chunks per row, rectangular channel counts."""
+    K.case_conv_split16_wgrad(be, 1, 128, 8, 8, 128, K.PAD_REFLECT)
+    K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 192, K.PAD_ZERO)
+    K.case_conv_split16_wgrad(be, 1, 192, 4, 24, 128, K.PAD_REFLECT)
