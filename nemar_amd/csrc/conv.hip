@@ -2121,6 +2121,26 @@ NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
     return NEMAR_OK;
 }
 
+// max |t| of a tensor, for callers that feed the same tensor to several split-16 convolution calls (forward + weight gradient take
+// x, data + weight gradient take gy): computed once, registered with nemar_absmax_hint, it replaces the max pass inside each call
+NEMAR_API int nemar_absmax(const float* t, long long n, void* workspace, size_t ws_bytes, void* out_word, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(t && workspace && out_word && n > 0, "absmax: null pointer");
+    if (ws_bytes < 8256) {
+        nemar_set_error("absmax: workspace %zu < 8256", ws_bytes);
+        return NEMAR_EWORKSPACE;
+    }
+    nemar_split16_absmax(t, n, workspace, out_word, (hipStream_t)stream);
+    NEMAR_CHECK_LAUNCH("absmax");
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_absmax_hint(const void* tensor, const void* word) {
+    NEMAR_REQUIRE(tensor, "absmax_hint: null tensor");
+    nemar_split16_set_hint(tensor, word);
+    return NEMAR_OK;
+}
+
 // Scratch bytes nemar_conv2d_fwd / nemar_conv2d_bwd_data want for this layer (0: the layer never uses the arena)
 NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return 0;

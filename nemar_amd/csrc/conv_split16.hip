@@ -129,17 +129,59 @@ __device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned 
     l = f16_rn(r);
 }
 
-// max |x| as the bit pattern of a non-negative float (ordered like an unsigned integer); *out zeroed by the caller
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+// max |x| as the bit pattern of a non-negative float (ordered like an unsigned integer).  16-byte loads; `n4` whole float4s + tail.
+__device__ __forceinline__ unsigned block_absmax(const float* __restrict__ x, long long n, unsigned* red) {
     unsigned m = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    const long long n4 = ((size_t)x & 15) == 0 ? n >> 2 : 0;          // (a view at an odd offset: scalar loads throughout)
+    const u32x4* x4 = reinterpret_cast<const u32x4*>(x);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4 v = x4[i];
+        m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
-    __shared__ unsigned red[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+    return max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+// *out zeroed by the caller (hipMemsetAsync): the stand-alone form used when no hint is registered
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+    __shared__ unsigned red[4];
+    const unsigned m = block_absmax(x, n, red);
+    if (threadIdx.x == 0) atomicMax(out, m);
+}
+
+// nemar_absmax: per-block maxima + a ticket; the last block to finish reduces them, writes *out and leaves the ticket at zero for
+// the next call (no memset launch, no atomics on the value).  ws[0 .. gridDim.x) partials, ws[2048] ticket.
+__global__ __launch_bounds__(256) void absmax_ticket_kernel(const float* __restrict__ x, long long n, unsigned* ws, unsigned* out) {
+    __shared__ unsigned red[4];
+    __shared__ unsigned last;
+    const unsigned m = block_absmax(x, n, red);
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x] = m;
+        __threadfence();
+        last = atomicAdd(ws + 2048, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    unsigned v = 0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
+        const unsigned pv = ((volatile unsigned*)ws)[i];
+        v = max(v, pv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *out = max(max(red[0], red[1]), max(red[2], red[3]));
+        ws[2048] = 0;
+    }
 }
 
 // one thread = one (n, channel group, row, slot): 8 strided reads (coalesced across the slots of a row), NPL x 16-byte writes
@@ -727,7 +769,48 @@ unsigned* scratch_max_word(void* scratch, int N, int Cred, int H, int W) {
     return (unsigned*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W) - 64);
 }
 unsigned* pack_max_word(void* packed, int M, int Cred) { return (unsigned*)((char*)packed + nemar_split16_pack_bytes(M, Cred) - 64); }
+
+// nemar_absmax_hint: max |t| words the caller has already computed for tensors the next calls take as sources
+const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr};
+const unsigned* g_hint_word[4] = {nullptr, nullptr, nullptr, nullptr};
 }  // namespace
+
+const unsigned* nemar_split16_hint(const void* tensor) {
+    for (int i = 0; i < 4; ++i)
+        if (g_hint_tensor[i] == tensor && tensor) return g_hint_word[i];
+    return nullptr;
+}
+
+void nemar_split16_set_hint(const void* tensor, const void* word) {
+    int slot = -1;
+    for (int i = 0; i < 4; ++i)
+        if (g_hint_tensor[i] == tensor) slot = i;
+    if (!word) {
+        if (slot >= 0) { g_hint_tensor[slot] = nullptr; g_hint_word[slot] = nullptr; }
+        return;
+    }
+    if (slot < 0)
+        for (int i = 0; i < 4 && slot < 0; ++i)
+            if (!g_hint_tensor[i]) slot = i;
+    if (slot < 0) slot = 0;
+    g_hint_tensor[slot] = tensor;
+    g_hint_word[slot] = (const unsigned*)word;
+}
+
+void nemar_split16_absmax(const float* x, long long n, void* ws, void* out, hipStream_t st) {
+    int grid = nemar_stream_grid(n, 256 * 16);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(absmax_ticket_kernel, dim3(grid), dim3(256), 0, st, x, n, (unsigned*)ws, (unsigned*)out);
+}
+
+// max |src| word for a split pass: the caller's hint, or computed here into `own`
+const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned* own, hipStream_t st) {
+    const unsigned* h = nemar_split16_hint(src);
+    if (h) return h;
+    (void)hipMemsetAsync(own, 0, sizeof(unsigned), st);
+    hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid(n, 256 * 16)), dim3(256), 0, st, src, n, own);
+    return own;
+}
 
 void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, int variant, hipStream_t st) {
     const int M = dgrad ? C : K, Cred = dgrad ? K : C;
@@ -735,7 +818,7 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, i
     if (variant == 4) {
         unsigned* mw = pack_max_word(packed, M, Cred);
         (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
-        hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid((long long)K * C * 9, 256 * 4)), dim3(256), 0, st, w, (long long)K * C * 9, mw);
+        hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid((long long)K * C * 9, 256 * 16)), dim3(256), 0, st, w, (long long)K * C * 9, mw);
         hipLaunchKernelGGL((split16_pack_kernel<2>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad, mw);
         return;
     }
@@ -747,12 +830,11 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
                     int mode, void* scratch, int xcd_map, int variant, long long* tl, hipStream_t st) {
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
+    const unsigned* xmax = xmw;
     if (variant == 4) {
-        (void)hipMemsetAsync(xmw, 0, sizeof(unsigned), st);
-        const long long nsrc = (long long)N * Cred * H * W;
-        hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid(nsrc, 256 * 8)), dim3(256), 0, st, src, nsrc, xmw);
+        xmax = nemar_split16_source_max(src, (long long)N * Cred * H * W, xmw, st);
         hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
-                           mode, total, xmw);
+                           mode, total, xmax);
     } else {
         hipLaunchKernelGGL((split_planes_kernel<3>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
                            mode, total, (const unsigned*)nullptr);
@@ -774,7 +856,7 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.aux_instr = p.fold ? nemar_cdiv((long long)2 * p.Ws * 16, 1024) : 0;
     p.plane16 = total;
     p.tl = tl;
-    p.xmax = xmw;
+    p.xmax = xmax;
     p.wmax = pack_max_word(const_cast<void*>(packed), M, Cred);
     p.halo16 = (p.RT + 2) * p.Ws;
     p.aux16 = p.fold ? 2 * p.Ws : 0;

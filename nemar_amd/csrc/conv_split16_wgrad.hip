@@ -122,18 +122,6 @@ __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void absmax2_kernel(const float* __restrict__ x, long long n, unsigned* out) {
-    unsigned m = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
-    __shared__ unsigned red[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
-}
-
 struct WgParams {
     const u32x4* G;            // [3 s][2 planes] blocks of gplane16 words
     const u32x4* X;            // [2 planes] blocks of xplane16 words
@@ -316,13 +304,11 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     u32x4* const G = (u32x4*)scratch;
     u32x4* const X = G + 6 * gtotal;
     unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K) - 64);
-    (void)hipMemsetAsync(mw, 0, 2 * sizeof(unsigned), st);
-    const long long ng = (long long)N * K * H * W, nx = (long long)N * C * H * W;
-    hipLaunchKernelGGL(absmax2_kernel, dim3(nemar_stream_grid(ng, 256 * 8)), dim3(256), 0, st, gy, ng, mw);
-    hipLaunchKernelGGL(absmax2_kernel, dim3(nemar_stream_grid(nx, 256 * 8)), dim3(256), 0, st, x, nx, mw + 1);
-    hipLaunchKernelGGL(split_wgrad_g_kernel, dim3(nemar_cdiv(gtotal, 256)), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, mw);
+    const unsigned* const gmax = nemar_split16_source_max(gy, (long long)N * K * H * W, mw, st);
+    const unsigned* const xmax = nemar_split16_source_max(x, (long long)N * C * H * W, mw + 1, st);
+    hipLaunchKernelGGL(split_wgrad_g_kernel, dim3(nemar_cdiv(gtotal, 256)), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, gmax);
     hipLaunchKernelGGL(split_wgrad_x_kernel, dim3(nemar_cdiv(xtotal, 256)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal,
-                       mw + 1);
+                       xmax);
     WgParams p;
     p.G = G; p.X = X; p.part = part;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
@@ -331,7 +317,7 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     p.spi = H / p.RB;
     p.KBLK = KBLK; p.CBLK = CBLK;
     p.gplane16 = gtotal; p.xplane16 = xtotal;
-    p.gmax = mw; p.xmax = mw + 1;
+    p.gmax = gmax; p.xmax = xmax;
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
     hipLaunchKernelGGL(wgrad_split16_kernel, dim3(grid), dim3(256), 0, st, p);

@@ -82,7 +82,7 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
     this layer.  Grow-only per device; stream-ordered like _workspace."""
     need = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
     if not need:
-        return
+        return False
     buf = _arena.get(device)
     if buf is None or buf.numel() * 4 < need:
         buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
@@ -91,6 +91,22 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
     if _arena_live[0] != live:
         L.set_scratch(_p(buf), live[1])
         _arena_live[0] = live
+    return True
+
+
+_absmax_ws = {}        # device -> zero-initialised ticket workspace of nemar_absmax (the kernel leaves it zeroed)
+
+
+def _absmax_word(t):
+    """max |t| as the one-word tensor nemar_absmax_hint takes (the fp16 split of the wide 3x3 layers scales by a power of two
+    derived from it).  Computed once per tensor and shared by the calls that take it as a source."""
+    ws = _absmax_ws.get(t.device)
+    if ws is None:
+        ws = torch.zeros(2112, dtype=torch.int32, device=t.device)
+        _absmax_ws[t.device] = ws
+    word = torch.empty(1, dtype=torch.int32, device=t.device)
+    L.absmax(_p(t), t.numel(), _p(ws), ws.numel() * 4, _p(word), _stream())
+    return word
 
 
 _zero_ws_cache = {}
@@ -195,11 +211,18 @@ class _Conv2d(Function):
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
         ws, hit = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
-        _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device)
+        split16 = _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device) and x2 is None
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
+            xmax = None
+            if split16:           # max |x| once: this call and the weight gradient in backward both scale x by it
+                xmax = _absmax_word(x)
+                L.absmax_hint(_p(x), _p(xmax))
             L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
                          slope, _p(ws), wsb, hit, _stream())
+            if split16:
+                L.absmax_hint(_p(x), None)
+        ctx.xmax = xmax
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
         ctx.cfg = (stride, pad, pad_mode, act, slope)
@@ -224,6 +247,12 @@ class _Conv2d(Function):
         need_x, need_x2, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
             ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gx = gx2 = None
+        hinted = []
+        if ctx.xmax is not None:      # split-16 layer: max |gy| once for the data and the weight gradient, max |x| from the forward
+            gmax = _absmax_word(g)
+            L.absmax_hint(_p(g), _p(gmax))
+            L.absmax_hint(_p(x), _p(ctx.xmax))
+            hinted = [g, x]
         if need_x or need_x2:
             gx = torch.empty_like(x) if need_x else None
             gx2 = torch.empty_like(x2) if (need_x2 and x2 is not None) else None
@@ -253,6 +282,8 @@ class _Conv2d(Function):
         elif want_b:
             _bias_grad(g, _grad_buffer(ctx.bias), N, K, OH * OW, st)
             grad_ready(ctx.bias)
+        for t in hinted:
+            L.absmax_hint(_p(t), None)
         return gx, gx2, None, None, None, None, None, None, None, None
 
 

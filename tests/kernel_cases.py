@@ -192,6 +192,43 @@ def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0):
             case_conv_fwd(be, N, C, 0, H, W, K, 3, 1, 1, pad_mode, act=O.ACT_NONE, seed=seed)
 
 
+def case_absmax_and_hint(be, seed=0):
+    """nemar_absmax (ticketed reduction: the ticket word is returned zero) against numpy, odd sizes and an unaligned view; and a
+    split-16 forward with the hint registered gives bit-identical results to one that runs its own max pass."""
+    rng = np.random.default_rng(seed)
+    ws = be.bytes_buf(8256)
+    for n, off in ((1, 0), (1027, 0), (40003, 1), (300000, 0)):
+        a = (rng.standard_normal(n + off) * 10.0 ** rng.uniform(-6, 3)).astype(np.float32)
+        d = be.dev(a)
+        word = be.bytes_buf(4)
+        view = d[off:]
+        be.lib.absmax(be.ptr(view), n, be.ptr(ws), 8256, be.ptr(word), be.stream)
+        got = np.asarray(be.np(word), dtype=np.float32)[:1].view(np.uint32)[0]
+        want = np.abs(a[off:]).max().astype(np.float32).view(np.uint32)
+        assert int(got) == int(want), (n, off, hex(int(got)), hex(int(want)))
+        assert be.np(ws)[2048] == 0, "nemar_absmax must leave its ticket word zero for the next call"
+    N, C, H, W, K = 1, 16, 8, 32, 128
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) / 12).astype(np.float32)
+    d_x, d_w = be.dev(x), be.dev(w)
+    outs = []
+    with scratch_arena(be, be.lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)):
+        for hint in (False, True):
+            d_y = be.full((N, K, H, W), np.nan)
+            wsb = be.lib.conv2d_fwd_workspace(N, H, W, K, C, 3, 3, 1, 1)
+            cws = be.bytes_buf(wsb)
+            if hint:
+                word = be.bytes_buf(4)
+                be.lib.absmax(be.ptr(d_x), x.size, be.ptr(ws), 8256, be.ptr(word), be.stream)
+                be.lib.absmax_hint(be.ptr(d_x), be.ptr(word))
+            be.lib.conv2d_fwd(be.ptr(d_x), C, None, 0, be.ptr(d_w), None, be.ptr(d_y), N, H, W, K, 3, 3, 1, 1, PAD_ZERO, 0, 0.2,
+                              be.ptr(cws), wsb, 0, be.stream)
+            if hint:
+                be.lib.absmax_hint(be.ptr(d_x), None)
+            outs.append(be.np(d_y))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def case_conv_split16_wgrad(be, N, C, H, W, K, pad_mode, seed=0):
     """Weight + bias gradient of a wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_bwd_weight with the scratch arena registered:
     the fp16 x 3 route (csrc/conv_split16_wgrad.hip) must be eligible and obey the tolerances of the exact-fp32 kernels."""

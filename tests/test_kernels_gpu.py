@@ -356,3 +356,7 @@ def test_conv_split16_weight_gradient(be):
     K.case_conv_split16_wgrad(be, 1, 128, 8, 8, 128, K.PAD_REFLECT)
     K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 192, K.PAD_ZERO)
     K.case_conv_split16_wgrad(be, 1, 192, 4, 24, 128, K.PAD_REFLECT)
+
+
+def test_absmax_and_hint(be):
+    K.case_absmax_and_hint(be)
