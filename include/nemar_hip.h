@@ -153,10 +153,10 @@ size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int
 int nemar_set_scratch(void* scratch, size_t bytes);
 /* The fp16 form of those kernels scales each source tensor by a power of two derived from max |t|.  A caller that feeds one tensor
  * to several calls (x: forward and weight gradient; gy: data and weight gradient) computes the word once with nemar_absmax
- * (workspace: >= 8256 bytes, zero-filled before its first use — the ticket word at byte 8192 is returned zero; out_word: 4 bytes) and registers it with
+ * (out_word: 4 bytes that are ZERO on entry — the kernel takes an atomic max of the bit patterns into it) and registers it with
  * nemar_absmax_hint(tensor, word) for the calls that follow; nemar_absmax_hint(tensor, NULL) withdraws it.  Without a hint every
  * call runs its own max pass.  (Process-global like the scratch arena; at most four hints.) */
-int nemar_absmax(const float* t, long long n, void* workspace, size_t ws_bytes, void* out_word, void* stream);
+int nemar_absmax(const float* t, long long n, void* out_word, void* stream);
 int nemar_absmax_hint(const void* tensor, const void* word);
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient; two fixed-order stages through `workspace`). */
 size_t nemar_bias_grad_workspace(int N, int C, int HW);

@@ -46,7 +46,7 @@ SIGNATURES = {
                                      _vp]),
     "nemar_conv2d_scratch": (_sz, [_i] * 9),
     "nemar_set_scratch": (_i, [_vp, _sz]),
-    "nemar_absmax": (_i, [_vp, _ll, _vp, _sz, _vp, _vp]),
+    "nemar_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "nemar_absmax_hint": (_i, [_vp, _vp]),
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -2123,14 +2123,10 @@ NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
 
 // max |t| of a tensor, for callers that feed the same tensor to several split-16 convolution calls (forward + weight gradient take
 // x, data + weight gradient take gy): computed once, registered with nemar_absmax_hint, it replaces the max pass inside each call
-NEMAR_API int nemar_absmax(const float* t, long long n, void* workspace, size_t ws_bytes, void* out_word, void* stream) {
+NEMAR_API int nemar_absmax(const float* t, long long n, void* out_word, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
-    NEMAR_REQUIRE(t && workspace && out_word && n > 0, "absmax: null pointer");
-    if (ws_bytes < 8256) {
-        nemar_set_error("absmax: workspace %zu < 8256", ws_bytes);
-        return NEMAR_EWORKSPACE;
-    }
-    nemar_split16_absmax(t, n, workspace, out_word, (hipStream_t)stream);
+    NEMAR_REQUIRE(t && out_word && n > 0, "absmax: null pointer");
+    nemar_split16_absmax(t, n, out_word, (hipStream_t)stream);
     NEMAR_CHECK_LAUNCH("absmax");
     return NEMAR_OK;
 }

@@ -26,8 +26,8 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
 
 // ---- max |t| of a source tensor (the fp16 form's power-of-two scale follows from it) ----
-// ws: >= 8256 bytes, zero-filled before its first use (the ticket word at byte 8192 is returned zero); out: one word
-void nemar_split16_absmax(const float* x, long long n, void* ws, void* out, hipStream_t st);
+// out: one word, ZERO on entry (the kernel takes an atomic max into it)
+void nemar_split16_absmax(const float* x, long long n, void* out, hipStream_t st);
 void nemar_split16_set_hint(const void* tensor, const void* word);            // word == NULL clears
 const unsigned* nemar_split16_hint(const void* tensor);
 const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned* own, hipStream_t st);

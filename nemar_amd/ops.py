@@ -94,18 +94,20 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
     return True
 
 
-_absmax_ws = {}        # device -> zero-initialised ticket workspace of nemar_absmax (the kernel leaves it zeroed)
+_absmax_pool = {}      # device -> [zero-filled int32 tensor, next free word]: nemar_absmax wants its output word zero on entry
 
 
 def _absmax_word(t):
     """max |t| as the one-word tensor nemar_absmax_hint takes (the fp16 split of the wide 3x3 layers scales by a power of two
-    derived from it).  Computed once per tensor and shared by the calls that take it as a source."""
-    ws = _absmax_ws.get(t.device)
-    if ws is None:
-        ws = torch.zeros(2112, dtype=torch.int32, device=t.device)
-        _absmax_ws[t.device] = ws
-    word = torch.empty(1, dtype=torch.int32, device=t.device)
-    L.absmax(_p(t), t.numel(), _p(ws), ws.numel() * 4, _p(word), _stream())
+    derived from it).  Computed once per tensor and shared by the calls that take it as a source.  Words come out of a
+    pre-zeroed pool: one fill launch per 4096 of them instead of one per word."""
+    pool = _absmax_pool.get(t.device)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=t.device), 0]
+        _absmax_pool[t.device] = pool
+    word = pool[0][pool[1]:pool[1] + 1]
+    pool[1] += 1
+    L.absmax(_p(t), t.numel(), _p(word), _stream())
     return word
 
 
