@@ -158,6 +158,11 @@ int nemar_set_scratch(void* scratch, size_t bytes);
  * call runs its own max pass.  (Process-global like the scratch arena; at most four hints.) */
 int nemar_absmax(const float* t, long long n, void* out_word, void* stream);
 int nemar_absmax_hint(const void* tensor, const void* word);
+/* Measurement hook for bench.py's roofline entry: while enabled, HIP events are recorded on the launch stream around the main
+ * kernel (igemm_split16_kernel) of every forward / data-gradient call of those layers; read -> summed duration and launch count
+ * (synchronises on the recorded events, resets the list). */
+int nemar_kernel_timer(int enable);
+int nemar_kernel_timer_read(double* total_ms, int* launches);
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient; two fixed-order stages through `workspace`). */
 size_t nemar_bias_grad_workspace(int N, int C, int HW);
 int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* workspace, size_t ws_bytes, void* stream);

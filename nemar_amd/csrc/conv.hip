@@ -2131,6 +2131,19 @@ NEMAR_API int nemar_absmax(const float* t, long long n, void* out_word, void* st
     return NEMAR_OK;
 }
 
+// bench.py's roofline entry: time the main kernel (igemm_split16_kernel) of every forward / data-gradient call of the wide 3x3
+// layers with HIP events recorded on the launch stream, between enable and read
+NEMAR_API int nemar_kernel_timer(int enable) {
+    nemar_split16_timer(enable);
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_kernel_timer_read(double* total_ms, int* launches) {
+    NEMAR_REQUIRE(total_ms && launches, "kernel_timer_read: null pointer");
+    *launches = nemar_split16_timer_read(total_ms);
+    return NEMAR_OK;
+}
+
 NEMAR_API int nemar_absmax_hint(const void* tensor, const void* word) {
     NEMAR_REQUIRE(tensor, "absmax_hint: null tensor");
     nemar_split16_set_hint(tensor, word);

@@ -31,3 +31,7 @@ void nemar_split16_absmax(const float* x, long long n, void* out, hipStream_t st
 void nemar_split16_set_hint(const void* tensor, const void* word);            // word == NULL clears
 const unsigned* nemar_split16_hint(const void* tensor);
 const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned* own, hipStream_t st);
+
+// ---- measurement hook: HIP events on the launch stream around the main kernel of every nemar_split16_conv call while enabled ----
+void nemar_split16_timer(int on);
+int nemar_split16_timer_read(double* total_ms);      // -> launches timed since enabled; synchronises on their events; resets

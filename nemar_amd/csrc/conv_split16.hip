@@ -783,6 +783,48 @@ const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned
     return own;
 }
 
+// ---- measurement hook (bench.py's roofline entry): HIP events around the main kernel of every convolution call ----
+namespace {
+constexpr int MAX_TIMED = 1024;
+hipEvent_t g_tev[MAX_TIMED][2];
+int g_tev_made = 0, g_tev_used = 0;
+bool g_timing = false;
+}  // namespace
+
+void nemar_split16_timer(int on) {
+    g_timing = on != 0;
+    if (on) g_tev_used = 0;
+}
+
+int nemar_split16_timer_read(double* total_ms) {
+    double t = 0.0;
+    for (int i = 0; i < g_tev_used; ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(g_tev[i][1]);
+        (void)hipEventElapsedTime(&ms, g_tev[i][0], g_tev[i][1]);
+        t += ms;
+    }
+    *total_ms = t;
+    const int n = g_tev_used;
+    g_tev_used = 0;
+    return n;
+}
+
+#define S16_TIMED_LAUNCH(launch_)                                              \
+    {                                                                          \
+        const bool tm_ = g_timing && g_tev_used < MAX_TIMED;                   \
+        if (tm_) {                                                             \
+            while (g_tev_made <= g_tev_used) {                                 \
+                (void)hipEventCreate(&g_tev[g_tev_made][0]);                   \
+                (void)hipEventCreate(&g_tev[g_tev_made][1]);                   \
+                ++g_tev_made;                                                  \
+            }                                                                  \
+            (void)hipEventRecord(g_tev[g_tev_used][0], st);                    \
+        }                                                                      \
+        launch_;                                                               \
+        if (tm_) (void)hipEventRecord(g_tev[g_tev_used++][1], st);             \
+    }
+
 void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, int variant, hipStream_t st) {
     const int M = dgrad ? C : K, Cred = dgrad ? K : C;
     const long long total = (long long)(Cred / 16) * 9 * (M / 128) * 256;
@@ -838,9 +880,10 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     if (variant == 4) {                 // fp16 x 3 (always fits: four regions per halo buffer, 8 KiB weight stages)
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), 6);
-        if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2>), g, dim3(256), 0, st, p);
-        else if (nbw == 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 2>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((igemm_split16_kernel<3, 2>), g, dim3(256), 0, st, p);
+        S16_TIMED_LAUNCH(
+            if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2>), g, dim3(256), 0, st, p);
+            else if (nbw == 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 2>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_split16_kernel<3, 2>), g, dim3(256), 0, st, p);)
         return;
     }
     if (variant == 3 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
