@@ -7,7 +7,8 @@
 enum { SPLIT16_ZERO = 0, SPLIT16_REFLECT = 1, SPLIT16_DGRAD_REFLECT = 2 };
 
 // M = output channels of the launch, Cred = reduction channels, source [N, Cred, H, W] -> destination [N, M, H, W]
-bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode);
+// variant: the nemar_tune(21) setting the call will run under (4 fp16 x 3, 3 bf16 x 6, 0 first generation): LDS budgets differ
+bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode, int variant);
 size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W);      // split activation planes
 size_t nemar_split16_pack_bytes(int M, int Cred);                       // split, tile-ordered weights
 // w [K, C, 3, 3].  dgrad == 0: M = K rows, reduction over C.  dgrad != 0: M = C rows, reduction over K, taps flipped.

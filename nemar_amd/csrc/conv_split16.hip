@@ -717,15 +717,18 @@ int ilog2(int v) {
 
 }  // namespace
 
-bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode) {
+bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode, int variant) {
     if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
     if (M % 128 != 0 || Cred % 16 != 0 || M <= 0 || Cred <= 0) return false;
-    if (!(W == 32 || W == 64 || W == 128)) return false;
+    if (!(W == 32 || W == 64 || W == 128 || W == 256)) return false;
     const int RT = 256 / W;
     if (H % RT != 0 || H < 4) return false;
-    if (W == 128 && mode == SPLIT16_DGRAD_REFLECT) return false;      // halo + folded rows of two buffers exceed the LDS
     if ((long long)N * Cred * (H + 4) * (W + 4) >= (1ll << 31)) return false;
-    return true;
+    if (variant == 0) return W <= 128 && !(W == 128 && mode == SPLIT16_DGRAD_REFLECT);       // first generation: whole-KiB LDS regions
+    // two halo buffers of 2 NPL regions + the 4-slot weight ring must fit the 152 KiB of LDS the kernel declares
+    const int npl = variant == 3 ? 3 : 2;
+    const int region16 = (RT + 2) * (W + 4) + (mode == SPLIT16_DGRAD_REFLECT ? 2 * (W + 4) : 0);
+    return 2 * 2 * npl * region16 + 4 * 256 * npl <= 9728;
 }
 
 size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W) {
@@ -877,7 +880,7 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
     const dim3 g(grid), b(384);
-    if (variant == 4) {                 // fp16 x 3 (always fits: four regions per halo buffer, 8 KiB weight stages)
+    if (variant == 4) {                 // fp16 x 3 (nemar_split16_eligible checked the LDS budget)
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), 6);
         S16_TIMED_LAUNCH(
@@ -886,7 +889,7 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
             else hipLaunchKernelGGL((igemm_split16_kernel<3, 2>), g, dim3(256), 0, st, p);)
         return;
     }
-    if (variant == 3 && 6 * (p.halo16 + p.aux16) * 2 + 4 * 768 <= 9728) {
+    if (variant == 3) {
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), 6);
         if (nbw <= 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 3>), g, dim3(256), 0, st, p);

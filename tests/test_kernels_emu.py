@@ -337,6 +337,7 @@ def test_conv_split16_matrix_pipe(be, variant):
         K.case_conv_split16(be, 1, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False)
         K.case_conv_split16(be, 1, 16, 8, 64, 128, K.PAD_REFLECT, dgrad=False)
         K.case_conv_split16(be, 1, 48, 4, 128, 128, K.PAD_REFLECT, dgrad=False)      # 128-pixel rows: two rows per tile, 3 chunks
+        K.case_conv_split16(be, 1, 16, 4, 256, 128, K.PAD_REFLECT, dgrad=False)      # 256-pixel rows: one row per tile (fp16 form only)
     finally:
         be.lib.tune(21, 4)
 
@@ -352,6 +353,7 @@ def test_conv_split16_reflect_data_gradient(be, variant):
         K.case_conv_split16(be, 2, 128, 16, 32, 32, K.PAD_REFLECT, dgrad=True)
         K.case_conv_split16(be, 1, 128, 12, 64, 16, K.PAD_REFLECT, dgrad=True)
         K.case_conv_split16(be, 1, 256, 8, 32, 16, K.PAD_ZERO, dgrad=True)
+        K.case_conv_split16(be, 1, 128, 4, 128, 16, K.PAD_REFLECT, dgrad=True)       # 128-pixel rows (fits the LDS in the fp16 form only)
     finally:
         be.lib.tune(21, 4)
 
