@@ -59,26 +59,32 @@ __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-// G_s planes: word (((s * 2 + pl) * N + n) * KBLK + kblk) * F + f) * 64 + kk, F = H * CPR.  One thread = one (n, k, y, chunk):
-// reads the 10 texels x' - 2 .. x' + 7 of its row once, writes the three shifted versions, two planes each.
+// G_s planes: word (((s * 2 + pl) * N + n) * KBLK + kblk) * F + f) * 64 + kk, F = H * CPR.  One workgroup = one image row y of one
+// 64-channel block: the 64 rows are read coalesced (256 B runs) into LDS, then thread (kk, chunk) takes the 10 texels x' - 2 .. x' + 7
+// of its chunk from there and writes the three shifted versions, two planes each — 64 consecutive channels = one 1 KiB store.
+// (A first version read straight from global memory, one channel row per lane: 7x over-fetch, 60 us; PMC in profiles/.)
+constexpr int SPLIT_MAXW = 256;
 __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restrict__ gy, u32x4* __restrict__ out, int N, int K, int H,
                                                             int W, int CPR, long long total, const unsigned* maxbits) {
+    __shared__ float tile[64][SPLIT_MAXW + 1];
     const float scale = pow2_scale(*maxbits);
     const int KBLK = K >> 6, F = H * CPR;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int kk = (int)(t & 63);
-        long long q = t >> 6;
-        const int f = (int)(q % F);
-        q /= F;
-        const int kblk = (int)(q % KBLK), n = (int)(q / KBLK);
-        const int y = f / CPR, x0 = (f - y * CPR) * 8;
-        const float* row = gy + (((size_t)n * K + kblk * 64 + kk) * H + y) * W;
+    const int y = blockIdx.x % H, kblk = (blockIdx.x / H) % KBLK, n = blockIdx.x / (H * KBLK);
+    const float* src = gy + (((size_t)n * K + kblk * 64) * H + y) * W;
+    for (int i = threadIdx.x; i < 64 * W; i += 256) {
+        const int kk = i / W, x = i - kk * W;
+        tile[kk][x] = src[(size_t)kk * H * W + x] * scale;
+    }
+    __syncthreads();
+    const int kk = threadIdx.x & 63;
+    for (int q = threadIdx.x >> 6; q < CPR; q += 4) {
         float v[10];
 #pragma unroll
         for (int e = 0; e < 10; ++e) {
-            const int x = x0 - 2 + e;
-            v[e] = (x >= 0 && x < W) ? row[x] * scale : 0.f;
+            const int x = q * 8 - 2 + e;
+            v[e] = (x >= 0 && x < W) ? tile[kk][x] : 0.f;
         }
+        const size_t t = (((size_t)n * KBLK + kblk) * F + (size_t)y * CPR + q) * 64 + kk;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             unsigned short h[8], l[8];
@@ -90,33 +96,37 @@ __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restr
     }
 }
 
-// X planes: word ((pl * N + n) * CBLK + cblk) * FX + f) * 64 + cc, FX = (H + 2) * CPR; padding materialised
+// X planes: word ((pl * N + n) * CBLK + cblk) * FX + f) * 64 + cc, FX = (H + 2) * CPR; padding materialised.  Same structure: one
+// workgroup = one padded row yp of one 64-channel block.
 __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C, int H,
                                                             int W, int CPR, int reflect, long long total, const unsigned* maxbits) {
+    __shared__ float tile[64][SPLIT_MAXW + 1];
     const float scale = pow2_scale(*maxbits);
-    const int CBLK = C >> 6, FX = (H + 2) * CPR;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int cc = (int)(t & 63);
-        long long q = t >> 6;
-        const int f = (int)(q % FX);
-        q /= FX;
-        const int cblk = (int)(q % CBLK), n = (int)(q / CBLK);
-        const int yp = f / CPR, x0 = (f - yp * CPR) * 8;
-        int y = yp - 1;
-        bool rowok = true;
-        if (reflect) y = mirror(y, H);
-        else rowok = (unsigned)y < (unsigned)H;
-        const float* row = x + (((size_t)n * C + cblk * 64 + cc) * H + (rowok ? y : 0)) * W;
+    const int CBLK = C >> 6, FX = (H + 2) * CPR, Hp = H + 2;
+    const int yp = blockIdx.x % Hp, cblk = (blockIdx.x / Hp) % CBLK, n = blockIdx.x / (Hp * CBLK);
+    int y = yp - 1;
+    bool rowok = true;
+    if (reflect) y = mirror(y, H);
+    else rowok = (unsigned)y < (unsigned)H;
+    const float* src = x + (((size_t)n * C + cblk * 64) * H + (rowok ? y : 0)) * W;
+    for (int i = threadIdx.x; i < 64 * W; i += 256) {
+        const int cc = i / W, xs = i - cc * W;
+        tile[cc][xs] = rowok ? src[(size_t)cc * H * W + xs] * scale : 0.f;
+    }
+    __syncthreads();
+    const int cc = threadIdx.x & 63;
+    for (int q = threadIdx.x >> 6; q < CPR; q += 4) {
         unsigned short h[8], l[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int xp = x0 + e;                   // padded column
+            const int xp = q * 8 + e;                // padded column
             int xs = xp - 1;
-            bool ok = rowok && xp < W + 2;
+            bool ok = xp < W + 2;
             if (reflect) xs = mirror(xs, W);
             else ok = ok && (unsigned)xs < (unsigned)W;
-            split2_f16(ok ? row[xs] * scale : 0.f, h[e], l[e]);
+            split2_f16(ok ? tile[cc][min(max(xs, 0), W - 1)] : 0.f, h[e], l[e]);
         }
+        const size_t t = (((size_t)n * CBLK + cblk) * FX + (size_t)yp * CPR + q) * 64 + cc;
         out[t] = pack8(h);
         out[total + t] = pack8(l);
     }
@@ -278,7 +288,7 @@ int rows_per_split(int N, int H, int CPR, int tiles) {
 
 bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
     if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
-    if (C % 64 || K % 64 || C < 128 || K < 128 || W % 8 || H < 4 || W < 8) return false;
+    if (C % 64 || K % 64 || C < 128 || K < 128 || W % 8 || H < 4 || W < 8 || W > SPLIT_MAXW) return false;
     const int CPR = (W + 2 + 7) / 8;
     if (rows_per_split(N, H, CPR, (K / 64) * (C / 64)) == 0) return false;
     if ((long long)N * (C > K ? C : K) * (H + 2) * CPR * 64 >= (1ll << 31)) return false;
@@ -306,8 +316,8 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K) - 64);
     const unsigned* const gmax = nemar_split16_source_max(gy, (long long)N * K * H * W, mw, st);
     const unsigned* const xmax = nemar_split16_source_max(x, (long long)N * C * H * W, mw + 1, st);
-    hipLaunchKernelGGL(split_wgrad_g_kernel, dim3(nemar_cdiv(gtotal, 256)), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, gmax);
-    hipLaunchKernelGGL(split_wgrad_x_kernel, dim3(nemar_cdiv(xtotal, 256)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal,
+    hipLaunchKernelGGL(split_wgrad_g_kernel, dim3(N * KBLK * H), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, gmax);
+    hipLaunchKernelGGL(split_wgrad_x_kernel, dim3(N * CBLK * (H + 2)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal,
                        xmax);
     WgParams p;
     p.G = G; p.X = X; p.part = part;
