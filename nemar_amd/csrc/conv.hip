@@ -1612,7 +1612,7 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     L.fold = refl && !L.ring;
     L.pack_stride = packed_floats(C, K * R * S);             // upper bound over parity classes and channel skips
     if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO, 4)) {     // room for either packed image
-        const size_t b = (nemar_split16_pack_bytes(C, K) + 3) / 4;
+        const size_t b = (nemar_split16_pack_bytes(C, K, R) + 3) / 4;
         if (b > L.pack_stride) L.pack_stride = b;
     }
     size_t o = L.pack_stride * (size_t)(stride * stride);
@@ -1670,7 +1670,7 @@ FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride
     FwdLayout L;
     L.pack = packed_floats(K, C * R * S);
     if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO, 4)) {     // room for either packed image
-        const size_t b = (nemar_split16_pack_bytes(K, C) + 3) / 4;
+        const size_t b = (nemar_split16_pack_bytes(K, C, R) + 3) / 4;
         if (b > L.pack) L.pack = b;
     }
     L.ksplit = 1;
@@ -1724,8 +1724,9 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         const int mode = pad_mode == BORDER_REFLECT ? SPLIT16_REFLECT : SPLIT16_ZERO;
         if (g_split16 && C1 == 0 && act == ACT_NONE && nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, mode, g_split16_variant) &&
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_bytes(N, C, H, W)) {
-            if (!prepacked) nemar_split16_pack(w, workspace, K, C, 0, g_split16_variant, st);
-            nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, mode, g_scratch, g_xcd_map, g_split16_variant, g_tl, st);
+            if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 0, g_split16_variant, st);
+            nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, R, 1, H, W, OH, OW, mode, g_scratch, g_xcd_map, g_split16_variant,
+                               g_tl, st);
             NEMAR_CHECK_LAUNCH("conv2d_fwd (bf16 x 6)");
             return NEMAR_OK;
         }
@@ -1797,8 +1798,9 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         const int mode = refl ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO;
         if (g_split16 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode, g_split16_variant) &&
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_bytes(N, K, H, W)) {
-            if (!prepacked) nemar_split16_pack(w, workspace, K, C, 1, g_split16_variant, st);
-            nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, mode, g_scratch, g_xcd_map, g_split16_variant, g_tl, st);
+            if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 1, g_split16_variant, st);
+            nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch, g_xcd_map,
+                               g_split16_variant, g_tl, st);
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (bf16 x 6)");
             return NEMAR_OK;
         }

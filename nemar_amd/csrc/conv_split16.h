@@ -10,12 +10,16 @@ enum { SPLIT16_ZERO = 0, SPLIT16_REFLECT = 1, SPLIT16_DGRAD_REFLECT = 2 };
 // variant: the nemar_tune(21) setting the call will run under (4 fp16 x 3, 3 bf16 x 6, 0 first generation): LDS budgets differ
 bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode, int variant);
 size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W);      // split activation planes
-size_t nemar_split16_pack_bytes(int M, int Cred);                       // split, tile-ordered weights
-// w [K, C, 3, 3].  dgrad == 0: M = K rows, reduction over C.  dgrad != 0: M = C rows, reduction over K, taps flipped.
-void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, int variant, hipStream_t st);
-// src [N, Cred, H, W] fp32 -> dst [N, M, H, W] fp32 (+ bias[M] when non-null); `scratch` >= nemar_split16_scratch_bytes
-void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M,
-                    int Cred, int mode, void* scratch, int xcd_map, int variant, long long* tl, hipStream_t st);
+size_t nemar_split16_pack_bytes(int M, int Cred, int KS);               // split, tile-ordered weights (KS x KS taps)
+// w [K, C, KS, KS].  dgrad == 0: M = K rows, reduction over C.  dgrad != 0: M = C rows, reduction over K, taps flipped.
+void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int dgrad, int variant, hipStream_t st);
+// src [N, Cred, Hs, Ws_src] fp32, seen through a padded H x W domain whose position (src_pad, src_pad) is source texel (0, 0)
+// -> dst [N, M, OH, OW] fp32 (+ bias[M] when non-null): outputs at rows >= OH / columns >= OW of the domain are not stored.
+// 3x3: Hs = OH = H, Ws_src = OW = W, src_pad = 1.  4x4 / pad 1 forward: Hs = H, OH = H - 1, src_pad = 1; its data gradient (a full
+// correlation of gy [H-1, W-1]): Hs = H - 1, OH = H, src_pad = 2.  `scratch` >= nemar_split16_scratch_bytes
+void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
+                         int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
+                         long long* tl, hipStream_t st);
 
 // ---- weight gradient of the same layers (conv_split16_wgrad.hip) ----
 bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);

@@ -61,18 +61,19 @@ __device__ __forceinline__ void split3(float v, unsigned short& b0, unsigned sho
 
 __device__ __forceinline__ int mirror(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-// value of plane position (row, slot) of one channel image xc [H, W]
-__device__ __forceinline__ float plane_value(const float* xc, int row, int slot, int H, int W, int mode) {
+// value of plane position (row, slot) of one channel image xc [Hs, Ws_] seen through a (H + 4) x (W + 4) plane whose row / slot
+// `pad` is source row / column 0 (pad = 1: the 3x3 and 4x4 pad-1 layers; pad = 2: the 4x4 data gradient, a full correlation)
+__device__ __forceinline__ float plane_value(const float* xc, int row, int slot, int H, int W, int mode, int pad, int Hs, int Ws_) {
     if (mode != SPLIT16_DGRAD_REFLECT) {
-        if (row > H + 1 || slot > W + 1) return 0.f;
-        int y = row - 1, x = slot - 1;
+        int y = row - pad, x = slot - pad;
         if (mode == SPLIT16_REFLECT) {
+            if (row > H + 1 || slot > W + 1) return 0.f;
             y = mirror(y, H);
             x = mirror(x, W);
-        } else if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) {
+        } else if ((unsigned)y >= (unsigned)Hs || (unsigned)x >= (unsigned)Ws_) {
             return 0.f;
         }
-        return xc[y * W + x];
+        return xc[y * Ws_ + x];
     }
     int ya, yb = -1, xa, xb = -1;
     if (row >= 1 && row <= H) ya = row - 1;
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // one thread = one (n, channel group, row, slot): 8 strided reads (coalesced across the slots of a row), NPL x 16-byte writes
 template <int NPL>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C,
-                                                           int H, int W, int mode, long long total, const unsigned* maxbits) {
+                                                           int H, int W, int mode, long long total, const unsigned* maxbits,
+                                                           int pad, int Hs, int Ws_) {
     const int Hp = H + 4, Ws = W + 4, CG = C >> 3;
     const float scale = NPL == 2 ? pow2_scale(*maxbits) : 1.f;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -167,11 +169,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const int row = (int)(q % Hp);
         q /= Hp;
         const int cg = (int)(q % CG), n = (int)(q / CG);
-        const float* xc = x + ((size_t)n * C + (size_t)cg * 8) * H * W;
+        const float* xc = x + ((size_t)n * C + (size_t)cg * 8) * Hs * Ws_;
         unsigned short b0[8], b1[8], b2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = plane_value(xc + (size_t)j * H * W, row, slot, H, W, mode);
+            const float v = plane_value(xc + (size_t)j * Hs * Ws_, row, slot, H, W, mode, pad, Hs, Ws_);
             if (NPL == 3) split3(v, b0[j], b1[j], b2[j]);
             else split2_f16(v * scale, b0[j], b1[j]);
         }
@@ -181,30 +183,30 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
-// packed weights: 16-byte word index (((chunk * 9 + tap) * mblks + mblk) * NPL + plane) * 256 + kgroup * 128 + m
+// packed weights: 16-byte word index (((chunk * NT + tap) * mblks + mblk) * NPL + plane) * 256 + kgroup * 128 + m, NT = KS * KS taps
 template <int NPL>
 __global__ __launch_bounds__(256) void split16_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int M, int Cred,
-                                                       int dgrad, const unsigned* maxbits) {
+                                                       int dgrad, const unsigned* maxbits, int NT) {
     const int mblks = M >> 7;
-    const long long total = (long long)(Cred >> 4) * 9 * mblks * 256;
+    const long long total = (long long)(Cred >> 4) * NT * mblks * 256;
     const float scale = NPL == 2 ? pow2_scale(*maxbits) : 1.f;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(t & 127), kg = (int)((t >> 7) & 1);
         long long q = t >> 8;
         const int mblk = (int)(q % mblks);
         q /= mblks;
-        const int tap = (int)(q % 9), chunk = (int)(q / 9);
+        const int tap = (int)(q % NT), chunk = (int)(q / NT);
         const int mg = mblk * 128 + m;
         unsigned short b0[8], b1[8], b2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int cr = chunk * 16 + kg * 8 + j;
             // forward: w[K = M][C = Cred][3][3];  data gradient: w[K = Cred][C = M][3][3] with the taps flipped
-            const float v = dgrad ? w[((size_t)cr * M + mg) * 9 + (8 - tap)] : w[((size_t)mg * Cred + cr) * 9 + tap];
+            const float v = dgrad ? w[((size_t)cr * M + mg) * NT + (NT - 1 - tap)] : w[((size_t)mg * Cred + cr) * NT + tap];
             if (NPL == 3) split3(v, b0[j], b1[j], b2[j]);
             else split2_f16(v * scale, b0[j], b1[j]);
         }
-        u32x4* o = out + (((size_t)(chunk * 9 + tap) * mblks + mblk) * NPL) * 256 + kg * 128 + m;
+        u32x4* o = out + (((size_t)(chunk * NT + tap) * mblks + mblk) * NPL) * 256 + kg * 128 + m;
         o[0] = pack8(b0);
         o[256] = pack8(b1);
         if (NPL == 3) o[512] = pack8(b2);
@@ -225,6 +227,7 @@ struct Split16Params {
     int fold;                  // reflect data gradient: select the folded rows / slots
     int xcd;                   // workgroup -> tile mapping keeps neighbouring tiles on one XCD
     long long plane16;         // 16-byte words per plane
+    int OH, OW;                // valid output extents (4x4 layers: H - 1, W - 1; stores beyond them are masked)
     const unsigned* xmax;      // fp16 x 3 form: max |source| and max |weight| bit patterns (the power-of-two scales follow from them)
     const unsigned* wmax;
     long long* tl;             // NEMAR_TIMELINE builds: cycle stamps of workgroup 0 (tools/timeline_split16.py)
@@ -440,9 +443,11 @@ __global__ __launch_bounds__(384) void igemm_split16_lw_kernel(Split16Params p) 
 //   clock, not the schedule, is what is left: under this MFMA density the chip runs at ~1.45 GHz.  Hence fp16 x 3: half the MFMAs.
 // Two chunks (18 taps) per loop iteration, so that the register-set parity is a compile-time constant of the tap position.
 // NPL = operand planes: 3 = bf16 x 6 products, 2 = fp16 x 3 products (scaled, see split2_f16)
-template <int NBW, int NPL>       // NBW = halo copy slots per wave per tap on taps 3..8 of a chunk (they carry the next chunk's halo)
+// KS = filter size (3x3, or the discriminator's 4x4 / pad 1 layers computed on the input-sized domain, last row / column masked)
+template <int NBW, int NPL, int KS = 3>   // NBW = halo copy slots per wave per tap on taps 3..NT-1 of a chunk (they carry the next chunk's halo)
 __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
-    constexpr int RING = 4, ASTAGE16 = 256 * NPL, KB = 6 * NBW, NREG = 2 * NPL, NP = NPL == 3 ? 6 : 3, NMFMA = 8 * NP;
+    constexpr int NT = KS * KS;                          // taps
+    constexpr int RING = 4, ASTAGE16 = 256 * NPL, KB = (NT - 3) * NBW, NREG = 2 * NPL, NP = NPL == 3 ? 6 : 3, NMFMA = 8 * NP;
     constexpr int ACOPY = NPL;                           // 1 KiB weight copies per wave per stage (a quarter of the stage)
     constexpr int SMEM16 = 9728;
     __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM16];
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
     if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
     const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
     const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
-    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
+    const int nchunks = p.Cred >> 4, nstage = nchunks * NT;
     const int CG = p.Cred >> 3;
 
     // ---- this wave's copies: weights = words [192 wid, 192 wid + 192) of every 768-word stage; halo = every fourth 1 KiB copy ----
@@ -583,9 +588,9 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
             if (half == 1 && chunk >= nchunks) break;
             const int hb = half;                      // = chunk & 1
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int cur = (tap + half) & 1, nxt = cur ^ 1;          // = T & 1 with T = 9 chunk + tap
-                const int T = chunk * 9 + tap;
+            for (int tap = 0; tap < NT; ++tap) {
+                const int cur = (tap + half * NT) & 1, nxt = cur ^ 1;     // = T & 1 with T = NT chunk + tap
+                const int T = chunk * NT + tap;
                 // tap T + 1: every fragment into the other register set (after the last tap: a harmless read of stale LDS);
                 // stage T + 4 into the slot of stage T (read during tap T - 1): two full taps ahead of its first use.
                 // 23 + NBW slots of [<= 1 memory instruction + its scalar / vector arithmetic][2 MFMAs], pinned: hipcc otherwise
@@ -597,11 +602,11 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 #define S16_STAMP(i_)
 #endif
                 S16_STAMP(0)
-                const int ntap = tap == 8 ? 0 : tap + 1;
-                const int nhb = tap == 8 ? hb ^ 1 : hb;
-                const int nr = ntap / 3, nsx = ntap % 3;
-                const int iti = tap + 4 >= 9 ? tap + 4 - 9 : tap + 4;
-                const int ici = tap + 4 >= 9 ? chunk + 1 : chunk;
+                const int ntap = tap == NT - 1 ? 0 : tap + 1;
+                const int nhb = tap == NT - 1 ? hb ^ 1 : hb;
+                const int nr = ntap / KS, nsx = ntap % KS;
+                const int iti = tap + 4 >= NT ? tap + 4 - NT : tap + 4;
+                const int ici = tap + 4 >= NT ? chunk + 1 : chunk;
 #define S16_MFMAS(beg_, end_)                 /* MFMAs [beg_, end_) of the tap's NMFMA: m = 8 q + 2 mt + nt */        \
                 _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < NMFMA; ++m_) {                              \
                     const int q_ = m_ >> 3, mt_ = (m_ & 7) >> 1, nt_ = m_ & 1;                                          \
@@ -622,11 +627,11 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     int ra_ = (row[nt] + nr + z) * p.Ws;
-                    if (nr == 2) ra_ = top[nt] ? auxoff : ra_;
-                    if (nr == 0) ra_ = bot[nt] ? auxoff + p.Ws : ra_;
+                    if (KS == 3 && nr == 2) ra_ = top[nt] ? auxoff : ra_;
+                    if (KS == 3 && nr == 0) ra_ = bot[nt] ? auxoff + p.Ws : ra_;
                     int sl_ = col[nt] + nsx;
-                    if (nsx == 2) sl_ = lft[nt] ? p.W + 2 : sl_;
-                    if (nsx == 0) sl_ = rgt[nt] ? p.W + 3 : sl_;
+                    if (KS == 3 && nsx == 2) sl_ = lft[nt] ? p.W + 2 : sl_;
+                    if (KS == 3 && nsx == 0) sl_ = rgt[nt] ? p.W + 3 : sl_;
                     baddr[nt] = ra_ + sl_;
                 }
                 const u32x4* const Bn_ = Bs + nhb * bbuf16 + lhi * region16;
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 #undef S16_SLOT
 #undef S16_MFMAS
                 // this wave's copies of stage T + 2 have landed; those of T + 3 and T + 4 may still be in flight
-                const int t3 = tap + 3 >= 9 ? tap + 3 - 9 : tap + 3;
+                const int t3 = tap + 3 >= NT ? tap + 3 - NT : tap + 3;
                 const int nfl = S16_COUNT(t3) + S16_COUNT(iti);     // compile-time after unrolling: one of three values
                 S16_STAMP(1)
                 if (nfl == 2 * ACOPY) S16_VMCNT(2 * ACOPY)
@@ -689,12 +694,13 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 #undef S16_COUNT
 #undef S16_COPIES
 
-    const size_t HW = (size_t)p.H * p.W;
+    const size_t HW = (size_t)p.OH * p.OW;
     // fp16 form: take the two power-of-two operand scales out again (exact)
     const float unscale = NPL == 2 ? 1.f / (pow2_scale(*p.xmax) * pow2_scale(*p.wmax)) : 1.f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
+        if (KS != 3 && (y0 + row[nt] >= p.OH || col[nt] >= p.OW)) continue;      // the row / column beyond the valid output
+        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -718,16 +724,17 @@ int ilog2(int v) {
 }  // namespace
 
 bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode, int variant) {
-    if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
+    if (R != S || (R != 3 && R != 4) || stride != 1 || pad != 1) return false;
     if (M % 128 != 0 || Cred % 16 != 0 || M <= 0 || Cred <= 0) return false;
     if (!(W == 32 || W == 64 || W == 128 || W == 256)) return false;
     const int RT = 256 / W;
     if (H % RT != 0 || H < 4) return false;
     if ((long long)N * Cred * (H + 4) * (W + 4) >= (1ll << 31)) return false;
+    if (R == 4 && (mode != SPLIT16_ZERO || variant == 0)) return false;       // the discriminator's 4x4 layers: zero padding only
     if (variant == 0) return W <= 128 && !(W == 128 && mode == SPLIT16_DGRAD_REFLECT);       // first generation: whole-KiB LDS regions
     // two halo buffers of 2 NPL regions + the 4-slot weight ring must fit the 152 KiB of LDS the kernel declares
     const int npl = variant == 3 ? 3 : 2;
-    const int region16 = (RT + 2) * (W + 4) + (mode == SPLIT16_DGRAD_REFLECT ? 2 * (W + 4) : 0);
+    const int region16 = (RT + R - 1) * (W + 4) + (mode == SPLIT16_DGRAD_REFLECT ? 2 * (W + 4) : 0);
     return 2 * 2 * npl * region16 + 4 * 256 * npl <= 9728;
 }
 
@@ -735,14 +742,16 @@ size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W) {
     return (size_t)3 * N * (Cred / 8) * (H + 4) * (W + 4) * 16 + 16384;     // + slack for whole-KiB halo reads
 }
 
-size_t nemar_split16_pack_bytes(int M, int Cred) { return (size_t)(Cred / 16) * 9 * (M / 128) * 768 * 16 + 16384; }
+size_t nemar_split16_pack_bytes(int M, int Cred, int KS) { return (size_t)(Cred / 16) * KS * KS * (M / 128) * 768 * 16 + 16384; }
 
 namespace {
 // the max words sit in the slack behind the planes / the packed weights
 unsigned* scratch_max_word(void* scratch, int N, int Cred, int H, int W) {
     return (unsigned*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W) - 64);
 }
-unsigned* pack_max_word(void* packed, int M, int Cred) { return (unsigned*)((char*)packed + nemar_split16_pack_bytes(M, Cred) - 64); }
+unsigned* pack_max_word(void* packed, int M, int Cred, int KS) {
+    return (unsigned*)((char*)packed + nemar_split16_pack_bytes(M, Cred, KS) - 64);
+}
 
 // nemar_absmax_hint: max |t| words the caller has already computed for tensors the next calls take as sources
 const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -828,32 +837,34 @@ int nemar_split16_timer_read(double* total_ms) {
         if (tm_) (void)hipEventRecord(g_tev[g_tev_used++][1], st);             \
     }
 
-void nemar_split16_pack(const float* w, void* packed, int K, int C, int dgrad, int variant, hipStream_t st) {
-    const int M = dgrad ? C : K, Cred = dgrad ? K : C;
-    const long long total = (long long)(Cred / 16) * 9 * (M / 128) * 256;
+void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int dgrad, int variant, hipStream_t st) {
+    const int M = dgrad ? C : K, Cred = dgrad ? K : C, NT = KS * KS;
+    const long long total = (long long)(Cred / 16) * NT * (M / 128) * 256;
     if (variant == 4) {
-        unsigned* mw = pack_max_word(packed, M, Cred);
+        unsigned* mw = pack_max_word(packed, M, Cred, KS);
         (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
-        hipLaunchKernelGGL(absmax_kernel, dim3(nemar_stream_grid((long long)K * C * 9, 256 * 16)), dim3(256), 0, st, w, (long long)K * C * 9, mw);
-        hipLaunchKernelGGL((split16_pack_kernel<2>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad, mw);
+        nemar_split16_absmax(w, (long long)K * C * NT, mw, st);
+        hipLaunchKernelGGL((split16_pack_kernel<2>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad, mw,
+                           NT);
         return;
     }
     hipLaunchKernelGGL((split16_pack_kernel<3>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad,
-                       (const unsigned*)nullptr);
+                       (const unsigned*)nullptr, NT);
 }
 
 void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
-                    int mode, void* scratch, int xcd_map, int variant, long long* tl, hipStream_t st) {
+                         int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
+                         long long* tl, hipStream_t st) {
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
     const unsigned* xmax = xmw;
     if (variant == 4) {
-        xmax = nemar_split16_source_max(src, (long long)N * Cred * H * W, xmw, st);
+        xmax = nemar_split16_source_max(src, (long long)N * Cred * Hs * Ws_src, xmw, st);
         hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
-                           mode, total, xmax);
+                           mode, total, xmax, src_pad, Hs, Ws_src);
     } else {
         hipLaunchKernelGGL((split_planes_kernel<3>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
-                           mode, total, (const unsigned*)nullptr);
+                           mode, total, (const unsigned*)nullptr, src_pad, Hs, Ws_src);
     }
     Split16Params p;
     p.planes = (const u32x4*)scratch;
@@ -867,14 +878,15 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.RT = 256 / W;
     p.tiles_per_img = H / p.RT;
     p.mblks = M / 128;
-    p.halo_instr = nemar_cdiv((long long)(p.RT + 2) * p.Ws * 16, 1024);
+    p.halo_instr = nemar_cdiv((long long)(p.RT + KS - 1) * p.Ws * 16, 1024);
     p.fold = mode == SPLIT16_DGRAD_REFLECT;
     p.aux_instr = p.fold ? nemar_cdiv((long long)2 * p.Ws * 16, 1024) : 0;
     p.plane16 = total;
     p.tl = tl;
     p.xmax = xmax;
-    p.wmax = pack_max_word(const_cast<void*>(packed), M, Cred);
-    p.halo16 = (p.RT + 2) * p.Ws;
+    p.wmax = pack_max_word(const_cast<void*>(packed), M, Cred, KS);
+    p.OH = OH; p.OW = OW;
+    p.halo16 = (p.RT + KS - 1) * p.Ws;
     p.aux16 = p.fold ? 2 * p.Ws : 0;
     const int grid = N * p.tiles_per_img * p.mblks;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % p.mblks == 0) ? 1 : 0;
@@ -882,17 +894,23 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     const dim3 g(grid), b(384);
     if (variant == 4) {                 // fp16 x 3 (nemar_split16_eligible checked the LDS budget)
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
-        const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), 6);
+        const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), KS * KS - 3);
         S16_TIMED_LAUNCH(
-            if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2>), g, dim3(256), 0, st, p);
+            if (KS == 4) {
+                if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2, 4>), g, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((igemm_split16_kernel<2, 2, 4>), g, dim3(256), 0, st, p);
+            } else if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2>), g, dim3(256), 0, st, p);
             else if (nbw == 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 2>), g, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((igemm_split16_kernel<3, 2>), g, dim3(256), 0, st, p);)
         return;
     }
     if (variant == 3) {
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
-        const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), 6);
-        if (nbw <= 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 3>), g, dim3(256), 0, st, p);
+        const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), KS * KS - 3);
+        if (KS == 4) {
+            if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 3, 4>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_split16_kernel<2, 3, 4>), g, dim3(256), 0, st, p);
+        } else if (nbw <= 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 3>), g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_split16_kernel<3, 3>), g, dim3(256), 0, st, p);
         return;
     }

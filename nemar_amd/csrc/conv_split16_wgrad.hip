@@ -117,14 +117,17 @@ __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restr
     const int cc = threadIdx.x & 63;
     for (int q = threadIdx.x >> 6; q < CPR; q += 4) {
         unsigned short h[8], l[8];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                // all eight LDS reads first (unconditional, clamped), then the masks
+            const int xs = q * 8 + e - 1;
+            v[e] = tile[cc][min(max(reflect ? mirror(xs, W) : xs, 0), W - 1)];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int xp = q * 8 + e;                // padded column
-            int xs = xp - 1;
-            bool ok = xp < W + 2;
-            if (reflect) xs = mirror(xs, W);
-            else ok = ok && (unsigned)xs < (unsigned)W;
-            split2_f16(ok ? tile[cc][min(max(xs, 0), W - 1)] : 0.f, h[e], l[e]);
+            const bool ok = xp < W + 2 && (reflect || (unsigned)(xp - 1) < (unsigned)W);
+            split2_f16(ok ? v[e] : 0.f, h[e], l[e]);
         }
         const size_t t = (((size_t)n * CBLK + cblk) * FX + (size_t)yp * CPR + q) * 64 + cc;
         out[t] = pack8(h);

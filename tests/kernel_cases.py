@@ -179,7 +179,7 @@ class scratch_arena:
         self.be.lib.set_scratch(None, 0)
 
 
-def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0):
+def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0, R=3):
     """One wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_fwd (dgrad False) or nemar_conv2d_bwd_data with the scratch
     arena registered: the split-16 route must be eligible for the shape, and obey the same tolerance against the float64 oracle
     as the exact-fp32 kernels."""

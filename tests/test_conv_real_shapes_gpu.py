@@ -87,6 +87,7 @@ SPLIT16_SHAPES = [
     ("T resblock 256->256 k3 reflect 64x64", 8, 256, 0, 64, 64, 256, 3, 1, 1, PAD_REFLECT),
     ("T resblock 256->256 k3 reflect 128x128 (512^2 input)", 2, 256, 0, 128, 128, 256, 3, 1, 1, PAD_REFLECT),
     ("wide zero-padded 128->128 k3 32x32", 8, 128, 0, 32, 32, 128, 3, 1, 1, PAD_ZERO),
+    ("D layer4 256->512 k4 s1 32x32->31x31", 8, 256, 0, 32, 32, 512, 4, 1, 1, PAD_ZERO),
 ]
 
 

@@ -369,3 +369,18 @@ def test_conv_split16_weight_gradient(be):
 
 def test_absmax_and_hint(be):
     K.case_absmax_and_hint(be)
+
+
+@pytest.mark.parametrize("variant", [4, 3])
+def test_conv_split16_4x4_layers(be, variant):
+    """The discriminator's 4x4 / stride 1 / pad 1 layers on the split-16 kernel: computed on the input-sized domain with the last
+    output row / column masked (forward), and as a full correlation of the (H-1) x (W-1) gradient with the flipped taps (data
+    gradient, source offset 2); 16 taps per 16-channel chunk."""
+    be.lib.tune(21, variant)
+    try:
+        K.case_conv_split16(be, 1, 32, 8, 32, 128, K.PAD_ZERO, dgrad=False, R=4)
+        K.case_conv_split16(be, 2, 16, 16, 32, 256, K.PAD_ZERO, dgrad=False, R=4)
+        K.case_conv_split16(be, 1, 128, 8, 32, 32, K.PAD_ZERO, dgrad=True, R=4)
+        K.case_conv_split16(be, 2, 256, 16, 32, 16, K.PAD_ZERO, dgrad=True, R=4)
+    finally:
+        be.lib.tune(21, 4)
