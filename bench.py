@@ -179,10 +179,10 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = False
     import ctypes
-    tk_ms_c, tk_n_c = ctypes.c_double(0.0), ctypes.c_int(0)
-    lib.kernel_timer_read(ctypes.byref(tk_ms_c), ctypes.byref(tk_n_c))
+    tk_ms_c, tk_fl_c, tk_n_c = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int(0)
+    lib.kernel_timer_read(ctypes.byref(tk_ms_c), ctypes.byref(tk_fl_c), ctypes.byref(tk_n_c))
     lib.kernel_timer(0)
-    tk_ms, tk_n = tk_ms_c.value, tk_n_c.value
+    tk_ms, tk_flop, tk_n = tk_ms_c.value, tk_fl_c.value, tk_n_c.value
     if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -220,21 +220,22 @@ def main():
             pmc = json.load(f)
     except OSError:
         pass
-    # Dominant kernel: igemm_split16_kernel (forward AND data gradient of the 256-channel 3x3 resblock convolutions: 72 launches per
-    # step, the same instantiation — what rocprofv3 --stats lists as one row).  Its launches are timed by HIP events recorded on the
-    # launch stream inside the library (nemar_kernel_timer).  One launch does 2 N C K HW 9 fp32-equivalent flops as three fp16
-    # partial products per product: the matrix pipe executes 3x the algorithmic flops, so the roofline of this formulation is the
-    # dense fp16 MFMA peak / 3.
+    # Dominant kernel: igemm_split16_kernel — forward AND data gradient of the 256-channel 3x3 resblock convolutions (72 launches per
+    # step) and of the discriminator's 256->512 4x4 layer (10).  Its launches are timed by HIP events recorded on the launch stream
+    # inside the library (nemar_kernel_timer), which also adds up their algorithmic flop (2 N OH OW K C R S, fp32-equivalent).  Every
+    # fp32 product is executed as three fp16 partial products, so the matrix pipe does 3x the algorithmic flop: the roofline of
+    # this formulation is the dense fp16 MFMA peak / 3.
     if tk_n:
         sec = tk_ms * 1e-3 / tk_n
-        flop = 2.0 * a.batch * C * hw * C * 9
+        flop = tk_flop / tk_n
         peak = F16_MFMA_PEAK_TF / 3.0
         out["roofline"] = {"bound": "mfma", "achieved": flop / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": flop / sec / 1e12 / peak,
                            "traffic": pmc.get("igemm_split16", {}).get("traffic_bytes") if std else None,
                            "traffic_source": PMC_FILE if std and pmc.get("igemm_split16") else None,
-                           "kernel": "igemm_split16_kernel<2,2> (conv2d_fwd / conv2d_bwd_data 256->256 k3 reflect @%dx%d, batch %d; fp32 "
-                                     "operands as fp16 x 3 partial products, fp32 accumulate)" % (a.size // 4, a.size // 4, a.batch),
+                           "kernel": "igemm_split16_kernel (conv2d_fwd / conv2d_bwd_data of the 256->256 3x3 reflect layers @%dx%d and of the "
+                                     "256->512 4x4 layer @%dx%d, batch %d; fp32 operands as fp16 x 3 partial products, fp32 accumulate)"
+                                     % (a.size // 4, a.size // 4, a.size // 8, a.size // 8, a.batch),
                            "launches_timed": tk_n, "avg_launch_us": sec * 1e6,
                            "algorithmic_flop_per_launch": flop,
                            "peak_basis": "2500 TFLOP/s dense fp16 MFMA / 3 products per fp32 product",

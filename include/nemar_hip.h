@@ -159,10 +159,10 @@ int nemar_set_scratch(void* scratch, size_t bytes);
 int nemar_absmax(const float* t, long long n, void* out_word, void* stream);
 int nemar_absmax_hint(const void* tensor, const void* word);
 /* Measurement hook for bench.py's roofline entry: while enabled, HIP events are recorded on the launch stream around the main
- * kernel (igemm_split16_kernel) of every forward / data-gradient call of those layers; read -> summed duration and launch count
- * (synchronises on the recorded events, resets the list). */
+ * kernel (igemm_split16_kernel) of every forward / data-gradient call of those layers; read -> summed duration, summed algorithmic
+ * (fp32-equivalent) flop 2 N OH OW K C R S of the timed launches, and their count (synchronises on the recorded events, resets). */
 int nemar_kernel_timer(int enable);
-int nemar_kernel_timer_read(double* total_ms, int* launches);
+int nemar_kernel_timer_read(double* total_ms, double* total_flop, int* launches);
 /* gb[C] += sum over batch and plane of g [N,C,HW] (bias gradient; two fixed-order stages through `workspace`). */
 size_t nemar_bias_grad_workspace(int N, int C, int HW);
 int nemar_bias_grad(const float* g, float* gb, int N, int C, int HW, void* workspace, size_t ws_bytes, void* stream);

@@ -49,7 +49,7 @@ SIGNATURES = {
     "nemar_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "nemar_absmax_hint": (_i, [_vp, _vp]),
     "nemar_kernel_timer": (_i, [_i]),
-    "nemar_kernel_timer_read": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "nemar_kernel_timer_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "nemar_tune": (_i, [_i, _i]),

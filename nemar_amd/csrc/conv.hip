@@ -2140,9 +2140,9 @@ NEMAR_API int nemar_kernel_timer(int enable) {
     return NEMAR_OK;
 }
 
-NEMAR_API int nemar_kernel_timer_read(double* total_ms, int* launches) {
-    NEMAR_REQUIRE(total_ms && launches, "kernel_timer_read: null pointer");
-    *launches = nemar_split16_timer_read(total_ms);
+NEMAR_API int nemar_kernel_timer_read(double* total_ms, double* total_flop, int* launches) {
+    NEMAR_REQUIRE(total_ms && total_flop && launches, "kernel_timer_read: null pointer");
+    *launches = nemar_split16_timer_read(total_ms, total_flop);
     return NEMAR_OK;
 }
 

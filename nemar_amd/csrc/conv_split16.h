@@ -39,4 +39,5 @@ const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned
 
 // ---- measurement hook: HIP events on the launch stream around the main kernel of every nemar_split16_conv call while enabled ----
 void nemar_split16_timer(int on);
-int nemar_split16_timer_read(double* total_ms);      // -> launches timed since enabled; synchronises on their events; resets
+int nemar_split16_timer_read(double* total_ms, double* total_flop);      // -> launches timed since enabled (their summed duration
+                                                                         // and algorithmic flop); synchronises on the events; resets

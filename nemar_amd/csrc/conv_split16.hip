@@ -800,15 +800,16 @@ namespace {
 constexpr int MAX_TIMED = 1024;
 hipEvent_t g_tev[MAX_TIMED][2];
 int g_tev_made = 0, g_tev_used = 0;
+double g_tev_flop = 0.0;          // algorithmic (fp32-equivalent) flop of the launches timed so far
 bool g_timing = false;
 }  // namespace
 
 void nemar_split16_timer(int on) {
     g_timing = on != 0;
-    if (on) g_tev_used = 0;
+    if (on) { g_tev_used = 0; g_tev_flop = 0.0; }
 }
 
-int nemar_split16_timer_read(double* total_ms) {
+int nemar_split16_timer_read(double* total_ms, double* total_flop) {
     double t = 0.0;
     for (int i = 0; i < g_tev_used; ++i) {
         float ms = 0.f;
@@ -817,8 +818,10 @@ int nemar_split16_timer_read(double* total_ms) {
         t += ms;
     }
     *total_ms = t;
+    *total_flop = g_tev_flop;
     const int n = g_tev_used;
     g_tev_used = 0;
+    g_tev_flop = 0.0;
     return n;
 }
 
@@ -834,7 +837,10 @@ int nemar_split16_timer_read(double* total_ms) {
             (void)hipEventRecord(g_tev[g_tev_used][0], st);                    \
         }                                                                      \
         launch_;                                                               \
-        if (tm_) (void)hipEventRecord(g_tev[g_tev_used++][1], st);             \
+        if (tm_) {                                                             \
+            (void)hipEventRecord(g_tev[g_tev_used++][1], st);                  \
+            g_tev_flop += 2.0 * N * OH * OW * (double)M * Cred * KS * KS;      \
+        }                                                                      \
     }
 
 void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int dgrad, int variant, hipStream_t st) {
