@@ -1723,7 +1723,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     {
         const int mode = pad_mode == BORDER_REFLECT ? SPLIT16_REFLECT : SPLIT16_ZERO;
         if (g_split16 && C1 == 0 && act == ACT_NONE && nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, mode, g_split16_variant) &&
-            g_scratch && g_scratch_bytes >= nemar_split16_scratch_bytes(N, C, H, W)) {
+            g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, K, C, OH, OW)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 0, g_split16_variant, st);
             nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, R, 1, H, W, OH, OW, mode, g_scratch, g_xcd_map, g_split16_variant,
                                g_tl, st);
@@ -1797,7 +1797,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         // 3x3 stride-1 layers: the data gradient is the same convolution with flipped, transposed weights (conv_split16.hip)
         const int mode = refl ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO;
         if (g_split16 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode, g_split16_variant) &&
-            g_scratch && g_scratch_bytes >= nemar_split16_scratch_bytes(N, K, H, W)) {
+            g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, C, K, H, W)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 1, g_split16_variant, st);
             nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch, g_xcd_map,
                                g_split16_variant, g_tl, st);
@@ -2156,9 +2156,9 @@ NEMAR_API int nemar_absmax_hint(const void* tensor, const void* word) {
 NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return 0;
     size_t b = 0;
-    if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO, 4)) b = nemar_split16_scratch_bytes(N, C, H, W);
+    if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO, 4)) b = nemar_split16_scratch_total(N, H, W, K, C, H, W);
     if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO, 4)) {
-        const size_t d = nemar_split16_scratch_bytes(N, K, H, W);
+        const size_t d = nemar_split16_scratch_total(N, H, W, C, K, H, W);
         if (d > b) b = d;
     }
     if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {

@@ -10,6 +10,8 @@ enum { SPLIT16_ZERO = 0, SPLIT16_REFLECT = 1, SPLIT16_DGRAD_REFLECT = 2 };
 // variant: the nemar_tune(21) setting the call will run under (4 fp16 x 3, 3 bf16 x 6, 0 first generation): LDS budgets differ
 bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, int stride, int pad, int mode, int variant);
 size_t nemar_split16_scratch_bytes(int N, int Cred, int H, int W);      // split activation planes
+int nemar_split16_ksplit(int N, int H, int W, int M, int Cred);          // reduction runs per tile (few-tile layers)
+size_t nemar_split16_scratch_total(int N, int H, int W, int M, int Cred, int OH, int OW);     // planes + slabs of those runs
 size_t nemar_split16_pack_bytes(int M, int Cred, int KS);               // split, tile-ordered weights (KS x KS taps)
 // w [K, C, KS, KS].  dgrad == 0: M = K rows, reduction over C.  dgrad != 0: M = C rows, reduction over K, taps flipped.
 void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int dgrad, int variant, hipStream_t st);

@@ -63,10 +63,13 @@ __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
 // 64-channel block: the 64 rows are read coalesced (256 B runs) into LDS, then thread (kk, chunk) takes the 10 texels x' - 2 .. x' + 7
 // of its chunk from there and writes the three shifted versions, two planes each — 64 consecutive channels = one 1 KiB store.
 // (A first version read straight from global memory, one channel row per lane: 7x over-fetch, 60 us; PMC in profiles/.)
+// TW = row-tile width class (>= W): 64 x (TW + 1) floats of LDS, so that narrow maps keep many workgroups per CU (the pass is
+// latency-bound per workgroup: load a row block, barrier, write)
 constexpr int SPLIT_MAXW = 256;
+template <int TW>
 __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restrict__ gy, u32x4* __restrict__ out, int N, int K, int H,
                                                             int W, int CPR, long long total, const unsigned* maxbits) {
-    __shared__ float tile[64][SPLIT_MAXW + 1];
+    __shared__ float tile[64][TW + 1];
     const float scale = pow2_scale(*maxbits);
     const int KBLK = K >> 6, F = H * CPR;
     const int y = blockIdx.x % H, kblk = (blockIdx.x / H) % KBLK, n = blockIdx.x / (H * KBLK);
@@ -98,9 +101,10 @@ __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restr
 
 // X planes: word ((pl * N + n) * CBLK + cblk) * FX + f) * 64 + cc, FX = (H + 2) * CPR; padding materialised.  Same structure: one
 // workgroup = one padded row yp of one 64-channel block.
+template <int TW>
 __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C, int H,
                                                             int W, int CPR, int reflect, long long total, const unsigned* maxbits) {
-    __shared__ float tile[64][SPLIT_MAXW + 1];
+    __shared__ float tile[64][TW + 1];
     const float scale = pow2_scale(*maxbits);
     const int CBLK = C >> 6, FX = (H + 2) * CPR, Hp = H + 2;
     const int yp = blockIdx.x % Hp, cblk = (blockIdx.x / Hp) % CBLK, n = blockIdx.x / (Hp * CBLK);
@@ -319,9 +323,12 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K) - 64);
     const unsigned* const gmax = nemar_split16_source_max(gy, (long long)N * K * H * W, mw, st);
     const unsigned* const xmax = nemar_split16_source_max(x, (long long)N * C * H * W, mw + 1, st);
-    hipLaunchKernelGGL(split_wgrad_g_kernel, dim3(N * KBLK * H), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, gmax);
-    hipLaunchKernelGGL(split_wgrad_x_kernel, dim3(N * CBLK * (H + 2)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal,
+#define WG_SPLIT(TW_)                                                                                                              \
+    hipLaunchKernelGGL((split_wgrad_g_kernel<TW_>), dim3(N * KBLK * H), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, gmax);       \
+    hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * (H + 2)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal, \
                        xmax);
+    if (W <= 64) { WG_SPLIT(64) } else if (W <= 128) { WG_SPLIT(128) } else { WG_SPLIT(256) }
+#undef WG_SPLIT
     WgParams p;
     p.G = G; p.X = X; p.part = part;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;

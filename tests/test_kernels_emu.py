@@ -338,6 +338,7 @@ def test_conv_split16_matrix_pipe(be, variant):
         K.case_conv_split16(be, 1, 16, 8, 64, 128, K.PAD_REFLECT, dgrad=False)
         K.case_conv_split16(be, 1, 48, 4, 128, 128, K.PAD_REFLECT, dgrad=False)      # 128-pixel rows: two rows per tile, 3 chunks
         K.case_conv_split16(be, 1, 16, 4, 256, 128, K.PAD_REFLECT, dgrad=False)      # 256-pixel rows: one row per tile (fp16 form only)
+        K.case_conv_split16(be, 1, 128, 8, 32, 128, K.PAD_ZERO, dgrad=False)         # one tile, 8 chunks: reduction cut into two slabs
     finally:
         be.lib.tune(21, 4)
 
