@@ -220,10 +220,12 @@ class _Conv2d(Function):
             if split16:           # max |x| once: this call and the weight gradient in backward both scale x by it
                 xmax = _absmax_word(x)
                 L.absmax_hint(_p(x), _p(xmax))
-            L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
-                         slope, _p(ws), wsb, hit, _stream())
-            if split16:
-                L.absmax_hint(_p(x), None)
+            try:
+                L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
+                             slope, _p(ws), wsb, hit, _stream())
+            finally:
+                if split16:
+                    L.absmax_hint(_p(x), None)
         ctx.xmax = xmax
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
@@ -255,6 +257,17 @@ class _Conv2d(Function):
             L.absmax_hint(_p(g), _p(gmax))
             L.absmax_hint(_p(x), _p(ctx.xmax))
             hinted = [g, x]
+        try:
+            return _Conv2d._backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st,
+                                          need_x, need_x2, need_w, need_b)
+        finally:
+            for t in hinted:
+                L.absmax_hint(_p(t), None)
+
+    @staticmethod
+    def _backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st, need_x, need_x2, need_w,
+                       need_b):
+        gx = gx2 = None
         if need_x or need_x2:
             gx = torch.empty_like(x) if need_x else None
             gx2 = torch.empty_like(x2) if (need_x2 and x2 is not None) else None
@@ -284,8 +297,6 @@ class _Conv2d(Function):
         elif want_b:
             _bias_grad(g, _grad_buffer(ctx.bias), N, K, OH * OW, st)
             grad_ready(ctx.bias)
-        for t in hinted:
-            L.absmax_hint(_p(t), None)
         return gx, gx2, None, None, None, None, None, None, None, None
 
 

@@ -157,3 +157,22 @@ def test_full_width_step_vs_reference(name):
     assert len(rows) > 300, len(rows)
     bad = [r for r in rows if not r[3]]
     assert not bad, (len(bad), bad[:8])
+
+
+def test_full_width_step_on_the_exact_fp32_route():
+    """The same C2 fixture with the split-16 kernels switched off (nemar_tune(20, 0): every convolution on the exact-fp32 MFMA / VALU
+    kernels) — both routes of the wide 3x3 layers stay pinned to the reference."""
+    from nemar_amd import ops
+    name = 'c2_full'
+    cfg = FULL_CONFIGS[name]
+    ops.tune(20, 0)
+    try:
+        m = build(name)
+        A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+        rec = full_step_record(m, A, B, cfg['seed'])
+        torch.cuda.synchronize()
+    finally:
+        ops.tune(20, 1)
+    rows = compare(name, rec)
+    bad = [r for r in rows if not r[3]]
+    assert len(rows) > 300 and not bad, (len(bad), bad[:8])
