@@ -139,7 +139,9 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   15 XCD-aware workgroup -> tile mapping of the wave-specialised kernels (1, default)
  *   16..19 loader / tile / ring-depth / narrow-kernel variants
  *   20 3x3 stride-1 layers with >= 128 output channels on the bf16 matrix pipe with three-way split operands (1, default;
- *      needs the scratch arena below; 0 = exact-fp32 MFMA kernels).  Packed weight images are per setting. */
+ *      needs the scratch arena below; 0 = exact-fp32 MFMA kernels).  Packed weight images are per setting.
+ *   21 operand split of those kernels: 4 fp16 x 3 (default), 3 bf16 x 6, 0 bf16 x 6 on the first-generation kernel
+ *   23 smallest layer (million multiply-adds, default 2000) that takes the split-16 route */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data.  The wide 3x3 stride-1 layers (the ResnetBlock

@@ -1071,6 +1071,10 @@ static int g_xcd_map = 1;        // tuning switch (key 15): XCD-aware workgroup 
 // key 20: 3x3 / stride-1 layers with >= 128 output channels run on the bf16 matrix pipe with three-way split operands
 // (conv_split16.hip) whenever the caller has registered a scratch arena large enough for the split source planes
 static int g_split16 = 1;
+// key 23: the split-16 route needs work to amortise its extra launches (max pass, split pass, slab sum): layers below this many
+// million multiply-adds (default 2000 = 4 GFLOP, ~40 us on the exact-fp32 kernels) stay on those — BASELINE config 1's 32x32
+// batch-1 resblocks (0.6 GMAC) lost 2 ms per step to launch overhead on the split-16 route
+static long long g_split16_min_mmac = 2000;
 static int g_split16_variant = 4;   // key 21: 4 fp16 x 3 products (default), 3 bf16 x 6 products, 0 bf16 x 6 on the first-generation
                                 // kernel with loader waves (kept for the A/B numbers in DESIGN.md)
 static void* g_scratch = nullptr;
@@ -1597,6 +1601,10 @@ int normalize_ksplit(int Kred, int ksplit) {
     return nemar_cdiv(nk_all, nk_per);
 }
 
+static bool split16_worth_it(int N, int OH, int OW, int K, int C, int R, int S) {
+    return (long long)N * OH * OW * K * C * R * S >= g_split16_min_mmac * 1000000ll;
+}
+
 // Workspace layout of nemar_conv2d_bwd_data (floats), shared by the size query and the operator:
 //   [packed weights x stride^2 parity classes][padded-domain scratch (strided reflect)][flipped weights (C <= 4)]
 //   [compact border-ring gradient (stride-1 reflect)][ksplit slabs of the gradient (split reductions)]
@@ -1722,7 +1730,8 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     }
     {
         const int mode = pad_mode == BORDER_REFLECT ? SPLIT16_REFLECT : SPLIT16_ZERO;
-        if (g_split16 && C1 == 0 && act == ACT_NONE && nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, mode, g_split16_variant) &&
+        if (g_split16 && C1 == 0 && act == ACT_NONE && split16_worth_it(N, OH, OW, K, C, R, S) &&
+            nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, mode, g_split16_variant) &&
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, K, C, OH, OW)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 0, g_split16_variant, st);
             nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, R, 1, H, W, OH, OW, mode, g_scratch, g_xcd_map, g_split16_variant,
@@ -1796,7 +1805,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     {
         // 3x3 stride-1 layers: the data gradient is the same convolution with flipped, transposed weights (conv_split16.hip)
         const int mode = refl ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO;
-        if (g_split16 && C1 == 0 && gx0 && !bias && act == ACT_NONE && nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode, g_split16_variant) &&
+        if (g_split16 && C1 == 0 && gx0 && !bias && act == ACT_NONE && split16_worth_it(N, OH, OW, K, C, R, S) &&
+            nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode, g_split16_variant) &&
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, C, K, H, W)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 1, g_split16_variant, st);
             nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch, g_xcd_map,
@@ -2027,7 +2037,8 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
-    if (g_split16 && g_split16_variant == 4 && part && C1 == 0 && nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
+    if (g_split16 && g_split16_variant == 4 && part && C1 == 0 && split16_worth_it(N, OH, OW, K, C0, R, S) &&
+        nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
         g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K)) {
         // wide 3x3 stride-1 layers: fp16 x 3 on the 16-bit matrix pipe (conv_split16_wgrad.hip); bias gradient as its own reduction
         nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map, st);
@@ -2101,6 +2112,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 20) { g_split16 = value != 0; return NEMAR_OK; }
+    if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = (value == 0 || value == 3) ? value : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
@@ -2155,6 +2167,7 @@ NEMAR_API int nemar_absmax_hint(const void* tensor, const void* word) {
 // Scratch bytes nemar_conv2d_fwd / nemar_conv2d_bwd_data want for this layer (0: the layer never uses the arena)
 NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return 0;
+    if (!g_split16 || !split16_worth_it(N, H + 2 * pad - R + 1, W + 2 * pad - S + 1, K, C, R, S)) return 0;
     size_t b = 0;
     if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO, 4)) b = nemar_split16_scratch_total(N, H, W, K, C, H, W);
     if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO, 4)) {

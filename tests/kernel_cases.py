@@ -171,19 +171,30 @@ class scratch_arena:
         self.be, self.buf, self.nbytes = be, be.bytes_buf(nbytes), nbytes
 
     def __enter__(self):
+        self.be.lib.tune(23, 0)          # test shapes are far below the work threshold of the route
         self.be.lib.set_scratch(self.be.ptr(self.buf), self.nbytes)
         return self
 
     def __exit__(self, *a):
         self.be.sync()
         self.be.lib.set_scratch(None, 0)
+        self.be.lib.tune(23, 2000)
+
+
+def split16_scratch(be, *shape):
+    """nemar_conv2d_scratch for a (small) test shape: with the work threshold of the route lifted"""
+    be.lib.tune(23, 0)
+    try:
+        return be.lib.conv2d_scratch(*shape)
+    finally:
+        be.lib.tune(23, 2000)
 
 
 def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0, R=3):
     """One wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_fwd (dgrad False) or nemar_conv2d_bwd_data with the scratch
     arena registered: the split-16 route must be eligible for the shape, and obey the same tolerance against the float64 oracle
     as the exact-fp32 kernels."""
-    need = be.lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
     assert need > 0, "shape is not eligible for the split-16 kernels"
     with scratch_arena(be, need):
         if dgrad:
@@ -210,7 +221,7 @@ def case_absmax_and_hint(be, seed=0):
     w = (rng.standard_normal((K, C, 3, 3)) / 12).astype(np.float32)
     d_x, d_w = be.dev(x), be.dev(w)
     outs = []
-    with scratch_arena(be, be.lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)):
+    with scratch_arena(be, split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)):
         for hint in (False, True):
             d_y = be.full((N, K, H, W), np.nan)
             wsb = be.lib.conv2d_fwd_workspace(N, H, W, K, C, 3, 3, 1, 1)
@@ -230,7 +241,7 @@ def case_absmax_and_hint(be, seed=0):
 def case_conv_split16_wgrad(be, N, C, H, W, K, pad_mode, seed=0):
     """Weight + bias gradient of a wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_bwd_weight with the scratch arena registered:
     the fp16 x 3 route (csrc/conv_split16_wgrad.hip) must be eligible and obey the tolerances of the exact-fp32 kernels."""
-    need = be.lib.conv2d_scratch(N, H, W, K, C, 3, 3, 1, 1)
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
     assert need > 0, "shape is not eligible for the split-16 kernels"
     with scratch_arena(be, need):
         case_conv_bwd_weight(be, N, C, 0, H, W, K, 3, 1, 1, pad_mode, seed=seed)

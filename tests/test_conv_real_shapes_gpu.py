@@ -95,9 +95,9 @@ SPLIT16_SHAPES = [
 def test_conv_real_shape_split16(be, shape):
     """Scratch arena registered, as nemar_amd/ops.py does: forward and data gradient of the wide 3x3 layers run on the
     split-16 kernels (csrc/conv_split16.hip) and must obey the SAME tolerances as the exact-fp32 kernels."""
-    from kernel_cases import scratch_arena
+    from kernel_cases import scratch_arena, split16_scratch
     name, N, C0, C1, H, W, K, R, stride, pad, pm = shape
-    need = be.lib.conv2d_scratch(N, H, W, K, C0 + C1, R, R, stride, pad)
+    need = split16_scratch(be, N, H, W, K, C0 + C1, R, R, stride, pad)
     assert need > 0
     with scratch_arena(be, need):
         _run_shape(be, shape)
