@@ -73,6 +73,7 @@ def _workspace(nbytes, device):
     return buf
 
 
+_scratch_need = {}     # layer shape -> nemar_conv2d_scratch bytes (depends on the nemar_tune switches: ops.tune clears it)
 _arena = {}            # device -> tensor registered with nemar_set_scratch
 _arena_live = [None]   # (data_ptr, bytes) the library currently holds
 
@@ -80,7 +81,10 @@ _arena_live = [None]   # (data_ptr, bytes) the library currently holds
 def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
     """Make sure the library's transient scratch arena (split source planes of the wide 3x3 layers, csrc/conv_split16.hip) covers
     this layer.  Grow-only per device; stream-ordered like _workspace."""
-    need = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
+    key = (N, H, W, K, C, R, S, stride, pad)
+    need = _scratch_need.get(key)
+    if need is None:                      # (a host-bound small config pays for every ctypes call: ask once per shape)
+        need = _scratch_need[key] = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
     if not need:
         return False
     buf = _arena.get(device)
@@ -151,6 +155,7 @@ def invalidate_packed_weights():
 def tune(key, value):
     """nemar_tune through the packed-weight cache: several switches (tile family, split-16 route) change the packed image."""
     L.tune(key, value)
+    _scratch_need.clear()
     invalidate_packed_weights()
 
 
