@@ -95,10 +95,12 @@ class NEMARModel(BaseModel):
         self.train_stn = True
         self.setup_visualizers()
         self.tb_visualizer = None
-        # NEMAR_BATCHED_PASSES=1: T's two applications and D's 3 + 2 applications per step run as single batches (valid
-        # without cross-sample ops, i.e. not with BatchNorm).  Measured on MI355X, config 2: 78.15 vs 78.00 ms/step —
-        # no gain (every layer already fills the chip at batch 8), so the reference's call order stays the default.
-        self._batched = opt.norm != 'batch' and os.environ.get('NEMAR_BATCHED_PASSES', '0') == '1'
+        # T's two applications and D's 3 + 2 applications per step run as single batches (valid without cross-sample ops, i.e. not
+        # with BatchNorm): the same graph with half the launches.  Round 1 measured no gain (78.15 vs 78.00 ms/step: every layer
+        # already filled the chip at batch 8); with the split-16 kernels, whose max / split / slab-sum passes are paid per launch,
+        # it is 47.9 vs 50.2 ms/step on the same box, so it is the default.  NEMAR_BATCHED_PASSES=0 restores the reference's call
+        # order (tests/test_step_gpu.py compares the two).
+        self._batched = opt.norm != 'batch' and os.environ.get('NEMAR_BATCHED_PASSES', '1') == '1'
         # dropout masks: one Philox stream per process, governed by torch.manual_seed() and different on every rank
         ops.manual_seed(torch.initial_seed() + dist.rank())
         self.define_networks()
