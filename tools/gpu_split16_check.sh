@@ -1,4 +1,5 @@
 #!/bin/bash
+# split-16 kernels: kernel + real-shape tests, layer timings with / without the arena, bench, step parity suites
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$1; mkdir -p $O
 cd $R
 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "split16 or absmax" --tb=short 2>&1 | tail -3
