@@ -1993,7 +1993,7 @@ NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, i
         if (f3 > fl) fl = f3;
     }
     if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {       // slabs of the split-16 route + bias partials
-        const size_t f5 = (size_t)nemar_split16_wgrad_splits(N, C, H, W, K) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
+        const size_t f5 = (size_t)nemar_split16_wgrad_splits(N, C, H, W, K, R) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
         if (f5 > fl) fl = f5;
     }
     return sizeof(float) * fl;
@@ -2039,12 +2039,12 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     }
     if (g_split16 && g_split16_variant == 4 && part && C1 == 0 && split16_worth_it(N, OH, OW, K, C0, R, S) &&
         nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
-        g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K)) {
+        (R == 3 || pad_mode == BORDER_ZERO) && g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K, R)) {
         // wide 3x3 stride-1 layers: fp16 x 3 on the 16-bit matrix pipe (conv_split16_wgrad.hip); bias gradient as its own reduction
-        nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map, st);
+        nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map, st);
         if (gb) {
             const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
-            float* pb = part + (size_t)nemar_split16_wgrad_splits(N, C0, H, W, K) * K * J;
+            float* pb = part + (size_t)nemar_split16_wgrad_splits(N, C0, H, W, K, R) * K * J;
             hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, pb, N, K, OH * OW, BIAS_CHUNK);
             nemar_sum_partials(pb, K, N * chunks, gb, K, true, st);
         }
@@ -2175,7 +2175,7 @@ NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, 
         if (d > b) b = d;
     }
     if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {
-        const size_t d = nemar_split16_wgrad_scratch_bytes(N, C, H, W, K);
+        const size_t d = nemar_split16_wgrad_scratch_bytes(N, C, H, W, K, R);
         if (d > b) b = d;
     }
     return b;

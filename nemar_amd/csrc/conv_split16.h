@@ -25,11 +25,11 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
 
 // ---- weight gradient of the same layers (conv_split16_wgrad.hip) ----
 bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
-size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K);     // split gy (three shifts) and padded x planes
-int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K);               // slabs of K C 9 floats the caller provides
-// gw [K][C][3][3] += dW from x [N,C,H,W] and gy [N,K,H,W]; slabs summed in order (bitwise reproducible)
-void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int reflect, void* scratch,
-                         float* part, int xcd_map, hipStream_t st);
+size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K, int KS);     // split gy (KS shifts) and padded x planes
+int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS);               // slabs of K C KS KS floats the caller provides
+// gw [K][C][KS][KS] += dW from x [N,C,H,W] and gy [N,K,H+3-KS,W+3-KS]; slabs summed in order (bitwise reproducible)
+void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
+                         void* scratch, float* part, int xcd_map, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
 
 // ---- max |t| of a source tensor (the fp16 form's power-of-two scale follows from it) ----

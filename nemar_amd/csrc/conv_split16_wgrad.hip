@@ -66,33 +66,36 @@ __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
 // TW = row-tile width class (>= W): 64 x (TW + 1) floats of LDS, so that narrow maps keep many workgroups per CU (the pass is
 // latency-bound per workgroup: load a row block, barrier, write)
 constexpr int SPLIT_MAXW = 256;
-template <int TW>
+// gy is [N, K, H, W] (H x W = ITS extents: one less than the layer's input for the 4x4 layers); the planes have Hg >= H rows (zero
+// below row H: the row count is rounded up to a whole number of row blocks) and KS shifted versions.
+template <int TW, int KS>
 __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restrict__ gy, u32x4* __restrict__ out, int N, int K, int H,
-                                                            int W, int CPR, long long total, const unsigned* maxbits) {
+                                                            int W, int Hg, int CPR, long long total, const unsigned* maxbits) {
     __shared__ float tile[64][TW + 1];
     const float scale = pow2_scale(*maxbits);
-    const int KBLK = K >> 6, F = H * CPR;
-    const int y = blockIdx.x % H, kblk = (blockIdx.x / H) % KBLK, n = blockIdx.x / (H * KBLK);
-    const float* src = gy + (((size_t)n * K + kblk * 64) * H + y) * W;
+    const int KBLK = K >> 6, F = Hg * CPR;
+    const int y = blockIdx.x % Hg, kblk = (blockIdx.x / Hg) % KBLK, n = blockIdx.x / (Hg * KBLK);
+    const bool rowok = y < H;
+    const float* src = gy + (((size_t)n * K + kblk * 64) * H + (rowok ? y : 0)) * W;
     for (int i = threadIdx.x; i < 64 * W; i += 256) {
         const int kk = i / W, x = i - kk * W;
-        tile[kk][x] = src[(size_t)kk * H * W + x] * scale;
+        tile[kk][x] = rowok ? src[(size_t)kk * H * W + x] * scale : 0.f;
     }
     __syncthreads();
     const int kk = threadIdx.x & 63;
     for (int q = threadIdx.x >> 6; q < CPR; q += 4) {
-        float v[10];
+        float v[8 + KS - 1];
 #pragma unroll
-        for (int e = 0; e < 10; ++e) {
-            const int x = q * 8 - 2 + e;
+        for (int e = 0; e < 8 + KS - 1; ++e) {
+            const int x = q * 8 - (KS - 1) + e;
             v[e] = (x >= 0 && x < W) ? tile[kk][x] : 0.f;
         }
         const size_t t = (((size_t)n * KBLK + kblk) * F + (size_t)y * CPR + q) * 64 + kk;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < KS; ++s) {
             unsigned short h[8], l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split2_f16(v[e + 2 - s], h[e], l[e]);
+            for (int e = 0; e < 8; ++e) split2_f16(v[e + KS - 1 - s], h[e], l[e]);
             out[(size_t)(s * 2) * total + t] = pack8(h);
             out[(size_t)(s * 2 + 1) * total + t] = pack8(l);
         }
@@ -103,15 +106,16 @@ __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restr
 // workgroup = one padded row yp of one 64-channel block.
 template <int TW>
 __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C, int H,
-                                                            int W, int CPR, int reflect, long long total, const unsigned* maxbits) {
+                                                            int W, int Hp, int CPR, int reflect, long long total,
+                                                            const unsigned* maxbits) {
     __shared__ float tile[64][TW + 1];
     const float scale = pow2_scale(*maxbits);
-    const int CBLK = C >> 6, FX = (H + 2) * CPR, Hp = H + 2;
+    const int CBLK = C >> 6, FX = Hp * CPR;            // Hp >= H + 2 plane rows (rows beyond the padded image: zero)
     const int yp = blockIdx.x % Hp, cblk = (blockIdx.x / Hp) % CBLK, n = blockIdx.x / (Hp * CBLK);
     int y = yp - 1;
-    bool rowok = true;
-    if (reflect) y = mirror(y, H);
-    else rowok = (unsigned)y < (unsigned)H;
+    bool rowok = yp < H + 2;
+    if (reflect) y = mirror(min(y, H), H);
+    else rowok = rowok && (unsigned)y < (unsigned)H;
     const float* src = x + (((size_t)n * C + cblk * 64) * H + (rowok ? y : 0)) * W;
     for (int i = threadIdx.x; i < 64 * W; i += 256) {
         const int cc = i / W, xs = i - cc * W;
@@ -143,7 +147,7 @@ struct WgParams {
     const u32x4* G;            // [3 s][2 planes] blocks of gplane16 words
     const u32x4* X;            // [2 planes] blocks of xplane16 words
     float* part;               // slabs [splits][K][C][9]
-    int N, H, W, C, K;
+    int N, H, W, C, K;         // H, W: the layer's INPUT extents
     int CPR, F, FX, RB, spi;   // chunks per row, flat chunks per image of G / X, rows per split, splits per image
     int KBLK, CBLK;
     long long gplane16, xplane16;
@@ -152,8 +156,11 @@ struct WgParams {
     int xcd;
 };
 
+template <int KS>        // 3x3 layers, or the discriminator's 4x4 / pad 1 layers (16 taps: 16 accumulators per wave)
 __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
-    constexpr int RING = 4, STAGE16 = 1536;            // 12 G words-columns + 12 X: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
+    constexpr int RING = 4, NCP = 2 * KS;              // copies per wave per stage: 4 KS of G + 4 KS of X over four waves
+    constexpr int STAGE16 = 8 * KS * 64;               // 4 KS G columns + 4 KS X columns: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
+    constexpr int NMF = 3 * KS * KS, NSL = 2 * 2 * KS + NCP;       // MFMAs and slots per step
     __shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int tiles = p.KBLK * p.CBLK;
@@ -164,43 +171,43 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     const int n = split / p.spi, y0 = (split - n * p.spi) * p.RB;
     const int nsteps = p.RB * p.CPR / 2, f0 = y0 * p.CPR;
 
-    // ---- this wave's six copies of a stage: copy i = 6 wid + q of 24 (i < 12: G, [s][plane][chunk]; else X, [r][plane][chunk]) ----
-    const u32x4* csrc[6];
+    // ---- this wave's copies of a stage: copy i = NCP wid + q of 8 KS (i < 4 KS: G, [s][plane][chunk]; else X, [r][plane][chunk]) ----
+    const u32x4* csrc[NCP];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int i = 6 * wid + q;
-        if (i < 12) {
+    for (int q = 0; q < NCP; ++q) {
+        const int i = NCP * wid + q;
+        if (i < 4 * KS) {
             const int s = i >> 2, pl = (i >> 1) & 1, ch = i & 1;
             csrc[q] = p.G + (size_t)(s * 2 + pl) * p.gplane16 + (((size_t)n * p.KBLK + kblk) * p.F + f0 + ch) * 64 + lane;
         } else {
-            const int j = i - 12, r = j >> 2, pl = (j >> 1) & 1, ch = j & 1;
+            const int j = i - 4 * KS, r = j >> 2, pl = (j >> 1) & 1, ch = j & 1;
             csrc[q] = p.X + (size_t)pl * p.xplane16 + (((size_t)n * p.CBLK + cblk) * p.FX + f0 + r * p.CPR + ch) * 64 + lane;
         }
     }
 #define WG_COPIES(stage_)                                                                                               \
     {                                                                                                                   \
         const int st_ = min((stage_), nsteps - 1);                   /* tail: harmless re-copies of the last stage */   \
-        u32x4* const d_ = smem + ((stage_) & (RING - 1)) * STAGE16 + wid * 384;                                         \
-        _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);                 \
+        u32x4* const d_ = smem + ((stage_) & (RING - 1)) * STAGE16 + wid * (NCP * 64);                                  \
+        _Pragma("unroll") for (int q = 0; q < NCP; ++q) glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);               \
     }
 #define WG_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14));
 
     const int l31 = lane & 31, lhi = lane >> 5;
     const int wk = wid >> 1, wc = wid & 1;
-    f32x16 acc[3][3];                                  // [s][r]
+    f32x16 acc[KS][KS];                                // [s][r]
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < KS; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[s][r][e] = 0.f;
-    u32x4 af[2][3][2], bf[2][3][2];                    // [register set][s | r][plane]
-    const int a_off = lhi * 64 + wk * 32 + l31, b_off = 768 + lhi * 64 + wc * 32 + l31;
+    u32x4 af[2][KS][2], bf[2][KS][2];                  // [register set][s | r][plane]
+    const int a_off = lhi * 64 + wk * 32 + l31, b_off = 4 * KS * 64 + lhi * 64 + wc * 32 + l31;
 #define WG_READ(set_, slot_)                                                                                            \
     {                                                                                                                   \
         const u32x4* const S_ = smem + (slot_) * STAGE16;                                                               \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) af[set_][i >> 1][i & 1] = S_[a_off + i * 128];                    \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) bf[set_][i >> 1][i & 1] = S_[b_off + i * 128];                    \
+        _Pragma("unroll") for (int i = 0; i < 2 * KS; ++i) af[set_][i >> 1][i & 1] = S_[a_off + i * 128];               \
+        _Pragma("unroll") for (int i = 0; i < 2 * KS; ++i) bf[set_][i >> 1][i & 1] = S_[b_off + i * 128];               \
     }
     // partial products, smallest first: (l h') (h l') (h h')
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     WG_COPIES(1)
     WG_COPIES(2)
     WG_COPIES(3)
-    WG_VMCNT(12)                                       // stages 0 and 1 have landed (2 and 3 may be in flight)
+    WG_VMCNT(2 * NCP)                                  // stages 0 and 1 have landed (2 and 3 may be in flight)
     __builtin_amdgcn_s_barrier();
     WG_READ(0, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -218,39 +225,39 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int T = T0 + half, cur = half, nxt = half ^ 1;
-            // 18 slots of [<= 1 memory instruction][its share of the 27 MFMAs], pinned (see conv_split16.hip)
-#define WG_MFMAS(beg_, end_)                              /* m = 9 q + 3 s + r */                                           \
-            _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < 27; ++m_) {                                     \
-                const int q_ = m_ / 9, s_ = (m_ % 9) / 3, r_ = m_ % 3;                                                  \
+            // NSL slots of [<= 1 memory instruction][its share of the NMF MFMAs], pinned (see conv_split16.hip)
+#define WG_MFMAS(beg_, end_)                              /* m = KS KS q + KS s + r */                                      \
+            _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < NMF; ++m_) {                                    \
+                const int q_ = m_ / (KS * KS), s_ = (m_ % (KS * KS)) / KS, r_ = m_ % KS;                                \
                 acc[s_][r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[cur][s_][PA[q_]]),    \
                                                                      __builtin_bit_cast(f16x8, bf[cur][r_][PB[q_]]),    \
                                                                      acc[s_][r_], 0, 0, 0);                             \
             }                                                                                                           \
             __builtin_amdgcn_sched_barrier(0);
-#define WG_SLOT(i_) WG_MFMAS((i_) * 27 / 18, ((i_) + 1) * 27 / 18)
+#define WG_SLOT(i_) WG_MFMAS((i_) * NMF / NSL, ((i_) + 1) * NMF / NSL)
             const u32x4* const S_ = smem + ((T + 1) & (RING - 1)) * STAGE16;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 2 * KS; ++i) {
                 af[nxt][i >> 1][i & 1] = S_[a_off + i * 128];
                 WG_SLOT(i)
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 2 * KS; ++i) {
                 bf[nxt][i >> 1][i & 1] = S_[b_off + i * 128];
-                WG_SLOT(6 + i)
+                WG_SLOT(2 * KS + i)
             }
             {
                 const int st_ = min(T + 4, nsteps - 1);
-                u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + wid * 384;
+                u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + wid * (NCP * 64);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
+                for (int q = 0; q < NCP; ++q) {
                     glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
-                    WG_SLOT(12 + q)
+                    WG_SLOT(4 * KS + q)
                 }
             }
 #undef WG_SLOT
 #undef WG_MFMAS
-            WG_VMCNT(12)                               // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)
+            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)
             __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers
             __builtin_amdgcn_s_barrier();              // stage T + 2 complete for all waves; slot of stage T + 1 is free
         }
@@ -260,18 +267,18 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #undef WG_VMCNT
 #undef WG_COPIES
 
-    // slab [split][k][c][tap = 3 r + s]; D register e of lane l = row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31
+    // slab [split][k][c][tap = KS r + s]; D register e of lane l = row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31
     const float unscale = 1.f / (pow2_scale(*p.gmax) * pow2_scale(*p.xmax));
-    float* const slab = p.part + (size_t)split * p.K * p.C * 9;
+    float* const slab = p.part + (size_t)split * p.K * p.C * (KS * KS);
     const int c = cblk * 64 + wc * 32 + l31;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int k = kblk * 64 + wk * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-        float* const o = slab + ((size_t)k * p.C + c) * 9;
+        float* const o = slab + ((size_t)k * p.C + c) * (KS * KS);
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < KS; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) o[3 * r + s] = acc[s][r][e] * unscale;
+            for (int s = 0; s < KS; ++s) o[KS * r + s] = acc[s][r][e] * unscale;
     }
 }
 
@@ -293,53 +300,63 @@ int rows_per_split(int N, int H, int CPR, int tiles) {
 
 }  // namespace
 
+// Hg = rows of the gy planes: gy's H + 2 - KS + 1... i.e. (H + 3 - KS) rounded up to a multiple of 4 (whole double steps for any CPR)
+static int g_rows(int H, int KS) { return (H + 3 - KS + 3) / 4 * 4; }
+
 bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
-    if (R != 3 || S != 3 || stride != 1 || pad != 1) return false;
+    if (R != S || (R != 3 && R != 4) || stride != 1 || pad != 1) return false;
     if (C % 64 || K % 64 || C < 128 || K < 128 || W % 8 || H < 4 || W < 8 || W > SPLIT_MAXW) return false;
     const int CPR = (W + 2 + 7) / 8;
-    if (rows_per_split(N, H, CPR, (K / 64) * (C / 64)) == 0) return false;
-    if ((long long)N * (C > K ? C : K) * (H + 2) * CPR * 64 >= (1ll << 31)) return false;
+    if (rows_per_split(N, g_rows(H, R), CPR, (K / 64) * (C / 64)) == 0) return false;
+    if ((long long)N * (C > K ? C : K) * (H + 6) * CPR * 64 >= (1ll << 31)) return false;
     return true;
 }
 
-size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K) {
-    const int CPR = (W + 2 + 7) / 8;
-    return ((size_t)6 * N * K * H * CPR + (size_t)2 * N * C * (H + 2) * CPR) * 16 + 16384;
+size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K, int KS) {
+    const int CPR = (W + 2 + 7) / 8, Hg = g_rows(H, KS);
+    return ((size_t)2 * KS * N * K * Hg * CPR + (size_t)2 * N * C * (Hg + KS - 1) * CPR) * 16 + 16384;
 }
 
-int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K) {
-    const int CPR = (W + 2 + 7) / 8;
-    const int rb = rows_per_split(N, H, CPR, (K / 64) * (C / 64));
-    return rb ? N * (H / rb) : 0;
+int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS) {
+    const int CPR = (W + 2 + 7) / 8, Hg = g_rows(H, KS);
+    const int rb = rows_per_split(N, Hg, CPR, (K / 64) * (C / 64));
+    return rb ? N * (Hg / rb) : 0;
 }
 
-// gw [K][C][3][3] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C 9 floats
-void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int reflect, void* scratch,
-                         float* part, int xcd_map, hipStream_t st) {
+// gw [K][C][KS][KS] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C KS KS floats.  x [N, C, H, W], gy [N, K, H + 3 - KS, W + 3 - KS]
+void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
+                         void* scratch, float* part, int xcd_map, hipStream_t st) {
     const int CPR = (W + 2 + 7) / 8, KBLK = K / 64, CBLK = C / 64;
-    const long long gtotal = (long long)N * K * H * CPR, xtotal = (long long)N * C * (H + 2) * CPR;      // words per plane block
+    const int OHg = H + 3 - KS, OWg = W + 3 - KS, Hg = g_rows(H, KS), Hx = Hg + KS - 1;
+    const long long gtotal = (long long)N * K * Hg * CPR, xtotal = (long long)N * C * Hx * CPR;      // words per plane block
     u32x4* const G = (u32x4*)scratch;
-    u32x4* const X = G + 6 * gtotal;
-    unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K) - 64);
-    const unsigned* const gmax = nemar_split16_source_max(gy, (long long)N * K * H * W, mw, st);
+    u32x4* const X = G + 2 * KS * gtotal;
+    unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K, KS) - 64);
+    const unsigned* const gmax = nemar_split16_source_max(gy, (long long)N * K * OHg * OWg, mw, st);
     const unsigned* const xmax = nemar_split16_source_max(x, (long long)N * C * H * W, mw + 1, st);
 #define WG_SPLIT(TW_)                                                                                                              \
-    hipLaunchKernelGGL((split_wgrad_g_kernel<TW_>), dim3(N * KBLK * H), dim3(256), 0, st, gy, G, N, K, H, W, CPR, gtotal, gmax);       \
-    hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * (H + 2)), dim3(256), 0, st, x, X, N, C, H, W, CPR, reflect, xtotal, \
+    if (KS == 3)                                                                                                                   \
+        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 3>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, G, N, K, OHg, OWg, Hg, CPR, gtotal, \
+                           gmax);                                                                                                  \
+    else                                                                                                                           \
+        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 4>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, G, N, K, OHg, OWg, Hg, CPR, gtotal, \
+                           gmax);                                                                                                  \
+    hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * Hx), dim3(256), 0, st, x, X, N, C, H, W, Hx, CPR, reflect, xtotal, \
                        xmax);
     if (W <= 64) { WG_SPLIT(64) } else if (W <= 128) { WG_SPLIT(128) } else { WG_SPLIT(256) }
 #undef WG_SPLIT
     WgParams p;
     p.G = G; p.X = X; p.part = part;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
-    p.CPR = CPR; p.F = H * CPR; p.FX = (H + 2) * CPR;
-    p.RB = rows_per_split(N, H, CPR, KBLK * CBLK);
-    p.spi = H / p.RB;
+    p.CPR = CPR; p.F = Hg * CPR; p.FX = Hx * CPR;
+    p.RB = rows_per_split(N, Hg, CPR, KBLK * CBLK);
+    p.spi = Hg / p.RB;
     p.KBLK = KBLK; p.CBLK = CBLK;
     p.gplane16 = gtotal; p.xplane16 = xtotal;
     p.gmax = gmax; p.xmax = xmax;
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(wgrad_split16_kernel, dim3(grid), dim3(256), 0, st, p);
-    nemar_sum_partials(part, (long long)K * C * 9, splits, gw, (long long)K * C * 9, true, st);
+    if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_split16_kernel<4>), dim3(grid), dim3(256), 0, st, p);
+    nemar_sum_partials(part, (long long)K * C * KS * KS, splits, gw, (long long)K * C * KS * KS, true, st);
 }

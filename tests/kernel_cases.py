@@ -238,13 +238,13 @@ def case_absmax_and_hint(be, seed=0):
     assert np.array_equal(outs[0], outs[1])
 
 
-def case_conv_split16_wgrad(be, N, C, H, W, K, pad_mode, seed=0):
+def case_conv_split16_wgrad(be, N, C, H, W, K, pad_mode, seed=0, R=3):
     """Weight + bias gradient of a wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_bwd_weight with the scratch arena registered:
     the fp16 x 3 route (csrc/conv_split16_wgrad.hip) must be eligible and obey the tolerances of the exact-fp32 kernels."""
-    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
+    need = split16_scratch(be, N, H, W, K, C, R, R, 1, 1)
     assert need > 0, "shape is not eligible for the split-16 kernels"
     with scratch_arena(be, need):
-        case_conv_bwd_weight(be, N, C, 0, H, W, K, 3, 1, 1, pad_mode, seed=seed)
+        case_conv_bwd_weight(be, N, C, 0, H, W, K, R, 1, 1, pad_mode, seed=seed)
 
 
 def case_conv_transpose_fwd(be, N, Ci, Co, H, W, R, out_pad, act=O.ACT_RELU, seed=0):

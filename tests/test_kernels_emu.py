@@ -366,6 +366,9 @@ def test_conv_split16_weight_gradient(be):
     K.case_conv_split16_wgrad(be, 1, 128, 8, 8, 128, K.PAD_REFLECT)
     K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 192, K.PAD_ZERO)
     K.case_conv_split16_wgrad(be, 1, 192, 4, 24, 128, K.PAD_REFLECT)
+    K.case_conv_split16_wgrad(be, 1, 128, 6, 16, 128, K.PAD_ZERO)                  # 6 rows -> 8 plane rows (two of zeros)
+    K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 128, K.PAD_ZERO, R=4)             # 4x4: 16 taps, gy 7x15, four shifts
+    K.case_conv_split16_wgrad(be, 1, 128, 5, 32, 192, K.PAD_ZERO, R=4)             # gy 4x31
 
 
 def test_absmax_and_hint(be):
