@@ -144,13 +144,15 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   23 smallest layer (million multiply-adds, default 2000) that takes the split-16 route */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
-/* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data.  The wide 3x3 stride-1 layers (the ResnetBlock
- * convolutions, reference models/networks.py:418-439) run on the bf16 matrix pipe at fp32-equivalent accuracy: each fp32
- * operand is split exactly into three bf16 terms and six partial products are accumulated in fp32 (csrc/conv_split16.hip).  The
- * split copy of the source tensor lives in this arena for the duration of the call.  nemar_conv2d_scratch -> bytes the layer
- * wants (0: never uses it); nemar_set_scratch registers a caller-owned device buffer (process-global like the tune switches:
- * one stream at a time may run operators that use it; bytes = 0 unregisters).  A layer whose need exceeds the registered
- * arena, or with no arena at all, runs on the exact-fp32 MFMA kernels instead — same results within fp32 rounding. */
+/* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data / nemar_conv2d_bwd_weight.  The wide stride-1 / pad-1
+ * layers (the 3x3 ResnetBlock convolutions, reference models/networks.py:418-439, and the discriminator's 256->512 4x4 layer,
+ * :576-597; >= 128 channels, >= 2 G multiply-adds) run on the 16-bit matrix pipe at fp32 accuracy: each fp32 operand is split into
+ * two power-of-two-scaled fp16 terms and three partial products are accumulated in fp32 (csrc/conv_split16*.hip; measured error
+ * against float64 below that of the exact-fp32 MFMA kernels).  The split copies of the source tensors live in this
+ * arena for the duration of the call.  nemar_conv2d_scratch -> bytes the layer wants (0: never uses it); nemar_set_scratch
+ * registers a caller-owned device buffer (process-global like the tune switches: one stream at a time may run operators that use
+ * it; bytes = 0 unregisters).  A layer whose need exceeds the registered arena, or with no arena at all, runs on the exact-fp32
+ * MFMA kernels instead — same results within fp32 rounding. */
 size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad);
 int nemar_set_scratch(void* scratch, size_t bytes);
 /* The fp16 form of those kernels scales each source tensor by a power of two derived from max |t|.  A caller that feeds one tensor

@@ -1,6 +1,7 @@
-// nemar_amd — 3x3 / stride-1 / pad-1 convolutions of the wide layers (the translation net's 256-channel residual blocks:
-// reference models/networks.py:418-439, 18 convolutions per pass, 36.5 of the 63.8 ms of convolution time in a round-1 step) on
-// the 16-BIT matrix pipe, at fp32 accuracy.
+// nemar_amd — stride-1 / pad-1 convolutions of the wide layers (the translation net's 256-channel 3x3 residual blocks: reference
+// models/networks.py:418-439, 18 convolutions per pass, 36.5 of the 63.8 ms of convolution time in a round-1 step; and the
+// discriminator's 256 -> 512 4x4 layer, networks.py:576-597) on the 16-BIT matrix pipe, at fp32 accuracy.  Forward and data
+// gradient here, weight gradient in conv_split16_wgrad.hip.
 //
 // gfx950 has no TF32-like mode and its fp32 MFMA runs at the vector rate (157 TFLOP/s); the 16-bit MFMAs run 16x faster.  Every
 // fp32 operand is split into 16-bit terms whose partial products, accumulated in fp32 by the MFMA, reproduce the fp32 product to
@@ -28,6 +29,8 @@
 //      copied once (global_load_lds, 16 bytes per lane, no VGPRs) into a double-buffered LDS region and all nine taps read it at
 //      shifted addresses — the source is fetched once per chunk, not once per tap — plus one stage of packed weights per tap
 //      into a 4-slot ring.  One workgroup barrier per tap.  How the copies are issued and why: see the kernel.
+//      Few-tile layers (32x32 maps) cut the reduction into slab runs summed in order; layers below 2 GMAC stay on the exact-fp32
+//      kernels (conv.hip decides); 4x4 layers run on the input-sized domain with the last output row / column masked.
 //   3. the reflect data gradient  dx = Pad^T(Conv^T(gy))  folds the padded border back: output row 1 receives the gradient of
 //      padded row 0, which only the first filter row produces, i.e. for that (row, tap) pair the source row is gy[0] + gy[2]
 //      instead of gy[2]; same for row H-2, columns 1 and W-2, and the four corners.  The split kernel writes those sums once
