@@ -199,7 +199,11 @@ def main():
         "metric": "train images/sec (256x256 A/B pairs)", "value": a.batch * world * a.steps / dt,
         "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic U[-1,1) A/B pairs resident in HBM; reference-equivalent random init",
+        "dtype": "f32",
+        "dtype_note": "fp32 tensors and fp32 accumulation throughout; the >=128-channel stride-1 3x3 / 4x4 convolutions form each fp32 "
+                      "product from three fp16 partial products on the 16-bit MFMA (measured error vs float64 below the exact-fp32 MFMA "
+                      "kernels', DESIGN.md 4c); every other kernel is exact fp32",
+        "data": "synthetic U[-1,1) A/B pairs resident in HBM; reference-equivalent random init",
         "config": {"workload": "BASELINE configs[1]: --stn_type unet --stn_cfg A, resnet_9blocks T, basic PatchGAN D, "
                                "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32%s"
                                % (a.size, a.size, a.batch, (" + " + " ".join(a.opt)) if a.opt else ""),
