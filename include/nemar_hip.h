@@ -141,8 +141,17 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   20 3x3 stride-1 layers with >= 128 output channels on the bf16 matrix pipe with three-way split operands (1, default;
  *      needs the scratch arena below; 0 = exact-fp32 MFMA kernels).  Packed weight images are per setting.
  *   21 operand split of those kernels: 4 fp16 x 3 (default), 3 bf16 x 6, 0 bf16 x 6 on the first-generation kernel
- *   23 smallest layer (million multiply-adds, default 2000) that takes the split-16 route */
+ *   23 smallest layer (million multiply-adds, default 2000) that takes the split-16 route
+ *   24 every other convolution with >= 16 output channels on the 16-bit matrix pipe with the operand split INSIDE the kernel
+ *      (csrc/conv_s16g*.hip; 1, default; 0 = exact-fp32 MFMA kernels)      25 its work threshold (million multiply-adds, 30) */
 int nemar_tune(int key, int value);
+/* Which kernel family served the calling thread's last nemar_conv2d_* call: 0 exact-fp32 implicit GEMM, 1 narrow (<= 4 channel)
+ * VALU kernels, 2 split-16 kernels of the wide residual-block layers, 3 general 16-bit-pipe kernels (tests / tools). */
+int nemar_last_route(void);
+/* Counter bumped by every nemar_tune / nemar_set_scratch call.  The route a shape takes — and with it the FORMAT of the packed
+ * weight image a `prepacked` call finds in its workspace — is a function of (shape, these settings): a caller that caches packed
+ * workspaces keys them with this value. */
+int nemar_config_epoch(void);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data / nemar_conv2d_bwd_weight.  The wide stride-1 / pad-1
  * layers (the 3x3 ResnetBlock convolutions, reference models/networks.py:418-439, and the discriminator's 256->512 4x4 layer,

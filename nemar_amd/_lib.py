@@ -53,6 +53,8 @@ SIGNATURES = {
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "nemar_tune": (_i, [_i, _i]),
+    "nemar_last_route": (_i, []),
+    "nemar_config_epoch": (_i, []),
     "nemar_grid_sample_tune": (_i, [_i]),
     "nemar_tune_ptr": (_i, [_vp]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
@@ -110,7 +112,7 @@ class Library:
         if full not in fns:
             raise AttributeError(name)
         fn = fns[full]
-        if SIGNATURES[full][0] is not _i or full == "nemar_version":
+        if SIGNATURES[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_config_epoch"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

@@ -30,6 +30,7 @@
 // conv_wgrad.hip (wave-specialised) for everything whose gy planes are 16-byte chunkable, wgrad_kernel below for the rest.
 #include "common.h"
 #include "conv_split16.h"
+#include "conv_s16g.h"
 
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
 bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW);
@@ -1077,6 +1078,12 @@ static int g_split16 = 1;
 static long long g_split16_min_mmac = 2000;
 static int g_split16_variant = 4;   // key 21: 4 fp16 x 3 products (default), 3 bf16 x 6 products, 0 bf16 x 6 on the first-generation
                                 // kernel with loader waves (kept for the A/B numbers in DESIGN.md)
+// which kernel family served the last conv call of this thread (nemar_last_route; tests and tools): 0 exact-fp32 implicit GEMM,
+// 1 narrow (<= 4 channel) VALU kernels, 2 split-16 kernel of the wide residual-block layers, 3 general 16-bit-pipe kernels
+static thread_local int g_last_route = 0;
+static int g_config_epoch = 0;      // bumped by every nemar_tune / nemar_set_scratch: routes (and packed-weight formats) may have changed
+static int g_s16g = 1;             // key 24: general layers on the 16-bit matrix pipe with the in-kernel operand split (conv_s16g.hip)
+static long long g_s16g_min_mmac = 30;   // key 25: ... above this many million multiply-adds (tiny layers are launch-bound either way)
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
@@ -1605,6 +1612,53 @@ static bool split16_worth_it(int N, int OH, int OW, int K, int C, int R, int S) 
     return (long long)N * OH * OW * K * C * R * S >= g_split16_min_mmac * 1000000ll;
 }
 
+// ---- routing to conv_s16g.hip (general layers on the 16-bit matrix pipe) ------------------------------------------------------
+void s16g_set_class(S16gProblem& q, int c, const TapTable& t, int OHc, int OWc, int ooy, int oox) {
+    q.ntaps[c] = t.n;
+    for (int i = 0; i < t.n && i < S16G_MAX_TAPS; ++i) { q.dy[c][i] = t.dy[i]; q.dx[c][i] = t.dx[i]; q.wofs[c][i] = t.wofs[i]; }
+    q.OH[c] = OHc; q.OW[c] = OWc; q.ooy[c] = ooy; q.oox[c] = oox;
+}
+bool s16g_worth_it(long long macs) { return g_s16g && macs >= g_s16g_min_mmac * 1000000ll; }
+
+// forward: geometry only (pointers are filled by the operator); false = not this route
+bool s16g_fwd_problem(S16gProblem& q, S16gPlan& pl, int N, int C0, int C1, int H, int W, int K, int R, int S, int stride, int pad,
+                      int pad_mode, int act, float slope) {
+    const int C = C0 + C1;
+    if (R * S > S16G_MAX_TAPS || stride > 2 || stride < 1) return false;
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    if (OH <= 0 || OW <= 0 || !s16g_worth_it((long long)N * OH * OW * K * C * R * S)) return false;
+    q = S16gProblem();
+    q.C0 = C0; q.C1 = C1; q.Hs = H; q.Ws = W; q.N = N; q.M = K; q.M0 = K;
+    q.act = act; q.slope = slope; q.border = pad_mode; q.sstride = stride;
+    q.OHf = OH; q.OWf = OW; q.osy = 1; q.osx = 1; q.ncls = 1;
+    TapTable t;
+    fwd_taps(t, R, S, pad);
+    s16g_set_class(q, 0, t, OH, OW, 0, 0);
+    pl = nemar_s16g_plan(q);
+    return pl.ok != 0;
+}
+
+// data gradient / transposed convolution (zero padding): one class per output parity
+bool s16g_dgrad_problem(S16gProblem& q, S16gPlan& pl, int N, int C, int mskip, int H, int W, int K, int OH, int OW, int R, int S,
+                        int stride, int pad, int act, float slope) {
+    if (R * S > S16G_MAX_TAPS || stride > 2 || stride < 1) return false;
+    if (!s16g_worth_it((long long)N * OH * OW * K * (C - mskip) * R * S)) return false;
+    q = S16gProblem();
+    q.C0 = K; q.C1 = 0; q.Hs = OH; q.Ws = OW; q.N = N; q.M = C - mskip;
+    q.act = act; q.slope = slope; q.border = BORDER_ZERO; q.sstride = 1;
+    q.OHf = H; q.OWf = W; q.osy = stride; q.osx = stride; q.ncls = 0;
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            TapTable t;
+            dgrad_taps(t, R, S, pad, stride, ph, pw);
+            const int OHc = (H - ph + stride - 1) / stride, OWc = (W - pw + stride - 1) / stride;
+            if (t.n == 0 || OHc <= 0 || OWc <= 0 || t.n > (stride > 1 ? S16G_CLS_TAPS : S16G_MAX_TAPS)) return false;
+            s16g_set_class(q, q.ncls++, t, OHc, OWc, ph, pw);
+        }
+    pl = nemar_s16g_plan(q);
+    return pl.ok != 0;
+}
+
 // Workspace layout of nemar_conv2d_bwd_data (floats), shared by the size query and the operator:
 //   [packed weights x stride^2 parity classes][padded-domain scratch (strided reflect)][flipped weights (C <= 4)]
 //   [compact border-ring gradient (stride-1 reflect)][ksplit slabs of the gradient (split reductions)]
@@ -1622,6 +1676,15 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     if (nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, SPLIT16_ZERO, 4)) {     // room for either packed image
         const size_t b = (nemar_split16_pack_bytes(C, K, R) + 3) / 4;
         if (b > L.pack_stride) L.pack_stride = b;
+    }
+    {
+        S16gProblem q;
+        S16gPlan pl;
+        const int OHd = (H + 2 * pad - R) / stride + 1, OWd = (W + 2 * pad - S) / stride + 1;
+        if (!refl && OHd > 0 && OWd > 0 && s16g_dgrad_problem(q, pl, N, C, 0, H, W, K, OHd, OWd, R, S, stride, pad, ACT_NONE, 0.f)) {
+            const size_t b = ((nemar_s16g_pack_bytes(q, pl) + 3) / 4 + stride * stride - 1) / (stride * stride);
+            if (b > L.pack_stride) L.pack_stride = b;
+        }
     }
     size_t o = L.pack_stride * (size_t)(stride * stride);
     L.padded_off = o;
@@ -1670,6 +1733,7 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     return L;
 }
 
+
 // Workspace of nemar_conv2d_fwd (floats): [packed weights][slabs of a split reduction].  Tiny, deep layers (the 2x2 .. 32x32
 // maps of the registration net: a 2x2-pixel 128->128 3x3 layer is 72 serial stages in two workgroups) split their reduction
 // like the data gradients do; per-split slabs summed in order keep the forward pass bitwise reproducible.
@@ -1680,6 +1744,14 @@ FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride
     if (nemar_split16_eligible(N, H, W, K, C, R, S, stride, pad, SPLIT16_ZERO, 4)) {     // room for either packed image
         const size_t b = (nemar_split16_pack_bytes(K, C, R) + 3) / 4;
         if (b > L.pack) L.pack = b;
+    }
+    {
+        S16gProblem q;
+        S16gPlan pl;
+        if (s16g_fwd_problem(q, pl, N, C, 0, H, W, K, R, S, stride, pad, BORDER_ZERO, ACT_NONE, 0.f)) {
+            const size_t b = (nemar_s16g_pack_bytes(q, pl) + 3) / 4;
+            if (b > L.pack) L.pack = b;
+        }
     }
     L.ksplit = 1;
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
@@ -1725,6 +1797,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         // channel-split mode (the split count is capped to what fits, see nemar_narrow_fwd)
         nemar_narrow_fwd(x0, w, bias, y, N, C, H, W, K, R, pad, pad_mode, act, slope,
                          g_deterministic ? (float*)workspace : nullptr, ws_bytes / sizeof(float), st);
+        g_last_route = 1;
         NEMAR_CHECK_LAUNCH("conv2d_fwd (narrow)");
         return NEMAR_OK;
     }
@@ -1736,7 +1809,20 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 0, g_split16_variant, st);
             nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, R, 1, H, W, OH, OW, mode, g_scratch, g_xcd_map, g_split16_variant,
                                g_tl, st);
-            NEMAR_CHECK_LAUNCH("conv2d_fwd (bf16 x 6)");
+            g_last_route = 2;
+            NEMAR_CHECK_LAUNCH("conv2d_fwd (split-16)");
+            return NEMAR_OK;
+        }
+    }
+    {
+        S16gProblem q;
+        S16gPlan pl;
+        if (s16g_fwd_problem(q, pl, N, C0, C1, H, W, K, R, S, stride, pad, pad_mode, act, slope)) {
+            q.src0 = x0; q.src1 = x1; q.dst0 = y; q.dst1 = nullptr; q.bias = bias;
+            if (!prepacked) nemar_s16g_pack(q, pl, w, (long long)C * R * S, (long long)R * S, workspace, st);
+            nemar_s16g_conv(q, pl, workspace, st);
+            g_last_route = 3;
+            NEMAR_CHECK_LAUNCH("conv2d_fwd (16-bit pipe, in-kernel split)");
             return NEMAR_OK;
         }
     }
@@ -1762,6 +1848,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     }
     launch_igemm(p, st);
     if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, y, p.part_stride, false, st);
+    g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_fwd");
     return NEMAR_OK;
 }
@@ -1811,7 +1898,24 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 1, g_split16_variant, st);
             nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch, g_xcd_map,
                                g_split16_variant, g_tl, st);
-            NEMAR_CHECK_LAUNCH("conv2d_bwd_data (bf16 x 6)");
+            g_last_route = 2;
+            NEMAR_CHECK_LAUNCH("conv2d_bwd_data (split-16)");
+            return NEMAR_OK;
+        }
+    }
+    if (!refl) {
+        const int mskip0 = (gx0 == nullptr) ? C0 : 0;
+        S16gProblem q;
+        S16gPlan pl;
+        if (s16g_dgrad_problem(q, pl, N, C, mskip0, H, W, K, OH, OW, R, S, stride, pad, act, slope)) {
+            q.src0 = gy; q.src1 = nullptr; q.bias = bias ? bias + mskip0 : nullptr;
+            if (mskip0) { q.dst0 = gx1; q.dst1 = nullptr; q.M0 = q.M; }
+            else { q.dst0 = gx0; q.dst1 = gx1; q.M0 = C0; }
+            // output row m = input channel m + mskip0, reduction channel = k:  w[k][c][r][s]
+            if (!prepacked) nemar_s16g_pack(q, pl, w + (size_t)mskip0 * R * S, (long long)R * S, (long long)C * R * S, workspace, st);
+            nemar_s16g_conv(q, pl, workspace, st);
+            g_last_route = 3;
+            NEMAR_CHECK_LAUNCH("conv2d_bwd_data (16-bit pipe, in-kernel split)");
             return NEMAR_OK;
         }
     }
@@ -1925,6 +2029,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st,
                            (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total);
     }
+    g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_bwd_data");
     return NEMAR_OK;
 }
@@ -2034,6 +2139,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
                 hipLaunchKernelGGL(bias_grad_atomic_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, gb, N, K, OH * OW, BIAS_CHUNK);
             }
         }
+        g_last_route = 1;
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
@@ -2048,12 +2154,14 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
             hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, pb, N, K, OH * OW, BIAS_CHUNK);
             nemar_sum_partials(pb, K, N * chunks, gb, K, true, st);
         }
+        g_last_route = 2;
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (split-16)");
         return NEMAR_OK;
     }
     if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
         nemar_wgrad2_launch(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
                             g_wgrad != 2, g_dbg, part, st);
+        g_last_route = 0;
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide)");
         return NEMAR_OK;
     }
@@ -2067,6 +2175,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         if (nemar_wgrad2_eligible(K, ohv, OW, gyp)) {
             nemar_wgrad2_launch(x0, C0, x1, C1, gyp, gw, gb, N, H, W, K, ohv, OW, R, S, stride, pad, pad_mode, g_wgrad_blocks,
                                 g_wgrad != 2, g_dbg, part, st);
+            g_last_route = 0;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (wide, padded gy)");
             return NEMAR_OK;
         }
@@ -2094,6 +2203,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         nemar_sum_partials(part, (long long)K * J, splits, gw, (long long)K * J, true, st);
         if (gb) nemar_sum_partials(p.partb, K, splits, gb, K, true, st);
     }
+    g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_bwd_weight");
     return NEMAR_OK;
 }
@@ -2101,7 +2211,11 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
 NEMAR_API int nemar_tune_ptr(void* p) { g_tl = (long long*)p; return NEMAR_OK; }
 
 // Tuning switches for A/B measurements (not part of the operator contract): key 0 = 128x128 workgroup shape.
+NEMAR_API int nemar_last_route(void) { return g_last_route; }
+NEMAR_API int nemar_config_epoch(void) { return g_config_epoch; }
+
 NEMAR_API int nemar_tune(int key, int value) {
+    ++g_config_epoch;
     if (key == 0) { g_cfg128 = value; return NEMAR_OK; }
     if (key == 1) { g_lds_pad = value; return NEMAR_OK; }
     if (key == 2) { g_dbg = value; return NEMAR_OK; }
@@ -2112,6 +2226,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 8) { g_reflect_aux = value != 0; return NEMAR_OK; }
     if (key == 15) { g_xcd_map = value != 0; return NEMAR_OK; }
     if (key == 20) { g_split16 = value != 0; return NEMAR_OK; }
+    if (key == 24) { g_s16g = value != 0; return NEMAR_OK; }
+    if (key == 25) { g_s16g_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = (value == 0 || value == 3) ? value : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
@@ -2130,6 +2246,7 @@ NEMAR_API int nemar_tune(int key, int value) {
 // Transient scratch arena shared by the operators of one stream (split source planes of the bf16 x 6 convolutions).  The
 // caller owns it and keeps it alive while calls that may use it are in flight; bytes == 0 unregisters.
 NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
+    ++g_config_epoch;
     g_scratch = bytes ? scratch : nullptr;
     g_scratch_bytes = scratch ? bytes : 0;
     return NEMAR_OK;

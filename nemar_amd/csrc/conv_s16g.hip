@@ -1,0 +1,557 @@
+// nemar_amd — GENERAL convolutions on the 16-bit matrix pipe at fp32 accuracy: every forward / data-gradient / transposed
+// convolution of the three networks that is not one of the translation net's wide residual-block layers (those have their own
+// kernel, conv_split16.hip) — the stride-2 3x3 layers and ConvTranspose2d of ResnetGenerator (reference models/networks.py:
+// 355-374), the discriminator's 4x4 stride-2 layers (networks.py:576-593), the registration net's 32 / 64-channel 3x3 layers incl.
+// the decoder's concatenated inputs (models/stn/unet_stn.py:28-102, layers.py:73-106).  On the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) these ran at 40-110 TF: 13 of the 45 ms of a round-2 step.
+//
+// Arithmetic: fp16 x 3 as in conv_split16.hip — every fp32 operand v becomes  v s = h + l + e  with h = RN16(v s),
+// l = RN16(v s - h), |e| <= 2^-22 |v s| while l stays a normal fp16 number, and the fp32 product is rebuilt from the three MFMA
+// products h h' + h l' + l h' accumulated in fp32.  What is different here:
+//   * THE SPLIT HAPPENS IN THE KERNEL.  The source is read as plain NCHW fp32 (4 bytes per element — exactly what two fp16
+//     planes would cost), converted in registers and written to LDS as channel-blocked hi / lo planes ([pixel][8 channels] =
+//     one 16-byte MFMA operand per word).  No split pass, no max pass, no scratch arena, no process-global state: the operator
+//     reads its inputs once and writes its output once.
+//   * ONLINE BLOCK SCALING.  fp16's exponent range is narrow, so the source is scaled by a power of two — chosen PER WORKGROUP
+//     TILE AND PER 16-CHANNEL CHUNK from the largest finite magnitude the tile's own halo holds (a register max over what was
+//     just loaded + one LDS exchange), monotone over the chunks: when a later chunk needs a smaller scale the fp32
+//     accumulators are multiplied by the exact power-of-two ratio first (the flash-attention running-max idea).  An output's
+//     error is therefore relative to ITS OWN tile's receptive field — samples, image regions or channels of very different
+//     magnitude inside one tensor do not share a scale.  Bound (include/nemar_hip.h): elements within 2^-11 of the running
+//     tile maximum keep the full 22 bits of h + l; below that the absolute error is 2^-36 of that maximum.  Non-finite
+//     inputs propagate as NaN / Inf to exactly the outputs whose receptive field holds them (they are excluded from the max).
+//     Weights: one power-of-two scale per tensor, from a max pass at pack time (once per optimizer step).
+//   * Halo tiles.  A workgroup owns MB = 32 MT output channels x NP = 128 NT output pixels (RT rows x TW columns of one image).
+//     Per 16-channel chunk the source halo of the tile ((RT - 1) stride + tap extent rows) is loaded ONCE, split once, and every
+//     tap reads it at a shifted LDS address: conversion work is per source element, not per (element, tap).  Stride-2 sources
+//     are stored with even and odd columns de-interleaved so that the 32 pixels of an MFMA operand tile stay consecutive words.
+//   * The chunk's packed weights ([tap][plane][k group][MB] 16-byte words, written by s16g_pack_kernel) come in by direct
+//     global -> LDS copies issued before the conversion of the chunk and waited for after it; the NEXT chunk's source loads are
+//     issued only then, so nothing inside the tap loop ever waits for memory.
+//   * Tap classes: a stride-2 data gradient / ConvTranspose2d is up to four stride-1 correlations (one per output parity) with
+//     their own taps — grid.z selects the class; all classes share the source.
+// Per chunk: [exchange the chunk max] barrier [rescale? convert + write the halo | weight copies land] barrier [all taps: LDS
+// fragment reads + MFMAs, no memory waits; the NEXT chunk's source loads are in flight] barrier.
+#include "common.h"
+#include "conv_s16g.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BORDER_REFLECT = 1;
+constexpr int ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;
+constexpr int BWORDS = 3568;          // LDS words of the halo region: 4 (2 planes x 2 k groups) x HR x HCP <= BWORDS
+constexpr int NSMAX = 7;              // halo pixels per loader thread (128 threads per k group)
+constexpr int TEXP = 14;              // scaled magnitudes stay below 2^15
+
+__device__ __forceinline__ unsigned short f16_rn(float v) {
+    const _Float16 h = (_Float16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned short& l) {
+    h = f16_rn(v);
+    const float r = v - (float)__builtin_bit_cast(_Float16, h);
+    l = f16_rn(r);
+}
+__device__ __forceinline__ u32x4 pack8(const unsigned short* b) {
+    u32x4 o;
+    o[0] = (unsigned)b[0] | ((unsigned)b[1] << 16);
+    o[1] = (unsigned)b[2] | ((unsigned)b[3] << 16);
+    o[2] = (unsigned)b[4] | ((unsigned)b[5] << 16);
+    o[3] = (unsigned)b[6] | ((unsigned)b[7] << 16);
+    return o;
+}
+__device__ __forceinline__ float pow2f(int biased) {          // 2^(biased - 127); 0 below the normal range
+    return biased < 1 ? 0.f : __builtin_bit_cast(float, (unsigned)(biased > 254 ? 254 : biased) << 23);
+}
+// biased exponent of the largest finite magnitude (bit pattern of a non-negative float), kept inside the range where both the
+// scale 2^(TEXP + 127 - E) and its inverse are normal numbers
+__device__ __forceinline__ int max_exponent(unsigned maxbits) {
+    int e = (int)(maxbits >> 23);
+    if (e < TEXP + 2) e = TEXP + 2;
+    if (e > 254) e = 254;
+    return e;
+}
+__device__ __forceinline__ float weight_scale(unsigned maxbits) { return pow2f(127 + TEXP + 127 - max_exponent(maxbits)); }
+
+__device__ __forceinline__ int mirror_clamp(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+__device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+struct S16gParams {
+    const float* src0; const float* src1; int C0, C1, Hs, Ws;
+    const u32x4* wp; const unsigned* wmax;
+    const float* bias; float* dst0; float* dst1; int M, M0, N;
+    int OHf, OWf, osy, osx;
+    int border, act; float slope;
+    int TW, RT, wshift, tiles_x, tiles_y, mblks, nchunks;
+    int HR, HC, HCP, HCH, hp16, dymin, dxmin;
+    FastDiv fd_hc;
+    long long cls_words;                     // packed words per class
+    int ntaps[S16G_MAX_CLS], OH[S16G_MAX_CLS], OW[S16G_MAX_CLS], ooy[S16G_MAX_CLS], oox[S16G_MAX_CLS];
+    int tapoff[S16G_MAX_TAPS];               // halo word offset of tap t of class c at [c * S16G_CLS_TAPS + t] (one class: all 64)
+};
+
+// packed weights: word ((((cls * nchunks + chunk) * mblks + mblk) * ntaps_cap + tap) * 2 + plane) * 2 + kg) * MB + m, element j of the
+// word = reduction channel chunk * 16 + kg * 8 + j; ntaps_cap = taps of the class (classes are packed one after the other)
+__global__ __launch_bounds__(256) void s16g_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int M, int Cred, int MB,
+                                                        int mblks, int nchunks, int ntaps, long long wsm, long long wsc,
+                                                        const unsigned* maxbits, const int* __restrict__ wofs_dev, int wofs0,
+                                                        int wofs_stride) {
+    // tap offsets are an arithmetic function of the tap for every caller (r * S + s walks): passed as a small table in LDS
+    __shared__ int s_wofs[S16G_MAX_TAPS];
+    (void)wofs0; (void)wofs_stride;
+    for (int i = threadIdx.x; i < S16G_MAX_TAPS; i += blockDim.x) s_wofs[i] = i < ntaps ? wofs_dev[i] : 0;
+    __syncthreads();
+    const float scale = weight_scale(*maxbits);
+    const long long total = (long long)nchunks * mblks * ntaps * 2 * MB;          // (kg, m) pairs x taps ...: one thread = both planes
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(t % MB);
+        long long q = t / MB;
+        const int kg = (int)(q & 1);
+        q >>= 1;
+        const int tap = (int)(q % ntaps);
+        q /= ntaps;
+        const int mblk = (int)(q % mblks), chunk = (int)(q / mblks);
+        const int mg = mblk * MB + m;
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cr = chunk * 16 + kg * 8 + j;
+            const float v = (mg < M && cr < Cred) ? w[(long long)mg * wsm + (long long)cr * wsc + s_wofs[tap]] : 0.f;
+            split2_f16(v * scale, h[j], l[j]);
+        }
+        u32x4* const o = out + ((((long long)chunk * mblks + mblk) * ntaps + tap) * 4 + kg) * MB + m;
+        o[0] = pack8(h);
+        o[2 * MB] = pack8(l);
+    }
+}
+
+// max |w| as a bit pattern (atomic max into a zeroed word)
+__global__ __launch_bounds__(256) void s16g_absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu;
+        m = max(m, u < 0x7f800000u ? u : 0u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride;
+// ATAPS = taps whose packed weights fit the LDS A region (per 16-channel chunk)
+template <int MT, int NT, int SX, int ATAPS>
+__global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
+    constexpr int MB = 32 * MT, NPW = 32 * NT;
+    constexpr int AW = ATAPS * 4 * MB;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[AW + BWORDS];
+    __shared__ unsigned red[4];
+    u32x4* const As = smem;
+    u32x4* const Bs = smem + AW;
+
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int cls = blockIdx.z, mblk = blockIdx.y;
+    int t = blockIdx.x;
+    const int txi = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tyi = t % p.tiles_y, n = t / p.tiles_y;
+    const int oy0 = tyi * p.RT, ox0 = txi * p.TW;
+    const int ntaps = p.ntaps[cls];
+    const int OH = p.OH[cls], OW = p.OW[cls];
+    if (oy0 >= OH || ox0 >= OW) return;                    // (classes of an odd-sized plane differ by one row / column of tiles)
+    const int C = p.C0 + p.C1;
+    const size_t HWs = (size_t)p.Hs * p.Ws;
+
+    // ---- loader role: waves 0, 1 fill k group 0 (channels 0..7 of the chunk), waves 2, 3 k group 1; thread = halo pixel ----
+    const int kgl = wid >> 1;
+    const int hpn = p.HR * p.HC;
+    int soff[NSMAX], lpos[NSMAX];
+#pragma unroll
+    for (int i = 0; i < NSMAX; ++i) {
+        const int hp = (tid & 127) + 128 * i;
+        soff[i] = -1;
+        lpos[i] = -1;
+        if (hp < hpn) {
+            const int hr = (int)fd_div((unsigned)hp, p.fd_hc), hc = hp - hr * p.HC;
+            int iy = oy0 * SX + p.dymin + hr, ix = ox0 * SX + p.dxmin + hc;
+            bool ok = true;
+            if (p.border == BORDER_REFLECT) {
+                iy = mirror_clamp(iy, p.Hs);
+                ix = mirror_clamp(ix, p.Ws);
+            } else {
+                ok = (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+            }
+            soff[i] = ok ? iy * p.Ws + ix : -1;
+            lpos[i] = kgl * p.hp16 + hr * p.HCP + (SX == 2 ? (hc & 1) * p.HCH + (hc >> 1) : hc);
+        }
+    }
+    float v[NSMAX][8];
+    // source values of chunk `ch_`: 8 channels (wave-uniform base pointers) x this thread's halo pixels
+#define S16G_LOAD(ch_)                                                                                                  \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                 \
+            const int c_ = (ch_) * 16 + kgl * 8 + j;                                                                    \
+            const float* cb_ = c_ < p.C0 ? p.src0 + ((size_t)n * p.C0 + c_) * HWs                                       \
+                                         : p.src1 + ((size_t)n * p.C1 + (c_ - p.C0)) * HWs;                             \
+            const bool cok_ = c_ < C;                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) v[i][j] = (cok_ && soff[i] >= 0) ? cb_[soff[i]] : 0.f;    \
+        }                                                                                                               \
+    }
+    // this wave's share of the chunk's packed weights: 1 KiB copies wid, wid + 4, ...
+    const int acopies = ntaps * 2 * MT;                        // ntaps * 4 * MB / 64
+    const u32x4* const wcls = p.wp + (size_t)cls * p.cls_words + (size_t)mblk * ntaps * 4 * MB;
+    const size_t wchunk = (size_t)p.mblks * ntaps * 4 * MB;
+#define S16G_WEIGHTS(ch_)                                                                                               \
+    {                                                                                                                   \
+        const u32x4* const a_ = wcls + (size_t)(ch_) * wchunk + lane;                                                   \
+        for (int q = wid; q < acopies; q += 4) glds16(a_ + 64 * q, As + 64 * q);                                        \
+    }
+
+    // ---- MFMA role ----
+    int bbase[NT], oyx[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int px = wid * NPW + 32 * nt + l31;
+        const int ty = px >> p.wshift, tx = px & (p.TW - 1);
+        bbase[nt] = lhi * p.hp16 + ty * SX * p.HCP + tx;
+        oyx[nt] = ((oy0 + ty) << 16) | (ox0 + tx);
+    }
+    const int abase = lhi * MB + l31;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    int E = 0;                                             // running biased exponent of the tile's source maximum
+    S16G_LOAD(0)
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        // -- the chunk's maximum over the four waves (its loads were issued a whole chunk ago) --
+        {
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < NSMAX; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned u = __builtin_bit_cast(unsigned, v[i][j]) & 0x7fffffffu;
+                    m = max(m, u < 0x7f800000u ? u : 0u);
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+            if (lane == 0) red[wid] = m;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the max word is written
+        __builtin_amdgcn_s_barrier();                      // (also: every wave has left the previous chunk's tap loop)
+        S16G_WEIGHTS(chunk)                                // land during the conversion below
+        {
+            const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
+            const int e = max_exponent(m);
+            if (e > E) {
+                if (chunk > 0) {
+                    const float f = pow2f(127 + E - e);    // exact (power of two); accumulators far below the new scale flush
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= f;
+                }
+                E = e;
+            }
+        }
+        {
+            const float scale = pow2f(127 + TEXP + 127 - E);
+#pragma unroll
+            for (int i = 0; i < NSMAX; ++i) {
+                if (lpos[i] < 0) continue;
+                unsigned short h[8], l[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split2_f16(v[i][j] * scale, h[j], l[j]);
+                Bs[lpos[i]] = pack8(h);
+                Bs[2 * p.hp16 + lpos[i]] = pack8(l);
+            }
+        }
+        // the weight copies are the only vector-memory operations in flight here: wait for them, THEN issue the next chunk's source
+        // loads (nothing waits for those until the top of the next iteration: they have the whole tap loop to arrive)
+        wait_vmem();
+        if (chunk + 1 < p.nchunks) S16G_LOAD(chunk + 1)
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's halo words are written
+        __builtin_amdgcn_s_barrier();                      // halo planes + weights of this chunk are in LDS for every wave
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int to = p.tapoff[cls * S16G_CLS_TAPS + tap];
+            u32x4 a[MT][2], b[NT][2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) b[nt][pl] = Bs[pl * 2 * p.hp16 + bbase[nt] + to];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[mt][pl] = As[(tap * 2 + pl) * 2 * MB + abase + mt * 32];
+            // partial products, smallest first: (l h') (h l') (h h')
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mt][q == 0 ? 1 : 0]),
+                                                                             __builtin_bit_cast(f16x8, b[nt][q == 1 ? 1 : 0]),
+                                                                             acc[mt][nt], 0, 0, 0);
+        }
+        // (the barrier at the top of the next chunk keeps the LDS regions until every wave is done with them)
+    }
+#undef S16G_LOAD
+#undef S16G_WEIGHTS
+
+    // ---- epilogue: take the two power-of-two scales out (exact), bias, activation ----
+    const float u1 = pow2f(E - TEXP), u2 = 1.f / weight_scale(*p.wmax);
+    const size_t plane = (size_t)p.OHf * p.OWf;
+    const int M1 = p.M - p.M0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
+        if (oy >= OH || ox >= OW) continue;
+        const size_t opix = (size_t)(oy * p.osy + p.ooy[cls]) * p.OWf + (size_t)(ox * p.osx + p.oox[cls]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mblk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m >= p.M) continue;
+                float o = (acc[mt][nt][r] * u1) * u2;
+                if (p.bias) o += p.bias[m];
+                o = act_apply(o, p.act, p.slope);
+                float* const d = m < p.M0 ? p.dst0 + ((size_t)n * p.M0 + m) * plane : p.dst1 + ((size_t)n * M1 + (m - p.M0)) * plane;
+                d[opix] = o;
+            }
+        }
+    }
+}
+
+int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+// ---- measurement hook: HIP events around every launch while enabled (bench.py roofline; shares the read-out with conv_split16) ----
+constexpr int MAX_TIMED = 2048;
+hipEvent_t g_tev[MAX_TIMED][2];
+int g_tev_made = 0, g_tev_used = 0;
+double g_tev_flop = 0.0;
+bool g_timing = false;
+
+}  // namespace
+
+void nemar_s16g_timer(int on) {
+    g_timing = on != 0;
+    if (on) { g_tev_used = 0; g_tev_flop = 0.0; }
+}
+
+int nemar_s16g_timer_read(double* total_ms, double* total_flop) {
+    double t = 0.0;
+    for (int i = 0; i < g_tev_used; ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(g_tev[i][1]);
+        (void)hipEventElapsedTime(&ms, g_tev[i][0], g_tev[i][1]);
+        t += ms;
+    }
+    *total_ms = t;
+    *total_flop = g_tev_flop;
+    const int n = g_tev_used;
+    g_tev_used = 0;
+    g_tev_flop = 0.0;
+    return n;
+}
+
+S16gPlan nemar_s16g_plan(const S16gProblem& q) {
+    S16gPlan pl;
+    pl.ok = 0;
+    const int C = q.C0 + q.C1;
+    if (q.ncls < 1 || q.ncls > S16G_MAX_CLS || (q.sstride != 1 && q.sstride != 2) || q.M < 16 || C < 1) return pl;
+    if (q.ncls > 1 && q.sstride != 1) return pl;
+    int maxtaps = 0, dymin = 1 << 20, dymax = -(1 << 20), dxmin = 1 << 20, dxmax = -(1 << 20), OH = 0, OW = 0;
+    for (int c = 0; c < q.ncls; ++c) {
+        if (q.ntaps[c] < 1 || q.ntaps[c] > (q.ncls > 1 ? S16G_CLS_TAPS : S16G_MAX_TAPS)) return pl;
+        if (q.ntaps[c] > maxtaps) maxtaps = q.ntaps[c];
+        for (int t = 0; t < q.ntaps[c]; ++t) {
+            if (q.dy[c][t] < dymin) dymin = q.dy[c][t];
+            if (q.dy[c][t] > dymax) dymax = q.dy[c][t];
+            if (q.dx[c][t] < dxmin) dxmin = q.dx[c][t];
+            if (q.dx[c][t] > dxmax) dxmax = q.dx[c][t];
+        }
+        if (q.OH[c] > OH) OH = q.OH[c];
+        if (q.OW[c] > OW) OW = q.OW[c];
+    }
+    if (OH < 1 || OW < 24 || OH >= 32768 || OW >= 32768) return pl;
+    // channel tile: as wide as the layer, but the LDS must hold a chunk's weights for every tap (ATAPS x MB x 64 B) next to the halo
+    pl.MT = q.M <= 32 ? 1 : (q.M <= 64 ? 2 : 4);
+    if (maxtaps > 9 && pl.MT == 4) pl.MT = 2;
+    if (maxtaps > 16 && pl.MT == 2) pl.MT = 1;
+    pl.ATAPS = maxtaps <= 9 ? 9 : (maxtaps <= 16 ? 16 : 49);
+    if (maxtaps > 49) return pl;
+    if (pl.ATAPS == 49 && pl.MT != 1) return pl;
+    const int MB = 32 * pl.MT;
+    pl.mblks = (q.M + MB - 1) / MB;
+    pl.nchunks = (C + 15) / 16;
+    // pixel tile: 128 NT pixels as RT rows x TW columns; the smallest halo that fits wins
+    const int sx = q.sstride, ey = dymax - dymin, ex = dxmax - dxmin;
+    long long best = -1;
+    for (int NT = (sx == 2 ? 1 : 2); NT >= 1; --NT) {
+        const int NP = 128 * NT;
+        for (int TW = 32; TW <= NP; TW *= 2) {
+            if (TW > 32 && TW / 2 >= OW) break;              // wider than the rows: pure waste
+            const int RT = NP / TW;
+            const int HR = (RT - 1) * sx + ey + 1, HC = (TW - 1) * sx + ex + 1;
+            const int HCH = (HC + 1) / 2, HCP = sx == 2 ? 2 * HCH : HC;
+            if (4 * HR * HCP > BWORDS || HR * HC > 128 * NSMAX) continue;
+            const int tx = (OW + TW - 1) / TW, ty = (OH + RT - 1) / RT;
+            // cost: halo elements loaded + converted per launch (short rows coalesce badly: 16 elements of overhead per row),
+            // plus the masked part of the tiles
+            const long long cost = (long long)tx * ty * (HR * HC + 16 * HR + NP / 2);
+            const long long wgs = (long long)tx * ty * q.N * pl.mblks * q.ncls;
+            if (NT == 2 && wgs < 256) continue;              // few tiles: prefer the smaller tile
+            if (best < 0 || cost < best) {
+                best = cost;
+                pl.NT = NT; pl.TW = TW; pl.RT = RT; pl.tiles_x = tx; pl.tiles_y = ty;
+                pl.HR = HR; pl.HC = HC; pl.HCP = HCP; pl.HCH = HCH;
+            }
+        }
+        if (best >= 0) break;
+    }
+    if (best < 0) return pl;
+    if ((long long)pl.tiles_x * pl.tiles_y * q.N >= (1ll << 31) || pl.mblks > 65535) return pl;
+    if ((long long)q.Hs * q.Ws >= (1ll << 30)) return pl;
+    pl.dymin = dymin;
+    pl.dxmin = dxmin;
+    // classes are packed with their own tap counts; reserve the largest for each
+    pl.pack_words_per_class = (size_t)pl.nchunks * pl.mblks * maxtaps * 4 * MB;
+    pl.ok = 1;
+    return pl;
+}
+
+size_t nemar_s16g_pack_bytes(const S16gProblem& q, const S16gPlan& pl) {
+    return pl.pack_words_per_class * 16 * (size_t)q.ncls + 64 + sizeof(int) * S16G_MAX_TAPS * S16G_MAX_CLS;
+}
+
+namespace {
+// layout of the packed buffer: [class 0 words][class 1 words]...[max word, 64 bytes][tap offset tables of the pack kernel]
+unsigned* pack_max_word(const S16gProblem& q, const S16gPlan& pl, void* packed) {
+    return (unsigned*)((char*)packed + pl.pack_words_per_class * 16 * (size_t)q.ncls);
+}
+__global__ void s16g_wofs_kernel(int* out, S16gProblem q) {
+    const int c = blockIdx.x;
+    for (int t = threadIdx.x; t < S16G_MAX_TAPS; t += blockDim.x) out[c * S16G_MAX_TAPS + t] = t < q.ntaps[c] ? q.wofs[c][t] : 0;
+}
+}  // namespace
+
+void nemar_s16g_pack(const S16gProblem& q, const S16gPlan& pl, const float* w, long long wsm, long long wsc, void* packed,
+                     hipStream_t st) {
+    const int C = q.C0 + q.C1, MB = 32 * pl.MT;
+    unsigned* const mw = pack_max_word(q, pl, packed);
+    int* const wofs_dev = (int*)((char*)mw + 64);
+    (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
+    // the max runs over the whole weight tensor the rows / channels / taps are drawn from: extent = last addressed element + 1
+    long long maxofs = 0;
+    for (int c = 0; c < q.ncls; ++c)
+        for (int t = 0; t < q.ntaps[c]; ++t)
+            if (q.wofs[c][t] > maxofs) maxofs = q.wofs[c][t];
+    const long long n = (long long)(q.M - 1) * wsm + (long long)(C - 1) * wsc + maxofs + 1;
+    int grid = nemar_stream_grid(n, 256 * 4);
+    hipLaunchKernelGGL(s16g_absmax_kernel, dim3(grid), dim3(256), 0, st, w, n, mw);
+    hipLaunchKernelGGL(s16g_wofs_kernel, dim3(q.ncls), dim3(64), 0, st, wofs_dev, q);
+    for (int c = 0; c < q.ncls; ++c) {
+        const long long total = (long long)pl.nchunks * pl.mblks * q.ntaps[c] * 2 * MB;
+        hipLaunchKernelGGL(s16g_pack_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w,
+                           (u32x4*)packed + (size_t)c * pl.pack_words_per_class, q.M, C, MB, pl.mblks, pl.nchunks, q.ntaps[c], wsm, wsc,
+                           (const unsigned*)mw, (const int*)(wofs_dev + c * S16G_MAX_TAPS), 0, 0);
+    }
+}
+
+void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packed, hipStream_t st) {
+    S16gParams p;
+    p.src0 = q.src0; p.src1 = q.src1; p.C0 = q.C0; p.C1 = q.C1; p.Hs = q.Hs; p.Ws = q.Ws;
+    p.wp = (const u32x4*)packed;
+    p.wmax = pack_max_word(q, pl, const_cast<void*>(packed));
+    p.bias = q.bias; p.dst0 = q.dst0; p.dst1 = q.dst1; p.M = q.M; p.M0 = q.M0; p.N = q.N;
+    p.OHf = q.OHf; p.OWf = q.OWf; p.osy = q.osy; p.osx = q.osx;
+    p.border = q.border; p.act = q.act; p.slope = q.slope;
+    p.TW = pl.TW; p.RT = pl.RT; p.wshift = ilog2(pl.TW); p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.mblks = pl.mblks;
+    p.nchunks = pl.nchunks;
+    p.HR = pl.HR; p.HC = pl.HC; p.HCP = pl.HCP; p.HCH = pl.HCH; p.hp16 = pl.HR * pl.HCP; p.dymin = pl.dymin; p.dxmin = pl.dxmin;
+    p.fd_hc = make_fastdiv((unsigned)pl.HC);
+    p.cls_words = (long long)pl.pack_words_per_class;
+    double flop = 0.0;
+    for (int c = 0; c < S16G_MAX_CLS; ++c) {
+        const bool on = c < q.ncls;
+        p.ntaps[c] = on ? q.ntaps[c] : 0;
+        p.OH[c] = on ? q.OH[c] : 0;
+        p.OW[c] = on ? q.OW[c] : 0;
+        p.ooy[c] = on ? q.ooy[c] : 0;
+        p.oox[c] = on ? q.oox[c] : 0;
+        if (on) flop += 2.0 * q.N * q.OH[c] * q.OW[c] * (double)q.M * (q.C0 + q.C1) * q.ntaps[c];
+    }
+    for (int i = 0; i < S16G_MAX_TAPS; ++i) p.tapoff[i] = 0;
+    for (int c = 0; c < q.ncls; ++c)
+        for (int t = 0; t < q.ntaps[c]; ++t) {
+            const int ddy = q.dy[c][t] - pl.dymin, ddx = q.dx[c][t] - pl.dxmin;
+            p.tapoff[c * S16G_CLS_TAPS + t] = ddy * pl.HCP + (q.sstride == 2 ? (ddx & 1) * pl.HCH + (ddx >> 1) : ddx);
+        }
+    const dim3 g(pl.tiles_x * pl.tiles_y * q.N, pl.mblks, q.ncls), b(256);
+    const bool tm = g_timing && g_tev_used < MAX_TIMED;
+    if (tm) {
+        while (g_tev_made <= g_tev_used) {
+            (void)hipEventCreate(&g_tev[g_tev_made][0]);
+            (void)hipEventCreate(&g_tev[g_tev_made][1]);
+            ++g_tev_made;
+        }
+        (void)hipEventRecord(g_tev[g_tev_used][0], st);
+    }
+#define S16G_GO(MT_, NT_, SX_, AT_) hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, AT_>), g, b, 0, st, p)
+#define S16G_BY_TAPS(MT_, NT_, SX_)                                 \
+    if (pl.ATAPS == 9) S16G_GO(MT_, NT_, SX_, 9);                   \
+    else S16G_GO(MT_, NT_, SX_, 16);
+    const int sx = q.sstride;
+    if (pl.ATAPS == 49) {
+        if (sx == 1 && pl.NT == 2) S16G_GO(1, 2, 1, 49);
+        else if (sx == 1) S16G_GO(1, 1, 1, 49);
+        else S16G_GO(1, 1, 2, 49);
+    } else if (pl.MT == 4) {
+        if (sx == 1 && pl.NT == 2) S16G_GO(4, 2, 1, 9);
+        else if (sx == 1) S16G_GO(4, 1, 1, 9);
+        else S16G_GO(4, 1, 2, 9);
+    } else if (pl.MT == 2) {
+        if (sx == 1 && pl.NT == 2) { S16G_BY_TAPS(2, 2, 1) }
+        else if (sx == 1) { S16G_BY_TAPS(2, 1, 1) }
+        else { S16G_BY_TAPS(2, 1, 2) }
+    } else {
+        if (sx == 1 && pl.NT == 2) { S16G_BY_TAPS(1, 2, 1) }
+        else if (sx == 1) { S16G_BY_TAPS(1, 1, 1) }
+        else { S16G_BY_TAPS(1, 1, 2) }
+    }
+#undef S16G_BY_TAPS
+#undef S16G_GO
+    if (tm) {
+        (void)hipEventRecord(g_tev[g_tev_used++][1], st);
+        g_tev_flop += flop;
+    }
+}

@@ -163,7 +163,10 @@ def _packed(weight, kind, nbytes):
     """-> (workspace tensor, prepacked flag) for `weight` used in direction `kind`."""
     key = (id(weight), kind)
     own = getattr(weight, '_pack_epoch', None)
-    token = (_param_epoch.n, own.n if own is not None else 0, weight._version, weight.data_ptr(), tuple(weight.shape))
+    # (the library's config epoch: which kernel family a shape routes to — and so the format of its packed image — depends on the
+    # nemar_tune switches and on the registered arena, whoever changed them)
+    token = (_param_epoch.n, own.n if own is not None else 0, weight._version, weight.data_ptr(), tuple(weight.shape),
+             L.config_epoch())
     ent = _pack_cache.get(key)
     # id() and device addresses are recycled once a tensor dies: an entry is only valid for the very object it was
     # made for (weak reference), with unchanged values (epoch, _version) at an unchanged address

@@ -190,6 +190,63 @@ def split16_scratch(be, *shape):
         be.lib.tune(23, 2000)
 
 
+class s16g_route:
+    """Lift the work threshold of the general 16-bit-pipe route (csrc/conv_s16g.hip: in-kernel operand split) for small test shapes;
+    `on=False` forces the exact-fp32 kernels instead."""
+
+    def __init__(self, be, on=True):
+        self.be, self.on = be, on
+
+    def __enter__(self):
+        self.be.lib.tune(24, 1 if self.on else 0)
+        self.be.lib.tune(25, 0)
+        return self
+
+    def __exit__(self, *a):
+        self.be.sync()
+        self.be.lib.tune(24, 1)
+        self.be.lib.tune(25, 30)
+
+
+def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NONE, bias=True, seed=0, xscale=None):
+    """Forward through nemar_conv2d_fwd on the general 16-bit-pipe route; `xscale` [N] or [N, C] multiplies the source per sample /
+    per channel (dynamic-range cases: the block scale is per tile and per 16-channel chunk)."""
+    rng = np.random.default_rng(seed)
+    C = C0 + C1
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    if xscale is not None:
+        xs = np.asarray(xscale, dtype=np.float32)
+        x = (x * xs.reshape(xs.shape + (1,) * (4 - xs.ndim))).astype(np.float32)
+    w = (rng.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32) if bias else None
+    want = O.act_fwd(O.conv2d_fwd(x.astype(np.float64), w.astype(np.float64),
+                                  None if b is None else b.astype(np.float64), stride, pad, _PM[pad_mode]), act)
+    # error scale of an output = what an fp32 dot product of the same terms may lose: 2^-19 of sum |w| |x| (+ bias)
+    mag = O.conv2d_fwd(np.abs(x).astype(np.float64), np.abs(w).astype(np.float64), None, stride, pad, _PM[pad_mode])
+    OH, OW = want.shape[2:]
+    d_x0 = be.dev(x[:, :C0])
+    d_x1 = be.dev(x[:, C0:]) if C1 else None
+    d_w, d_b = be.dev(w), (be.dev(b) if bias else None)
+    d_y = be.full((N, K, OH, OW), np.nan)
+    with s16g_route(be):
+        ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, R, R, stride, pad))
+        be.lib.conv2d_fwd(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_w), be.ptr(d_b), be.ptr(d_y), N, H, W, K, R, R,
+                          stride, pad, pad_mode, act, 0.2, be.ptr(ws), wsb, 0, be.stream)
+    assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
+    got = be.np(d_y)
+    err = np.abs(got - want)
+    lim = 2e-6 * mag + 1e-6 * (np.abs(want) + (0 if b is None else np.abs(b)[None, :, None, None])) + 1e-30
+    if not np.all(err <= lim):
+        i = np.unravel_index(np.argmax(err / lim), err.shape)
+        raise AssertionError("conv2d_fwd (s16g): err %.3e > %.3e at %s (got %.6g want %.6g)" % (err[i], lim[i], i, got[i], want[i]))
+
+
+def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0):
+    with s16g_route(be):
+        case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, PAD_ZERO, skip0=skip0, seed=seed)
+        assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
+
+
 def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0, R=3):
     """One wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_fwd (dgrad False) or nemar_conv2d_bwd_data with the scratch
     arena registered: the split-16 route must be eligible for the shape, and obey the same tolerance against the float64 oracle

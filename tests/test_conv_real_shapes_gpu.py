@@ -77,10 +77,17 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("route", ["default", "exact"])
 @pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
-def test_conv_real_shape(be, shape):
-    """No scratch arena registered: every layer on the exact-fp32 MFMA / VALU kernels."""
-    _run_shape(be, shape)
+def test_conv_real_shape(be, shape, route):
+    """No scratch arena registered.  default: the library's own dispatch — the general 16-bit-pipe kernels with the in-kernel operand
+    split (csrc/conv_s16g*.hip) for every layer they take; exact: nemar_tune(24, 0), every layer on the exact-fp32 MFMA / VALU
+    kernels.  Same tolerances."""
+    be.lib.tune(24, 0 if route == "exact" else 1)
+    try:
+        _run_shape(be, shape)
+    finally:
+        be.lib.tune(24, 1)
 
 
 SPLIT16_SHAPES = [
@@ -238,8 +245,17 @@ CONVT = [("T up1 convT 256->128 k3 s2 64x64->128x128", 8, 256, 128, 64, 64, 3, 1
          ("T up2 convT 128->64 k3 s2 128x128->256x256", 8, 128, 64, 128, 128, 3, 1)]
 
 
+@pytest.mark.parametrize("route", ["default", "exact"])
 @pytest.mark.parametrize("shape", CONVT, ids=[s[0] for s in CONVT])
-def test_conv_transpose_real_shape(be, shape):
+def test_conv_transpose_real_shape(be, shape, route):
+    be.lib.tune(24, 0 if route == "exact" else 1)
+    try:
+        _run_convt(be, shape)
+    finally:
+        be.lib.tune(24, 1)
+
+
+def _run_convt(be, shape):
     name, N, Ci, Co, H, W, R, op = shape
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
     x = torch.rand((N, Ci, H, W), generator=g) * 2 - 1

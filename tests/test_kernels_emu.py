@@ -1,6 +1,7 @@
 """CPU tier: the unmodified HIP kernel sources, compiled for the host SIMT emulator (tests/emu), checked
 against the oracle.  This validates index arithmetic, tiling and wave-collective logic without a GPU;
 the `-m gpu` tier (tests/test_kernels_gpu.py) runs the same bodies on the real gfx950 library."""
+import numpy as np
 import pytest
 
 import kernel_cases as K
@@ -388,3 +389,62 @@ def test_conv_split16_4x4_layers(be, variant):
         K.case_conv_split16(be, 2, 256, 16, 32, 16, K.PAD_ZERO, dgrad=True, R=4)
     finally:
         be.lib.tune(21, 4)
+
+
+S16G_FWD = [
+    # N, C0, C1, H,  W,  K,  R, stride, pad, pad_mode
+    (1, 16, 0, 8, 32, 32, 3, 1, 1, K.PAD_REFLECT),      # one 256-pixel tile, MT = 1
+    (2, 24, 8, 6, 40, 64, 3, 1, 1, K.PAD_ZERO),         # two sources, ragged rows (40 = 32 + 8), MT = 2, 2 chunks
+    (1, 6, 0, 9, 66, 48, 4, 2, 1, K.PAD_ZERO),          # 4x4 stride 2 (D's first layer): 6 of 16 channels, de-interleaved columns
+    (1, 32, 0, 8, 64, 128, 3, 2, 1, K.PAD_ZERO),        # 3x3 stride 2, MT = 4, odd halo width
+    (1, 20, 0, 5, 33, 40, 1, 1, 0, K.PAD_ZERO),         # 1x1, ragged everything
+    (1, 16, 16, 4, 64, 160, 3, 1, 1, K.PAD_ZERO),       # two channel blocks of 128 (second ragged), concat on a chunk boundary
+]
+
+
+@pytest.mark.parametrize("case", S16G_FWD)
+def test_conv_s16g_forward(be, case):
+    """General layers on the 16-bit matrix pipe with the operand split inside the kernel (conv_s16g.hip): halo tiles, online block
+    scale, packed weights by direct LDS copies; stride 1 / 2, reflect / zero borders, one and two sources."""
+    K.case_conv_s16g_fwd(be, *case)
+
+
+def test_conv_s16g_forward_act_bias(be):
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, act=2, bias=True)
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, act=0, bias=False)
+
+
+def test_conv_s16g_dynamic_range(be):
+    """The block scale is per tile and per chunk: samples / channel blocks of wildly different magnitude keep their own relative
+    accuracy (error bound relative to each output's own sum |w||x|), and an all-zero source gives exact zeros."""
+    K.case_conv_s16g_fwd(be, 3, 32, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=[1.0, 1e-6, 1e5])
+    chan = np.concatenate([np.full(16, 1e4), np.full(16, 1e-3)])
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=np.stack([chan]))       # a later chunk is 1e7 smaller
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=np.stack([chan[::-1]]))  # ... larger: accumulators rescale
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=[0.0], bias=False)
+
+
+S16G_DGRAD = [
+    # N, C0, C1, H,  W,  K,  R, stride, pad
+    (1, 32, 0, 8, 32, 16, 3, 1, 1),
+    (2, 16, 16, 4, 64, 24, 3, 1, 1),                    # two destinations
+    (1, 64, 0, 8, 64, 32, 3, 2, 1),                     # stride 2: four parity classes of 1 / 2 / 2 / 4 taps (= ConvTranspose2d)
+    (1, 48, 0, 10, 66, 16, 4, 2, 1),                    # 4x4 stride 2: four classes of 4 taps
+    (1, 32, 0, 7, 32, 16, 4, 1, 1),                     # 4x4 stride 1 (full correlation of the 6 x 31 gradient)
+]
+
+
+@pytest.mark.parametrize("case", S16G_DGRAD)
+def test_conv_s16g_data_gradient(be, case):
+    K.case_conv_s16g_bwd_data(be, *case)
+
+
+def test_conv_s16g_data_gradient_skip_first_source(be):
+    K.case_conv_s16g_bwd_data(be, 1, 16, 16, 4, 32, 24, 3, 1, 1, skip0=True)
+
+
+@pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
+def test_conv_s16g_transpose_forward(be, R, op):
+    with K.s16g_route(be):
+        K.case_conv_transpose_fwd(be, 2, 32, 24, 8, 32, R, op)
+        assert be.lib.last_route() == 3

@@ -1,5 +1,6 @@
 """`-m gpu` tier: the real gfx950 library (nemar_amd/lib/libnemar_hip.so) through its C-ABI, against the
 oracle, with the same bodies as the CPU/emulator tier plus hot-path sizes."""
+import numpy as np
 import pytest
 
 import kernel_cases as K
@@ -381,3 +382,48 @@ def test_conv_split16_4x4_layers(be, variant):
         K.case_conv_split16(be, 2, 256, 16, 32, 16, K.PAD_ZERO, dgrad=True, R=4)
     finally:
         be.lib.tune(21, 4)
+
+
+from test_kernels_emu import S16G_FWD, S16G_DGRAD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", S16G_FWD)
+def test_conv_s16g_forward(be, case):
+    K.case_conv_s16g_fwd(be, *case)
+
+
+@pytest.mark.gpu
+def test_conv_s16g_forward_act_bias(be):
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, act=2, bias=True)
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, act=0, bias=False)
+
+
+@pytest.mark.gpu
+def test_conv_s16g_dynamic_range(be):
+    """Adversarial magnitudes through the C ABI: per-sample 1 : 1e-6 : 1e5, channel blocks 1e7 apart in either order, all-zero."""
+    K.case_conv_s16g_fwd(be, 3, 32, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=[1.0, 1e-6, 1e5])
+    chan = np.concatenate([np.full(16, 1e4), np.full(16, 1e-3)])
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=np.stack([chan]))
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=np.stack([chan[::-1]]))
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 4, 32, 32, 3, 1, 1, K.PAD_ZERO, xscale=[0.0], bias=False)
+    K.case_conv_s16g_fwd(be, 8, 64, 0, 64, 64, 128, 3, 2, 1, K.PAD_ZERO, xscale=10.0 ** np.arange(-4, 4))      # a real-sized layer
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", S16G_DGRAD)
+def test_conv_s16g_data_gradient(be, case):
+    K.case_conv_s16g_bwd_data(be, *case)
+
+
+@pytest.mark.gpu
+def test_conv_s16g_data_gradient_skip_first_source(be):
+    K.case_conv_s16g_bwd_data(be, 1, 16, 16, 4, 32, 24, 3, 1, 1, skip0=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
+def test_conv_s16g_transpose_forward(be, R, op):
+    with K.s16g_route(be):
+        K.case_conv_transpose_fwd(be, 2, 32, 24, 8, 32, R, op)
+        assert be.lib.last_route() == 3
