@@ -1818,7 +1818,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         S16gProblem q;
         S16gPlan pl;
         if (s16g_fwd_problem(q, pl, N, C0, C1, H, W, K, R, S, stride, pad, pad_mode, act, slope)) {
-            q.src0 = x0; q.src1 = x1; q.dst0 = y; q.dst1 = nullptr; q.bias = bias;
+            q.src0 = x0; q.src1 = x1; q.dst0 = y; q.dst1 = nullptr; q.bias = bias; q.dbg = g_dbg;
             if (!prepacked) nemar_s16g_pack(q, pl, w, (long long)C * R * S, (long long)R * S, workspace, st);
             nemar_s16g_conv(q, pl, workspace, st);
             g_last_route = 3;
@@ -2097,6 +2097,10 @@ NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, i
         const size_t f3 = (size_t)nemar_narrow_wgrad_splits(N, C, OH, OW) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
         if (f3 > fl) fl = f3;
     }
+    if (nemar_s16g_wgrad_eligible(N, C, 0, H, W, K, OH, OW, R, S, stride, pad, BORDER_ZERO)) {      // (slab count: same for any channel split)
+        const size_t f6 = (size_t)nemar_s16g_wgrad_slabs_max(N, C, K, OH) * ((size_t)K * J + K);
+        if (f6 > fl) fl = f6;
+    }
     if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {       // slabs of the split-16 route + bias partials
         const size_t f5 = (size_t)nemar_split16_wgrad_splits(N, C, H, W, K, R) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
         if (f5 > fl) fl = f5;
@@ -2156,6 +2160,13 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         }
         g_last_route = 2;
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (split-16)");
+        return NEMAR_OK;
+    }
+    if (part && s16g_worth_it((long long)N * OH * OW * K * (C0 + C1) * R * S) &&
+        nemar_s16g_wgrad_eligible(N, C0, C1, H, W, K, OH, OW, R, S, stride, pad, pad_mode)) {
+        nemar_s16g_wgrad(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, stride, pad_mode, part, st);
+        g_last_route = 3;
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (16-bit pipe, in-kernel split)");
         return NEMAR_OK;
     }
     if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {

@@ -42,7 +42,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BORDER_REFLECT = 1;
-constexpr int ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;
+constexpr int ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;      // (tanh: not served here, see nemar_s16g_plan)
 constexpr int BWORDS = 3568;          // LDS words of the halo region: 4 (2 planes x 2 k groups) x HR x HCP <= BWORDS
 constexpr int NSMAX = 7;              // halo pixels per loader thread (128 threads per k group)
 constexpr int TEXP = 14;              // scaled magnitudes stay below 2^15
@@ -55,6 +55,21 @@ __device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned 
     h = f16_rn(v);
     const float r = v - (float)__builtin_bit_cast(_Float16, h);
     l = f16_rn(r);
+}
+// v s = h + l (+ e): both halves of eight values as two 16-byte words.  v * s is exact (s a power of two), so fmaf(v, s, -h) is the
+// exact residual — written as an fma so that hipcc selects v_fma_mix (fp16 operand read in place) instead of convert + multiply + subtract
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const float* v, float s, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f16x2 h, l;
+        h[0] = (_Float16)(v[2 * j] * s);
+        h[1] = (_Float16)(v[2 * j + 1] * s);
+        l[0] = (_Float16)__builtin_fmaf(v[2 * j], s, -(float)h[0]);
+        l[1] = (_Float16)__builtin_fmaf(v[2 * j + 1], s, -(float)h[1]);
+        hi[j] = __builtin_bit_cast(unsigned, h);
+        lo[j] = __builtin_bit_cast(unsigned, l);
+    }
 }
 __device__ __forceinline__ u32x4 pack8(const unsigned short* b) {
     u32x4 o;
@@ -82,15 +97,28 @@ __device__ __forceinline__ int mirror_clamp(int i, int n) {
     i = i >= n ? 2 * (n - 1) - i : i;
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
-__device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
-    if (act == ACT_TANH) return tanhf(v);
-    return v;
-}
 __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// max over the wavefront of a non-negative word, valid in lane 63 (DPP row shifts + row broadcasts: six VALU instructions; the
+// __shfl_xor form goes through ds_bpermute — six LDS round trips per chunk)
+__device__ __forceinline__ unsigned wave_max_to_lane63(unsigned x) {
+#ifdef NEMAR_HOST_EMULATION
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, o, 64));
+    return x;
+#else
+    // lanes a shift does not reach read `old` = 0: the neutral element of an unsigned max
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));      // row_shr:1
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));      // row_shr:2
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));      // row_shr:4
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));      // row_shr:8 -> lane 15 of every row
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1, 3
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2, 3
+    return x;
+#endif
 }
 
 struct S16gParams {
@@ -99,8 +127,10 @@ struct S16gParams {
     const float* bias; float* dst0; float* dst1; int M, M0, N;
     int OHf, OWf, osy, osx;
     int border, act; float slope;
+    int dbg;                                 // ablation bits (nemar_tune key 2, tools/ only): 1 no tap loop, 2 no source loads, 4 no conversion
     int TW, RT, wshift, tiles_x, tiles_y, mblks, nchunks;
     int HR, HC, HCP, HCH, hp16, dymin, dxmin;
+    int aw16;                                // LDS words of the weight region
     FastDiv fd_hc;
     long long cls_words;                     // packed words per class
     int ntaps[S16G_MAX_CLS], OH[S16G_MAX_CLS], OW[S16G_MAX_CLS], ooy[S16G_MAX_CLS], oox[S16G_MAX_CLS];
@@ -154,16 +184,20 @@ __global__ __launch_bounds__(256) void s16g_absmax_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
-// MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride;
-// ATAPS = taps whose packed weights fit the LDS A region (per 16-channel chunk)
-template <int MT, int NT, int SX, int ATAPS>
+// MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride.
+// LDS (dynamic: exactly what the layer needs, so that narrow layers keep several workgroups per CU): [weights of one chunk,
+// p.aw16 words][halo planes, 4 p.hp16 words]
+template <int MT, int NT, int SX>
 __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     constexpr int MB = 32 * MT, NPW = 32 * NT;
-    constexpr int AW = ATAPS * 4 * MB;
-    __shared__ __attribute__((aligned(16))) u32x4 smem[AW + BWORDS];
+#ifdef NEMAR_HOST_EMULATION
+    __shared__ __attribute__((aligned(16))) u32x4 smem[49 * 4 * 32 * 4 + BWORDS];      // (the emulator has no dynamic LDS)
+#else
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+#endif
     __shared__ unsigned red[4];
     u32x4* const As = smem;
-    u32x4* const Bs = smem + AW;
+    u32x4* const Bs = smem + p.aw16;
 
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int cls = blockIdx.z, mblk = blockIdx.y;
@@ -181,7 +215,8 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     // ---- loader role: waves 0, 1 fill k group 0 (channels 0..7 of the chunk), waves 2, 3 k group 1; thread = halo pixel ----
     const int kgl = wid >> 1;
     const int hpn = p.HR * p.HC;
-    int soff[NSMAX], lpos[NSMAX];
+    int soff[NSMAX], lpos[NSMAX];      // soff: source offset inside a channel image (always a valid address), < 0 flags in svalid
+    bool svalid[NSMAX], sany[NSMAX];   // this lane's halo pixel is inside the image / some lane of the wave is not (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NSMAX; ++i) {
         const int hp = (tid & 127) + 128 * i;
@@ -200,6 +235,9 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             soff[i] = ok ? iy * p.Ws + ix : -1;
             lpos[i] = kgl * p.hp16 + hr * p.HCP + (SX == 2 ? (hc & 1) * p.HCH + (hc >> 1) : hc);
         }
+        svalid[i] = soff[i] >= 0;
+        sany[i] = __any(lpos[i] >= 0 && !svalid[i]) != 0;
+        soff[i] = svalid[i] ? soff[i] : 0;
     }
     float v[NSMAX][8];
     // source values of chunk `ch_`: 8 channels (wave-uniform base pointers) x this thread's halo pixels
@@ -209,8 +247,21 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             const int c_ = (ch_) * 16 + kgl * 8 + j;                                                                    \
             const float* cb_ = c_ < p.C0 ? p.src0 + ((size_t)n * p.C0 + c_) * HWs                                       \
                                          : p.src1 + ((size_t)n * p.C1 + (c_ - p.C0)) * HWs;                             \
-            const bool cok_ = c_ < C;                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) v[i][j] = (cok_ && soff[i] >= 0) ? cb_[soff[i]] : 0.f;    \
+            (void)cb_;                                                                                                  \
+            const float* cbs_ = c_ < C ? cb_ : p.src0;      /* beyond the last channel: any valid address, zeroed below */  \
+            if (p.dbg & 2) { _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) v[i][j] = 1.f; }                         \
+            else { _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) v[i][j] = cbs_[soff[i]]; }  /* unconditional: no branches */ \
+        }                                                                                                               \
+    }
+    // what the unconditional loads fetched for padding pixels / channels beyond C becomes zero (wave-uniform tests: interior tiles
+    // of layers with C % 16 == 0 skip all of it)
+#define S16G_MASK(ch_)                                                                                                  \
+    {                                                                                                                   \
+        const int jlim_ = C - (ch_) * 16 - kgl * 8;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) {                                                             \
+            if (sany[i] || jlim_ < 8) {                                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = (svalid[i] && j < jlim_) ? v[i][j] : 0.f;       \
+            }                                                                                                           \
         }                                                                                                               \
     }
     // this wave's share of the chunk's packed weights: 1 KiB copies wid, wid + 4, ...
@@ -220,7 +271,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
 #define S16G_WEIGHTS(ch_)                                                                                               \
     {                                                                                                                   \
         const u32x4* const a_ = wcls + (size_t)(ch_) * wchunk + lane;                                                   \
-        for (int q = wid; q < acopies; q += 4) glds16(a_ + 64 * q, As + 64 * q);                                        \
+        if (!(p.dbg & 8)) for (int q = wid; q < acopies; q += 4) glds16(a_ + 64 * q, As + 64 * q);                      \
     }
 
     // ---- MFMA role ----
@@ -243,23 +294,33 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
 
     int E = 0;                                             // running biased exponent of the tile's source maximum
     S16G_LOAD(0)
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    for (int chunk = 0; chunk < ((p.dbg & 64) ? 0 : p.nchunks); ++chunk) {
         // -- the chunk's maximum over the four waves (its loads were issued a whole chunk ago) --
-        {
-            unsigned m = 0;
+        S16G_MASK(chunk)
+        if (!(p.dbg & 16)) {
+            // |v| as floats: one v_max3_f32 per two elements (fmaxf ignores NaN; an infinity sends this thread through the slow
+            // path that leaves non-finite values out of the maximum — they must not flush the finite ones)
+            float mf = 0.f;
 #pragma unroll
             for (int i = 0; i < NSMAX; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned u = __builtin_bit_cast(unsigned, v[i][j]) & 0x7fffffffu;
-                    m = max(m, u < 0x7f800000u ? u : 0u);
-                }
+                for (int j = 0; j < 8; j += 2) mf = fmaxf(mf, fmaxf(__builtin_fabsf(v[i][j]), __builtin_fabsf(v[i][j + 1])));
+            unsigned m = __builtin_bit_cast(unsigned, mf);
+            if (m >= 0x7f800000u) {
+                m = 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-            if (lane == 0) red[wid] = m;
+                for (int i = 0; i < NSMAX; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned u = __builtin_bit_cast(unsigned, v[i][j]) & 0x7fffffffu;
+                        m = max(m, u < 0x7f800000u ? u : 0u);
+                    }
+            }
+            m = wave_max_to_lane63(m);
+            if (lane == 63) red[wid] = m;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the max word is written
-        __builtin_amdgcn_s_barrier();                      // (also: every wave has left the previous chunk's tap loop)
+        if (!(p.dbg & 32)) __builtin_amdgcn_s_barrier();   // (also: every wave has left the previous chunk's tap loop)
         S16G_WEIGHTS(chunk)                                // land during the conversion below
         {
             const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
@@ -281,12 +342,11 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             const float scale = pow2f(127 + TEXP + 127 - E);
 #pragma unroll
             for (int i = 0; i < NSMAX; ++i) {
-                if (lpos[i] < 0) continue;
-                unsigned short h[8], l[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) split2_f16(v[i][j] * scale, h[j], l[j]);
-                Bs[lpos[i]] = pack8(h);
-                Bs[2 * p.hp16 + lpos[i]] = pack8(l);
+                if (lpos[i] < 0 || (p.dbg & 4)) continue;
+                u32x4 hi, lo;
+                split8(v[i], scale, hi, lo);
+                Bs[lpos[i]] = hi;
+                Bs[2 * p.hp16 + lpos[i]] = lo;
             }
         }
         // the weight copies are the only vector-memory operations in flight here: wait for them, THEN issue the next chunk's source
@@ -295,51 +355,87 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         if (chunk + 1 < p.nchunks) S16G_LOAD(chunk + 1)
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's halo words are written
         __builtin_amdgcn_s_barrier();                      // halo planes + weights of this chunk are in LDS for every wave
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int to = p.tapoff[cls * S16G_CLS_TAPS + tap];
-            u32x4 a[MT][2], b[NT][2];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) b[nt][pl] = Bs[pl * 2 * p.hp16 + bbase[nt] + to];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[mt][pl] = As[(tap * 2 + pl) * 2 * MB + abase + mt * 32];
-            // partial products, smallest first: (l h') (h l') (h h')
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mt][q == 0 ? 1 : 0]),
-                                                                             __builtin_bit_cast(f16x8, b[nt][q == 1 ? 1 : 0]),
-                                                                             acc[mt][nt], 0, 0, 0);
+        // fragments of tap t + 1 are read while the MFMAs of tap t issue (two register sets)
+        u32x4 fa[2][MT][2], fb[2][NT][2];
+#define S16G_READ(set_, tap_)                                                                                           \
+        {                                                                                                               \
+            const int to_ = p.tapoff[cls * S16G_CLS_TAPS + (tap_)];                                                     \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                           \
+                _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) fb[set_][nt][pl] = Bs[pl * 2 * p.hp16 + bbase[nt] + to_]; \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
+                _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) fa[set_][mt][pl] = As[((tap_) * 2 + pl) * 2 * MB + abase + mt * 32]; \
         }
+        // partial products, smallest first: (l h') (h l') (h h')
+#define S16G_MMA(set_)                                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                       \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set_][mt][q == 0 ? 1 : 0]), \
+                                                                         __builtin_bit_cast(f16x8, fb[set_][nt][q == 1 ? 1 : 0]), \
+                                                                         acc[mt][nt], 0, 0, 0);
+        S16G_READ(0, 0)
+        for (int tap = 0; tap + 1 < ntaps && !(p.dbg & 1); tap += 2) {
+            S16G_READ(1, tap + 1)
+            S16G_MMA(0)
+            if (tap + 2 < ntaps) S16G_READ(0, tap + 2)
+            S16G_MMA(1)
+        }
+        if (ntaps & 1) { S16G_MMA(0) }
+#undef S16G_READ
+#undef S16G_MMA
         // (the barrier at the top of the next chunk keeps the LDS regions until every wave is done with them)
     }
 #undef S16G_LOAD
+#undef S16G_MASK
 #undef S16G_WEIGHTS
 
     // ---- epilogue: take the two power-of-two scales out (exact), bias, activation ----
+    if (p.dbg & 128) return;
     const float u1 = pow2f(E - TEXP), u2 = 1.f / weight_scale(*p.wmax);
     const size_t plane = (size_t)p.OHf * p.OWf;
     const int M1 = p.M - p.M0;
+    float bv[MT][16];                  // the bias of this lane's rows: all loads in flight at once (one wait, not one per row)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mblk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            bv[mt][r] = p.bias ? p.bias[m < p.M ? m : 0] : 0.f;
+        }
+    // full channel block into one destination (every layer of the three nets; ragged blocks below): plain stores, the activation
+    // chosen once per wave — three compact store loops (an inlined tanhf per element made this epilogue 30 000 instructions and
+    // instruction-fetch bound: 24 of 160 us; tanh layers have <= 4 output channels and never come here)
+    const bool plain = (mblk + 1) * MB <= p.M && ((mblk + 1) * MB <= p.M0 || mblk * MB >= p.M0);
+    float* const dplain = mblk * MB >= p.M0 ? p.dst1 + ((size_t)n * M1 + (mblk * MB - p.M0)) * plane : p.dst0 + ((size_t)n * p.M0 + mblk * MB) * plane;
+    const float u12 = u1 * u2;                               // (both powers of two; their product is a normal number for any finite result)
+    const bool one_mul = u12 != 0.f && u12 < 3.0e38f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
         if (oy >= OH || ox >= OW) continue;
         const size_t opix = (size_t)(oy * p.osy + p.ooy[cls]) * p.OWf + (size_t)(ox * p.osx + p.oox[cls]);
+        if (plain) {
+            float* const d0 = dplain + opix + (size_t)(4 * lhi) * plane;
+#define S16G_STORES(EXPR_)                                                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                    const float o_ = (one_mul ? acc[mt][nt][r] * u12 : (acc[mt][nt][r] * u1) * u2) + bv[mt][r];         \
+                    d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * plane] = (EXPR_);                                   \
+                }
+            if (p.act == ACT_RELU) { S16G_STORES(fmaxf(o_, 0.f)) }
+            else if (p.act == ACT_LRELU) { S16G_STORES(o_ > 0.f ? o_ : o_ * p.slope) }
+            else { S16G_STORES(o_) }
+#undef S16G_STORES
+            continue;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mblk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m >= p.M) continue;
-                float o = (acc[mt][nt][r] * u1) * u2;
-                if (p.bias) o += p.bias[m];
-                o = act_apply(o, p.act, p.slope);
+                float o = (acc[mt][nt][r] * u1) * u2 + bv[mt][r];
+                o = p.act == ACT_RELU ? fmaxf(o, 0.f) : (p.act == ACT_LRELU ? (o > 0.f ? o : o * p.slope) : o);
                 float* const d = m < p.M0 ? p.dst0 + ((size_t)n * p.M0 + m) * plane : p.dst1 + ((size_t)n * M1 + (m - p.M0)) * plane;
                 d[opix] = o;
             }
@@ -389,6 +485,7 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     const int C = q.C0 + q.C1;
     if (q.ncls < 1 || q.ncls > S16G_MAX_CLS || (q.sstride != 1 && q.sstride != 2) || q.M < 16 || C < 1) return pl;
     if (q.ncls > 1 && q.sstride != 1) return pl;
+    if (q.act == ACT_TANH) return pl;
     int maxtaps = 0, dymin = 1 << 20, dymax = -(1 << 20), dxmin = 1 << 20, dxmax = -(1 << 20), OH = 0, OW = 0;
     for (int c = 0; c < q.ncls; ++c) {
         if (q.ntaps[c] < 1 || q.ntaps[c] > (q.ncls > 1 ? S16G_CLS_TAPS : S16G_MAX_TAPS)) return pl;
@@ -407,9 +504,8 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     pl.MT = q.M <= 32 ? 1 : (q.M <= 64 ? 2 : 4);
     if (maxtaps > 9 && pl.MT == 4) pl.MT = 2;
     if (maxtaps > 16 && pl.MT == 2) pl.MT = 1;
-    pl.ATAPS = maxtaps <= 9 ? 9 : (maxtaps <= 16 ? 16 : 49);
+    pl.ATAPS = maxtaps;
     if (maxtaps > 49) return pl;
-    if (pl.ATAPS == 49 && pl.MT != 1) return pl;
     const int MB = 32 * pl.MT;
     pl.mblks = (q.M + MB - 1) / MB;
     pl.nchunks = (C + 15) / 16;
@@ -424,6 +520,7 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
             const int HR = (RT - 1) * sx + ey + 1, HC = (TW - 1) * sx + ex + 1;
             const int HCH = (HC + 1) / 2, HCP = sx == 2 ? 2 * HCH : HC;
             if (4 * HR * HCP > BWORDS || HR * HC > 128 * NSMAX) continue;
+            if (maxtaps * 4 * MB + 4 * HR * HCP > 10200) continue;            // weights of a chunk + halo planes within the 160 KiB of LDS
             const int tx = (OW + TW - 1) / TW, ty = (OH + RT - 1) / RT;
             // cost: halo elements loaded + converted per launch (short rows coalesce badly: 16 elements of overhead per row),
             // plus the masked part of the tiles
@@ -494,7 +591,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     p.wmax = pack_max_word(q, pl, const_cast<void*>(packed));
     p.bias = q.bias; p.dst0 = q.dst0; p.dst1 = q.dst1; p.M = q.M; p.M0 = q.M0; p.N = q.N;
     p.OHf = q.OHf; p.OWf = q.OWf; p.osy = q.osy; p.osx = q.osx;
-    p.border = q.border; p.act = q.act; p.slope = q.slope;
+    p.border = q.border; p.act = q.act; p.slope = q.slope; p.dbg = q.dbg;
     p.TW = pl.TW; p.RT = pl.RT; p.wshift = ilog2(pl.TW); p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.mblks = pl.mblks;
     p.nchunks = pl.nchunks;
     p.HR = pl.HR; p.HC = pl.HC; p.HCP = pl.HCP; p.HCH = pl.HCH; p.hp16 = pl.HR * pl.HCP; p.dymin = pl.dymin; p.dxmin = pl.dxmin;
@@ -526,29 +623,34 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
         }
         (void)hipEventRecord(g_tev[g_tev_used][0], st);
     }
-#define S16G_GO(MT_, NT_, SX_, AT_) hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, AT_>), g, b, 0, st, p)
-#define S16G_BY_TAPS(MT_, NT_, SX_)                                 \
-    if (pl.ATAPS == 9) S16G_GO(MT_, NT_, SX_, 9);                   \
-    else S16G_GO(MT_, NT_, SX_, 16);
-    const int sx = q.sstride;
-    if (pl.ATAPS == 49) {
-        if (sx == 1 && pl.NT == 2) S16G_GO(1, 2, 1, 49);
-        else if (sx == 1) S16G_GO(1, 1, 1, 49);
-        else S16G_GO(1, 1, 2, 49);
-    } else if (pl.MT == 4) {
-        if (sx == 1 && pl.NT == 2) S16G_GO(4, 2, 1, 9);
-        else if (sx == 1) S16G_GO(4, 1, 1, 9);
-        else S16G_GO(4, 1, 2, 9);
-    } else if (pl.MT == 2) {
-        if (sx == 1 && pl.NT == 2) { S16G_BY_TAPS(2, 2, 1) }
-        else if (sx == 1) { S16G_BY_TAPS(2, 1, 1) }
-        else { S16G_BY_TAPS(2, 1, 2) }
-    } else {
-        if (sx == 1 && pl.NT == 2) { S16G_BY_TAPS(1, 2, 1) }
-        else if (sx == 1) { S16G_BY_TAPS(1, 1, 1) }
-        else { S16G_BY_TAPS(1, 1, 2) }
+    int maxtaps = 0;
+    for (int c = 0; c < q.ncls; ++c) maxtaps = q.ntaps[c] > maxtaps ? q.ntaps[c] : maxtaps;
+    p.aw16 = maxtaps * 4 * 32 * pl.MT;
+    const size_t lds = ((size_t)p.aw16 + 4 * (size_t)p.hp16) * 16;
+#ifdef NEMAR_HOST_EMULATION
+#define S16G_GO(MT_, NT_, SX_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_>), g, b, lds, st, p); }
+#else
+    // more than 64 KiB of dynamic LDS needs the attribute (set once per instantiation)
+#define S16G_GO(MT_, NT_, SX_)                                                                                          \
+    {                                                                                                                   \
+        static bool attr_ = false;                                                                                      \
+        if (!attr_) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);                     \
+            attr_ = true;                                                                                               \
+        }                                                                                                               \
+        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_>), g, b, lds, st, p);                                             \
     }
-#undef S16G_BY_TAPS
+#endif
+#define S16G_BY_TILE(MT_)                                           \
+    if (sx == 1 && pl.NT == 2) S16G_GO(MT_, 2, 1)                   \
+    else if (sx == 1) S16G_GO(MT_, 1, 1)                            \
+    else S16G_GO(MT_, 1, 2)
+    const int sx = q.sstride;
+    if (pl.MT == 4) { S16G_BY_TILE(4) }
+    else if (pl.MT == 2) { S16G_BY_TILE(2) }
+    else { S16G_BY_TILE(1) }
+#undef S16G_BY_TILE
 #undef S16G_GO
     if (tm) {
         (void)hipEventRecord(g_tev[g_tev_used++][1], st);

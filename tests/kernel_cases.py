@@ -247,6 +247,42 @@ def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False,
         assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
 
 
+def case_conv_s16g_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, seed=0, gscale=None):
+    """Weight + bias gradient through nemar_conv2d_bwd_weight on the general 16-bit-pipe route (csrc/conv_s16g_wgrad.hip);
+    `gscale` [K] multiplies the gradient rows (per-row running scales: rows of very different magnitude keep their accuracy)."""
+    rng = np.random.default_rng(seed)
+    C = C0 + C1
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    gy = (rng.standard_normal((N, K, OH, OW)) / np.sqrt(N * OH * OW)).astype(np.float32)
+    if gscale is not None:
+        gy = (gy * np.asarray(gscale, dtype=np.float32)[None, :, None, None]).astype(np.float32)
+    w = np.zeros((K, C, R, R))
+    _, want_gw, want_gb = O.conv2d_bwd(x.astype(np.float64), w, gy.astype(np.float64), stride, pad, _PM[pad_mode])
+    _, mag_gw, mag_gb = O.conv2d_bwd(np.abs(x).astype(np.float64), w, np.abs(gy).astype(np.float64), stride, pad, _PM[pad_mode])
+    d_x0 = be.dev(x[:, :C0])
+    d_x1 = be.dev(x[:, C0:]) if C1 else None
+    d_gy = be.dev(gy)
+    outs = []
+    with s16g_route(be):
+        for rep in range(2):
+            d_gw = be.full((K, C, R, R), 0.0)
+            d_gb = be.full((K,), 0.0)
+            ws, wsb = _ws(be, be.lib.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, R, stride, pad))
+            be.lib.conv2d_bwd_weight(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_gy), be.ptr(d_gw), be.ptr(d_gb), N, H, W, K,
+                                     OH, OW, R, R, stride, pad, pad_mode, be.ptr(ws), wsb, be.stream)
+            assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
+            outs.append((be.np(d_gw), be.np(d_gb)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), "not bitwise reproducible"
+    for got, want, mag, what in ((outs[0][0], want_gw, mag_gw, "gw"), (outs[0][1], want_gb, mag_gb, "gb")):
+        err = np.abs(got - want)
+        lim = 2e-6 * mag + 1e-30
+        if not np.all(err <= lim):
+            i = np.unravel_index(np.argmax(err / lim), err.shape)
+            raise AssertionError("conv2d_bwd_weight (s16g) %s: err %.3e > %.3e at %s (got %.6g want %.6g)" %
+                                 (what, err[i], lim[i], i, got[i], want[i]))
+
+
 def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0, R=3):
     """One wide 3x3 / stride 1 / pad 1 layer through nemar_conv2d_fwd (dgrad False) or nemar_conv2d_bwd_data with the scratch
     arena registered: the split-16 route must be eligible for the shape, and obey the same tolerance against the float64 oracle

@@ -448,3 +448,26 @@ def test_conv_s16g_transpose_forward(be, R, op):
     with K.s16g_route(be):
         K.case_conv_transpose_fwd(be, 2, 32, 24, 8, 32, R, op)
         assert be.lib.last_route() == 3
+
+
+S16G_WGRAD = [
+    # N, C0, C1, H,  W,  K,  R, stride, pad, pad_mode
+    (1, 64, 0, 6, 32, 64, 3, 1, 1, K.PAD_ZERO),         # 64 x 64 tiles, one step per row, 3 slabs
+    (2, 64, 0, 4, 64, 128, 3, 1, 1, K.PAD_REFLECT),     # reflect fold in the first / last chunk, mirrored rows, two steps per row
+    (1, 32, 0, 5, 64, 32, 3, 1, 1, K.PAD_REFLECT),      # 32 x 32 tile: the waves split the four k-steps of a 64-position step
+    (2, 64, 32, 4, 64, 32, 3, 1, 1, K.PAD_ZERO),        # two sources on a 32-channel boundary -> 32 x 32 tiles, 1 x 3 tiles
+    (1, 64, 0, 8, 64, 64, 3, 2, 1, K.PAD_ZERO),         # stride 2: parity planes of x, two shifts of gy (4 x 32 outputs)
+    (1, 32, 0, 4, 64, 64, 1, 1, 0, K.PAD_ZERO),         # 1x1
+]
+
+
+@pytest.mark.parametrize("case", S16G_WGRAD)
+def test_conv_s16g_weight_gradient(be, case):
+    """Weight + bias gradient on the 16-bit matrix pipe with the operand split inside the kernel (conv_s16g_wgrad.hip): shifted
+    gy copies from one register window, per-row running scales published as bytes, slabs summed in order."""
+    K.case_conv_s16g_bwd_weight(be, *case)
+
+
+def test_conv_s16g_weight_gradient_row_scales(be):
+    """gradient rows spanning 12 orders of magnitude: every row keeps fp32-class relative accuracy (scales are per row)"""
+    K.case_conv_s16g_bwd_weight(be, 1, 64, 0, 4, 32, 64, 3, 1, 1, K.PAD_ZERO, gscale=10.0 ** np.linspace(-6, 6, 64))

@@ -384,7 +384,7 @@ def test_conv_split16_4x4_layers(be, variant):
         be.lib.tune(21, 4)
 
 
-from test_kernels_emu import S16G_FWD, S16G_DGRAD
+from test_kernels_emu import S16G_FWD, S16G_DGRAD, S16G_WGRAD
 
 
 @pytest.mark.gpu
@@ -427,3 +427,15 @@ def test_conv_s16g_transpose_forward(be, R, op):
     with K.s16g_route(be):
         K.case_conv_transpose_fwd(be, 2, 32, 24, 8, 32, R, op)
         assert be.lib.last_route() == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", S16G_WGRAD)
+def test_conv_s16g_weight_gradient(be, case):
+    K.case_conv_s16g_bwd_weight(be, *case)
+
+
+@pytest.mark.gpu
+def test_conv_s16g_weight_gradient_row_scales(be):
+    K.case_conv_s16g_bwd_weight(be, 1, 64, 0, 4, 32, 64, 3, 1, 1, K.PAD_ZERO, gscale=10.0 ** np.linspace(-6, 6, 64))
+    K.case_conv_s16g_bwd_weight(be, 8, 64, 0, 64, 64, 128, 3, 2, 1, K.PAD_ZERO, gscale=10.0 ** np.linspace(-5, 5, 128))     # a real-sized layer
