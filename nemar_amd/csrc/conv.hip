@@ -1083,6 +1083,8 @@ static int g_split16_variant = 4;   // key 21: 4 fp16 x 3 products (default), 3 
 static thread_local int g_last_route = 0;
 static int g_config_epoch = 0;      // bumped by every nemar_tune / nemar_set_scratch: routes (and packed-weight formats) may have changed
 static int g_s16g = 1;             // key 24: general layers on the 16-bit matrix pipe with the in-kernel operand split (conv_s16g.hip)
+static int g_s16g_wgrad_first = 0;  // key 26: 1 = the in-kernel-split weight gradient also takes the wide residual-block layers (stand-alone 374 vs
+                                    // 393 us per call, but 44.3 vs 41.8 ms per step inside the bench: off)
 static long long g_s16g_min_mmac = 30;   // key 25: ... above this many million multiply-adds (tiny layers are launch-bound either way)
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
@@ -2098,7 +2100,7 @@ NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, i
         if (f3 > fl) fl = f3;
     }
     if (nemar_s16g_wgrad_eligible(N, C, 0, H, W, K, OH, OW, R, S, stride, pad, BORDER_ZERO)) {      // (slab count: same for any channel split)
-        const size_t f6 = (size_t)nemar_s16g_wgrad_slabs_max(N, C, K, OH) * ((size_t)K * J + K);
+        const size_t f6 = (size_t)nemar_s16g_wgrad_slabs_max(N, C, K, OH, W, stride) * ((size_t)K * J + K);
         if (f6 > fl) fl = f6;
     }
     if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {       // slabs of the split-16 route + bias partials
@@ -2147,6 +2149,17 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
+    const bool s16g_wg = part && s16g_worth_it((long long)N * OH * OW * K * (C0 + C1) * R * S) &&
+        nemar_s16g_wgrad_eligible(N, C0, C1, H, W, K, OH, OW, R, S, stride, pad, pad_mode);
+    const bool split16_wg = g_split16 && g_split16_variant == 4 && part && C1 == 0 && split16_worth_it(N, OH, OW, K, C0, R, S) &&
+        nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
+        (R == 3 || pad_mode == BORDER_ZERO) && g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K, R);
+    if (s16g_wg && (g_s16g_wgrad_first || !split16_wg)) {
+        nemar_s16g_wgrad(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, stride, pad_mode, part, g_dbg, st);
+        g_last_route = 3;
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (16-bit pipe, in-kernel split)");
+        return NEMAR_OK;
+    }
     if (g_split16 && g_split16_variant == 4 && part && C1 == 0 && split16_worth_it(N, OH, OW, K, C0, R, S) &&
         nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
         (R == 3 || pad_mode == BORDER_ZERO) && g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K, R)) {
@@ -2160,13 +2173,6 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         }
         g_last_route = 2;
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (split-16)");
-        return NEMAR_OK;
-    }
-    if (part && s16g_worth_it((long long)N * OH * OW * K * (C0 + C1) * R * S) &&
-        nemar_s16g_wgrad_eligible(N, C0, C1, H, W, K, OH, OW, R, S, stride, pad, pad_mode)) {
-        nemar_s16g_wgrad(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, stride, pad_mode, part, st);
-        g_last_route = 3;
-        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (16-bit pipe, in-kernel split)");
         return NEMAR_OK;
     }
     if (g_wgrad != 1 && nemar_wgrad2_eligible(K, OH, OW, gy)) {
@@ -2239,6 +2245,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 20) { g_split16 = value != 0; return NEMAR_OK; }
     if (key == 24) { g_s16g = value != 0; return NEMAR_OK; }
     if (key == 25) { g_s16g_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
+    if (key == 26) { g_s16g_wgrad_first = value != 0; return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = (value == 0 || value == 3) ? value : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }

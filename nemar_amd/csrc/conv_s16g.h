@@ -46,11 +46,11 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
 // ---- weight + bias gradient (conv_s16g_wgrad.hip) ----
 bool nemar_s16g_wgrad_eligible(int N, int C0, int C1, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
                                int pad_mode);
-int nemar_s16g_wgrad_slabs(int N, int C0, int C1, int K, int OH);
-int nemar_s16g_wgrad_slabs_max(int N, int C, int K, int OH);            // ... whatever the split C0 + C1 = C (workspace queries)         // slabs of K C R S (+ K for the bias) floats in `part`
+int nemar_s16g_wgrad_slabs(int N, int C0, int C1, int K, int OH, int W, int stride);
+int nemar_s16g_wgrad_slabs_max(int N, int C, int K, int OH, int W, int stride);            // ... whatever the split C0 + C1 = C (workspace queries)         // slabs of K C R S (+ K for the bias) floats in `part`
 // gw [K][C][KS][KS] += dW, gb [K] += sum gy (gb may be null); slabs summed in order (bitwise reproducible)
 void nemar_s16g_wgrad(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N, int H, int W,
-                      int K, int OH, int OW, int KS, int stride, int pad_mode, float* part, hipStream_t st);
+                      int K, int OH, int OW, int KS, int stride, int pad_mode, float* part, int dbg, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
 
 // measurement hook shared with conv_split16.hip (bench.py's roofline entry)

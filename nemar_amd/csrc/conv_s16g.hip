@@ -47,15 +47,6 @@ constexpr int BWORDS = 3568;          // LDS words of the halo region: 4 (2 plan
 constexpr int NSMAX = 7;              // halo pixels per loader thread (128 threads per k group)
 constexpr int TEXP = 14;              // scaled magnitudes stay below 2^15
 
-__device__ __forceinline__ unsigned short f16_rn(float v) {
-    const _Float16 h = (_Float16)v;
-    return __builtin_bit_cast(unsigned short, h);
-}
-__device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned short& l) {
-    h = f16_rn(v);
-    const float r = v - (float)__builtin_bit_cast(_Float16, h);
-    l = f16_rn(r);
-}
 // v s = h + l (+ e): both halves of eight values as two 16-byte words.  v * s is exact (s a power of two), so fmaf(v, s, -h) is the
 // exact residual — written as an fma so that hipcc selects v_fma_mix (fp16 operand read in place) instead of convert + multiply + subtract
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -70,14 +61,6 @@ __device__ __forceinline__ void split8(const float* v, float s, u32x4& hi, u32x4
         hi[j] = __builtin_bit_cast(unsigned, h);
         lo[j] = __builtin_bit_cast(unsigned, l);
     }
-}
-__device__ __forceinline__ u32x4 pack8(const unsigned short* b) {
-    u32x4 o;
-    o[0] = (unsigned)b[0] | ((unsigned)b[1] << 16);
-    o[1] = (unsigned)b[2] | ((unsigned)b[3] << 16);
-    o[2] = (unsigned)b[4] | ((unsigned)b[5] << 16);
-    o[3] = (unsigned)b[6] | ((unsigned)b[7] << 16);
-    return o;
 }
 __device__ __forceinline__ float pow2f(int biased) {          // 2^(biased - 127); 0 below the normal range
     return biased < 1 ? 0.f : __builtin_bit_cast(float, (unsigned)(biased > 254 ? 254 : biased) << 23);
@@ -127,6 +110,7 @@ struct S16gParams {
     const float* bias; float* dst0; float* dst1; int M, M0, N;
     int OHf, OWf, osy, osx;
     int border, act; float slope;
+    int ncls, xcd;
     int dbg;                                 // ablation bits (nemar_tune key 2, tools/ only): 1 no tap loop, 2 no source loads, 4 no conversion
     int TW, RT, wshift, tiles_x, tiles_y, mblks, nchunks;
     int HR, HC, HCP, HCH, hp16, dymin, dxmin;
@@ -137,51 +121,66 @@ struct S16gParams {
     int tapoff[S16G_MAX_TAPS];               // halo word offset of tap t of class c at [c * S16G_CLS_TAPS + t] (one class: all 64)
 };
 
-// packed weights: word ((((cls * nchunks + chunk) * mblks + mblk) * ntaps_cap + tap) * 2 + plane) * 2 + kg) * MB + m, element j of the
-// word = reduction channel chunk * 16 + kg * 8 + j; ntaps_cap = taps of the class (classes are packed one after the other)
-__global__ __launch_bounds__(256) void s16g_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int M, int Cred, int MB,
-                                                        int mblks, int nchunks, int ntaps, long long wsm, long long wsc,
-                                                        const unsigned* maxbits, const int* __restrict__ wofs_dev, int wofs0,
-                                                        int wofs_stride) {
-    // tap offsets are an arithmetic function of the tap for every caller (r * S + s walks): passed as a small table in LDS
-    __shared__ int s_wofs[S16G_MAX_TAPS];
-    (void)wofs0; (void)wofs_stride;
-    for (int i = threadIdx.x; i < S16G_MAX_TAPS; i += blockDim.x) s_wofs[i] = i < ntaps ? wofs_dev[i] : 0;
-    __syncthreads();
-    const float scale = weight_scale(*maxbits);
-    const long long total = (long long)nchunks * mblks * ntaps * 2 * MB;          // (kg, m) pairs x taps ...: one thread = both planes
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int m = (int)(t % MB);
-        long long q = t / MB;
-        const int kg = (int)(q & 1);
-        q >>= 1;
-        const int tap = (int)(q % ntaps);
-        q /= ntaps;
-        const int mblk = (int)(q % mblks), chunk = (int)(q / mblks);
-        const int mg = mblk * MB + m;
-        unsigned short h[8], l[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int cr = chunk * 16 + kg * 8 + j;
-            const float v = (mg < M && cr < Cred) ? w[(long long)mg * wsm + (long long)cr * wsc + s_wofs[tap]] : 0.f;
-            split2_f16(v * scale, h[j], l[j]);
-        }
-        u32x4* const o = out + ((((long long)chunk * mblks + mblk) * ntaps + tap) * 4 + kg) * MB + m;
-        o[0] = pack8(h);
-        o[2 * MB] = pack8(l);
-    }
-}
-
-// max |w| as a bit pattern (atomic max into a zeroed word)
+// max |w| of a weight tensor as a bit pattern, stage 1: ABSMAX_WGS workgroups, one partial each (plain stores — no zero-fill, no
+// atomics); the pack kernel and the convolution take the maximum of the partials themselves
+constexpr int ABSMAX_WGS = 16;
 __global__ __launch_bounds__(256) void s16g_absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+    __shared__ unsigned red[4];
     unsigned m = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += 256ll * ABSMAX_WGS) {
         const unsigned u = __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu;
         m = max(m, u < 0x7f800000u ? u : 0u);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+__device__ __forceinline__ unsigned absmax_of_partials(const unsigned* part) {
+    const u32x4* const q = reinterpret_cast<const u32x4*>(part);
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < ABSMAX_WGS / 4; ++i) {
+        const u32x4 v = q[i];
+        m = max(max(m, v[0]), max(max(v[1], v[2]), v[3]));
+    }
+    return m;
+}
+
+// packed weights of class c: word (((chunk * mblks + mblk) * ntaps[c] + tap) * 2 + plane) * 2 + kg) * MB + m behind c * cls_words; element j
+// of the word = reduction channel chunk * 16 + kg * 8 + j.  One launch for all classes (grid.y = class).
+__global__ __launch_bounds__(256) void s16g_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int M, int Cred, int MB,
+                                                        int mblks, int nchunks, long long wsm, long long wsc, long long cls_words,
+                                                        const unsigned* maxbits, S16gProblem q) {
+    __shared__ int s_wofs[S16G_MAX_TAPS];
+    const int cls = blockIdx.y, ntaps = q.ntaps[cls];
+    for (int i = threadIdx.x; i < S16G_MAX_TAPS; i += blockDim.x) s_wofs[i] = i < ntaps ? q.wofs[cls][i] : 0;
+    __syncthreads();
+    const float scale = weight_scale(absmax_of_partials(maxbits));
+    out += (size_t)cls * cls_words;
+    const long long total = (long long)nchunks * mblks * ntaps * 2 * MB;          // one thread = both planes of a word
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(t % MB);
+        long long r = t / MB;
+        const int kg = (int)(r & 1);
+        r >>= 1;
+        const int tap = (int)(r % ntaps);
+        r /= ntaps;
+        const int mblk = (int)(r % mblks), chunk = (int)(r / mblks);
+        const int mg = mblk * MB + m;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cr = chunk * 16 + kg * 8 + j;
+            v[j] = (mg < M && cr < Cred) ? w[(long long)mg * wsm + (long long)cr * wsc + s_wofs[tap]] : 0.f;
+        }
+        u32x4 hi, lo;
+        split8(v, scale, hi, lo);
+        u32x4* const o = out + ((((long long)chunk * mblks + mblk) * ntaps + tap) * 4 + kg) * MB + m;
+        o[0] = hi;
+        o[2 * MB] = lo;
+    }
 }
 
 // MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride.
@@ -200,8 +199,14 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     u32x4* const Bs = smem + p.aw16;
 
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int cls = blockIdx.z, mblk = blockIdx.y;
+    // 1-D grid; consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous run of (tile, class, channel block)
+    // triples, so that the channel blocks / classes of a tile (same halo) and neighbouring tiles (shared halo rows) share one L2
     int t = blockIdx.x;
+    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
+    const int mblk = t % p.mblks;
+    t /= p.mblks;
+    const int cls = t % p.ncls;
+    t /= p.ncls;
     const int txi = t % p.tiles_x;
     t /= p.tiles_x;
     const int tyi = t % p.tiles_y, n = t / p.tiles_y;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
 
     // ---- epilogue: take the two power-of-two scales out (exact), bias, activation ----
     if (p.dbg & 128) return;
-    const float u1 = pow2f(E - TEXP), u2 = 1.f / weight_scale(*p.wmax);
+    const float u1 = pow2f(E - TEXP), u2 = 1.f / weight_scale(absmax_of_partials(p.wmax));
     const size_t plane = (size_t)p.OHf * p.OWf;
     const int M1 = p.M - p.M0;
     float bv[MT][16];                  // the bias of this lane's rows: all loads in flight at once (one wait, not one per row)
@@ -483,7 +488,7 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     S16gPlan pl;
     pl.ok = 0;
     const int C = q.C0 + q.C1;
-    if (q.ncls < 1 || q.ncls > S16G_MAX_CLS || (q.sstride != 1 && q.sstride != 2) || q.M < 16 || C < 1) return pl;
+    if (q.ncls < 1 || q.ncls > S16G_MAX_CLS || (q.sstride != 1 && q.sstride != 2) || q.M < 5 || C < 1) return pl;       // (<= 4 rows: the narrow VALU kernels)
     if (q.ncls > 1 && q.sstride != 1) return pl;
     if (q.act == ACT_TANH) return pl;
     int maxtaps = 0, dymin = 1 << 20, dymax = -(1 << 20), dxmin = 1 << 20, dxmax = -(1 << 20), OH = 0, OW = 0;
@@ -536,7 +541,7 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
         if (best >= 0) break;
     }
     if (best < 0) return pl;
-    if ((long long)pl.tiles_x * pl.tiles_y * q.N >= (1ll << 31) || pl.mblks > 65535) return pl;
+    if ((long long)pl.tiles_x * pl.tiles_y * q.N * pl.mblks * q.ncls >= (1ll << 31)) return pl;
     if ((long long)q.Hs * q.Ws >= (1ll << 30)) return pl;
     pl.dymin = dymin;
     pl.dxmin = dxmin;
@@ -547,17 +552,13 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
 }
 
 size_t nemar_s16g_pack_bytes(const S16gProblem& q, const S16gPlan& pl) {
-    return pl.pack_words_per_class * 16 * (size_t)q.ncls + 64 + sizeof(int) * S16G_MAX_TAPS * S16G_MAX_CLS;
+    return pl.pack_words_per_class * 16 * (size_t)q.ncls + 64;
 }
 
 namespace {
-// layout of the packed buffer: [class 0 words][class 1 words]...[max word, 64 bytes][tap offset tables of the pack kernel]
+// layout of the packed buffer: [class 0 words][class 1 words]...[max word, 64 bytes]
 unsigned* pack_max_word(const S16gProblem& q, const S16gPlan& pl, void* packed) {
     return (unsigned*)((char*)packed + pl.pack_words_per_class * 16 * (size_t)q.ncls);
-}
-__global__ void s16g_wofs_kernel(int* out, S16gProblem q) {
-    const int c = blockIdx.x;
-    for (int t = threadIdx.x; t < S16G_MAX_TAPS; t += blockDim.x) out[c * S16G_MAX_TAPS + t] = t < q.ntaps[c] ? q.wofs[c][t] : 0;
 }
 }  // namespace
 
@@ -565,23 +566,20 @@ void nemar_s16g_pack(const S16gProblem& q, const S16gPlan& pl, const float* w, l
                      hipStream_t st) {
     const int C = q.C0 + q.C1, MB = 32 * pl.MT;
     unsigned* const mw = pack_max_word(q, pl, packed);
-    int* const wofs_dev = (int*)((char*)mw + 64);
-    (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
     // the max runs over the whole weight tensor the rows / channels / taps are drawn from: extent = last addressed element + 1
     long long maxofs = 0;
-    for (int c = 0; c < q.ncls; ++c)
+    int maxtaps = 0;
+    for (int c = 0; c < q.ncls; ++c) {
+        maxtaps = q.ntaps[c] > maxtaps ? q.ntaps[c] : maxtaps;
         for (int t = 0; t < q.ntaps[c]; ++t)
             if (q.wofs[c][t] > maxofs) maxofs = q.wofs[c][t];
-    const long long n = (long long)(q.M - 1) * wsm + (long long)(C - 1) * wsc + maxofs + 1;
-    int grid = nemar_stream_grid(n, 256 * 4);
-    hipLaunchKernelGGL(s16g_absmax_kernel, dim3(grid), dim3(256), 0, st, w, n, mw);
-    hipLaunchKernelGGL(s16g_wofs_kernel, dim3(q.ncls), dim3(64), 0, st, wofs_dev, q);
-    for (int c = 0; c < q.ncls; ++c) {
-        const long long total = (long long)pl.nchunks * pl.mblks * q.ntaps[c] * 2 * MB;
-        hipLaunchKernelGGL(s16g_pack_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w,
-                           (u32x4*)packed + (size_t)c * pl.pack_words_per_class, q.M, C, MB, pl.mblks, pl.nchunks, q.ntaps[c], wsm, wsc,
-                           (const unsigned*)mw, (const int*)(wofs_dev + c * S16G_MAX_TAPS), 0, 0);
     }
+    const long long n = (long long)(q.M - 1) * wsm + (long long)(C - 1) * wsc + maxofs + 1;
+    hipLaunchKernelGGL(s16g_absmax_kernel, dim3(ABSMAX_WGS), dim3(256), 0, st, w, n, mw);
+    const long long total = (long long)pl.nchunks * pl.mblks * maxtaps * 2 * MB;
+    S16gProblem qq = q;                      // (pointers unused by the kernel)
+    hipLaunchKernelGGL(s16g_pack_kernel, dim3(nemar_stream_grid(total, 256), q.ncls), dim3(256), 0, st, w, (u32x4*)packed, q.M, C, MB,
+                       pl.mblks, pl.nchunks, wsm, wsc, (long long)pl.pack_words_per_class, (const unsigned*)mw, qq);
 }
 
 void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packed, hipStream_t st) {
@@ -613,7 +611,9 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
             const int ddy = q.dy[c][t] - pl.dymin, ddx = q.dx[c][t] - pl.dxmin;
             p.tapoff[c * S16G_CLS_TAPS + t] = ddy * pl.HCP + (q.sstride == 2 ? (ddx & 1) * pl.HCH + (ddx >> 1) : ddx);
         }
-    const dim3 g(pl.tiles_x * pl.tiles_y * q.N, pl.mblks, q.ncls), b(256);
+    const dim3 g(pl.tiles_x * pl.tiles_y * q.N * pl.mblks * q.ncls), b(256);
+    p.ncls = q.ncls;
+    p.xcd = g.x % 8 == 0 ? 1 : 0;
     const bool tm = g_timing && g_tev_used < MAX_TIMED;
     if (tm) {
         while (g_tev_made <= g_tev_used) {
