@@ -1820,7 +1820,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         S16gProblem q;
         S16gPlan pl;
         if (s16g_fwd_problem(q, pl, N, C0, C1, H, W, K, R, S, stride, pad, pad_mode, act, slope)) {
-            q.src0 = x0; q.src1 = x1; q.dst0 = y; q.dst1 = nullptr; q.bias = bias; q.dbg = g_dbg;
+            q.src0 = x0; q.src1 = x1; q.dst0 = y; q.dst1 = nullptr; q.bias = bias; q.dbg = g_dbg; q.tl = g_tl;
             if (!prepacked) nemar_s16g_pack(q, pl, w, (long long)C * R * S, (long long)R * S, workspace, st);
             nemar_s16g_conv(q, pl, workspace, st);
             g_last_route = 3;
@@ -2246,6 +2246,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 24) { g_s16g = value != 0; return NEMAR_OK; }
     if (key == 25) { g_s16g_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 26) { g_s16g_wgrad_first = value != 0; return NEMAR_OK; }
+    if (key == 27) { nemar_s16g_tune(0, value); return NEMAR_OK; }
+    if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = (value == 0 || value == 3) ? value : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }

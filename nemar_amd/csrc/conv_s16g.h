@@ -20,6 +20,7 @@ struct S16gProblem {
     int act; float slope;
     int border;                                            // 0 zero, 1 reflect (source index mirrored)
     int dbg;                                               // ablation bits for tools/ (0 in the product)
+    long long* tl;                                         // timeline buffer (NEMAR_TIMELINE builds) or null
     int sstride;                                           // source stride (1 or 2)
     int OHf, OWf, osy, osx;                                // destination plane extents, output stride
     int ncls;
@@ -52,6 +53,8 @@ int nemar_s16g_wgrad_slabs_max(int N, int C, int K, int OH, int W, int stride); 
 void nemar_s16g_wgrad(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N, int H, int W,
                       int K, int OH, int OW, int KS, int stride, int pad_mode, float* part, int dbg, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
+
+void nemar_s16g_tune(int key, int value);      // tile-plan switches for A/B runs (nemar_tune keys 27, 28)
 
 // measurement hook shared with conv_split16.hip (bench.py's roofline entry)
 void nemar_s16g_timer(int on);

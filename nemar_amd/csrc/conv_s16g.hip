@@ -111,6 +111,7 @@ struct S16gParams {
     int OHf, OWf, osy, osx;
     int border, act; float slope;
     int ncls, xcd;
+    long long* tl;                           // NEMAR_TIMELINE builds: cycle stamps of one workgroup (tools/timeline_s16g.py)
     int dbg;                                 // ablation bits (nemar_tune key 2, tools/ only): 1 no tap loop, 2 no source loads, 4 no conversion
     int TW, RT, wshift, tiles_x, tiles_y, mblks, nchunks;
     int HR, HC, HCP, HCH, hp16, dymin, dxmin;
@@ -298,9 +299,15 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     int E = 0;                                             // running biased exponent of the tile's source maximum
+#ifdef NEMAR_TIMELINE
+#define S16G_STAMP(i_) if (p.tl != nullptr && blockIdx.x == 8 && lane == 0 && chunk < 8) p.tl[(wid * 8 + chunk) * 8 + (i_)] = clock64();
+#else
+#define S16G_STAMP(i_)
+#endif
     S16G_LOAD(0)
     for (int chunk = 0; chunk < ((p.dbg & 64) ? 0 : p.nchunks); ++chunk) {
         // -- the chunk's maximum over the four waves (its loads were issued a whole chunk ago) --
+        S16G_STAMP(0)
         S16G_MASK(chunk)
         if (!(p.dbg & 16)) {
             // |v| as floats: one v_max3_f32 per two elements (fmaxf ignores NaN; an infinity sends this thread through the slow
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the max word is written
         if (!(p.dbg & 32)) __builtin_amdgcn_s_barrier();   // (also: every wave has left the previous chunk's tap loop)
+        S16G_STAMP(1)
         S16G_WEIGHTS(chunk)                                // land during the conversion below
         {
             const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
@@ -356,10 +364,13 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         }
         // the weight copies are the only vector-memory operations in flight here: wait for them, THEN issue the next chunk's source
         // loads (nothing waits for those until the top of the next iteration: they have the whole tap loop to arrive)
+        S16G_STAMP(2)
         wait_vmem();
+        S16G_STAMP(3)
         if (chunk + 1 < p.nchunks) S16G_LOAD(chunk + 1)
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's halo words are written
         __builtin_amdgcn_s_barrier();                      // halo planes + weights of this chunk are in LDS for every wave
+        S16G_STAMP(4)
         // fragments of tap t + 1 are read while the MFMAs of tap t issue (two register sets)
         u32x4 fa[2][MT][2], fb[2][NT][2];
 #define S16G_READ(set_, tap_)                                                                                           \
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             S16G_MMA(1)
         }
         if (ntaps & 1) { S16G_MMA(0) }
+        S16G_STAMP(5)
 #undef S16G_READ
 #undef S16G_MMA
         // (the barrier at the top of the next chunk keeps the LDS regions until every wave is done with them)
@@ -484,6 +496,13 @@ int nemar_s16g_timer_read(double* total_ms, double* total_flop) {
     return n;
 }
 
+static int g_s16g_maxmt = 4;      // widest channel tile (x 32): nemar_s16g_tune(0, v)
+static int g_s16g_lds_pref = 0;   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
+void nemar_s16g_tune(int key, int value) {
+    if (key == 0) g_s16g_maxmt = value == 1 || value == 2 ? value : 4;
+    if (key == 1) g_s16g_lds_pref = value;
+}
+
 S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     S16gPlan pl;
     pl.ok = 0;
@@ -507,6 +526,7 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     if (OH < 1 || OW < 24 || OH >= 32768 || OW >= 32768) return pl;
     // channel tile: as wide as the layer, but the LDS must hold a chunk's weights for every tap (ATAPS x MB x 64 B) next to the halo
     pl.MT = q.M <= 32 ? 1 : (q.M <= 64 ? 2 : 4);
+    if (pl.MT > g_s16g_maxmt) pl.MT = g_s16g_maxmt;
     if (maxtaps > 9 && pl.MT == 4) pl.MT = 2;
     if (maxtaps > 16 && pl.MT == 2) pl.MT = 1;
     pl.ATAPS = maxtaps;
@@ -529,7 +549,8 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
             const int tx = (OW + TW - 1) / TW, ty = (OH + RT - 1) / RT;
             // cost: halo elements loaded + converted per launch (short rows coalesce badly: 16 elements of overhead per row),
             // plus the masked part of the tiles
-            const long long cost = (long long)tx * ty * (HR * HC + 16 * HR + NP / 2);
+            long long cost = (long long)tx * ty * (HR * HC + 16 * HR + NP / 2);
+            if (g_s16g_lds_pref && (maxtaps * 4 * MB + 4 * HR * HCP) * 16 > 80 * 1024 - 256) cost = cost * 3 / 2;      // one workgroup per CU only
             const long long wgs = (long long)tx * ty * q.N * pl.mblks * q.ncls;
             if (NT == 2 && wgs < 256) continue;              // few tiles: prefer the smaller tile
             if (best < 0 || cost < best) {
@@ -589,7 +610,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     p.wmax = pack_max_word(q, pl, const_cast<void*>(packed));
     p.bias = q.bias; p.dst0 = q.dst0; p.dst1 = q.dst1; p.M = q.M; p.M0 = q.M0; p.N = q.N;
     p.OHf = q.OHf; p.OWf = q.OWf; p.osy = q.osy; p.osx = q.osx;
-    p.border = q.border; p.act = q.act; p.slope = q.slope; p.dbg = q.dbg;
+    p.border = q.border; p.act = q.act; p.slope = q.slope; p.dbg = q.dbg; p.tl = q.tl;
     p.TW = pl.TW; p.RT = pl.RT; p.wshift = ilog2(pl.TW); p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.mblks = pl.mblks;
     p.nchunks = pl.nchunks;
     p.HR = pl.HR; p.HC = pl.HC; p.HCP = pl.HCP; p.HCH = pl.HCH; p.hp16 = pl.HR * pl.HCP; p.dymin = pl.dymin; p.dxmin = pl.dxmin;
