@@ -1,6 +1,7 @@
 """bench.py — NeMAR training-step throughput on MI355X (BASELINE.json metric: train images/sec, 256x256 A/B pairs).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU over RCCL — under torch.distributed.run, or, started
+                                                        directly, bench.py spawns its N ranks itself: nemar_amd/launch.py)
 
 A step = one NEMARModel.optimize_parameters() (forward, discriminator update, translation+registration update, three
 fused Adam steps) on one synthetic batch already resident in HBM.  Workload = BASELINE.json configs[1]:
@@ -121,10 +122,16 @@ def main():
                     help='extra reference-style option for other BASELINE configs, e.g. --opt=--multi_resolution --opt=2')
     a = ap.parse_args()
 
+    from nemar_amd import launch
+    if a.gpus > 1 and not launch.under_launcher():
+        # started directly (`python bench.py --gpus N`): become N ranks, one per GPU, over RCCL — never a silent 1-rank run
+        raise SystemExit(launch.spawn_local_ranks(a.gpus))
     from nemar_amd import distributed as dist
     rank, world, local = dist.init_from_env()
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit('rank %d: local rank %d has no GPU (%d visible)' % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -183,10 +190,14 @@ def main():
     lib.kernel_timer_read(ctypes.byref(tk_ms_c), ctypes.byref(tk_fl_c), ctypes.byref(tk_n_c))
     lib.kernel_timer(0)
     tk_ms, tk_flop, tk_n = tk_ms_c.value, tk_fl_c.value, tk_n_c.value
+    rank_ms = [dt / a.steps * 1e3]
+    buckets = sum(len(getattr(model, n).launched) for n in ("sync_T", "sync_D", "sync_R"))
     if multi:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = dt
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)         # every rank's own wall time
+        rank_ms = [float(x) / a.steps * 1e3 for x in t.tolist()]
+        dt = float(t.max().item())
     losses = model.get_current_losses()
     if multi:
         torch.distributed.barrier()
@@ -210,10 +221,13 @@ def main():
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world, "stn_cfg": opt.stn_cfg,
                    "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"},
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
+        "rank_ms_per_step": rank_ms,                      # one entry per rank: the N > 1 run cannot degrade to one rank unnoticed
+        "dist": {"backend": "nccl (RCCL)" if multi else None, "buckets_launched_last_step": buckets,
+                 "launcher": "self-spawned ranks" if os.environ.get("NEMAR_SPAWNED") else ("torchrun" if multi else None)},
     }
     if os.environ.get("NEMAR_BENCH_DUMP_LOSSES"):       # tests: the losses of the last step + how many gradient buckets went out
         out["losses"] = {k: float(v) for k, v in losses.items()}
-        out["dist_buckets_launched"] = sum(len(getattr(model, n).launched) for n in ("sync_T", "sync_D", "sync_R"))
+        out["dist_buckets_launched"] = buckets
     C = 256
     hw = (a.size // 4) ** 2
     # HBM traffic comes from separate rocprofv3 --pmc passes over the same kernels (tools/profile_round.sh); it is

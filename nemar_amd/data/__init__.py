@@ -39,7 +39,12 @@ class DeviceBatchLoader:
     def __init__(self, opt):
         self.opt = opt
         self.dataset = find_dataset_using_name(opt.dataset_mode)(opt)
-        print("dataset [%s] was created" % type(self.dataset).__name__)
+        # data parallel (nemar_amd/train.py): opt.batch_size is the GLOBAL batch; every rank walks the SAME epoch order (a shuffle
+        # seeded by data_seed + epoch) and takes its equal slice of each global batch
+        self.rank, self.world = int(getattr(opt, 'shard_rank', 0)), int(getattr(opt, 'shard_world', 1))
+        self.epoch = 0
+        if self.rank == 0:
+            print("dataset [%s] was created" % type(self.dataset).__name__)
 
     def load_data(self):
         return self
@@ -53,9 +58,16 @@ class DeviceBatchLoader:
         n, bs = len(self), self.opt.batch_size
         order = list(range(n))
         if not self.opt.serial_batches:
-            random.shuffle(order)
+            # (one process: the reference's unseeded shuffle would do; ranks must agree on the order)
+            random.Random(int(getattr(self.opt, 'data_seed', 1234)) * 1000003 + self.epoch).shuffle(order)
+        self.epoch += 1
+        per = bs // self.world
         for i in range(0, n, bs):
             idx = order[i:i + bs]
+            if self.world > 1:
+                if len(idx) < bs:
+                    break                       # a ragged last batch cannot be cut into equal shards (mean of means != mean)
+                idx = idx[self.rank * per:(self.rank + 1) * per]
             if hasattr(self.dataset, 'batch'):
                 yield self.dataset.batch(idx)
             else:

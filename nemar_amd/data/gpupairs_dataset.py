@@ -27,7 +27,8 @@ class GpuPairsDataset(BaseDataset):
     def __init__(self, opt):
         BaseDataset.__init__(self, opt)
         self.device = torch.device('cuda', opt.gpu_ids[0]) if opt.gpu_ids else torch.device('cuda')
-        self.rng = random.Random(getattr(opt, 'data_seed', 1234))
+        # crop positions / flips: one stream per rank (every rank augments its own samples)
+        self.rng = random.Random(getattr(opt, 'data_seed', 1234) + 7919 * int(getattr(opt, 'shard_rank', 0)))
         size = max(opt.crop_size, getattr(opt, 'load_size', opt.crop_size))
         if self.root == 'synthetic':
             m = int(getattr(opt, 'pool_size_pairs', 64))

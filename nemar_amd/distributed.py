@@ -106,17 +106,32 @@ class GradSync:
         for p in opt.params:
             self.n_params[self.bucket_of[id(p)]] += 1
         self.active = False
+        self.counting = False
+        self.uses = {}
         self.works = []
         self.launched = []
         self._side = None
         for p in opt.params:
             p._grad_sync = self
 
-    def begin(self, expected=1):
+    def count_uses(self):
+        """Start counting how often each parameter is applied in the forward passes that follow (ops.conv2d & co. call
+        note_use): begin() without an argument then expects exactly that many gradient contributions per parameter — no
+        constants that mirror the model's call pattern."""
+        self.uses = {}
+        self.counting = is_distributed()
+
+    def note_use(self, param):
+        if self.counting:
+            k = id(param)
+            self.uses[k] = self.uses.get(k, 0) + 1
+
+    def begin(self, expected=None):
+        self.counting = False
         if not is_distributed():
             return
         self.active = True
-        self.expected = int(expected)
+        self.expected = None if expected is None else int(expected)
         self.seen = {}
         self.remaining = list(self.n_params)
         self.works = []
@@ -129,10 +144,11 @@ class GradSync:
         k = id(param)
         c = self.seen.get(k, 0) + 1
         self.seen[k] = c
-        if c > self.expected:
+        expected = self.uses.get(k, 0) if self.expected is None else self.expected
+        if c > expected:
             raise RuntimeError("GradSync: parameter received %d gradient contributions, %d were announced — its bucket has "
-                               "already been all-reduced" % (c, self.expected))
-        if c == self.expected:
+                               "already been all-reduced" % (c, expected))
+        if c == expected:
             b = self.bucket_of[k]
             self.remaining[b] -= 1
             if self.remaining[b] == 0:

@@ -61,7 +61,10 @@ def _loss_property(name):
     key = '_lazy_loss_' + name
 
     def get(self):
-        return self.__dict__[key].value()
+        try:
+            return self.__dict__[key].value()
+        except KeyError:        # as a plain attribute of the reference would: hasattr / getattr(default) keep working
+            raise AttributeError('loss_%s has not been computed yet (no optimize_parameters() call so far)' % name) from None
 
     def put(self, parts):
         self.__dict__[key] = parts if isinstance(parts, _LazyLoss) else _LazyLoss([(parts, 1.0)])
@@ -287,11 +290,17 @@ class NEMARModel(BaseModel):
                          [(self.stn_reg_term, float(opt.lambda_smooth))])
 
     def optimize_parameters(self):
+        # data parallel: how many gradient contributions each parameter will receive is COUNTED while the forward passes run
+        # (T: once batched / twice; every discriminator: once batched / three times) — GradSync launches a bucket's all-reduce when
+        # its last contribution has been issued
+        self.sync_T.count_uses()
+        self.sync_R.count_uses()
         self.forward()
         # D step
         self.set_requires_grad([self.netT, self.netR], False)
         self.optimizer_D.zero_grad()
-        self.sync_D.begin(expected=1 if self._batched else 3)     # real, fake_TR, fake_RT passes through every discriminator
+        self.sync_D.count_uses()
+        self.sync_D.begin()
         self.backward_D()
         self.sync_D.finish()
         self.optimizer_D.step()
@@ -300,8 +309,8 @@ class NEMARModel(BaseModel):
         self.set_requires_grad([self.netD, *self.netD_multiresolution], False)
         self.optimizer_R.zero_grad()
         self.optimizer_T.zero_grad()
-        self.sync_T.begin(expected=1 if self._batched else 2)     # T(a) and T(R(a))
-        self.sync_R.begin(expected=1)
+        self.sync_T.begin()
+        self.sync_R.begin()
         self.backward_T_and_R()
         self.sync_R.finish()
         self.sync_T.finish()

@@ -186,6 +186,13 @@ def grad_ready(param):
         gs.ready(param)
 
 
+def _note_use(param):
+    """`param` is applied once more in a forward pass (GradSync counts how many gradient contributions to expect)."""
+    gs = getattr(param, '_grad_sync', None)
+    if gs is not None and param is not None:
+        gs.note_use(param)
+
+
 def _grad_buffer(param):
     """param.grad as an accumulation target.  Parameters owned by a FlatAdam accumulate into their view of the optimizer's
     flat gradient buffer: if user code re-seated or cleared `.grad` (`p.grad = None`, `zero_grad(set_to_none=True)` of some
@@ -237,6 +244,9 @@ class _Conv2d(Function):
         ctx.xmax = xmax
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
+        _note_use(weight)
+        if bias is not None:
+            _note_use(bias)
         ctx.cfg = (stride, pad, pad_mode, act, slope)
         return y
 
@@ -338,6 +348,9 @@ class _ConvTranspose2d(Function):
                           PAD_ZERO, _p(ws), wsb, hit, _stream())
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
+        _note_use(weight)
+        if bias is not None:
+            _note_use(bias)
         ctx.cfg = (stride, pad, act, slope)
         return y
 

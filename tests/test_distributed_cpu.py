@@ -109,6 +109,28 @@ def _sync_worker(rank, world, port, out):
         sync.begin(expected=1)
         ops.grad_ready(params[-1])
         ops.grad_ready(params[-1])
+    sync.active = False
+    # counted expectations (what NEMARModel uses): the forward passes announce every application of a parameter, begin() without
+    # an argument then waits for exactly that many contributions — the last layer is applied three times, the others twice
+    opt.zero_grad()
+    sync.count_uses()
+    for pas in range(3):
+        for i, p in enumerate(params):
+            if pas < 2 or i >= len(params) - 2:
+                ops._note_use(p)
+    sync.begin()
+    order = []
+    for pas in range(3):
+        for i in range(len(params) - 1, -1, -1):
+            if pas < 2 or i >= len(params) - 2:
+                params[i].grad.add_(contrib[pas % 2][i])
+                ops.grad_ready(params[i])
+                order.append(list(sync.launched))
+    assert sync.launched and 0 in sync.launched and len(sync.launched) == len(sync.buckets)
+    # bucket 0 holds the last layers: it may only leave once their THIRD contribution is in
+    first_seen = next(k for k, l in enumerate(order) if 0 in l)
+    assert first_seen >= 2 * len(params), first_seen
+    sync.finish()
     out.put(rank)
     td.destroy_process_group()
 
@@ -153,3 +175,82 @@ def test_mean_of_shard_gradients_equals_full_batch_gradient():
     for k, g in full.grads_D.items():
         mean = (shards[0].grads_D[k] + shards[1].grads_D[k]) / 2
         np.testing.assert_allclose(mean.numpy(), g.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_launcher_spawns_ranks_and_propagates_failure(tmp_path):
+    """nemar_amd.launch: one command -> N ranks with torchrun's environment contract on 127.0.0.1; a failing rank fails the run."""
+    import subprocess, sys
+    script = tmp_path / "job.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from nemar_amd import launch\n"
+        "if not launch.under_launcher():\n"
+        "    raise SystemExit(launch.spawn_local_ranks(2))\n"
+        "import torch.distributed as td\n"
+        "from nemar_amd import distributed as dist\n"
+        "rk, ws, lr = dist.init_from_env(backend='gloo')\n"
+        "import torch\n"
+        "t = torch.tensor([float(rk + 1)]); td.all_reduce(t)\n"
+        "open(os.path.join(%r, 'rank%%d' %% rk), 'w').write('%%d %%d %%g %%s' %% (ws, lr, t.item(), os.environ['MASTER_ADDR']))\n"
+        "td.destroy_process_group()\n"
+        "sys.exit(3 if (rk == 1 and len(sys.argv) > 1) else 0)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path)))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for rk in range(2):
+        assert open(tmp_path / ("rank%d" % rk)).read() == "2 %d 3 127.0.0.1" % rk
+    r = subprocess.run([sys.executable, str(script), "fail"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3
+
+
+def test_bench_with_gpus_2_never_runs_as_one_rank():
+    """`python bench.py --gpus 2` started directly must become two ranks (or fail): here, without a GPU, both ranks must fail
+    loudly — the run may not print a 1-GPU line."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU box: the driver's scaling tier covers this")
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_loader_shards_every_global_batch_by_rank():
+    """nemar_amd.data.DeviceBatchLoader under data parallelism: the ranks walk the same epoch order and take disjoint, equal
+    slices of each global batch (a ragged last batch is dropped); a second epoch reshuffles identically on every rank."""
+    import argparse
+    import nemar_amd.data as D
+
+    class _DS(D.BaseDataset):
+        def __init__(self, opt):
+            self.n = 22
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return i
+
+        def batch(self, idx):
+            return list(idx)
+
+    orig = D.find_dataset_using_name
+    D.find_dataset_using_name = lambda name: _DS
+    try:
+        def loader(rank, world):
+            opt = argparse.Namespace(dataset_mode='x', batch_size=8, serial_batches=False, max_dataset_size=float('inf'),
+                                     data_seed=5, shard_rank=rank, shard_world=world)
+            return D.DeviceBatchLoader(opt)
+        l0, l1, single = loader(0, 2), loader(1, 2), loader(0, 1)
+        for epoch in range(2):
+            b0, b1, bs = list(l0), list(l1), list(single)
+            assert len(b0) == len(b1) == 2 and len(bs) == 3            # 22 = 8 + 8 + 6: the ragged batch only exists un-sharded
+            for x, y, z in zip(b0, b1, bs):
+                assert len(x) == len(y) == 4 and x + y == z            # the two shards ARE the global batch, in order
+            if epoch == 0:
+                first = b0
+        assert first != b0                                             # reshuffled per epoch
+    finally:
+        D.find_dataset_using_name = orig
