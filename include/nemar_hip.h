@@ -164,13 +164,20 @@ int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycl
  * MFMA kernels instead — same results within fp32 rounding. */
 size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad);
 int nemar_set_scratch(void* scratch, size_t bytes);
-/* The fp16 form of those kernels scales each source tensor by a power of two derived from max |t|.  A caller that feeds one tensor
- * to several calls (x: forward and weight gradient; gy: data and weight gradient) computes the word once with nemar_absmax
- * (out_word: 4 bytes that are ZERO on entry — the kernel takes an atomic max of the bit patterns into it) and registers it with
- * nemar_absmax_hint(tensor, word) for the calls that follow; nemar_absmax_hint(tensor, NULL) withdraws it.  Without a hint every
- * call runs its own max pass.  (Process-global like the scratch arena; at most four hints.) */
+/* The fp16 form of those kernels scales every SAMPLE of a source tensor by its own power of two, derived from the largest finite
+ * magnitude of the sample (so samples of very different magnitude in one batch — the batched real / fake passes — do not share a
+ * scale).  Error bound of the fp16 x 3 form, per product v w: |error| <= 3 * 2^-22 |v w| as long as |v| >= 2^-14 max_sample|v|
+ * (both fp16 terms normal); below that the absolute error of v is 2^-37 max_sample|v|.  Non-finite elements do not take part in the
+ * maximum and propagate as Inf / NaN; an all-zero sample has scale 1.  (The general kernels of tune key 24 go further: their scale
+ * is per workgroup tile and 16-channel chunk, or per channel row in the weight gradient — csrc/conv_s16g*.hip.)
+ * A caller that feeds one tensor to several calls (x: forward and weight gradient; gy: data and weight gradient) computes the words
+ * once with nemar_absmax_samples (out_words: `samples` 4-byte words that are ZERO on entry — the kernel takes an atomic max of the bit
+ * patterns into them; nemar_absmax = one sample) and registers them with nemar_absmax_hint(tensor, words, count) for the calls that
+ * follow (count = the tensor's batch size, or 1 = one word for the whole tensor); nemar_absmax_hint(tensor, NULL, 0) withdraws it.
+ * Without a hint every call runs its own max pass.  (Process-global like the scratch arena; at most four hints.) */
 int nemar_absmax(const float* t, long long n, void* out_word, void* stream);
-int nemar_absmax_hint(const void* tensor, const void* word);
+int nemar_absmax_samples(const float* t, int samples, long long per_sample, void* out_words, void* stream);
+int nemar_absmax_hint(const void* tensor, const void* words, int count);
 /* Measurement hook for bench.py's roofline entry: while enabled, HIP events are recorded on the launch stream around the main
  * kernel (igemm_split16_kernel) of every forward / data-gradient call of those layers; read -> summed duration, summed algorithmic
  * (fp32-equivalent) flop 2 N OH OW K C R S of the timed launches, and their count (synchronises on the recorded events, resets). */

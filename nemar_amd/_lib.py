@@ -47,7 +47,8 @@ SIGNATURES = {
     "nemar_conv2d_scratch": (_sz, [_i] * 9),
     "nemar_set_scratch": (_i, [_vp, _sz]),
     "nemar_absmax": (_i, [_vp, _ll, _vp, _vp]),
-    "nemar_absmax_hint": (_i, [_vp, _vp]),
+    "nemar_absmax_samples": (_i, [_vp, _i, _ll, _vp, _vp]),
+    "nemar_absmax_hint": (_i, [_vp, _vp, _i]),
     "nemar_kernel_timer": (_i, [_i]),
     "nemar_kernel_timer_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),

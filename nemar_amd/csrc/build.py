@@ -18,10 +18,15 @@ LIB_PATH = os.path.join(LIB_DIR, "libnemar_hip.so")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-    "-munsafe-fp-atomics",      # fp32 atomicAdd -> global_atomic_add_f32, not a CAS loop
     "-ffp-contract=off",        # keep a*b+c un-fused unless the source says fmaf (parity with the oracle)
     "-Wall", "-Wno-unused-function",
 ]
+
+
+# fp32 atomicAdd -> global_atomic_add_f32 instead of a CAS loop: only the sources that HAVE floating-point atomics (the non-default
+# nemar_tune(14, 0) accumulation, the legacy grid_sample / resize gradients of shapes the gather kernels do not take).  The default
+# path of every operator is atomic-free and bitwise reproducible.
+UNSAFE_FP_ATOMICS = {"conv.hip", "conv_narrow.hip", "conv_wgrad.hip", "pointwise.hip", "warp.hip"}
 
 
 def sources():
@@ -46,7 +51,8 @@ def _compile(src, force):
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
     if force or _stale(obj, deps):
-        cmd = [_hipcc(), *HIPCC_FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        extra = ["-munsafe-fp-atomics"] if src in UNSAFE_FP_ATOMICS else []
+        cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -2249,7 +2249,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 27) { nemar_s16g_tune(0, value); return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
-    if (key == 21) { g_split16_variant = (value == 0 || value == 3) ? value : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
+    if (key == 21) { g_split16_variant = value == 3 ? 3 : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }
     if (key == 17) { g_mt8 = value; return NEMAR_OK; }
     if (key == 19) { extern int g_narrow_fwd4; g_narrow_fwd4 = value != 0; return NEMAR_OK; }
@@ -2272,13 +2272,22 @@ NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
     return NEMAR_OK;
 }
 
-// max |t| of a tensor, for callers that feed the same tensor to several split-16 convolution calls (forward + weight gradient take
-// x, data + weight gradient take gy): computed once, registered with nemar_absmax_hint, it replaces the max pass inside each call
+// max |t| (finite elements) per sample of a tensor, for callers that feed the same tensor to several split-16 convolution calls
+// (forward + weight gradient take x, data + weight gradient take gy): computed once, registered with nemar_absmax_hint, it replaces
+// the max pass inside each call.  nemar_absmax = one sample of n elements.
 NEMAR_API int nemar_absmax(const float* t, long long n, void* out_word, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(t && out_word && n > 0, "absmax: null pointer");
-    nemar_split16_absmax(t, n, out_word, (hipStream_t)stream);
+    nemar_split16_absmax(t, 1, n, out_word, (hipStream_t)stream);
     NEMAR_CHECK_LAUNCH("absmax");
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_absmax_samples(const float* t, int samples, long long per_sample, void* out_words, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(t && out_words && samples > 0 && samples <= 65535 && per_sample > 0, "absmax_samples: bad arguments");
+    nemar_split16_absmax(t, samples, per_sample, out_words, (hipStream_t)stream);
+    NEMAR_CHECK_LAUNCH("absmax_samples");
     return NEMAR_OK;
 }
 
@@ -2295,9 +2304,9 @@ NEMAR_API int nemar_kernel_timer_read(double* total_ms, double* total_flop, int*
     return NEMAR_OK;
 }
 
-NEMAR_API int nemar_absmax_hint(const void* tensor, const void* word) {
-    NEMAR_REQUIRE(tensor, "absmax_hint: null tensor");
-    nemar_split16_set_hint(tensor, word);
+NEMAR_API int nemar_absmax_hint(const void* tensor, const void* words, int count) {
+    NEMAR_REQUIRE(tensor && (!words || count >= 1), "absmax_hint: null tensor / bad count");
+    nemar_split16_set_hint(tensor, words, count);
     return NEMAR_OK;
 }
 

@@ -33,11 +33,12 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
 
 // ---- max |t| of a source tensor (the fp16 form's power-of-two scale follows from it) ----
-// out: one word, ZERO on entry (the kernel takes an atomic max into it)
-void nemar_split16_absmax(const float* x, long long n, void* out, hipStream_t st);
-void nemar_split16_set_hint(const void* tensor, const void* word);            // word == NULL clears
-const unsigned* nemar_split16_hint(const void* tensor);
-const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned* own, hipStream_t st);
+// The scale is PER SAMPLE: out = `samples` words, ZERO on entry (the kernel takes an atomic max of the finite elements of sample i
+// — `per` consecutive floats — into word i)
+void nemar_split16_absmax(const float* x, int samples, long long per, void* out, hipStream_t st);
+void nemar_split16_set_hint(const void* tensor, const void* word, int count);  // word == NULL clears; count = words (N or 1)
+const unsigned* nemar_split16_hint(const void* tensor, int* count);
+const unsigned* nemar_split16_source_max(const float* src, int N, long long per, unsigned* own, int* stride, hipStream_t st);
 
 // ---- measurement hook: HIP events on the launch stream around the main kernel of every nemar_split16_conv call while enabled ----
 void nemar_split16_timer(int on);

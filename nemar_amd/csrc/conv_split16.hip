@@ -133,17 +133,23 @@ __device__ __forceinline__ void split2_f16(float v, unsigned short& h, unsigned 
     l = f16_rn(r);
 }
 
-// max |x| as the bit pattern of a non-negative float (ordered like an unsigned integer).  16-byte loads; `n4` whole float4s + tail.
+// max |x| over the FINITE elements as the bit pattern of a non-negative float (ordered like an unsigned integer); non-finite
+// elements do not take part: they become fp16 infinities / NaN on their own and must not push the scale of everything else to 1.
+// 16-byte loads; `n4` whole float4s + tail.
+__device__ __forceinline__ unsigned finite_bits(unsigned u) {
+    u &= 0x7fffffffu;
+    return u < 0x7f800000u ? u : 0u;
+}
 __device__ __forceinline__ unsigned block_absmax(const float* __restrict__ x, long long n, unsigned* red) {
     unsigned m = 0;
     const long long n4 = ((size_t)x & 15) == 0 ? n >> 2 : 0;          // (a view at an odd offset: scalar loads throughout)
     const u32x4* x4 = reinterpret_cast<const u32x4*>(x);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const u32x4 v = x4[i];
-        m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
+        m = max(max(m, finite_bits(v[0])), max(max(finite_bits(v[1]), finite_bits(v[2])), finite_bits(v[3])));
     }
     for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
+        m = max(m, finite_bits(__builtin_bit_cast(unsigned, x[i])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -151,27 +157,28 @@ __device__ __forceinline__ unsigned block_absmax(const float* __restrict__ x, lo
     return max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
-// *out zeroed by the caller.  (A ticketed last-block reduction that needs no zeroing was measured at 53 us against 22 us for this
-// form on the 33 MB bench tensors: its device-scope release fence per block writes back the XCD's L2.)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+// out[sample] zeroed by the caller; grid.y = sample (`per` elements each).  (A ticketed last-block reduction that needs no zeroing
+// was measured at 53 us against 22 us for this form on the 33 MB bench tensors: its device-scope release fence per block writes back
+// the XCD's L2.)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long per, unsigned* out) {
     __shared__ unsigned red[4];
-    const unsigned m = block_absmax(x, n, red);
-    if (threadIdx.x == 0) atomicMax(out, m);
+    const unsigned m = block_absmax(x + (size_t)blockIdx.y * per, per, red);
+    if (threadIdx.x == 0 && m) atomicMax(out + blockIdx.y, m);
 }
 
 // one thread = one (n, channel group, row, slot): 8 strided reads (coalesced across the slots of a row), NPL x 16-byte writes
 template <int NPL>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C,
                                                            int H, int W, int mode, long long total, const unsigned* maxbits,
-                                                           int pad, int Hs, int Ws_) {
+                                                           int mstride, int pad, int Hs, int Ws_) {
     const int Hp = H + 4, Ws = W + 4, CG = C >> 3;
-    const float scale = NPL == 2 ? pow2_scale(*maxbits) : 1.f;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int slot = (int)(t % Ws);
         long long q = t / Ws;
         const int row = (int)(q % Hp);
         q /= Hp;
         const int cg = (int)(q % CG), n = (int)(q / CG);
+        const float scale = NPL == 2 ? pow2_scale(maxbits[n * mstride]) : 1.f;        // one scale per SAMPLE (mstride 0: per tensor)
         const float* xc = x + ((size_t)n * C + (size_t)cg * 8) * Hs * Ws_;
         unsigned short b0[8], b1[8], b2[8];
 #pragma unroll
@@ -233,8 +240,9 @@ struct Split16Params {
     int ksplit;                // reduction runs per tile (1: none); slab z of a tile starts at dst + z * slab_stride
     long long slab_stride;
     int OH, OW;                // valid output extents (4x4 layers: H - 1, W - 1; stores beyond them are masked)
-    const unsigned* xmax;      // fp16 x 3 form: max |source| and max |weight| bit patterns (the power-of-two scales follow from them)
-    const unsigned* wmax;
+    const unsigned* xmax;      // fp16 x 3 form: max |source| per sample (word n * xstride) and max |weight| bit patterns (the
+    const unsigned* wmax;      // power-of-two scales follow from them)
+    int xstride;
     long long* tl;             // NEMAR_TIMELINE builds: cycle stamps of workgroup 0 (tools/timeline_split16.py)
 };
 
@@ -246,185 +254,6 @@ __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
 // scalar (wave-uniform) base + per-lane byte offset: hipcc selects the SGPR-base form of global_load_lds for it
 __device__ __forceinline__ void glds16u(const u32x4* ubase, unsigned lane_bytes, u32x4* lds) {
     glds16(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + lane_bytes), lds);
-}
-
-// ---- first generation (nemar_tune(21, 0), bf16 x 6): 4 MFMA waves + 2 loader waves, kept for the A/B numbers of DESIGN.md §5.
-// Its loader waves share SIMDs 0 and 1 with two of the MFMA waves and starve (see the kernel below).
-// REGION_KB = KiB of LDS per (plane, k group) halo region = DMA instructions per region; RING = weight-stage ring depth
-template <int REGION_KB, int RING>
-__global__ __launch_bounds__(384) void igemm_split16_lw_kernel(Split16Params p) {
-    constexpr int REGION16 = REGION_KB * 64;             // 16-byte words per region
-    constexpr int BBUF16 = 6 * REGION16;                 // 3 planes x 2 k groups
-    constexpr int ASTAGE16 = 6 * 128;                    // 3 planes x 2 k groups x 128 rows
-    constexpr int NBL = 3 * REGION_KB;                   // halo instructions per loader per chunk (loader = k group)
-    constexpr int WINDOW = 10 - RING;                    // stages (taps RING-1 .. 8) that carry the next chunk's halo
-    constexpr int NB = (NBL + WINDOW - 1) / WINDOW;      // halo instruction slots per stage
-    constexpr int PER = 6 + NB;                          // DMA instructions per loader per stage (constant: counted waits)
-    static_assert((RING - 1) * PER < 64, "vmcnt is a 6-bit counter");
-    static_assert((2 * BBUF16 + RING * ASTAGE16) * 16 <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * BBUF16 + RING * ASTAGE16];
-    u32x4* const Bs = smem;
-    u32x4* const As = smem + 2 * BBUF16;
-
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    // consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous run of tiles, and both channel halves of a
-    // pixel tile (same halo) to the same one
-    int t = blockIdx.x;
-    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
-    const int ptile = t / p.mblks, mblk = t - ptile * p.mblks;
-    const int n = ptile / p.tiles_per_img, y0 = (ptile - n * p.tiles_per_img) * p.RT;
-    const int nchunks = p.Cred >> 4, nstage = nchunks * 9;
-    const int CG = p.Cred >> 3;
-
-    if (wid >= 4) {
-        // ================================ loader waves: wave 4 = k group 0, wave 5 = k group 1 ================================
-        const int kg = wid - 4;
-        const int ipr = p.halo_instr + p.aux_instr;                      // <= REGION_KB
-        const int nbl = 3 * ipr;
-        const u32x4* const wsrc0 = p.wp + (size_t)mblk * 768 + kg * 384 + lane;
-        const size_t wstage = (size_t)p.mblks * 768;
-        // source of this loader's halo words of chunk c, plane t: planes + t * plane16 + ((n * CG + 2c + kg) * HpWs) + ...
-        const u32x4* const bsrc0 = p.planes + ((size_t)n * CG + kg) * p.HpWs + lane;
-        const int halo_off = y0 * p.Ws, aux_off = (p.H + 2) * p.Ws;
-        int islot = 0, ci = 0, ti = 0;        // ring slot / chunk / tap of the next stage to issue
-        int bpl = 0, bin = 0, bcnt = nbl;      // halo stream of chunk ci + 1: plane, instruction within the region, issued count
-        const u32x4* asrc = wsrc0;
-
-#define SPLIT16_HALO_ONE(chunk_, pl_, in_)                                                                                  \
-        {                                                                                                               \
-            const u32x4* g_ = bsrc0 + (size_t)(pl_) * p.plane16 + (size_t)(2 * (chunk_)) * p.HpWs +                     \
-                              ((in_) < p.halo_instr ? halo_off + (in_) * 64 : aux_off + ((in_) - p.halo_instr) * 64);   \
-            glds16(g_, Bs + ((chunk_) & 1) * BBUF16 + ((pl_) * 2 + kg) * REGION16 + (in_) * 64);                        \
-        }
-#define SPLIT16_ISSUE()                                                                                                     \
-        {                                                                                                               \
-            u32x4* const ad_ = As + islot * ASTAGE16 + kg * 384;                                                        \
-            _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(asrc + q * 64, ad_ + q * 64);                          \
-            if (ti == RING - 1) { bpl = 0; bin = 0; bcnt = (ci + 1 < nchunks) ? 0 : nbl; }                              \
-            _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                            \
-                if (bcnt < nbl) {                                                                                       \
-                    SPLIT16_HALO_ONE(ci + 1, bpl, bin);                                                                     \
-                    ++bcnt;                                                                                             \
-                    if (++bin == ipr) { bin = 0; ++bpl; }                                                               \
-                } else {                                                                                                \
-                    glds16(asrc, ad_);             /* filler: keeps the per-stage instruction count constant */          \
-                }                                                                                                       \
-            }                                                                                                           \
-            asrc += wstage;                                                                                             \
-            islot = islot + 1 == RING ? 0 : islot + 1;                                                                  \
-            if (++ti == 9) { ti = 0; ++ci; }                                                                            \
-        }
-#define SPLIT16_WAIT_IN_FLIGHT(n_)                                                                                          \
-        {                                                                                                               \
-            const int ns_ = (n_);                                                                                       \
-            if (ns_ <= 0) wait_vmem();                                                                                  \
-            else if (ns_ == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER & 15) | ((PER >> 4) << 14));                    \
-            else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 15) | (((2 * PER) >> 4) << 14));                      \
-        }
-        static_assert(RING <= 4, "two stages in flight at most");
-        // halo of chunk 0, then RING - 1 weight stages, before anything is consumed
-        for (int pl = 0; pl < 3; ++pl)
-            for (int in = 0; in < ipr; ++in) SPLIT16_HALO_ONE(0, pl, in);
-        int issued = 0;
-        for (; issued < RING - 1 && issued < nstage; ++issued) SPLIT16_ISSUE();
-        SPLIT16_WAIT_IN_FLIGHT(issued - 1);
-        __builtin_amdgcn_s_barrier();                 // stage 0 (and the first halo) are in LDS
-        if (issued < nstage) { SPLIT16_ISSUE(); ++issued; }
-        for (int ks = 0; ks < nstage; ++ks) {
-            SPLIT16_WAIT_IN_FLIGHT(issued - (ks + 2));    // stage ks + 1 has landed (with everything issued before it)
-            __builtin_amdgcn_s_barrier();             // every MFMA wave has finished reading ring slot ks % RING
-            if (issued < nstage) { SPLIT16_ISSUE(); ++issued; }
-        }
-#undef SPLIT16_WAIT_IN_FLIGHT
-#undef SPLIT16_ISSUE
-#undef SPLIT16_HALO_ONE
-        return;
-    }
-
-    // ================================ MFMA waves: 128 channels x 64 pixels each ================================
-    const int l31 = lane & 31, lhi = lane >> 5;
-    int row[2], col[2];
-    bool top[2], bot[2], lft[2], rgt[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int px = 64 * wid + 32 * nt + l31;
-        row[nt] = px >> p.wshift;
-        col[nt] = px & (p.W - 1);
-        const int y = y0 + row[nt];
-        top[nt] = p.fold && y == 1;
-        bot[nt] = p.fold && y == p.H - 2;
-        lft[nt] = p.fold && col[nt] == 1;
-        rgt[nt] = p.fold && col[nt] == p.W - 2;
-    }
-    const int auxoff = p.halo_instr * 64;             // the two folded rows sit behind the halo rows of a region
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    __builtin_amdgcn_s_barrier();                     // stage 0 is in LDS
-    int slot = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const u32x4* const Bb = Bs + (chunk & 1) * BBUF16 + lhi * REGION16;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int r = tap / 3, sx = tap - 3 * (tap / 3);
-            u32x4 bf[2][3], af[4][3];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                int ra = (row[nt] + r) * p.Ws;
-                if (r == 2) ra = top[nt] ? auxoff : ra;
-                if (r == 0) ra = bot[nt] ? auxoff + p.Ws : ra;
-                int sl = col[nt] + sx;
-                if (sx == 2) sl = lft[nt] ? p.W + 2 : sl;
-                if (sx == 0) sl = rgt[nt] ? p.W + 3 : sl;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = Bb[pl * 2 * REGION16 + ra + sl];
-            }
-            const u32x4* const Ab = As + slot * ASTAGE16 + lhi * 128 + l31;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[mt][pl] = Ab[pl * 256 + mt * 32];
-            // six partial products, smallest first; consecutive MFMAs go to different accumulators
-#define SPLIT16_TERM(pa_, pb_)                                                                                              \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                        \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][pa_]),      \
-                                                                          __builtin_bit_cast(bf16x8, bf[nt][pb_]),      \
-                                                                          acc[mt][nt], 0, 0, 0);
-            SPLIT16_TERM(2, 0)
-            SPLIT16_TERM(1, 1)
-            SPLIT16_TERM(0, 2)
-            SPLIT16_TERM(1, 0)
-            SPLIT16_TERM(0, 1)
-            SPLIT16_TERM(0, 0)
-#undef SPLIT16_TERM
-            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): this wave is done reading the stage
-            __builtin_amdgcn_s_barrier();             // the next stage has landed; this ring slot goes back to the loaders
-            slot = slot + 1 == RING ? 0 : slot + 1;
-        }
-    }
-
-    // epilogue: D register r of lane l = channel (r & 3) + 8 (r >> 2) + 4 (l >> 5), pixel l & 31 of the 32 x 32 tile
-    const size_t HW = (size_t)p.H * p.W;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        float* const d0 = p.dst + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.W + col[nt];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float v = acc[mt][nt][r];
-                if (p.bias) v += p.bias[m];
-                d0[(size_t)m * HW] = v;
-            }
-        }
-    }
 }
 
 // ---- the product kernel --------------------------------------------------------------------------------------------------
@@ -706,7 +535,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 
     const size_t HW = (size_t)p.OH * p.OW;
     // fp16 form: take the two power-of-two operand scales out again (exact)
-    const float unscale = NPL == 2 ? 1.f / (pow2_scale(*p.xmax) * pow2_scale(*p.wmax)) : 1.f;
+    const float unscale = NPL == 2 ? 1.f / (pow2_scale(p.xmax[n * p.xstride]) * pow2_scale(*p.wmax)) : 1.f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         if (KS != 3 && (y0 + row[nt] >= p.OH || col[nt] >= p.OW)) continue;      // the row / column beyond the valid output
@@ -739,9 +568,9 @@ bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, 
     if (!(W == 32 || W == 64 || W == 128 || W == 256)) return false;
     const int RT = 256 / W;
     if (H % RT != 0 || H < 4) return false;
-    if ((long long)N * Cred * (H + 4) * (W + 4) >= (1ll << 31)) return false;
+    if ((long long)N * Cred * (H + 4) * (W + 4) >= (1ll << 31) || N > 256) return false;
     if (R == 4 && (mode != SPLIT16_ZERO || variant == 0)) return false;       // the discriminator's 4x4 layers: zero padding only
-    if (variant == 0) return W <= 128 && !(W == 128 && mode == SPLIT16_DGRAD_REFLECT);       // first generation: whole-KiB LDS regions
+    if (variant == 0) return false;       // (the first-generation kernel with loader waves is gone: tools/ history)
     // two halo buffers of 2 NPL regions + the 4-slot weight ring must fit the 152 KiB of LDS the kernel declares
     const int npl = variant == 3 ? 3 : 2;
     const int region16 = (RT + R - 1) * (W + 4) + (mode == SPLIT16_DGRAD_REFLECT ? 2 * (W + 4) : 0);
@@ -771,29 +600,34 @@ size_t nemar_split16_pack_bytes(int M, int Cred, int KS) { return (size_t)(Cred 
 namespace {
 // the max words sit in the slack behind the planes / the packed weights
 unsigned* scratch_max_word(void* scratch, int N, int Cred, int H, int W) {
-    return (unsigned*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W) - 64);
+    return (unsigned*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W) - 1024);      // up to 256 per-sample words
 }
 unsigned* pack_max_word(void* packed, int M, int Cred, int KS) {
     return (unsigned*)((char*)packed + nemar_split16_pack_bytes(M, Cred, KS) - 64);
 }
 
-// nemar_absmax_hint: max |t| words the caller has already computed for tensors the next calls take as sources
+// nemar_absmax_hint: max |t| words the caller has already computed for tensors the next calls take as sources (count words: one per
+// sample of the tensor, or 1 = one for the whole tensor)
 const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr};
 const unsigned* g_hint_word[4] = {nullptr, nullptr, nullptr, nullptr};
+int g_hint_count[4] = {0, 0, 0, 0};
 }  // namespace
 
-const unsigned* nemar_split16_hint(const void* tensor) {
+const unsigned* nemar_split16_hint(const void* tensor, int* count) {
     for (int i = 0; i < 4; ++i)
-        if (g_hint_tensor[i] == tensor && tensor) return g_hint_word[i];
+        if (g_hint_tensor[i] == tensor && tensor) {
+            *count = g_hint_count[i];
+            return g_hint_word[i];
+        }
     return nullptr;
 }
 
-void nemar_split16_set_hint(const void* tensor, const void* word) {
+void nemar_split16_set_hint(const void* tensor, const void* word, int count) {
     int slot = -1;
     for (int i = 0; i < 4; ++i)
         if (g_hint_tensor[i] == tensor) slot = i;
     if (!word) {
-        if (slot >= 0) { g_hint_tensor[slot] = nullptr; g_hint_word[slot] = nullptr; }
+        if (slot >= 0) { g_hint_tensor[slot] = nullptr; g_hint_word[slot] = nullptr; g_hint_count[slot] = 0; }
         return;
     }
     if (slot < 0)
@@ -802,20 +636,28 @@ void nemar_split16_set_hint(const void* tensor, const void* word) {
     if (slot < 0) slot = 0;
     g_hint_tensor[slot] = tensor;
     g_hint_word[slot] = (const unsigned*)word;
+    g_hint_count[slot] = count;
 }
 
-void nemar_split16_absmax(const float* x, long long n, void* out, hipStream_t st) {
-    int grid = nemar_stream_grid(n, 256 * 16);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, n, (unsigned*)out);
+// out: `samples` words, zero on entry
+void nemar_split16_absmax(const float* x, int samples, long long per, void* out, hipStream_t st) {
+    int grid = nemar_stream_grid(per, 256 * 16);
+    if (grid * samples > 2048) grid = (2048 + samples - 1) / samples;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid, samples), dim3(256), 0, st, x, per, (unsigned*)out);
 }
 
-// max |src| word for a split pass: the caller's hint, or computed here into `own`
-const unsigned* nemar_split16_source_max(const float* src, long long n, unsigned* own, hipStream_t st) {
-    const unsigned* h = nemar_split16_hint(src);
-    if (h) return h;
-    (void)hipMemsetAsync(own, 0, sizeof(unsigned), st);
-    nemar_split16_absmax(src, n, own, st);
+// per-sample max |src| words for a split pass: the caller's hint (one word per sample, or one for all: *stride = 0), or computed
+// here into `own` (N words)
+const unsigned* nemar_split16_source_max(const float* src, int N, long long per, unsigned* own, int* stride, hipStream_t st) {
+    int count = 0;
+    const unsigned* h = nemar_split16_hint(src, &count);
+    if (h && (count == N || count == 1)) {
+        *stride = count == N && N > 1 ? 1 : 0;
+        return h;
+    }
+    (void)hipMemsetAsync(own, 0, sizeof(unsigned) * N, st);
+    nemar_split16_absmax(src, N, per, own, st);
+    *stride = N > 1 ? 1 : 0;
     return own;
 }
 
@@ -874,7 +716,7 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int 
     if (variant == 4) {
         unsigned* mw = pack_max_word(packed, M, Cred, KS);
         (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
-        nemar_split16_absmax(w, (long long)K * C * NT, mw, st);
+        nemar_split16_absmax(w, 1, (long long)K * C * NT, mw, st);
         hipLaunchKernelGGL((split16_pack_kernel<2>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad, mw,
                            NT);
         return;
@@ -889,13 +731,14 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
     const unsigned* xmax = xmw;
+    int xstride = 0;
     if (variant == 4) {
-        xmax = nemar_split16_source_max(src, (long long)N * Cred * Hs * Ws_src, xmw, st);
+        xmax = nemar_split16_source_max(src, N, (long long)Cred * Hs * Ws_src, xmw, &xstride, st);
         hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
-                           mode, total, xmax, src_pad, Hs, Ws_src);
+                           mode, total, xmax, xstride, src_pad, Hs, Ws_src);
     } else {
         hipLaunchKernelGGL((split_planes_kernel<3>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
-                           mode, total, (const unsigned*)nullptr, src_pad, Hs, Ws_src);
+                           mode, total, (const unsigned*)nullptr, 0, src_pad, Hs, Ws_src);
     }
     Split16Params p;
     p.planes = (const u32x4*)scratch;
@@ -915,19 +758,20 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.plane16 = total;
     p.tl = tl;
     p.xmax = xmax;
+    p.xstride = xstride;
     p.wmax = pack_max_word(const_cast<void*>(packed), M, Cred, KS);
     p.OH = OH; p.OW = OW;
     p.halo16 = (p.RT + KS - 1) * p.Ws;
     p.aux16 = p.fold ? 2 * p.Ws : 0;
     const int tiles = N * p.tiles_per_img * p.mblks;
-    p.ksplit = variant == 0 ? 1 : nemar_split16_ksplit(N, H, W, M, Cred);
+    p.ksplit = nemar_split16_ksplit(N, H, W, M, Cred);
     p.slab_stride = (long long)N * M * OH * OW;
     float* const final_dst = dst;
     if (p.ksplit > 1) p.dst = (float*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W));       // slabs behind the planes
     const int grid = tiles * p.ksplit;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (p.mblks * p.ksplit) == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
-    const dim3 g(grid), b(384);
+    const dim3 g(grid);
     if (variant == 4) {                 // fp16 x 3 (nemar_split16_eligible checked the LDS budget)
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), KS * KS - 3);
@@ -952,9 +796,5 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
         return;
     }
-    if (region <= 6) hipLaunchKernelGGL((igemm_split16_lw_kernel<6, 4>), g, b, 0, st, p);
-    else if (region == 7) hipLaunchKernelGGL((igemm_split16_lw_kernel<7, 4>), g, b, 0, st, p);
-    else if (region == 8) hipLaunchKernelGGL((igemm_split16_lw_kernel<8, 4>), g, b, 0, st, p);
-    else if (region == 9) hipLaunchKernelGGL((igemm_split16_lw_kernel<9, 4>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((igemm_split16_lw_kernel<10, 3>), g, b, 0, st, p);
+    (void)region;
 }

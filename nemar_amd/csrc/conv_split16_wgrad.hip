@@ -70,11 +70,12 @@ constexpr int SPLIT_MAXW = 256;
 // below row H: the row count is rounded up to a whole number of row blocks) and KS shifted versions.
 template <int TW, int KS>
 __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restrict__ gy, u32x4* __restrict__ out, int N, int K, int H,
-                                                            int W, int Hg, int CPR, long long total, const unsigned* maxbits) {
+                                                            int W, int Hg, int CPR, long long total, const unsigned* maxbits,
+                                                            int mstride) {
     __shared__ float tile[64][TW + 1];
-    const float scale = pow2_scale(*maxbits);
     const int KBLK = K >> 6, F = Hg * CPR;
     const int y = blockIdx.x % Hg, kblk = (blockIdx.x / Hg) % KBLK, n = blockIdx.x / (Hg * KBLK);
+    const float scale = pow2_scale(maxbits[n * mstride]);        // per sample
     const bool rowok = y < H;
     const float* src = gy + (((size_t)n * K + kblk * 64) * H + (rowok ? y : 0)) * W;
     for (int i = threadIdx.x; i < 64 * W; i += 256) {
@@ -107,11 +108,11 @@ __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restr
 template <int TW>
 __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int N, int C, int H,
                                                             int W, int Hp, int CPR, int reflect, long long total,
-                                                            const unsigned* maxbits) {
+                                                            const unsigned* maxbits, int mstride) {
     __shared__ float tile[64][TW + 1];
-    const float scale = pow2_scale(*maxbits);
     const int CBLK = C >> 6, FX = Hp * CPR;            // Hp >= H + 2 plane rows (rows beyond the padded image: zero)
     const int yp = blockIdx.x % Hp, cblk = (blockIdx.x / Hp) % CBLK, n = blockIdx.x / (Hp * CBLK);
+    const float scale = pow2_scale(maxbits[n * mstride]);        // per sample
     int y = yp - 1;
     bool rowok = yp < H + 2;
     if (reflect) y = mirror(min(y, H), H);
@@ -151,8 +152,9 @@ struct WgParams {
     int CPR, F, FX, RB, spi;   // chunks per row, flat chunks per image of G / X, rows per split, splits per image
     int KBLK, CBLK;
     long long gplane16, xplane16;
-    const unsigned* gmax;
+    const unsigned* gmax;      // per-sample max words (word n * stride)
     const unsigned* xmax;
+    int gstride, xstride;
     int xcd;
 };
 
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #undef WG_COPIES
 
     // slab [split][k][c][tap = KS r + s]; D register e of lane l = row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31
-    const float unscale = 1.f / (pow2_scale(*p.gmax) * pow2_scale(*p.xmax));
+    const float unscale = 1.f / (pow2_scale(p.gmax[n * p.gstride]) * pow2_scale(p.xmax[n * p.xstride]));     // a slab = rows of ONE image
     float* const slab = p.part + (size_t)split * p.K * p.C * (KS * KS);
     const int c = cblk * 64 + wc * 32 + l31;
 #pragma unroll
@@ -305,7 +307,7 @@ static int g_rows(int H, int KS) { return (H + 3 - KS + 3) / 4 * 4; }
 
 bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
     if (R != S || (R != 3 && R != 4) || stride != 1 || pad != 1) return false;
-    if (C % 64 || K % 64 || C < 128 || K < 128 || W % 8 || H < 4 || W < 8 || W > SPLIT_MAXW) return false;
+    if (C % 64 || K % 64 || C < 128 || K < 128 || W % 8 || H < 4 || W < 8 || W > SPLIT_MAXW || N > 256) return false;
     const int CPR = (W + 2 + 7) / 8;
     if (rows_per_split(N, g_rows(H, R), CPR, (K / 64) * (C / 64)) == 0) return false;
     if ((long long)N * (C > K ? C : K) * (H + 6) * CPR * 64 >= (1ll << 31)) return false;
@@ -331,18 +333,19 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     const long long gtotal = (long long)N * K * Hg * CPR, xtotal = (long long)N * C * Hx * CPR;      // words per plane block
     u32x4* const G = (u32x4*)scratch;
     u32x4* const X = G + 2 * KS * gtotal;
-    unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K, KS) - 64);
-    const unsigned* const gmax = nemar_split16_source_max(gy, (long long)N * K * OHg * OWg, mw, st);
-    const unsigned* const xmax = nemar_split16_source_max(x, (long long)N * C * H * W, mw + 1, st);
+    unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K, KS) - 2048);    // 2 x 256 words
+    int gstride = 0, xstride = 0;
+    const unsigned* const gmax = nemar_split16_source_max(gy, N, (long long)K * OHg * OWg, mw, &gstride, st);
+    const unsigned* const xmax = nemar_split16_source_max(x, N, (long long)C * H * W, mw + 256, &xstride, st);
 #define WG_SPLIT(TW_)                                                                                                              \
     if (KS == 3)                                                                                                                   \
         hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 3>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, G, N, K, OHg, OWg, Hg, CPR, gtotal, \
-                           gmax);                                                                                                  \
+                           gmax, gstride);                                                                                         \
     else                                                                                                                           \
         hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 4>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, G, N, K, OHg, OWg, Hg, CPR, gtotal, \
-                           gmax);                                                                                                  \
+                           gmax, gstride);                                                                                         \
     hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * Hx), dim3(256), 0, st, x, X, N, C, H, W, Hx, CPR, reflect, xtotal, \
-                       xmax);
+                       xmax, xstride);
     if (W <= 64) { WG_SPLIT(64) } else if (W <= 128) { WG_SPLIT(128) } else { WG_SPLIT(256) }
 #undef WG_SPLIT
     WgParams p;
@@ -353,7 +356,7 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     p.spi = Hg / p.RB;
     p.KBLK = KBLK; p.CBLK = CBLK;
     p.gplane16 = gtotal; p.xplane16 = xtotal;
-    p.gmax = gmax; p.xmax = xmax;
+    p.gmax = gmax; p.xmax = xmax; p.gstride = gstride; p.xstride = xstride;
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
     if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3>), dim3(grid), dim3(256), 0, st, p);

@@ -2,7 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 
-#define NEMAR_HIP_VERSION 100  // major*10000 + minor*100 + patch  (0.1.0)
+#define NEMAR_HIP_VERSION 300  // major*10000 + minor*100 + patch  (0.3.0: round 3 — general 16-bit-pipe kernels, per-sample scales, route / epoch queries)
 
 static thread_local char g_err[512] = "";
 

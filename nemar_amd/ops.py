@@ -102,16 +102,17 @@ _absmax_pool = {}      # device -> [zero-filled int32 tensor, next free word]: n
 
 
 def _absmax_word(t):
-    """max |t| as the one-word tensor nemar_absmax_hint takes (the fp16 split of the wide 3x3 layers scales by a power of two
-    derived from it).  Computed once per tensor and shared by the calls that take it as a source.  Words come out of a
-    pre-zeroed pool: one fill launch per 4096 of them instead of one per word."""
+    """max |t| PER SAMPLE as the N-word tensor nemar_absmax_hint takes (the fp16 split of the wide 3x3 layers scales every sample by
+    a power of two derived from its own maximum).  Computed once per tensor and shared by the calls that take it as a source.
+    Words come out of a pre-zeroed pool: one fill launch per 4096 of them instead of one per tensor."""
+    n = int(t.shape[0])
     pool = _absmax_pool.get(t.device)
-    if pool is None or pool[1] >= pool[0].numel():
+    if pool is None or pool[1] + n > pool[0].numel():
         pool = [torch.zeros(4096, dtype=torch.int32, device=t.device), 0]
         _absmax_pool[t.device] = pool
-    word = pool[0][pool[1]:pool[1] + 1]
-    pool[1] += 1
-    L.absmax(_p(t), t.numel(), _p(word), _stream())
+    word = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    L.absmax_samples(_p(t), n, t.numel() // n, _p(word), _stream())
     return word
 
 
@@ -234,13 +235,13 @@ class _Conv2d(Function):
             xmax = None
             if split16:           # max |x| once: this call and the weight gradient in backward both scale x by it
                 xmax = _absmax_word(x)
-                L.absmax_hint(_p(x), _p(xmax))
+                L.absmax_hint(_p(x), _p(xmax), xmax.numel())
             try:
                 L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
                              slope, _p(ws), wsb, hit, _stream())
             finally:
                 if split16:
-                    L.absmax_hint(_p(x), None)
+                    L.absmax_hint(_p(x), None, 0)
         ctx.xmax = xmax
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
@@ -272,15 +273,15 @@ class _Conv2d(Function):
         hinted = []
         if ctx.xmax is not None:      # split-16 layer: max |gy| once for the data and the weight gradient, max |x| from the forward
             gmax = _absmax_word(g)
-            L.absmax_hint(_p(g), _p(gmax))
-            L.absmax_hint(_p(x), _p(ctx.xmax))
+            L.absmax_hint(_p(g), _p(gmax), gmax.numel())
+            L.absmax_hint(_p(x), _p(ctx.xmax), ctx.xmax.numel())
             hinted = [g, x]
         try:
             return _Conv2d._backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st,
                                           need_x, need_x2, need_w, need_b)
         finally:
             for t in hinted:
-                L.absmax_hint(_p(t), None)
+                L.absmax_hint(_p(t), None, 0)
 
     @staticmethod
     def _backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st, need_x, need_x2, need_w,

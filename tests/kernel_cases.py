@@ -296,6 +296,81 @@ def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0, R=3):
             case_conv_fwd(be, N, C, 0, H, W, K, 3, 1, 1, pad_mode, act=O.ACT_NONE, seed=seed)
 
 
+def case_conv_split16_dynamic_range(be, what, N=3, C=128, H=8, W=32, K=128, seed=0):
+    """The fp16 x 3 route of the wide layers (csrc/conv_split16*.hip) on adversarial magnitudes, through the C ABI: the scale is per
+    SAMPLE, so every sample keeps fp32-class accuracy relative to its own magnitude.  what: 'samples' = per-sample magnitudes
+    1 : 1e-6 : 1e4; 'outlier' = one 1e4 outlier in an otherwise O(1) sample; 'zero' = an all-zero sample next to a normal one;
+    'inf' = one infinity: only the outputs whose receptive field holds it are non-finite."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    gy = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    if what == 'samples':
+        sc = np.array([1.0, 1e-6, 1e4], dtype=np.float32)[:N].reshape(N, 1, 1, 1)
+        x, gy = x * sc, gy * sc[::-1]
+    elif what == 'outlier':
+        x[0, 3, 2, 5] = 1e4
+        gy[1, 7, 3, 9] = -1e4
+    elif what == 'zero':
+        x[1] = 0.0
+        gy[0] = 0.0
+    elif what == 'inf':
+        x[0, 5, 4, 10] = np.inf
+    x, gy = x.astype(np.float32), gy.astype(np.float32)
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
+    assert need > 0
+    d_x, d_gy, d_w = be.dev(x), be.dev(gy), be.dev(w)
+    with scratch_arena(be, need):
+        d_y = be.full((N, K, H, W), np.nan)
+        ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, 3, 3, 1, 1))
+        be.lib.conv2d_fwd(be.ptr(d_x), C, None, 0, be.ptr(d_w), None, be.ptr(d_y), N, H, W, K, 3, 3, 1, 1, PAD_REFLECT, 0, 0.2,
+                          be.ptr(ws), wsb, 0, be.stream)
+        assert be.lib.last_route() == 2
+        d_gx = be.full((N, C, H, W), np.nan)
+        ws, wsb = _ws(be, be.lib.conv2d_bwd_data_workspace(N, C, H, W, K, 3, 3, 1, 1, PAD_REFLECT))
+        be.lib.conv2d_bwd_data(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gx), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1,
+                               PAD_REFLECT, be.ptr(ws), wsb, 0, be.stream)
+        assert be.lib.last_route() == 2
+        d_gw = be.full((K, C, 3, 3), 0.0)
+        ws, wsb = _ws(be, be.lib.conv2d_bwd_weight_workspace(N, C, H, W, K, H, W, 3, 3, 1, 1))
+        be.lib.tune(26, 0)
+        be.lib.conv2d_bwd_weight(be.ptr(d_x), C, None, 0, be.ptr(d_gy), be.ptr(d_gw), None, N, H, W, K, H, W, 3, 3, 1, 1,
+                                 PAD_REFLECT, be.ptr(ws), wsb, be.stream)
+        assert be.lib.last_route() == 2
+    y, gx, gw = be.np(d_y), be.np(d_gx), be.np(d_gw)
+    x64, gy64, w64 = x.astype(np.float64), gy.astype(np.float64), w.astype(np.float64)
+    if what == 'inf':
+        fin = x64.copy()
+        fin[0, 5, 4, 10] = 0.0
+        want = O.conv2d_fwd(fin, w64, None, 1, 1, 'reflect')
+        hit = O.conv2d_fwd((~np.isfinite(x64)).astype(np.float64), np.ones_like(w64), None, 1, 1, 'reflect') > 0
+        assert not np.isfinite(y[hit]).any(), "outputs whose receptive field holds the infinity must be non-finite"
+        err = np.abs(y[~hit] - want[~hit])
+        mag = O.conv2d_fwd(np.abs(fin), np.abs(w64), None, 1, 1, 'reflect')[~hit]
+        per = np.abs(fin[0]).max()       # the infinity's own sample is scaled by its finite maximum
+        assert np.all(err <= 4e-6 * mag + 2e-11 * per), (err.max(),)
+        return
+    want = O.conv2d_fwd(x64, w64, None, 1, 1, 'reflect')
+    want_gx, want_gw, _ = O.conv2d_bwd(x64, w64, gy64, 1, 1, 'reflect')
+    mag = O.conv2d_fwd(np.abs(x64), np.abs(w64), None, 1, 1, 'reflect')
+    mag_gx, _, _ = O.conv2d_bwd(np.abs(x64), np.abs(w64), np.abs(gy64), 1, 1, 'reflect')
+    # bound (include/nemar_hip.h): 3 * 2^-22 relative per product while the fp16 terms are normal, i.e. relative to sum |w||x| of the
+    # output's own receptive field; + 2^-36 of the SAMPLE's maximum times sum |w| for elements far below it
+    xs = np.abs(x64).reshape(N, -1).max(axis=1).reshape(N, 1, 1, 1)
+    gs = np.abs(gy64).reshape(N, -1).max(axis=1).reshape(N, 1, 1, 1)
+    wsum = np.abs(w64).sum(axis=(1, 2, 3)).reshape(1, K, 1, 1)
+    wsum_t = np.abs(w64).sum(axis=(0, 2, 3)).reshape(1, C, 1, 1)
+    # (4e-6 = 2^-18: the fp32 accumulation of a 1152-term dot product, as in the exact-fp32 kernels, on top of the operand split)
+    lim = 4e-6 * mag + 3e-11 * xs * wsum + 1e-30
+    assert np.all(np.abs(y - want) <= lim), ("fwd", float((np.abs(y - want) / lim).max()))
+    lim = 4e-6 * mag_gx + 3e-11 * gs * wsum_t + 1e-30
+    assert np.all(np.abs(gx - want_gx) <= lim), ("dgrad", float((np.abs(gx - want_gx) / lim).max()))
+    # weight gradient: a sum over samples, each accurate relative to its own magnitudes
+    _, mag_gw, _ = O.conv2d_bwd(np.abs(x64), w64 * 0, np.abs(gy64), 1, 1, 'reflect')
+    lim = 4e-6 * mag_gw + 3e-11 * float((xs * gs).sum()) * H * W + 1e-30
+    assert np.all(np.abs(gw - want_gw) <= lim), ("wgrad", float((np.abs(gw - want_gw) / lim).max()))
+
+
 def case_absmax_and_hint(be, seed=0):
     """nemar_absmax against numpy, odd sizes and an unaligned view; and a
     split-16 forward with the hint registered gives bit-identical results to one that runs its own max pass."""
@@ -322,13 +397,22 @@ def case_absmax_and_hint(be, seed=0):
             if hint:
                 word = be.bytes_buf(4)
                 be.lib.absmax(be.ptr(d_x), x.size, be.ptr(word), be.stream)
-                be.lib.absmax_hint(be.ptr(d_x), be.ptr(word))
+                be.lib.absmax_hint(be.ptr(d_x), be.ptr(word), 1)
             be.lib.conv2d_fwd(be.ptr(d_x), C, None, 0, be.ptr(d_w), None, be.ptr(d_y), N, H, W, K, 3, 3, 1, 1, PAD_ZERO, 0, 0.2,
                               be.ptr(cws), wsb, 0, be.stream)
             if hint:
-                be.lib.absmax_hint(be.ptr(d_x), None)
+                be.lib.absmax_hint(be.ptr(d_x), None, 0)
             outs.append(be.np(d_y))
     assert np.array_equal(outs[0], outs[1])
+    # per-sample words: finite maxima only (an infinity / NaN does not take part)
+    a = (rng.standard_normal((3, 1000)) * np.array([[1e-5], [1.0], [300.0]])).astype(np.float32)
+    a[1, 7] = np.inf
+    a[2, 9] = np.nan
+    words = be.bytes_buf(12)
+    be.lib.absmax_samples(be.ptr(be.dev(a)), 3, 1000, be.ptr(words), be.stream)
+    got = np.asarray(be.np(words), dtype=np.float32)[:3].view(np.uint32)
+    fin = np.where(np.isfinite(a), np.abs(a), 0).max(axis=1).astype(np.float32).view(np.uint32)
+    assert list(map(int, got)) == list(map(int, fin))
 
 
 def case_conv_split16_wgrad(be, N, C, H, W, K, pad_mode, seed=0, R=3):

@@ -325,13 +325,12 @@ def test_adam(be):
     K.case_adam(be)
 
 
-@pytest.mark.parametrize("variant", [4, 3, 0])
+@pytest.mark.parametrize("variant", [4, 3])
 def test_conv_split16_matrix_pipe(be, variant):
     """3x3 stride-1 layers with >= 128 output channels on the bf16 MFMA with three-way split operands (conv_split16.hip): padded,
     channel-blocked split planes; halo staged once per 16-channel chunk; weight-stage ring; zero and reflect padding; one and
     several row tiles per image, both 128-channel halves, 32- and 64-pixel rows."""
-    # 4 = fp16 x 3 products (two scaled fp16 planes; the default), 3 = bf16 x 6 products, 0 = bf16 x 6 on the first-generation
-    # kernel (loader waves)
+    # 4 = fp16 x 3 products (two scaled fp16 planes; the default), 3 = bf16 x 6 products
     be.lib.tune(21, variant)
     try:
         K.case_conv_split16(be, 2, 32, 8, 32, 128, K.PAD_REFLECT, dgrad=False)
@@ -344,7 +343,7 @@ def test_conv_split16_matrix_pipe(be, variant):
         be.lib.tune(21, 4)
 
 
-@pytest.mark.parametrize("variant", [4, 3, 0])
+@pytest.mark.parametrize("variant", [4, 3])
 def test_conv_split16_reflect_data_gradient(be, variant):
     """Data gradient of a reflect-padded 3x3 layer on the split-16 kernel: the folded border rows / slots written by the split
     pass are selected by address for (row 1, last filter row), (row H-2, first filter row) and the same in x; tiles that hold
@@ -471,3 +470,9 @@ def test_conv_s16g_weight_gradient(be, case):
 def test_conv_s16g_weight_gradient_row_scales(be):
     """gradient rows spanning 12 orders of magnitude: every row keeps fp32-class relative accuracy (scales are per row)"""
     K.case_conv_s16g_bwd_weight(be, 1, 64, 0, 4, 32, 64, 3, 1, 1, K.PAD_ZERO, gscale=10.0 ** np.linspace(-6, 6, 64))
+
+
+@pytest.mark.parametrize("what", ["samples", "outlier", "zero", "inf"])
+def test_conv_split16_dynamic_range(be, what):
+    """The fp16 x 3 route of the wide layers on adversarial magnitudes (per-sample scales): see kernel_cases."""
+    K.case_conv_split16_dynamic_range(be, what)
