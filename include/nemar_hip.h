@@ -197,6 +197,13 @@ int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* s
                        float eps, int act, float slope, void* stream);
 int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                        int act, float slope, void* stream);
+/* The same, and max |output| (finite elements) of every SAMPLE into max_words[plane / planes_per_sample] (4-byte words, ZERO on
+ * entry): what nemar_absmax_samples would compute in a pass of its own — the producer has the values in registers.  The words are
+ * what nemar_absmax_hint takes (the fp16 x 3 convolutions consume them). */
+int nemar_instnorm_fwd_max(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
+                           float eps, int act, float slope, void* max_words, int planes_per_sample, void* stream);
+int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
+                           int act, float slope, void* max_words, int planes_per_sample, void* stream);
 
 /* ---- K5/K6/K7: pointwise, pooling, resize, dropout -----------------------------------------------------------------
  * act_bwd: gx = gy * f'(.) expressed with the activation OUTPUT y (f fused into a conv epilogue):
@@ -218,6 +225,10 @@ int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, int W, int
  * Philox4x32-10(seed, offset); the backward is the same call on the upstream gradient (mask regenerated). */
 int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned offset,
                   void* stream);
+/* ... with the per-sample maxima of the output (max_words[i], zero on entry) for `samples` samples of `per_sample` elements
+ * (a multiple of 4); the masks are those of nemar_dropout over all samples * per_sample elements. */
+int nemar_dropout_max(const float* x, float* y, int samples, long long per_sample, float p, unsigned long long seed,
+                      unsigned offset, void* max_words, void* stream);
 
 /* Input pipeline, on the GPU: random crop + horizontal flip + ToTensor/Normalize(0.5, 0.5) of a pool of images resident in
  * HBM — reference data/base_dataset.py:63-78 (get_params: ONE crop position / flip per A-B pair) and :81-112

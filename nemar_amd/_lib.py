@@ -60,6 +60,8 @@ SIGNATURES = {
     "nemar_tune_ptr": (_i, [_vp]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
+    "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
+    "nemar_instnorm_bwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _i, _vp]),
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -68,6 +70,7 @@ SIGNATURES = {
     "nemar_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nemar_crop_flip_normalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _fl, _vp]),
     "nemar_dropout": (_i, [_vp, _vp, _ll, _fl, _u64, _u32, _vp]),
+    "nemar_dropout_max": (_i, [_vp, _vp, _i, _ll, _fl, _u64, _u32, _vp, _vp]),
     "nemar_loss_workspace": (_sz, []),
     "nemar_l1_loss_fwd": (_i, [_vp, _vp, _ll, _fl, _vp, _i, _vp, _sz, _vp]),
     "nemar_l1_loss_bwd": (_i, [_vp, _vp, _ll, _vp, _fl, _vp, _i, _vp]),

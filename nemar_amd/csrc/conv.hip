@@ -1085,6 +1085,8 @@ static int g_config_epoch = 0;      // bumped by every nemar_tune / nemar_set_sc
 static int g_s16g = 1;             // key 24: general layers on the 16-bit matrix pipe with the in-kernel operand split (conv_s16g.hip)
 static int g_s16g_wgrad_first = 0;  // key 26: 1 = the in-kernel-split weight gradient also takes the wide residual-block layers (stand-alone 374 vs
                                     // 393 us per call, but 44.3 vs 41.8 ms per step inside the bench: off)
+static int g_s16g_wgrad = 1;        // key 29: weight gradients on the in-kernel-split kernels (conv_s16g_wgrad.hip)
+static int g_s16g_fold = 1;         // key 30: stride-1 reflect data gradients on the padded domain + fold
 static long long g_s16g_min_mmac = 30;   // key 25: ... above this many million multiply-adds (tiny layers are launch-bound either way)
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
@@ -1667,7 +1669,7 @@ bool s16g_dgrad_problem(S16gProblem& q, S16gPlan& pl, int N, int C, int mskip, i
 struct DgradLayout {
     size_t pack_stride, padded_off, w2_off, ring_off, ring_slab_off, slab_off, aux_rows_off, aux_cols_off, total;
     int ring_len, ksplit, ring_ksplit;
-    bool ring, fold;
+    bool ring, fold, fold16;
 };
 DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
     DgradLayout L;
@@ -1688,9 +1690,23 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
             if (b > L.pack_stride) L.pack_stride = b;
         }
     }
+    // stride-1 reflect layers the general 16-bit-pipe kernel takes: the data gradient of the PADDED input (a plain zero-padded full
+    // correlation on the (H + 2p) x (W + 2p) domain) into scratch, then the fold — one extra pass over the gradient, but the
+    // implicit GEMM runs at several times the exact-fp32 rate (R net: 175 -> ~95 us per call)
+    L.fold16 = false;
+    if (L.ring && g_s16g_fold && R * S <= 9) {          // (49-tap layers: the 32-row tile would cost more than it saves)
+        S16gProblem q;
+        S16gPlan pl;
+        const int OHd = H + 2 * pad - R + 1, OWd = W + 2 * pad - S + 1;
+        if (OHd > 0 && OWd > 0 && s16g_dgrad_problem(q, pl, N, C, 0, H + 2 * pad, W + 2 * pad, K, OHd, OWd, R, S, 1, 0, ACT_NONE, 0.f)) {
+            L.fold16 = true;
+            const size_t b = (nemar_s16g_pack_bytes(q, pl) + 3) / 4;
+            if (b > L.pack_stride) L.pack_stride = b;
+        }
+    }
     size_t o = L.pack_stride * (size_t)(stride * stride);
     L.padded_off = o;
-    if (L.fold) o += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
+    if (L.fold || L.fold16) o += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
     L.w2_off = o;
     if (C <= 4) o += (size_t)C * K * R * S;
     L.ring_off = o;
@@ -1918,6 +1934,23 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             nemar_s16g_conv(q, pl, workspace, st);
             g_last_route = 3;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (16-bit pipe, in-kernel split)");
+            return NEMAR_OK;
+        }
+    }
+    if (refl && L.fold16 && gx1 == nullptr && gx0 && !bias && act == ACT_NONE) {
+        S16gProblem q;
+        S16gPlan pl;
+        const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+        if (s16g_dgrad_problem(q, pl, N, C, 0, Hp, Wp, K, OH, OW, R, S, 1, 0, ACT_NONE, 0.f)) {
+            float* const padded16 = wsf + L.padded_off;
+            q.src0 = gy; q.src1 = nullptr; q.bias = nullptr; q.dst0 = padded16; q.dst1 = nullptr; q.M0 = q.M;
+            if (!prepacked) nemar_s16g_pack(q, pl, w, (long long)R * S, (long long)C * R * S, workspace, st);
+            nemar_s16g_conv(q, pl, workspace, st);
+            const long long total = (long long)N * C * H * W;
+            hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded16, gx0, H,
+                               W, pad, total);
+            g_last_route = 3;
+            NEMAR_CHECK_LAUNCH("conv2d_bwd_data (16-bit pipe on the padded domain + fold)");
             return NEMAR_OK;
         }
     }
@@ -2149,7 +2182,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (narrow)");
         return NEMAR_OK;
     }
-    const bool s16g_wg = part && s16g_worth_it((long long)N * OH * OW * K * (C0 + C1) * R * S) &&
+    const bool s16g_wg = g_s16g_wgrad && part && s16g_worth_it((long long)N * OH * OW * K * (C0 + C1) * R * S) &&
         nemar_s16g_wgrad_eligible(N, C0, C1, H, W, K, OH, OW, R, S, stride, pad, pad_mode);
     const bool split16_wg = g_split16 && g_split16_variant == 4 && part && C1 == 0 && split16_worth_it(N, OH, OW, K, C0, R, S) &&
         nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
@@ -2247,6 +2280,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 25) { g_s16g_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 26) { g_s16g_wgrad_first = value != 0; return NEMAR_OK; }
     if (key == 27) { nemar_s16g_tune(0, value); return NEMAR_OK; }
+    if (key == 29) { g_s16g_wgrad = value != 0; return NEMAR_OK; }
+    if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = value == 3 ? 3 : 4; return NEMAR_OK; }      // packed images made under the other setting are stale

@@ -26,13 +26,35 @@ __device__ __forceinline__ float act_df(float xhat, int act, float slope) {
     return 1.f;
 }
 
+// Per-sample maximum of what a kernel writes, for the consumers that scale by it (the fp16 x 3 convolutions, csrc/conv_split16*.hip):
+// the producer has every output element in a register anyway, so the max pass over the tensor disappears.  One word per sample,
+// zero on entry; a workgroup only touches the word when its own maximum would change it (16 words x ~256 workgroups each: no hot
+// atomic).  Finite magnitudes only, as nemar_absmax_samples.
+__device__ __forceinline__ unsigned finite_mag(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+    return u < 0x7f800000u ? u : 0u;
+}
+__device__ __forceinline__ void publish_max(unsigned m, unsigned* word, unsigned* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; ++i) m = max(m, red[i]);
+        if (m > *reinterpret_cast<volatile unsigned*>(word)) atomicMax(word, m);
+    }
+}
+
 // PER > 0: register-cached plane (HW <= THREADS*PER).  PER == 0: streaming (shifted one-pass statistics).
 template <int THREADS, int PER>
 __global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ residual,
                                                                float* __restrict__ y, float* __restrict__ stats, int HW,
-                                                               float eps, int act, float slope) {
+                                                               float eps, int act, float slope, unsigned* maxw, int pps) {
     __shared__ float red[16];
+    unsigned omax = 0;                                    // max |y| of this plane (maxw != null)
     const size_t base = (size_t)blockIdx.x * HW;
     const float* xp = x + base;
     float* yp = y + base;
@@ -64,6 +86,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __re
                 float o = act_f((v[k] - mean) * rstd, act, slope);
                 if (rp) o += rp[i];
                 yp[i] = o;
+                omax = max(omax, finite_mag(o));
             }
         }
     } else {
@@ -82,20 +105,23 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __re
             float o = act_f((xp[i] - mean) * rstd, act, slope);
             if (rp) o += rp[i];
             yp[i] = o;
+            omax = max(omax, finite_mag(o));
         }
     }
     if (threadIdx.x == 0) {
         stats[2 * (size_t)blockIdx.x] = mean;
         stats[2 * (size_t)blockIdx.x + 1] = rstd;
     }
+    if (maxw) publish_max(omax, maxw + blockIdx.x / pps, reinterpret_cast<unsigned*>(red));
 }
 
 template <int THREADS, int PER>
 __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ stats,
                                                                const float* __restrict__ gy, float* __restrict__ gx,
-                                                               int HW, int act, float slope) {
+                                                               int HW, int act, float slope, unsigned* maxw, int pps) {
     __shared__ float red[16];
+    unsigned omax = 0;
     const size_t base = (size_t)blockIdx.x * HW;
     const float* xp = x + base;
     const float* gp = gy + base;
@@ -123,7 +149,11 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * THREADS;
-            if (i < HW) op[i] = rstd * (g[k] - m1 - xh[k] * m2);
+            if (i < HW) {
+                const float o = rstd * (g[k] - m1 - xh[k] * m2);
+                op[i] = o;
+                omax = max(omax, finite_mag(o));
+            }
         }
     } else {
         float s1 = 0.f, s2 = 0.f;
@@ -138,16 +168,34 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __re
         for (int i = threadIdx.x; i < HW; i += THREADS) {
             const float xh = (xp[i] - mean) * rstd;
             const float g = gp[i] * act_df(xh, act, slope);
-            op[i] = rstd * (g - m1 - xh * m2);
+            const float o = rstd * (g - m1 - xh * m2);
+            op[i] = o;
+            omax = max(omax, finite_mag(o));
         }
     }
+    if (maxw) publish_max(omax, maxw + blockIdx.x / pps, reinterpret_cast<unsigned*>(red));
 }
 
 }  // namespace
 
 // x, y, residual (nullable): [planes, HW] with planes = N*C;  stats: [planes, 2] = (mean, rstd)
+static int instnorm_fwd_impl(const float* x, const float* residual, float* y, float* stats, int planes, int HW, float eps, int act,
+                             float slope, unsigned* maxw, int pps, void* stream);
+
 NEMAR_API int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
                                  float eps, int act, float slope, void* stream) {
+    return instnorm_fwd_impl(x, residual, y, stats, planes, HW, eps, act, slope, nullptr, 1, stream);
+}
+
+// ... and max |y| per sample into max_words[plane / planes_per_sample] (words zero on entry; see publish_max)
+NEMAR_API int nemar_instnorm_fwd_max(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
+                                     float eps, int act, float slope, void* max_words, int planes_per_sample, void* stream) {
+    NEMAR_REQUIRE(max_words && planes_per_sample > 0 && planes % planes_per_sample == 0, "instnorm_fwd_max: bad max words");
+    return instnorm_fwd_impl(x, residual, y, stats, planes, HW, eps, act, slope, (unsigned*)max_words, planes_per_sample, stream);
+}
+
+static int instnorm_fwd_impl(const float* x, const float* residual, float* y, float* stats, int planes, int HW, float eps, int act,
+                             float slope, unsigned* maxw, int pps, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && y && stats, "instnorm_fwd: null pointer");
     NEMAR_REQUIRE(planes > 0 && HW > 0, "instnorm_fwd: bad shape planes=%d HW=%d", planes, HW);
@@ -155,21 +203,35 @@ NEMAR_API int nemar_instnorm_fwd(const float* x, const float* residual, float* y
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(planes);
     if (HW <= 64 * 8)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 256 * 16)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 1024 * 16)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 1024 * 64)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 64>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 64>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else
-        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     NEMAR_CHECK_LAUNCH("instnorm_fwd");
     return NEMAR_OK;
 }
 
+static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW, int act, float slope,
+                             unsigned* maxw, int pps, void* stream);
+
 NEMAR_API int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                                  int act, float slope, void* stream) {
+    return instnorm_bwd_impl(x, stats, gy, gx, planes, HW, act, slope, nullptr, 1, stream);
+}
+
+NEMAR_API int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
+                                     int act, float slope, void* max_words, int planes_per_sample, void* stream) {
+    NEMAR_REQUIRE(max_words && planes_per_sample > 0 && planes % planes_per_sample == 0, "instnorm_bwd_max: bad max words");
+    return instnorm_bwd_impl(x, stats, gy, gx, planes, HW, act, slope, (unsigned*)max_words, planes_per_sample, stream);
+}
+
+static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW, int act, float slope,
+                             unsigned* maxw, int pps, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && stats && gy && gx, "instnorm_bwd: null pointer");
     NEMAR_REQUIRE(planes > 0 && HW > 0, "instnorm_bwd: bad shape planes=%d HW=%d", planes, HW);
@@ -177,15 +239,15 @@ NEMAR_API int nemar_instnorm_bwd(const float* x, const float* stats, const float
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(planes);
     if (HW <= 64 * 8)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (HW <= 256 * 16)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (HW <= 1024 * 16)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (HW <= 1024 * 32)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 32>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 32>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else
-        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     NEMAR_CHECK_LAUNCH("instnorm_bwd");
     return NEMAR_OK;
 }

@@ -245,14 +245,22 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// grid.y = sample (maxw != null: `n` = elements per sample, a multiple of 4; the Philox counter stays the GLOBAL float4 index, so the
+// masks are those of the one-sample launch over the whole tensor)
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
                                                       unsigned thresh, float scale, unsigned seed_lo, unsigned seed_hi,
-                                                      unsigned offset) {
+                                                      unsigned offset, unsigned* maxw) {
+    __shared__ unsigned red[4];
     const long long n4 = (n + 3) >> 2;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+    const long long q0 = (long long)blockIdx.y * n4;
+    x += (size_t)blockIdx.y * n;
+    y += (size_t)blockIdx.y * n;
+    unsigned omax = 0;
+    for (long long ql = (long long)blockIdx.x * blockDim.x + threadIdx.x; ql < n4; ql += (long long)gridDim.x * blockDim.x) {
+        const long long q = q0 + ql;
         unsigned r[4];
         philox4x32_10((unsigned)q, (unsigned)(q >> 32), offset, 0u, seed_lo, seed_hi, r);
-        const long long i = q << 2;
+        const long long i = ql << 2;
         if (i + 3 < n) {
             const float4 v = *reinterpret_cast<const float4*>(x + i);
             float4 o;
@@ -261,8 +269,23 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
             o.z = r[2] >= thresh ? v.z * scale : 0.f;
             o.w = r[3] >= thresh ? v.w * scale : 0.f;
             *reinterpret_cast<float4*>(y + i) = o;
+            if (maxw) {
+                const unsigned a = __builtin_bit_cast(unsigned, o.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, o.y) & 0x7fffffffu,
+                               c = __builtin_bit_cast(unsigned, o.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, o.w) & 0x7fffffffu;
+                omax = max(omax, max(max(a < 0x7f800000u ? a : 0u, b < 0x7f800000u ? b : 0u), max(c < 0x7f800000u ? c : 0u, d < 0x7f800000u ? d : 0u)));
+            }
         } else {
             for (int k = 0; k < 4 && i + k < n; ++k) y[i + k] = r[k] >= thresh ? x[i + k] * scale : 0.f;
+        }
+    }
+    if (maxw) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = omax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
+            if (m > *reinterpret_cast<volatile unsigned*>(maxw + blockIdx.y)) atomicMax(maxw + blockIdx.y, m);
         }
     }
 }
@@ -380,8 +403,26 @@ NEMAR_API int nemar_dropout(const float* x, float* y, long long n, float p, unsi
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     hipLaunchKernelGGL(dropout_kernel, dim3(nemar_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n,
-                       thresh, 1.f / (1.f - p), (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset);
+                       thresh, 1.f / (1.f - p), (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)nullptr);
     NEMAR_CHECK_LAUNCH("dropout");
+    return NEMAR_OK;
+}
+
+// ... over `samples` samples of `per_sample` elements (a multiple of 4), and max |y| of sample i into max_words[i] (zero on entry).
+// Same masks as nemar_dropout over the samples * per_sample elements.
+NEMAR_API int nemar_dropout_max(const float* x, float* y, int samples, long long per_sample, float p, unsigned long long seed,
+                                unsigned offset, void* max_words, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(x && y && max_words && samples > 0 && samples <= 65535 && per_sample > 0 && per_sample % 4 == 0 && p >= 0.f && p < 1.f,
+                  "dropout_max: bad arguments");
+    NEMAR_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "dropout_max: pointers must be 16-byte aligned");
+    const double t = (double)p * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    int gx = nemar_stream_grid(per_sample / 4, 256);
+    if (gx * samples > 4096) gx = (4096 + samples - 1) / samples;
+    hipLaunchKernelGGL(dropout_kernel, dim3(gx, samples), dim3(256), 0, (hipStream_t)stream, x, y, per_sample, thresh, 1.f / (1.f - p),
+                       (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)max_words);
+    NEMAR_CHECK_LAUNCH("dropout_max");
     return NEMAR_OK;
 }
 

@@ -127,7 +127,8 @@ class GradSync:
             self.uses[k] = self.uses.get(k, 0) + 1
 
     def begin(self, expected=None):
-        self.counting = False
+        # (counting stays on: the discriminator's forward passes run inside backward_D(), after begin(); every forward use
+        # precedes the first gradient contribution of its pass)
         if not is_distributed():
             return
         self.active = True
@@ -178,6 +179,7 @@ class GradSync:
     def finish(self):
         """Issue the buckets that never filled up (parameters without a gradient this pass), then make the compute stream
         wait for every collective of this pass."""
+        self.counting = False
         if not self.active:
             return
         for b in range(len(self.buckets)):

@@ -101,7 +101,37 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
 _absmax_pool = {}      # device -> [zero-filled int32 tensor, next free word]: nemar_absmax wants its output word zero on entry
 
 
+def _max_words(n, device):
+    """n zeroed 4-byte words (per-sample maxima a producer kernel fills in)"""
+    pool = _absmax_pool.get(device)
+    if pool is None or pool[1] + n > pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+        _absmax_pool[device] = pool
+    word = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    return word
+
+
+# producers (InstanceNorm forward / backward, dropout) publish the per-sample maxima of what they write when the consumer is likely to
+# be one of the wide fp16 x 3 layers: the tensor carries the words as `_nemar_absmax` (Python attributes survive autograd in both
+# directions as long as the tensor itself is handed on), and the convolution takes them instead of running a max pass
+def _wants_max(t):
+    return t.dim() == 4 and t.shape[1] >= 128 and t.shape[1] % 16 == 0 and t.shape[0] <= 256
+
+
+def _tag_max(t, words):
+    # (with the tensor's version: autograd may accumulate another gradient INTO this tensor in place — the words are then stale)
+    t._nemar_absmax = (words, t._version)
+
+
 def _absmax_word(t):
+    have = getattr(t, '_nemar_absmax', None)
+    if have is not None and have[1] == t._version and have[0].numel() == t.shape[0]:
+        return have[0]
+    return _absmax_word_compute(t)
+
+
+def _absmax_word_compute(t):
     """max |t| PER SAMPLE as the N-word tensor nemar_absmax_hint takes (the fp16 split of the wide 3x3 layers scales every sample by
     a power of two derived from its own maximum).  Computed once per tensor and shared by the calls that take it as a source.
     Words come out of a pre-zeroed pool: one fill launch per 4096 of them instead of one per tensor."""
@@ -425,7 +455,12 @@ class _InstanceNorm(Function):
         N, C, H, W = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((N * C, 2), dtype=torch.float32, device=x.device)
-        L.instnorm_fwd(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _stream())
+        if _wants_max(x):
+            words = _max_words(N, x.device)
+            L.instnorm_fwd_max(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _p(words), C, _stream())
+            _tag_max(y, words)
+        else:
+            L.instnorm_fwd(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _stream())
         ctx.save_for_backward(x, stats)
         ctx.cfg = (act, slope)
         return y
@@ -440,7 +475,12 @@ class _InstanceNorm(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            L.instnorm_bwd(_p(x), _p(stats), _p(gy), _p(gx), N * C, H * W, act, slope, _stream())
+            if _wants_max(x):
+                words = _max_words(N, x.device)
+                L.instnorm_bwd_max(_p(x), _p(stats), _p(gy), _p(gx), N * C, H * W, act, slope, _p(words), C, _stream())
+                _tag_max(gx, words)
+            else:
+                L.instnorm_bwd(_p(x), _p(stats), _p(gy), _p(gx), N * C, H * W, act, slope, _stream())
         gres = gy if ctx.needs_input_grad[1] else None
         return gx, gres, None, None, None
 
@@ -513,6 +553,16 @@ def manual_seed(seed):
     _dropout_state["offset"] = 0
 
 
+def _dropout_launch(x, y, p, seed, off):
+    n = x.shape[0] if x.dim() == 4 else 0
+    if n and _wants_max(x) and (x.numel() // n) % 4 == 0:
+        words = _max_words(n, x.device)
+        L.dropout_max(_p(x), _p(y), n, x.numel() // n, p, seed, off, _p(words), _stream())
+        _tag_max(y, words)
+    else:
+        L.dropout(_p(x), _p(y), x.numel(), p, seed, off, _stream())
+
+
 class _Dropout(Function):
     @staticmethod
     def forward(ctx, x, p):
@@ -520,7 +570,7 @@ class _Dropout(Function):
         y = torch.empty_like(x)
         _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
         ctx.key = (p, _dropout_state["seed"], _dropout_state["offset"])
-        L.dropout(_p(x), _p(y), x.numel(), p, ctx.key[1], ctx.key[2], _stream())
+        _dropout_launch(x, y, p, ctx.key[1], ctx.key[2])
         return y
 
     @staticmethod
@@ -529,7 +579,7 @@ class _Dropout(Function):
         gy = _c(gy)
         gx = torch.empty_like(gy)
         p, seed, off = ctx.key
-        L.dropout(_p(gy), _p(gx), gy.numel(), p, seed, off, _stream())
+        _dropout_launch(gy, gx, p, seed, off)
         return gx, None
 
 

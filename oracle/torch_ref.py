@@ -63,12 +63,23 @@ def resnet_generator(P, x, n_blocks, use_dropout=False, dropout_masks=None):
     return torch.tanh(_conv(P, 'model.%d' % (17 + n_blocks), h, 1, 3, True))
 
 
-def nlayer_discriminator(P, x):
+def _lrelu(x, knife=None):
+    """LeakyReLU(0.2).  `knife` (tests only, see RefModel.knife_band) = {'band': t, 'count': n}: the elements whose
+    pre-activation lies within t x mean|x| of zero take the OTHER branch — the evaluation another correctly rounded fp32
+    implementation could have produced; `count` accumulates how many there were."""
+    if knife is None:
+        return F.leaky_relu(x, 0.2)
+    near = x.detach().abs() < knife['band'] * x.detach().abs().mean()
+    knife['count'] += int(near.sum())
+    return torch.where((x > 0) ^ near, x, 0.2 * x)
+
+
+def nlayer_discriminator(P, x, knife=None):
     """NLayerDiscriminator('basic').forward — reference models/networks.py:556-602."""
-    h = F.leaky_relu(_conv(P, 'model.0', x, 2, 1), 0.2)
-    h = F.leaky_relu(_in(_conv(P, 'model.2', h, 2, 1)), 0.2)
-    h = F.leaky_relu(_in(_conv(P, 'model.5', h, 2, 1)), 0.2)
-    h = F.leaky_relu(_in(_conv(P, 'model.8', h, 1, 1)), 0.2)
+    h = _lrelu(_conv(P, 'model.0', x, 2, 1), knife)
+    h = _lrelu(_in(_conv(P, 'model.2', h, 2, 1)), knife)
+    h = _lrelu(_in(_conv(P, 'model.5', h, 2, 1)), knife)
+    h = _lrelu(_in(_conv(P, 'model.8', h, 1, 1)), knife)
     return _conv(P, 'model.11', h, 1, 1)
 
 
@@ -183,6 +194,11 @@ class RefModel:
         self.cfg = dict(n_blocks=n_blocks, stn_type=stn_type, gan_mode=gan_mode, lambda_GAN=lambda_GAN,
                         lambda_recon=lambda_recon, lambda_smooth=lambda_smooth, alpha=alpha, multires_reg=multires_reg,
                         stn_cfg=stn_cfg)
+        # Knife-edge calibration of the D step (tests/step_parity.py): when set, optimize_parameters() also evaluates D's gradients
+        # with every LeakyReLU pre-activation within knife_band x mean|x| of zero on its other branch -> grads_D_knife /
+        # grads_D_mr_knife / knife_count.  One such element moves a whole layer's weight gradient by ~1 % whichever way an fp32
+        # implementation happened to round it.
+        self.knife_band = None
         mk = lambda ps: torch.optim.Adam(ps, lr=lr, betas=(beta1, 0.999))
         self.opt_T = mk(list(self.T.values()))
         self.opt_R = mk(list(self.R.values()))
@@ -215,15 +231,15 @@ class RefModel:
             return unet_stn(self.R, a, b, apply_on, self.cfg['alpha'], self.cfg['multires_reg'], self.cfg['stn_cfg'])
         return affine_stn(self.R, a, b, apply_on)
 
-    def _d_all(self, a, img, real):
+    def _d_all(self, a, img, real, knife=None):
         """sum over the full-res D and every reduced-resolution D of GANLoss(D(cat(a, img)), real)."""
         m = self.cfg['gan_mode']
-        loss = gan_loss(nlayer_discriminator(self.D, torch.cat([a, img], 1)), real, m)
+        loss = gan_loss(nlayer_discriminator(self.D, torch.cat([a, img], 1), knife), real, m)
         for i, Dm in enumerate(self.D_mr):
             size = (a.size(2) // 2 ** (i + 1), a.size(3) // 2 ** (i + 1))
             ar = F.interpolate(a, size, mode='bilinear', align_corners=False)
             ir = F.interpolate(img, size, mode='bilinear', align_corners=False)
-            loss = loss + gan_loss(nlayer_discriminator(Dm, torch.cat([ar, ir], 1)), real, m)
+            loss = loss + gan_loss(nlayer_discriminator(Dm, torch.cat([ar, ir], 1), knife), real, m)
         return loss
 
     def forward(self, A, B):
@@ -256,6 +272,15 @@ class RefModel:
         loss_D.backward()
         self.grads_D = OrderedDict((k, p.grad.clone()) for k, p in self.D.items())
         self.grads_D_mr = [OrderedDict((k, p.grad.clone()) for k, p in d.items()) for d in self.D_mr]
+        if self.knife_band:
+            knife = {'band': self.knife_band, 'count': 0}
+            alt = 0.5 * c['lambda_GAN'] * (self._d_all(A, B, True, knife) + self._d_all(A, self.fake_TR_B.detach(), False, knife)
+                                           + self._d_all(A, self.fake_RT_B.detach(), False, knife))
+            ps = list(self.D.values()) + [p for d in self.D_mr for p in d.values()]
+            gs = iter(torch.autograd.grad(alt, ps))
+            self.grads_D_knife = OrderedDict((k, next(gs)) for k in self.D)
+            self.grads_D_mr_knife = [OrderedDict((k, next(gs)) for k in d) for d in self.D_mr]
+            self.knife_count = knife['count']
         self.opt_D.step()
         self._freeze([self.T, self.R], True)
         # translation + registration step (reference :175-215, 278-284)

@@ -18,11 +18,18 @@ def full_step_record(m, A, B, seed):
     out = {}
     p0 = next(m.netT.parameters())
     a, b = torch.from_numpy(A).to(p0.device, p0.dtype), torch.from_numpy(B).to(p0.device, p0.dtype)
-    with torch.no_grad():
-        off = m.netR.offset_map(a, b)            # the deformation field, before the update
-    out['offsets/mean'], out['offsets/absmean'] = off.double().mean().item(), off.double().abs().mean().item()
-    out['offsets/proj'] = proj(off, seed, 900)
-    out['offsets/cropc'] = _cropc(off)
+    if hasattr(m.netR, 'offset_map'):            # (the affine STN has no dense field: its sampling grid is recorded instead)
+        with torch.no_grad():
+            off = m.netR.offset_map(a, b)        # the deformation field, before the update
+        out['offsets/mean'], out['offsets/absmean'] = off.double().mean().item(), off.double().abs().mean().item()
+        out['offsets/proj'] = proj(off, seed, 900)
+        out['offsets/cropc'] = _cropc(off)
+    else:
+        with torch.no_grad():
+            grid = m.netR.get_grid(a, b).permute(0, 3, 1, 2)
+        out['offsets/mean'], out['offsets/absmean'] = grid.double().mean().item(), grid.double().abs().mean().item()
+        out['offsets/proj'] = proj(grid, seed, 900)
+        out['offsets/cropc'] = _cropc(grid)
     m.set_input({'A': a, 'B': b, 'A_paths': ['a'], 'B_paths': ['b']})
     m.optimize_parameters()
     for k, v in m.get_current_losses().items():

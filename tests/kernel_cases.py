@@ -241,9 +241,9 @@ def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.A
         raise AssertionError("conv2d_fwd (s16g): err %.3e > %.3e at %s (got %.6g want %.6g)" % (err[i], lim[i], i, got[i], want[i]))
 
 
-def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0):
+def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO):
     with s16g_route(be):
-        case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, PAD_ZERO, skip0=skip0, seed=seed)
+        case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=skip0, seed=seed)
         assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
 
 
@@ -520,6 +520,44 @@ def case_instnorm(be, N, C, H, W, act, residual=False, seed=0):
     d_gx = be.full((N, C, H, W), np.nan)
     be.lib.instnorm_bwd(be.ptr(d_x), be.ptr(d_st), be.ptr(d_gy), be.ptr(d_gx), N * C, H * W, act, 0.2, be.stream)
     _assert_close(be.np(d_gx), want_gx, atol=3e-5 * np.abs(want_gx).max(), rtol=1e-4, what="instnorm_bwd")
+
+
+def case_producer_max_words(be, seed=0):
+    """InstanceNorm forward / backward and dropout with the per-sample maximum of their output as a by-product (the words the fp16 x 3
+    convolutions scale by): same outputs as the plain entry points, words == numpy's per-sample finite maximum."""
+    rng = np.random.default_rng(seed)
+    N, C, H, W = 3, 8, 6, 10
+    x = (rng.standard_normal((N, C, H, W)) * np.array([1.0, 1e-3, 50.0]).reshape(N, 1, 1, 1)).astype(np.float32)
+    res = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    gy = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    d_x, d_res, d_gy = be.dev(x), be.dev(res), be.dev(gy)
+
+    def words_of(buf):
+        return list(map(int, np.asarray(be.np(buf), dtype=np.float32)[:N].view(np.uint32)))
+
+    def want(a):
+        return list(map(int, np.abs(a.reshape(N, -1)).max(axis=1).astype(np.float32).view(np.uint32)))
+
+    for act, r in ((1, None), (0, d_res)):
+        y0, y1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
+        st0, st1 = be.zeros(N * C, 2), be.zeros(N * C, 2)
+        w = be.bytes_buf(4 * N)
+        be.lib.instnorm_fwd(be.ptr(d_x), be.ptr(r), be.ptr(y0), be.ptr(st0), N * C, H * W, 1e-5, act, 0.2, be.stream)
+        be.lib.instnorm_fwd_max(be.ptr(d_x), be.ptr(r), be.ptr(y1), be.ptr(st1), N * C, H * W, 1e-5, act, 0.2, be.ptr(w), C, be.stream)
+        a = np.asarray(be.np(y1), dtype=np.float32)
+        assert np.array_equal(be.np(y0), be.np(y1)) and words_of(w) == want(a)
+        g0, g1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
+        w = be.bytes_buf(4 * N)
+        be.lib.instnorm_bwd(be.ptr(d_x), be.ptr(st0), be.ptr(d_gy), be.ptr(g0), N * C, H * W, act, 0.2, be.stream)
+        be.lib.instnorm_bwd_max(be.ptr(d_x), be.ptr(st0), be.ptr(d_gy), be.ptr(g1), N * C, H * W, act, 0.2, be.ptr(w), C, be.stream)
+        a = np.asarray(be.np(g1), dtype=np.float32)
+        assert np.array_equal(be.np(g0), be.np(g1)) and words_of(w) == want(a)
+    y0, y1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
+    w = be.bytes_buf(4 * N)
+    be.lib.dropout(be.ptr(d_x), be.ptr(y0), x.size, 0.5, 1234567, 9, be.stream)
+    be.lib.dropout_max(be.ptr(d_x), be.ptr(y1), N, x.size // N, 0.5, 1234567, 9, be.ptr(w), be.stream)
+    a = np.asarray(be.np(y1), dtype=np.float32)
+    assert np.array_equal(be.np(y0), be.np(y1)) and words_of(w) == want(a)
 
 
 def case_pointwise(be, seed=0):

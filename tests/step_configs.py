@@ -23,9 +23,15 @@ STEP_CONFIGS = {
 # the reference itself (fp32 and fp64 — the gap between them calibrates each quantity's tolerance).  Scalars only
 # (losses, image statistics, per-parameter gradient norms / seeded projections, post-Adam checksums): SURVEY.md §8c.
 FULL_CONFIGS = {
+    # C1: BASELINE config 1 at full width — affine STN, resnet_6blocks, 128x128, batch 1 (the reference's own CPU-runnable case)
+    'c1_full': dict(stn_type='affine', netG='resnet_6blocks', ngf=64, ndf=64, size=128, batch=1, seed=37,
+                    lambda_smooth=0.5, steps=1, overrides_R={'net.local.2.weight': 0.02, 'net.local.2.bias': 0.05}),
     # C2: unet cfg 'A', 256x256 (the bench workload, at batch 1)
     'c2_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=256, batch=1, seed=41,
                     lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+    # C2 at the BENCH batch (8): the batched T / D passes, the batch-16 / batch-24 kernel launches of the timed step
+    'c2_b8': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=256, batch=8, seed=59,
+                  lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
     # C3: + multi-resolution discriminators, batch 2
     'c3_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=256, batch=2, seed=43,
                     lambda_smooth=10.0, multi_resolution=2, steps=1,
@@ -36,7 +42,7 @@ FULL_CONFIGS = {
                     overrides_R={'offset_map.output.conv2d.weight': 0.02}),
     # C5: 1024x1024, the deeper registration net (stn_cfg 'deep': 9 levels -> 2x2 bottleneck at 1024x1024)
     'c5_full': dict(stn_type='unet', stn_cfg='deep', netG='resnet_9blocks', ngf=64, ndf=64, size=1024, batch=1,
-                    seed=53, lambda_smooth=10.0, steps=1, f64=False, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+                    seed=53, lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
 }
 
 # BASELINE.json config 5's "deep" registration cfg does not exist in the reference (models/stn/unet_stn.py:11-25 defines

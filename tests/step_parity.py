@@ -14,6 +14,17 @@ from step_configs import STEP_CONFIGS, make_opt
 from test_oracle_golden import GOLD, build_ref_model
 
 LR = 2e-4
+# Conditioning estimates.  (a) The gap |fp32 oracle - fp64 oracle| of a quantity is ONE sample of how far two correct fp32
+# evaluations lie apart; N_PERTURBED further fp32 oracle runs on inputs moved by PERTURB_ULPS ulps (what a different summation
+# order does to the first layer's outputs) give more samples of the same distribution — the estimate is their elementwise maximum.
+# The registration net's 2x2 bottleneck (InstanceNorm over 4 values) makes single samples of its gradients unreliable.
+# (b) The D step on identical inputs is compared with the fp32 oracle itself, where the only ill-conditioned operation is the
+# LeakyReLU branch of a pre-activation at rounding distance of zero: the oracle re-evaluates D's gradients with every
+# pre-activation within KNIFE_BAND x mean|x| of zero on the other branch (oracle/torch_ref.py knife_band), and that difference —
+# exactly zero when no element is that close — widens the tolerance of the tensors it touches.
+N_PERTURBED = 2
+PERTURB_ULPS = 4.0
+KNIFE_BAND = 2e-6
 
 
 def load_seeded_into(net, seed, overrides):
@@ -75,10 +86,16 @@ def run(name, report=None, check=True):
     cfg = STEP_CONFIGS[name]
     g = np.load(os.path.join(GOLD, 'step_%s.npz' % name))
     ref = build_ref_model(name)
+    ref.knife_band = KNIFE_BAND
     ref64 = build_ref_model(name, dtype=torch.float64)
+    refp = [build_ref_model(name) for _ in range(N_PERTURBED)]
     hip = build_hip_model(name)
     A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
     tA, tB = torch.from_numpy(A), torch.from_numpy(B)
+    eps = PERTURB_ULPS * 2.0 ** -24
+    pert = [(torch.from_numpy(A * (1 + eps * seeded.uniform(A.shape, cfg['seed'], 7000 + 2 * i)).astype(np.float32)),
+             torch.from_numpy(B * (1 + eps * seeded.uniform(B.shape, cfg['seed'], 7001 + 2 * i)).astype(np.float32)))
+            for i in range(N_PERTURBED)]
     rows = []
 
     def add(what, err, tol):
@@ -89,8 +106,13 @@ def run(name, report=None, check=True):
         if step > 0:
             _force(ref, hip)
             _force(ref64, hip)
+            for rp in refp:
+                _force(rp, hip)
         ref_losses = ref.optimize_parameters(tA, tB)
         ref64_losses = ref64.optimize_parameters(tA, tB)
+        for rp, (pA, pB) in zip(refp, pert):
+            rp.optimize_parameters(pA, pB)
+        fp32_runs = [ref] + refp
         hip.set_input({'A': tA, 'B': tB, 'A_paths': ['a'], 'B_paths': ['b']})
         with torch.no_grad():       # deformation field / affine parameters of the registration net, before the update
             if cfg['stn_type'] == 'unet':
@@ -149,25 +171,27 @@ def run(name, report=None, check=True):
             2e-6 + 4 * _maxabs(ref.offsets.detach().numpy(), off))
         # D step on identical inputs: per-tensor max-abs error relative to the tensor's max (fp32 oracle)
         gmax = max(float(v.abs().max()) for v in ref.grads_D.values())
-        worst, errs = (0.0, None), []
-        pairs = [(k, v, gD_forced[k]) for k, v in ref.grads_D.items()]
+        worst, errs = (0.0, None, 0.0, 0.0), []
+        pairs = [(k, v, gD_forced[k], ref.grads_D_knife[k]) for k, v in ref.grads_D.items()]
         for i, (gref, gmine) in enumerate(zip(ref.grads_D_mr, gDmr_forced)):     # reduced-resolution discriminators too
-            pairs += [('mr%d.%s' % (i, k), v, gmine[k]) for k, v in gref.items()]
-        for k, v, mine in pairs:
+            pairs += [('mr%d.%s' % (i, k), v, gmine[k], ref.grads_D_mr_knife[i][k]) for k, v in gref.items()]
+        for k, v, mine, alt in pairs:
             vmax = float(v.abs().max())
             if vmax < 1e-5 * gmax:
                 continue                  # conv biases in front of InstanceNorm: exactly-zero gradient + noise
+            knife = _maxabs(alt.numpy(), v.numpy()) / vmax          # 0 unless a pre-activation sits on the knife edge
             e = _maxabs(mine, v.numpy()) / vmax
             errs.append(e)
-            if e > worst[0]:
-                worst = (e, k)
-        # Typical tensor 2e-4, worst tensor 1e-3 of the tensor's max.  (Round 1 allowed 2e-2 on the worst tensor plus a second
-        # attempt: one LeakyReLU pre-activation of these tiny discriminators at rounding distance of 0 moves a layer's gradient
-        # by ~1 %, and whether a run hit one changed from run to run with the atomically summed weights of the previous step.
-        # The backward pass is now bitwise reproducible, so the seeded configurations either contain such a knife edge or
-        # they do not — they do not.)
-        add(pre + 'grad/D on identical fakes, median tensor', float(np.median(errs)), 2e-4)
-        add(pre + 'grad/D on identical fakes, worst tensor (%s)' % worst[1], worst[0], 1e-3)
+            if e / (1e-3 + 1.5 * knife) > worst[0]:
+                worst = (e / (1e-3 + 1.5 * knife), k, e, knife)
+        # Typical tensor 2e-4, worst tensor 1e-3 of the tensor's max, + 1.5 x what the oracle's own knife-edge re-evaluation moves
+        # that tensor by.  One LeakyReLU pre-activation of these tiny discriminators at rounding distance of 0 moves a layer's
+        # weight gradient by ~1 % (measured: tools/diag_dgrad.py, profiles/r3_knife_edge.txt — the exact-fp32 route and the 16-bit
+        # route give the SAME 1.04e-2 on mr0.model.8.weight in the second step of unet256, bitwise reproducibly); which seeded
+        # state contains one changes with any rounding-level change of the previous step's update.
+        add(pre + 'grad/D on identical fakes, median tensor', float(np.median(errs)), 2e-4 if ref.knife_count == 0 else 1e-3)
+        add(pre + 'grad/D on identical fakes, worst tensor (%s: %.2e, knife-edge allowance %.2e, %d elements in the band)'
+            % (worst[1], worst[2], 1.5 * worst[3], ref.knife_count), worst[0], 1.0)
         # full-step gradients (own forward values): direction agreement with the fp64 oracle per network / tensor
         for nm, mine, g64 in (('T', gT, ref64.grads_T), ('R', gR, ref64.grads_R), ('D', gD, ref64.grads_D)):
             gmax = max(float(v.abs().max()) for v in g64.values())
@@ -190,7 +214,7 @@ def run(name, report=None, check=True):
             # oracle's — one ReLU / LeakyReLU / max-pool mask that flips upstream moves a handful of elements by
             # ~1e-2 of the tensor's max in ANY pair of fp32 evaluations (measured: gpurun_out/r2r, 1.07e-2 on one element of R's
             # localisation weights in the 128x128 affine config while every norm / cosine row passed).  Reported: worst tensor.
-            g32 = {'T': ref.grads_T, 'R': ref.grads_R, 'D': ref.grads_D}[nm]
+            g32s = [{'T': r.grads_T, 'R': r.grads_R, 'D': r.grads_D}[nm] for r in fp32_runs]
             worst_e = (0.0, None, 0.0)
             for k, v in g64.items():
                 b = v.numpy().astype(np.float64)
@@ -198,7 +222,7 @@ def run(name, report=None, check=True):
                 if vmax < 1e-5 * gmax:
                     continue
                 e = np.abs(np.asarray(mine[k], dtype=np.float64) - b).ravel() / vmax
-                cond = np.abs(g32[k].numpy().astype(np.float64) - b).ravel() / vmax
+                cond = np.max([np.abs(g[k].numpy().astype(np.float64) - b).ravel() for g in g32s], axis=0) / vmax
                 # large tensors: 99th and 99.9th percentiles (a mask flip upstream moves a handful of elements, the single worst of
                 # which is a coin toss between any two fp32 evaluations: 3.4e-2 of the tensor max was seen on D's last 4x4 weight
                 # in the second step of the 128x128 config with every other row green); small ones: the worst element, wider base
@@ -212,15 +236,14 @@ def run(name, report=None, check=True):
             add(pre + 'grad/%s elementwise, worst tensor %s (max err %.2e of the tensor max)' % (nm, worst_e[1], worst_e[2]),
                 worst_e[0], 1.0)
         # post-Adam weights vs the fp64 oracle: elements whose update differs by more than half a step
-        for nm, net, p32, p64 in (('T', hip.netT, ref.T, ref64.T), ('R', hip.netR, ref.R, ref64.R),
-                                  ('D', hip.netD, ref.D, ref64.D)):
+        for nm, net, p64 in (('T', hip.netT, ref64.T), ('R', hip.netR, ref64.R), ('D', hip.netD, ref64.D)):
             bad = bad32 = tot = 0
             for k, p in net.named_parameters():
                 if not k.endswith('weight'):
                     continue
                 q = p64[k].detach()
                 bad += int(((p.detach().cpu().double() - q).abs() > 0.5 * LR).sum())
-                bad32 += int(((p32[k].detach().double() - q).abs() > 0.5 * LR).sum())
+                bad32 += max(int(((getattr(r, nm)[k].detach().double() - q).abs() > 0.5 * LR).sum()) for r in fp32_runs)
                 tot += q.numel()
             add(pre + 'adam/%s fraction of weights off by > lr/2' % nm, bad / max(tot, 1), 2e-3 + 4 * bad32 / max(tot, 1))
     if report:

@@ -476,3 +476,14 @@ def test_conv_s16g_weight_gradient_row_scales(be):
 def test_conv_split16_dynamic_range(be, what):
     """The fp16 x 3 route of the wide layers on adversarial magnitudes (per-sample scales): see kernel_cases."""
     K.case_conv_split16_dynamic_range(be, what)
+
+
+def test_producer_max_words(be):
+    K.case_producer_max_words(be)
+
+
+def test_conv_s16g_reflect_data_gradient(be):
+    """Reflect-padded stride-1 layers outside the wide residual blocks (the registration net's 32 / 64-channel ResnetBlocks): data
+    gradient of the padded input on the general 16-bit-pipe kernel, then the fold of the mirrored border."""
+    K.case_conv_s16g_bwd_data(be, 2, 32, 0, 8, 32, 32, 3, 1, 1, pad_mode=K.PAD_REFLECT)
+    K.case_conv_s16g_bwd_data(be, 1, 64, 0, 6, 40, 48, 3, 1, 1, pad_mode=K.PAD_REFLECT)

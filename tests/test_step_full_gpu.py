@@ -16,6 +16,8 @@ statistically equal to the reference's own fp32 gaps — R net median 6e-4 vs 1.
     rounding distance of zero moves by 2 lr = 4e-4 between ANY two fp32 implementations; three such elements are
     allowed per tensor on top of the relative bound, and biases in front of an InstanceNorm (true gradient exactly zero,
     i.e. pure rounding noise with a random sign) are not compared.
+c1_full is BASELINE config 1 at full width (affine STN, resnet_6blocks, 128x128, batch 1), c2_b8 the bench workload at the bench
+batch (8: the batched T / D passes launch their kernels at batch 16 / 24, as the timed step does).
 The 1024x1024 config has no fp64 run (one fp64 step of the reference needs > 60 GB: it was tried, tests/golden/make_golden.py
 died in a 26 GB allocation), so there the build is compared with the reference's FP32 run — both sides carry rounding error —
 with the gap per quantity class taken from the 512x512 config's measured relative gaps (90th percentile of the class), tripled
@@ -154,18 +156,19 @@ def test_full_width_step_vs_reference(name):
     rec = full_step_record(m, A, B, cfg['seed'])
     torch.cuda.synchronize()
     rows = compare(name, rec, report=os.environ.get('NEMAR_FULL_REPORT'))
-    assert len(rows) > 300, len(rows)
+    assert len(rows) > (200 if cfg['stn_type'] == 'affine' else 300), len(rows)     # (the affine STN has 8 parameter tensors)
     bad = [r for r in rows if not r[3]]
     assert not bad, (len(bad), bad[:8])
 
 
 def test_full_width_step_on_the_exact_fp32_route():
-    """The same C2 fixture with the split-16 kernels switched off (nemar_tune(20, 0): every convolution on the exact-fp32 MFMA / VALU
-    kernels) — both routes of the wide 3x3 layers stay pinned to the reference."""
+    """The same C2 fixture with every 16-bit-pipe kernel switched off (nemar_tune(20, 0) and (24, 0): all convolutions on the
+    exact-fp32 MFMA / VALU kernels) — both arithmetic routes stay pinned to the reference."""
     from nemar_amd import ops
     name = 'c2_full'
     cfg = FULL_CONFIGS[name]
     ops.tune(20, 0)
+    ops.tune(24, 0)
     try:
         m = build(name)
         A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
@@ -173,6 +176,7 @@ def test_full_width_step_on_the_exact_fp32_route():
         torch.cuda.synchronize()
     finally:
         ops.tune(20, 1)
+        ops.tune(24, 1)
     rows = compare(name, rec)
     bad = [r for r in rows if not r[3]]
     assert len(rows) > 300 and not bad, (len(bad), bad[:8])

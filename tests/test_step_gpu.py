@@ -45,8 +45,8 @@ def test_step_is_bitwise_reproducible():
 
 @pytest.mark.parametrize("name", ["affine128", "unet256"])
 def test_batched_passes_match_reference_call_order(name, monkeypatch):
-    """T([a ; R(a)]) / D([real ; fake_TR ; fake_RT]) as single batches (NEMAR_BATCHED_PASSES=1) against the reference's
-    separate calls (the default): same losses, same gradients up to fp32 summation order."""
+    """T([a ; R(a)]) / D([real ; fake_TR ; fake_RT]) as single batches (NEMAR_BATCHED_PASSES=1, the default) against the reference's
+    separate calls (NEMAR_BATCHED_PASSES=0): same losses, same gradients up to fp32 summation order."""
     import torch
     import seeded
     cfg = STEP_CONFIGS[name]
