@@ -197,9 +197,14 @@ int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* s
                        float eps, int act, float slope, void* stream);
 int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                        int act, float slope, void* stream);
-/* The same, and max |output| (finite elements) of every SAMPLE into max_words[plane / planes_per_sample] (4-byte words, ZERO on
- * entry): what nemar_absmax_samples would compute in a pass of its own — the producer has the values in registers.  The words are
- * what nemar_absmax_hint takes (the fp16 x 3 convolutions consume them). */
+/* The same, and max |output| (finite elements) of every SAMPLE into max_words[sample]: what nemar_absmax_samples would compute in a
+ * pass of its own — the producer has the values in registers.  The words are what nemar_absmax_hint takes (the fp16 x 3
+ * convolutions consume them).  max_words is a buffer of NEMAR_MAX_WORDS(samples) 4-byte words, no initialisation needed: the first
+ * `samples` words are the result, the rest is scratch for the per-workgroup partials a second tiny launch reduces (no atomics —
+ * thousands of workgroups' device-scope atomicMax on a handful of words cost more than the pass they replaced).
+ * planes_per_sample <= NEMAR_MAX_PARTIALS. */
+#define NEMAR_MAX_PARTIALS 2048
+#define NEMAR_MAX_WORDS(samples) ((size_t)(samples) * (1 + NEMAR_MAX_PARTIALS))
 int nemar_instnorm_fwd_max(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
                            float eps, int act, float slope, void* max_words, int planes_per_sample, void* stream);
 int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
@@ -225,8 +230,8 @@ int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, int W, int
  * Philox4x32-10(seed, offset); the backward is the same call on the upstream gradient (mask regenerated). */
 int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned offset,
                   void* stream);
-/* ... with the per-sample maxima of the output (max_words[i], zero on entry) for `samples` samples of `per_sample` elements
- * (a multiple of 4); the masks are those of nemar_dropout over all samples * per_sample elements. */
+/* ... with the per-sample maxima of the output (max_words[i]; a NEMAR_MAX_WORDS(samples) buffer as above) for `samples` samples of
+ * `per_sample` elements (a multiple of 4); the masks are those of nemar_dropout over all samples * per_sample elements. */
 int nemar_dropout_max(const float* x, float* y, int samples, long long per_sample, float p, unsigned long long seed,
                       unsigned offset, void* max_words, void* stream);
 

@@ -10,6 +10,7 @@
 // HBM-bound.  One workgroup per (n,c) plane; planes up to THREADS*PER elements are held in registers so x (and gy)
 // are read from memory exactly once and the variance is the exact two-pass form.
 #include "common.h"
+#include "max_words.h"
 
 namespace {
 
@@ -34,6 +35,7 @@ __device__ __forceinline__ unsigned finite_mag(float v) {
     const unsigned u = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
     return u < 0x7f800000u ? u : 0u;
 }
+// the workgroup's maximum -> its own partial word (max_words.h)
 __device__ __forceinline__ void publish_max(unsigned m, unsigned* word, unsigned* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
@@ -43,7 +45,7 @@ __device__ __forceinline__ void publish_max(unsigned m, unsigned* word, unsigned
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         for (int i = 1; i < nw; ++i) m = max(m, red[i]);
-        if (m > *reinterpret_cast<volatile unsigned*>(word)) atomicMax(word, m);
+        *word = m;
     }
 }
 
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __re
         stats[2 * (size_t)blockIdx.x] = mean;
         stats[2 * (size_t)blockIdx.x + 1] = rstd;
     }
-    if (maxw) publish_max(omax, maxw + blockIdx.x / pps, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
 }
 
 template <int THREADS, int PER>
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __re
             omax = max(omax, finite_mag(o));
         }
     }
-    if (maxw) publish_max(omax, maxw + blockIdx.x / pps, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
 }
 
 }  // namespace
@@ -190,7 +192,8 @@ NEMAR_API int nemar_instnorm_fwd(const float* x, const float* residual, float* y
 // ... and max |y| per sample into max_words[plane / planes_per_sample] (words zero on entry; see publish_max)
 NEMAR_API int nemar_instnorm_fwd_max(const float* x, const float* residual, float* y, float* stats, int planes, int HW,
                                      float eps, int act, float slope, void* max_words, int planes_per_sample, void* stream) {
-    NEMAR_REQUIRE(max_words && planes_per_sample > 0 && planes % planes_per_sample == 0, "instnorm_fwd_max: bad max words");
+    NEMAR_REQUIRE(max_words && planes_per_sample > 0 && planes_per_sample <= NEMAR_MAX_PARTIALS && planes % planes_per_sample == 0,
+                  "instnorm_fwd_max: bad max words");
     return instnorm_fwd_impl(x, residual, y, stats, planes, HW, eps, act, slope, (unsigned*)max_words, planes_per_sample, stream);
 }
 
@@ -212,6 +215,7 @@ static int instnorm_fwd_impl(const float* x, const float* residual, float* y, fl
         hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 64>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else
         hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    if (maxw) max_words_finalize(maxw, planes / pps, pps, st);
     NEMAR_CHECK_LAUNCH("instnorm_fwd");
     return NEMAR_OK;
 }
@@ -226,7 +230,8 @@ NEMAR_API int nemar_instnorm_bwd(const float* x, const float* stats, const float
 
 NEMAR_API int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                                      int act, float slope, void* max_words, int planes_per_sample, void* stream) {
-    NEMAR_REQUIRE(max_words && planes_per_sample > 0 && planes % planes_per_sample == 0, "instnorm_bwd_max: bad max words");
+    NEMAR_REQUIRE(max_words && planes_per_sample > 0 && planes_per_sample <= NEMAR_MAX_PARTIALS && planes % planes_per_sample == 0,
+                  "instnorm_bwd_max: bad max words");
     return instnorm_bwd_impl(x, stats, gy, gx, planes, HW, act, slope, (unsigned*)max_words, planes_per_sample, stream);
 }
 
@@ -248,6 +253,7 @@ static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy
         hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 32>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else
         hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+    if (maxw) max_words_finalize(maxw, planes / pps, pps, st);
     NEMAR_CHECK_LAUNCH("instnorm_bwd");
     return NEMAR_OK;
 }

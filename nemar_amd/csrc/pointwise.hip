@@ -7,6 +7,7 @@
 //                  188-195 ; models/nemar_model.py:187-188,204-205,226-227,240-241,254-255
 //   dropout        nn.Dropout(0.5) — reference models/networks.py:427-428 (ON by default, nemar_model.py:102)
 #include "common.h"
+#include "max_words.h"
 
 namespace {
 
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
-            if (m > *reinterpret_cast<volatile unsigned*>(maxw + blockIdx.y)) atomicMax(maxw + blockIdx.y, m);
+            maxw[gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] = m;          // this workgroup's partial (max_words.h)
         }
     }
 }
@@ -408,7 +409,8 @@ NEMAR_API int nemar_dropout(const float* x, float* y, long long n, float p, unsi
     return NEMAR_OK;
 }
 
-// ... over `samples` samples of `per_sample` elements (a multiple of 4), and max |y| of sample i into max_words[i] (zero on entry).
+// ... over `samples` samples of `per_sample` elements (a multiple of 4), and max |y| of sample i into max_words[i] (a
+// NEMAR_MAX_WORDS(samples) buffer, max_words.h).
 // Same masks as nemar_dropout over the samples * per_sample elements.
 NEMAR_API int nemar_dropout_max(const float* x, float* y, int samples, long long per_sample, float p, unsigned long long seed,
                                 unsigned offset, void* max_words, void* stream) {
@@ -419,9 +421,10 @@ NEMAR_API int nemar_dropout_max(const float* x, float* y, int samples, long long
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     int gx = nemar_stream_grid(per_sample / 4, 256);
-    if (gx * samples > 4096) gx = (4096 + samples - 1) / samples;
+    if (gx * samples > 8192) gx = (8192 + samples - 1) / samples;
     hipLaunchKernelGGL(dropout_kernel, dim3(gx, samples), dim3(256), 0, (hipStream_t)stream, x, y, per_sample, thresh, 1.f / (1.f - p),
                        (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)max_words);
+    max_words_finalize((unsigned*)max_words, samples, gx, (hipStream_t)stream);
     NEMAR_CHECK_LAUNCH("dropout_max");
     return NEMAR_OK;
 }

@@ -101,27 +101,24 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
 _absmax_pool = {}      # device -> [zero-filled int32 tensor, next free word]: nemar_absmax wants its output word zero on entry
 
 
+MAX_PARTIALS = 2048      # include/nemar_hip.h NEMAR_MAX_PARTIALS
+
+
 def _max_words(n, device):
-    """n zeroed 4-byte words (per-sample maxima a producer kernel fills in)"""
-    pool = _absmax_pool.get(device)
-    if pool is None or pool[1] + n > pool[0].numel():
-        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
-        _absmax_pool[device] = pool
-    word = pool[0][pool[1]:pool[1] + n]
-    pool[1] += n
-    return word
+    """a NEMAR_MAX_WORDS(n) buffer for a producer's per-sample maxima: [n results | n x 2048 partial words], no initialisation needed"""
+    return torch.empty(n * (1 + MAX_PARTIALS), dtype=torch.int32, device=device)
 
 
 # producers (InstanceNorm forward / backward, dropout) publish the per-sample maxima of what they write when the consumer is likely to
 # be one of the wide fp16 x 3 layers: the tensor carries the words as `_nemar_absmax` (Python attributes survive autograd in both
 # directions as long as the tensor itself is handed on), and the convolution takes them instead of running a max pass
 def _wants_max(t):
-    return t.dim() == 4 and t.shape[1] >= 128 and t.shape[1] % 16 == 0 and t.shape[0] <= 256
+    return t.dim() == 4 and 128 <= t.shape[1] <= MAX_PARTIALS and t.shape[1] % 16 == 0 and t.shape[0] <= 256
 
 
 def _tag_max(t, words):
     # (with the tensor's version: autograd may accumulate another gradient INTO this tensor in place — the words are then stale)
-    t._nemar_absmax = (words, t._version)
+    t._nemar_absmax = (words[:t.shape[0]], t._version)
 
 
 def _absmax_word(t):

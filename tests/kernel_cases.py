@@ -541,19 +541,19 @@ def case_producer_max_words(be, seed=0):
     for act, r in ((1, None), (0, d_res)):
         y0, y1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
         st0, st1 = be.zeros(N * C, 2), be.zeros(N * C, 2)
-        w = be.bytes_buf(4 * N)
+        w = be.bytes_buf(4 * N * 2049)          # NEMAR_MAX_WORDS(N): results + per-workgroup partials, uninitialised
         be.lib.instnorm_fwd(be.ptr(d_x), be.ptr(r), be.ptr(y0), be.ptr(st0), N * C, H * W, 1e-5, act, 0.2, be.stream)
         be.lib.instnorm_fwd_max(be.ptr(d_x), be.ptr(r), be.ptr(y1), be.ptr(st1), N * C, H * W, 1e-5, act, 0.2, be.ptr(w), C, be.stream)
         a = np.asarray(be.np(y1), dtype=np.float32)
         assert np.array_equal(be.np(y0), be.np(y1)) and words_of(w) == want(a)
         g0, g1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
-        w = be.bytes_buf(4 * N)
+        w = be.bytes_buf(4 * N * 2049)          # NEMAR_MAX_WORDS(N): results + per-workgroup partials, uninitialised
         be.lib.instnorm_bwd(be.ptr(d_x), be.ptr(st0), be.ptr(d_gy), be.ptr(g0), N * C, H * W, act, 0.2, be.stream)
         be.lib.instnorm_bwd_max(be.ptr(d_x), be.ptr(st0), be.ptr(d_gy), be.ptr(g1), N * C, H * W, act, 0.2, be.ptr(w), C, be.stream)
         a = np.asarray(be.np(g1), dtype=np.float32)
         assert np.array_equal(be.np(g0), be.np(g1)) and words_of(w) == want(a)
     y0, y1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
-    w = be.bytes_buf(4 * N)
+    w = be.bytes_buf(4 * N * 2049)
     be.lib.dropout(be.ptr(d_x), be.ptr(y0), x.size, 0.5, 1234567, 9, be.stream)
     be.lib.dropout_max(be.ptr(d_x), be.ptr(y1), N, x.size // N, 0.5, 1234567, 9, be.ptr(w), be.stream)
     a = np.asarray(be.np(y1), dtype=np.float32)

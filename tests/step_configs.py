@@ -40,9 +40,11 @@ FULL_CONFIGS = {
     'c4_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=512, batch=2, seed=47,
                     lambda_smooth=10.0, stn_bilateral_alpha=1.5, stn_multires_reg=2, steps=1,
                     overrides_R={'offset_map.output.conv2d.weight': 0.02}),
-    # C5: 1024x1024, the deeper registration net (stn_cfg 'deep': 9 levels -> 2x2 bottleneck at 1024x1024)
+    # C5: 1024x1024, the deeper registration net (stn_cfg 'deep': 9 levels -> 2x2 bottleneck at 1024x1024).  fp32 reference run
+    # only: the fp64 run of the reference needs more host memory than the build container has (a 26 GB single allocation failed
+    # under a 56 GB limit, /tmp/make_golden_c5.log of round 3), so C5's tolerances are the fixed bases of compare().
     'c5_full': dict(stn_type='unet', stn_cfg='deep', netG='resnet_9blocks', ngf=64, ndf=64, size=1024, batch=1,
-                    seed=53, lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
+                    seed=53, lambda_smooth=10.0, steps=1, f64=False, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
 }
 
 # BASELINE.json config 5's "deep" registration cfg does not exist in the reference (models/stn/unet_stn.py:11-25 defines
