@@ -210,6 +210,29 @@ int nemar_instnorm_fwd_max(const float* x, const float* residual, float* y, floa
 int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                            int act, float slope, void* max_words, int planes_per_sample, void* stream);
 
+/* InstanceNorm (+ activation, + Dropout(p) drawn exactly as nemar_dropout draws it over the [N,C,H,W] tensor, + residual) that ALSO
+ * writes its output as the fp16 x 3 planes a following 3x3 / pad-1 REFLECT convolution of the wide-layer route consumes
+ * (reference: the conv -> InstanceNorm -> ReLU -> [Dropout] -> ReflectionPad2d(1) -> conv chain of ResnetBlock,
+ * models/networks.py:418-446) — the consumer then skips its max and split passes (nemar_planes_hint + nemar_absmax_hint below).
+ *   y          fp32 output or NULL (planes only: nothing else reads it)
+ *   planes     2 * N * (C/8) * (H+4) * (W+4) 16-byte words (hi plane, lo plane), layout of conv_split16.hip
+ *   scale_words[N]  out: the a-priori BOUND each sample was scaled by, sqrt(HW) [/ (1-p)] [+ max |residual| of the sample] —
+ *              InstanceNorm's output cannot exceed it, so the scale is known before the first element exists; pass these words to
+ *              nemar_absmax_hint for the consuming convolution (its epilogue unscales with them).  A bound 2^k above the actual
+ *              maximum costs nothing for k <= 8: elements above 2^(k-14) x max keep the split's 22 bits, smaller ones are off by
+ *              <= 2^(k-36) x max (norm_planes.hip).
+ *   residual_max_words[N]  required with a residual: its per-sample maxima (a producer's max words)
+ *   max_words  NEMAR_MAX_WORDS(N) buffer or NULL: the ACTUAL per-sample maxima of the output (the next layer's residual bound)
+ * Limits: C % 8 == 0, W % 4 == 0, H * W <= 4096, N <= 256. */
+int nemar_instnorm_fwd_planes(const float* x, const float* residual, const void* residual_max_words, float* y, float* stats,
+                              int N, int C, int H, int W, float eps, int act, float slope, float dropout_p,
+                              unsigned long long seed, unsigned offset, void* planes, void* scale_words, void* max_words,
+                              void* stream);
+/* "the planes of `tensor` ([N,C,H,W], reflect 3x3 layout) already exist at `planes`": consumed by the next nemar_conv2d_fwd whose
+ * source is `tensor` when that layer runs on the fp16 x 3 wide-layer route AND an nemar_absmax_hint with N words is registered for
+ * the same tensor (the words the planes were scaled by); ignored otherwise.  planes = NULL clears. */
+int nemar_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W);
+
 /* ---- K5/K6/K7: pointwise, pooling, resize, dropout -----------------------------------------------------------------
  * act_bwd: gx = gy * f'(.) expressed with the activation OUTPUT y (f fused into a conv epilogue):
  *     nn.LeakyReLU / nn.ReLU / nn.Tanh — reference models/networks.py:377,576 ; models/stn/layers.py:61-64. */

@@ -61,6 +61,8 @@ SIGNATURES = {
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
+    "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp]),
+    "nemar_planes_hint": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "nemar_instnorm_bwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _i, _vp]),
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),

@@ -32,6 +32,8 @@
 #include "conv_split16.h"
 #include "conv_s16g.h"
 
+void nemar_norm_planes_debug(int bits);          // norm_planes.hip: ablation bits of the fused producer (measurement only)
+
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
 bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int OH, int OW);
 int nemar_narrow_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int K, int R,
@@ -2281,6 +2283,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 26) { g_s16g_wgrad_first = value != 0; return NEMAR_OK; }
     if (key == 27) { nemar_s16g_tune(0, value); return NEMAR_OK; }
     if (key == 29) { g_s16g_wgrad = value != 0; return NEMAR_OK; }
+    if (key == 31) { nemar_norm_planes_debug(value); return NEMAR_OK; }
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
@@ -2342,6 +2345,12 @@ NEMAR_API int nemar_kernel_timer_read(double* total_ms, double* total_flop, int*
 NEMAR_API int nemar_absmax_hint(const void* tensor, const void* words, int count) {
     NEMAR_REQUIRE(tensor && (!words || count >= 1), "absmax_hint: null tensor / bad count");
     nemar_split16_set_hint(tensor, words, count);
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W) {
+    NEMAR_REQUIRE(tensor && (!planes || (N > 0 && C > 0 && H > 0 && W > 0)), "planes_hint: null tensor / bad shape");
+    nemar_split16_set_planes_hint(tensor, planes, N, C, H, W);
     return NEMAR_OK;
 }
 

@@ -38,6 +38,7 @@ void nemar_sum_partials(const float* part, long long stride, int splits, float* 
 void nemar_split16_absmax(const float* x, int samples, long long per, void* out, hipStream_t st);
 void nemar_split16_set_hint(const void* tensor, const void* word, int count);  // word == NULL clears; count = words (N or 1)
 const unsigned* nemar_split16_hint(const void* tensor, int* count);
+void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W);
 const unsigned* nemar_split16_source_max(const float* src, int N, long long per, unsigned* own, int* stride, hipStream_t st);
 
 // ---- measurement hook: HIP events on the launch stream around the main kernel of every nemar_split16_conv call while enabled ----

@@ -611,7 +611,30 @@ unsigned* pack_max_word(void* packed, int M, int Cred, int KS) {
 const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr};
 const unsigned* g_hint_word[4] = {nullptr, nullptr, nullptr, nullptr};
 int g_hint_count[4] = {0, 0, 0, 0};
+// nemar_planes_hint: the fp16 x 3 planes of a source already exist (a producer wrote them: norm_planes.hip) — reflect 3x3 layout only
+struct PlanesHint { const void* tensor; const void* planes; int N, C, H, W; };
+PlanesHint g_planes_hint[2] = {{nullptr, nullptr, 0, 0, 0, 0}, {nullptr, nullptr, 0, 0, 0, 0}};
 }  // namespace
+
+void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W) {
+    int slot = -1;
+    for (int i = 0; i < 2; ++i)
+        if (g_planes_hint[i].tensor == tensor) slot = i;
+    if (!planes) {
+        if (slot >= 0) g_planes_hint[slot] = PlanesHint{nullptr, nullptr, 0, 0, 0, 0};
+        return;
+    }
+    if (slot < 0) slot = g_planes_hint[0].tensor ? 1 : 0;
+    g_planes_hint[slot] = PlanesHint{tensor, planes, N, C, H, W};
+}
+
+static const void* planes_hint_for(const void* tensor, int N, int C, int H, int W) {
+    for (int i = 0; i < 2; ++i) {
+        const PlanesHint& h = g_planes_hint[i];
+        if (h.tensor == tensor && tensor && h.N == N && h.C == C && h.H == H && h.W == W) return h.planes;
+    }
+    return nullptr;
+}
 
 const unsigned* nemar_split16_hint(const void* tensor, int* count) {
     for (int i = 0; i < 4; ++i)
@@ -732,16 +755,23 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
     const unsigned* xmax = xmw;
     int xstride = 0;
+    const void* ready = nullptr;          // planes a producer already wrote (with the max-word hint they were scaled by)
+    if (variant == 4 && mode == SPLIT16_REFLECT && src_pad == 1 && Hs == H && Ws_src == W) {
+        int count = 0;
+        ready = planes_hint_for(src, N, Cred, H, W);
+        if (ready && !(nemar_split16_hint(src, &count) && count == N)) ready = nullptr;
+    }
     if (variant == 4) {
         xmax = nemar_split16_source_max(src, N, (long long)Cred * Hs * Ws_src, xmw, &xstride, st);
-        hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
-                           mode, total, xmax, xstride, src_pad, Hs, Ws_src);
+        if (!ready)
+            hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
+                               mode, total, xmax, xstride, src_pad, Hs, Ws_src);
     } else {
         hipLaunchKernelGGL((split_planes_kernel<3>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
                            mode, total, (const unsigned*)nullptr, 0, src_pad, Hs, Ws_src);
     }
     Split16Params p;
-    p.planes = (const u32x4*)scratch;
+    p.planes = ready ? (const u32x4*)ready : (const u32x4*)scratch;
     p.wp = (const u32x4*)packed;
     p.bias = bias;
     p.dst = dst;

@@ -286,10 +286,13 @@ class UnetGenerator(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------
-def _norm_act(x, norm, act, residual=None):
-    """InstanceNorm + activation (+ residual) as one kernel; with norm None the activation was already fused."""
+def _norm_act(x, norm, act, residual=None, planes=False, dropout_p=0.0):
+    """InstanceNorm + activation (+ dropout) (+ residual) as one kernel; with norm None the activation was already fused.
+    planes: the consumer is a 3x3 reflect-padded convolution (ops.instance_norm)."""
     if norm == 'instance':
-        return ops.instance_norm(x, act=act, residual=residual)
+        return ops.instance_norm(x, act=act, residual=residual, planes=planes, dropout_p=dropout_p)
+    if dropout_p > 0.0:
+        x = ops.dropout(x, dropout_p, True)
     if residual is not None:
         raise NotImplementedError('residual add without normalisation')
     return x
@@ -306,6 +309,7 @@ class ResnetBlock(nn.Module):
             raise NotImplementedError('padding [%s] is not implemented' % padding_type)
         self.pad_mode = ops.PAD_REFLECT if padding_type == 'reflect' else ops.PAD_ZERO
         self.norm, self.use_dropout = norm_layer, use_dropout
+        self.feeds_block = False        # set by the generator: the next layer is another ResnetBlock (a 3x3 reflect convolution)
         self.conv_block = Slots()
         first = 1 if padding_type == 'reflect' else 0
         _ref(self, 'c1', self.conv_block.put(first, ConvParams(dim, dim, 3, bias=use_bias)))
@@ -314,13 +318,13 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):
         fused_act = ops.ACT_NONE if self.norm else ops.ACT_RELU
+        reflect = self.pad_mode == ops.PAD_REFLECT
         h = ops.conv2d(x, self.c1.weight, self.c1.bias, 1, 1, self.pad_mode, act=fused_act)
-        h = _norm_act(h, self.norm, ops.ACT_RELU)
-        if self.use_dropout:
-            h = ops.dropout(h, 0.5, self.training)
+        # (norm + ReLU + Dropout in one pass; where conv2 runs on the fp16 x 3 route its operand planes come out of the same pass)
+        h = _norm_act(h, self.norm, ops.ACT_RELU, planes=reflect, dropout_p=0.5 if (self.use_dropout and self.training) else 0.0)
         h = ops.conv2d(h, self.c2.weight, self.c2.bias, 1, 1, self.pad_mode)
         if self.norm:
-            return _norm_act(h, self.norm, ops.ACT_NONE, residual=x)
+            return _norm_act(h, self.norm, ops.ACT_NONE, residual=x, planes=reflect and self.feeds_block)
         return x + h
 
 
@@ -347,6 +351,9 @@ class ResnetGenerator(nn.Module):
         for _ in range(n_blocks):
             self.blocks.append(m.put(idx, ResnetBlock(ngf * 4, padding_type, norm_layer, use_dropout, use_bias)))
             idx += 1
+        for b in self.blocks[:-1]:
+            b.feeds_block = True
+        self.reflect_blocks = padding_type == 'reflect' 
         self.up = []
         for i in range(2):
             mult = 2 ** (2 - i)
@@ -359,9 +366,9 @@ class ResnetGenerator(nn.Module):
         a = ops.ACT_NONE if self.norm else ops.ACT_RELU
         h = ops.conv2d(x, self.stem.weight, self.stem.bias, 1, 3, ops.PAD_REFLECT, act=a)
         h = _norm_act(h, self.norm, ops.ACT_RELU)
-        for c in self.down:
+        for i, c in enumerate(self.down):
             h = ops.conv2d(h, c.weight, c.bias, 2, 1, ops.PAD_ZERO, act=a)
-            h = _norm_act(h, self.norm, ops.ACT_RELU)
+            h = _norm_act(h, self.norm, ops.ACT_RELU, planes=self.reflect_blocks and self.n_blocks > 0 and i == len(self.down) - 1)
         for b in self.blocks:
             h = b(h)
         for c in self.up:

@@ -11,6 +11,7 @@ Conventions
   * loss Functions return 0-dim tensors already multiplied by their lambda.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -259,9 +260,14 @@ class _Conv2d(Function):
         split16 = _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device) and x2 is None
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
-            xmax = None
+            xmax = ready = None
             if split16:           # max |x| once: this call and the weight gradient in backward both scale x by it
-                xmax = _absmax_word(x)
+                ready = _planes_of(x) if (pad_mode == PAD_REFLECT and R == 3 and S == 3 and stride == 1 and pad == 1) else None
+                if ready is not None:             # the producer wrote x's planes, scaled by its a-priori bound words
+                    xmax = ready[1]
+                    L.planes_hint(_p(x), _p(ready[0]), N, C, H, W)
+                else:
+                    xmax = _absmax_word(x)
                 L.absmax_hint(_p(x), _p(xmax), xmax.numel())
             try:
                 L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
@@ -269,6 +275,8 @@ class _Conv2d(Function):
             finally:
                 if split16:
                     L.absmax_hint(_p(x), None, 0)
+                    if ready is not None:
+                        L.planes_hint(_p(x), None, 0, 0, 0, 0)
         ctx.xmax = xmax
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
@@ -445,19 +453,58 @@ def conv_transpose2d(x, weight, bias=None, stride=2, pad=1, out_pad=1, act=ACT_N
 
 
 # ------------------------------------------------------------------------------------------------------
+def _planes_ok(x, residual):
+    """InstanceNorm output -> fp16 x 3 planes in the same pass (norm_planes.hip): shapes the kernel covers and the wide-layer route takes"""
+    N, C, H, W = x.shape
+    return _planes_on[0] and _wants_max(x) and W % 4 == 0 and H >= 4 and H * W <= 4096 and _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, x.device)
+
+
+_planes_on = [os.environ.get("NEMAR_PLANES", "1") != "0"]       # A/B switch for the fused producer (NEMAR_PLANES=0, ops.tune_planes)
+
+
+def tune_planes(on):
+    _planes_on[0] = bool(on)
+
+
+def _planes_of(t):
+    have = getattr(t, '_nemar_planes', None)
+    return have if have is not None and have[2] == t._version else None
+
+
 class _InstanceNorm(Function):
     @staticmethod
-    def forward(ctx, x, residual, act, slope, eps):
+    def forward(ctx, x, residual, act, slope, eps, planes, drop_p):
         x, residual = _c(x), _c(residual)
         N, C, H, W = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((N * C, 2), dtype=torch.float32, device=x.device)
-        if _wants_max(x):
+        ctx.drop = None
+        if planes and _planes_ok(x, residual):
+            # the consumer is a 3x3 reflect convolution of the fp16 x 3 route: write its operand planes here, scaled by the a-priori
+            # bound sqrt(HW) [/ (1-p)] [+ max |residual|]; dropout drawn in the same pass
             words = _max_words(N, x.device)
-            L.instnorm_fwd_max(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _p(words), C, _stream())
+            scale_words = torch.empty(N, dtype=torch.int32, device=x.device)
+            buf = torch.empty(2 * N * (C // 8) * (H + 4) * (W + 4) * 16, dtype=torch.uint8, device=x.device)
+            seed = off = 0
+            if drop_p > 0.0:
+                _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
+                seed, off = _dropout_state["seed"], _dropout_state["offset"]
+                ctx.drop = (drop_p, seed, off)
+            L.instnorm_fwd_planes(_p(x), _p(residual), _p(_absmax_word(residual)) if residual is not None else None, _p(y), _p(stats),
+                                  N, C, H, W, eps, act, slope, drop_p, seed, off, _p(buf), _p(scale_words), _p(words), _stream())
             _tag_max(y, words)
+            y._nemar_planes = (buf, scale_words, y._version)
         else:
-            L.instnorm_fwd(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _stream())
+            if _wants_max(x) and drop_p <= 0.0:
+                words = _max_words(N, x.device)
+                L.instnorm_fwd_max(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _p(words), C, _stream())
+                _tag_max(y, words)
+            else:
+                L.instnorm_fwd(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _stream())
+            if drop_p > 0.0:
+                _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
+                ctx.drop = (drop_p, _dropout_state["seed"], _dropout_state["offset"])
+                _dropout_launch(y, y, *ctx.drop)                       # in place: nothing else has seen y
         ctx.save_for_backward(x, stats)
         ctx.cfg = (act, slope)
         return y
@@ -471,20 +518,27 @@ class _InstanceNorm(Function):
         N, C, H, W = x.shape
         gx = None
         if ctx.needs_input_grad[0]:
+            g = gy
+            if ctx.drop is not None:              # the dropout between the activation and the consumer: mask regenerated
+                if ctx.needs_input_grad[1]:
+                    raise RuntimeError("instance_norm: dropout and a residual cannot be fused in one call")
+                g = torch.empty_like(gy)
+                L.dropout(_p(gy), _p(g), gy.numel(), ctx.drop[0], ctx.drop[1], ctx.drop[2], _stream())
             gx = torch.empty_like(x)
             if _wants_max(x):
                 words = _max_words(N, x.device)
-                L.instnorm_bwd_max(_p(x), _p(stats), _p(gy), _p(gx), N * C, H * W, act, slope, _p(words), C, _stream())
+                L.instnorm_bwd_max(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _p(words), C, _stream())
                 _tag_max(gx, words)
             else:
-                L.instnorm_bwd(_p(x), _p(stats), _p(gy), _p(gx), N * C, H * W, act, slope, _stream())
+                L.instnorm_bwd(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _stream())
         gres = gy if ctx.needs_input_grad[1] else None
-        return gx, gres, None, None, None
+        return gx, gres, None, None, None, None, None
 
 
-def instance_norm(x, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5):
-    """(residual +) act(InstanceNorm2d(x)) with affine=False, track_running_stats=False."""
-    return _InstanceNorm.apply(x, residual, act, slope, eps)
+def instance_norm(x, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5, planes=False, dropout_p=0.0):
+    """(residual +) dropout(act(InstanceNorm2d(x))) with affine=False, track_running_stats=False.  planes=True: the consumer is a
+    3x3 / pad-1 reflect convolution — where the wide-layer fp16 x 3 route applies, its operand planes are written in the same pass."""
+    return _InstanceNorm.apply(x, residual, act, slope, eps, bool(planes), float(dropout_p))
 
 
 class _MaxPool2(Function):

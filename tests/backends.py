@@ -30,6 +30,10 @@ class EmuBackend:
     def np(self, h):
         return np.array(h, dtype=np.float64)
 
+    def raw(self, h):
+        """the buffer's bytes, bit for bit"""
+        return np.array(h).view(np.uint8).copy()
+
     def bytes_buf(self, nbytes):
         return np.zeros(max(1, (nbytes + 3) // 4), dtype=np.float32)
 
@@ -67,6 +71,10 @@ class HipBackend:
 
     def np(self, h):
         return h.detach().cpu().numpy().astype(np.float64)
+
+    def raw(self, h):
+        """the buffer's bytes, bit for bit"""
+        return h.detach().contiguous().view(self.torch.uint8).cpu().numpy().copy()
 
     def bytes_buf(self, nbytes):
         return self.torch.zeros(max(1, (nbytes + 3) // 4), dtype=self.torch.float32, device=self.device)

@@ -560,6 +560,112 @@ def case_producer_max_words(be, seed=0):
     assert np.array_equal(be.np(y0), be.np(y1)) and words_of(w) == want(a)
 
 
+def _decode_planes(raw, N, C, H, W):
+    """conv_split16.hip's plane layout -> float64 [2 (hi, lo)][N][C][H+4][W+4]"""
+    a = raw.view(np.float16).astype(np.float64).reshape(2, N, C // 8, H + 4, W + 4, 8)
+    return a.transpose(0, 1, 2, 5, 3, 4).reshape(2, N, C, H + 4, W + 4)
+
+
+def case_instnorm_planes(be, act, use_residual, drop_p, N=2, C=16, H=6, W=8, seed=0):
+    """InstanceNorm (+ activation, + dropout, + residual) that also writes its output as the fp16 x 3 planes of the following 3x3
+    reflect convolution (csrc/norm_planes.hip): fp32 output / statistics against float64, the dropout mask against nemar_dropout's,
+    the planes decoded word by word (interior = the fp32 output to 22 bits under the a-priori bound's scale, mirrored border,
+    zero spare rows / slots), the bound and maximum words."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((N, C, H, W)) * 3 + 1).astype(np.float32)
+    res = (rng.standard_normal((N, C, H, W)) * np.array([1.0, 40.0]).reshape(2, 1, 1, 1)[:N]).astype(np.float32) if use_residual else None
+    HW = H * W
+    mean = x.astype(np.float64).mean(axis=(2, 3), keepdims=True)
+    var = x.astype(np.float64).var(axis=(2, 3), keepdims=True)
+    want = (x - mean) / np.sqrt(var + 1e-5)
+    if act == 1:
+        want = np.maximum(want, 0)
+    elif act == 2:
+        want = np.where(want > 0, want, 0.2 * want)
+    keep = np.ones_like(want, dtype=bool)
+    if drop_p > 0:
+        ones, m = be.dev(np.ones_like(x)), be.full(x.shape, np.nan)
+        be.lib.dropout(be.ptr(ones), be.ptr(m), x.size, drop_p, 424242, 5, be.stream)
+        keep = be.np(m) != 0
+        want = np.where(keep, want / (1 - drop_p), 0.0)
+    resmax = None
+    if use_residual:
+        want = want + res
+        resmax = be.dev(np.abs(res).reshape(N, -1).max(axis=1).astype(np.float32))
+    d_x, d_res = be.dev(x), (be.dev(res) if use_residual else None)
+    d_y, d_st = be.full(x.shape, np.nan), be.full((N * C, 2), np.nan)
+    planes = be.bytes_buf(2 * N * (C // 8) * (H + 4) * (W + 4) * 16)
+    scale_w, max_w = be.bytes_buf(4 * N), be.bytes_buf(4 * N * 2049)
+    be.lib.instnorm_fwd_planes(be.ptr(d_x), be.ptr(d_res), be.ptr(resmax), be.ptr(d_y), be.ptr(d_st), N, C, H, W, 1e-5, act, 0.2,
+                               drop_p, 424242, 5, be.ptr(planes), be.ptr(scale_w), be.ptr(max_w), be.stream)
+    be.sync()
+    y = be.np(d_y)
+    assert np.array_equal(y != 0, keep & (y != 0)) and np.abs(y - want).max() < 2e-5 * max(1.0, np.abs(want).max()), np.abs(y - want).max()
+    if drop_p > 0:
+        assert np.all(y[~keep] == 0)
+    st = be.np(d_st).reshape(N, C, 2)
+    assert np.abs(st[..., 0] - mean[..., 0, 0]).max() < 1e-5 and np.abs(st[..., 1] * np.sqrt(var[..., 0, 0] + 1e-5) - 1).max() < 1e-5
+    # the words: bound = sqrt(HW) / (1 - p) + max |residual|;  maximum = max |y| per sample, bit for bit
+    bound = be.raw(scale_w)[:4 * N].view(np.float32).astype(np.float64)
+    want_bound = np.sqrt(HW) / (1 - drop_p) + (np.abs(res).reshape(N, -1).max(axis=1) if use_residual else 0.0)
+    assert np.allclose(bound, want_bound, rtol=1e-6), (bound, want_bound)
+    assert np.all(bound >= np.abs(y).reshape(N, -1).max(axis=1))
+    got_max = be.raw(max_w)[:4 * N].view(np.uint32)
+    assert np.array_equal(got_max, np.abs(y).reshape(N, -1).max(axis=1).astype(np.float32).view(np.uint32))
+    # the planes
+    scale = 2.0 ** (11 - np.floor(np.log2(bound)))
+    pl = _decode_planes(be.raw(planes)[:2 * N * (C // 8) * (H + 4) * (W + 4) * 16], N, C, H, W)
+    val = (pl[0] + pl[1]) / scale.reshape(N, 1, 1, 1)
+    ypad = np.pad(y, ((0, 0), (0, 0), (1, 1), (1, 1)), mode='reflect')
+    err = np.abs(val[:, :, :H + 2, :W + 2] - ypad)
+    assert np.all(err <= 2.0 ** -21 * np.abs(ypad) + 2.0 ** -24 / scale.reshape(N, 1, 1, 1)), err.max()
+    assert np.all(pl[:, :, :, H + 2:, :] == 0) and np.all(pl[:, :, :, :, W + 2:] == 0)
+    hi = pl[0] / scale.reshape(N, 1, 1, 1)                       # the high plane alone is the fp16 rounding of the value
+    assert np.all(np.abs(hi[:, :, :H + 2, :W + 2] - ypad) <= 2.0 ** -11 * np.abs(ypad) + 2.0 ** -24 / scale.reshape(N, 1, 1, 1))
+
+
+def case_conv_from_producer_planes(be, N=3, C=128, H=8, W=32, K=128, seed=0):
+    """A wide 3x3 reflect convolution that takes its operand planes from the InstanceNorm pass that produced its input
+    (nemar_planes_hint + the bound words as nemar_absmax_hint): same accuracy bound as with its own max + split passes; and the
+    planes really are what it read (zeroed planes -> zero output)."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((N, C, H, W)) * np.array([1.0, 1e-3, 30.0]).reshape(3, 1, 1, 1)[:N]).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
+    assert need > 0
+    d_x, d_w = be.dev(x), be.dev(w)
+    d_h, d_st = be.full(x.shape, np.nan), be.full((N * C, 2), np.nan)
+    nb = 2 * N * (C // 8) * (H + 4) * (W + 4) * 16
+    planes, scale_w = be.bytes_buf(nb), be.bytes_buf(4 * N)
+    be.lib.instnorm_fwd_planes(be.ptr(d_x), None, None, be.ptr(d_h), be.ptr(d_st), N, C, H, W, 1e-5, 1, 0.2, 0.0, 0, 0, be.ptr(planes),
+                               be.ptr(scale_w), None, be.stream)
+    outs = []
+    with scratch_arena(be, need):
+        for mode in ('planes', 'own passes', 'zeroed planes'):
+            d_y = be.full((N, K, H, W), np.nan)
+            ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, 3, 3, 1, 1))
+            src = planes if mode == 'planes' else be.bytes_buf(nb)
+            if mode != 'own passes':
+                be.lib.planes_hint(be.ptr(d_h), be.ptr(src), N, C, H, W)
+                be.lib.absmax_hint(be.ptr(d_h), be.ptr(scale_w), N)
+            be.lib.conv2d_fwd(be.ptr(d_h), C, None, 0, be.ptr(d_w), None, be.ptr(d_y), N, H, W, K, 3, 3, 1, 1, PAD_REFLECT, 0, 0.2,
+                              be.ptr(ws), wsb, 0, be.stream)
+            assert be.lib.last_route() == 2
+            be.lib.planes_hint(be.ptr(d_h), None, 0, 0, 0, 0)
+            be.lib.absmax_hint(be.ptr(d_h), None, 0)
+            be.sync()
+            outs.append(be.np(d_y))
+    h64, w64 = be.np(d_h), w.astype(np.float64)
+    want = O.conv2d_fwd(h64, w64, None, 1, 1, 'reflect')
+    mag = O.conv2d_fwd(np.abs(h64), np.abs(w64), None, 1, 1, 'reflect')
+    bound = be.raw(scale_w)[:4 * N].view(np.float32).astype(np.float64).reshape(N, 1, 1, 1)
+    wsum = np.abs(w64).sum(axis=(1, 2, 3)).reshape(1, K, 1, 1)
+    for y, who in zip(outs[:2], ('planes', 'own passes')):
+        lim = 4e-6 * mag + 3e-11 * bound * wsum + 1e-30
+        assert np.all(np.abs(y - want) <= lim), (who, float((np.abs(y - want) / lim).max()))
+    assert np.all(outs[2] == 0), "the convolution did not read the hinted planes"
+
+
 def case_pointwise(be, seed=0):
     rng = np.random.default_rng(seed)
     # act_bwd

@@ -448,6 +448,17 @@ def test_conv_split16_dynamic_range(be, what):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("act,res,drop", [(1, False, 0.5), (0, True, 0.0), (2, False, 0.0), (1, True, 0.0)])
+def test_instnorm_planes(be, act, res, drop):
+    K.case_instnorm_planes(be, act, res, drop)
+
+
+@pytest.mark.gpu
+def test_conv_from_producer_planes(be):
+    K.case_conv_from_producer_planes(be)
+
+
+@pytest.mark.gpu
 def test_producer_max_words(be):
     K.case_producer_max_words(be)
 
