@@ -197,7 +197,8 @@ class NEMARModel(BaseModel):
             n = self.real_A.size(0)
             field = self.netR.predict(self.real_A, self.real_B)
             self.registered_real_A = self.netR.warp(field, [self.real_A])[0]
-            both = self.netT(torch.cat([self.real_A, self.registered_real_A], 0))
+            # (only the second half is differentiated: the stem's data gradient runs on it alone)
+            both = self.netT(ops.grad_from(torch.cat([self.real_A, self.registered_real_A], 0), n))
             self.fake_B, self.fake_TR_B = both[:n], both[n:]
             self.fake_RT_B = self.netR.warp(field, [self.fake_B])[0]
             self.stn_reg_term = self.netR.regularization(field, self.registered_real_A)

@@ -278,6 +278,7 @@ class _Conv2d(Function):
                     if ready is not None:
                         L.planes_hint(_p(x), None, 0, 0, 0, 0)
         ctx.xmax = xmax
+        ctx.grad_from = int(getattr(x, '_nemar_grad_from', 0)) if x2 is None else 0
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
         _note_use(weight)
@@ -332,9 +333,18 @@ class _Conv2d(Function):
             if pad_mode == PAD_REFLECT and pad > 0 and x2 is not None:
                 raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
             # the packed image depends on which source halves are differentiated (channel skip) and on the geometry
-            ws, hit = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, N, H, W), wsb)
-            _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
-            L.conv2d_bwd_data(_p(g), _p(w), None, ACT_NONE, 0.0, _p(gx), C0, _p(gx2), C1, N, H, W, K, OH, OW, R, S,
+            n0 = getattr(ctx, 'grad_from', 0)
+            if 0 < n0 < N:
+                # only samples [n0:] of the input are differentiated (ops.grad_from: T's batch [real_A ; R(real_A)]): the data
+                # gradient of the others is never read — run the kernel on the sub-batch
+                gx[:n0].zero_()
+                Nd, gd, gxd = N - n0, g[n0:], gx[n0:]
+            else:
+                Nd, gd, gxd = N, g, gx
+            wsb = L.conv2d_bwd_data_workspace(Nd, C, H, W, K, R, S, stride, pad, pad_mode)
+            ws, hit = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, Nd, H, W), wsb)
+            _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
+            L.conv2d_bwd_data(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
                               stride, pad, pad_mode, _p(ws), wsb, hit, st)
             if not need_x2:
                 gx2 = None
@@ -533,6 +543,13 @@ class _InstanceNorm(Function):
                 L.instnorm_bwd(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _stream())
         gres = gy if ctx.needs_input_grad[1] else None
         return gx, gres, None, None, None, None, None
+
+
+def grad_from(x, n0):
+    """Declare that only samples [n0:] of the batch `x` are differentiated (the others are inputs): the first convolution that takes
+    `x` computes its data gradient on that sub-batch only."""
+    x._nemar_grad_from = int(n0)
+    return x
 
 
 def instance_norm(x, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5, planes=False, dropout_p=0.0):
