@@ -124,6 +124,35 @@ size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, int K, int 
 int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
                             int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
                             int pad_mode, void* workspace, size_t ws_bytes, void* stream);
+/* The same three entry points with their SIDE INPUTS passed per call instead of registered process-wide (nemar_set_scratch,
+ * nemar_absmax_hint, nemar_planes_hint below — those remain and are what a thin autograd binding uses; the registered hints are
+ * per calling thread).  Any member may be NULL / 0 = "not given".  Same kernels, bit-identical results.
+ *   scratch / scratch_bytes     transient arena of the wide-layer fp16 x 3 route for THIS call (nemar_conv2d_scratch bytes)
+ *   src_max_words / _count      per-sample max |source| words (source = x0 for fwd / bwd_weight, gy for bwd_data); count = N or 1
+ *   src2_max_words / _count     bwd_weight only: the same for gy
+ *   src_planes                  fwd only: the source's operand planes written by its producer (nemar_instnorm_fwd_planes), scaled by
+ *                               src_max_words
+ * A packed-weight workspace (prepacked = 1) must be reused under the same route conditions it was written under (arena present or
+ * not, nemar_config_epoch unchanged). */
+typedef struct nemar_conv_extras {
+    void* scratch;
+    size_t scratch_bytes;
+    const void* src_max_words;
+    int src_max_count;
+    const void* src2_max_words;
+    int src2_max_count;
+    const void* src_planes;
+} nemar_conv_extras;
+int nemar_conv2d_fwd_ex(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias, float* y, int N,
+                        int H, int W, int K, int R, int S, int stride, int pad, int pad_mode, int act, float slope,
+                        void* workspace, size_t ws_bytes, int prepacked, void* stream, const nemar_conv_extras* extras);
+int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const float* bias, int act, float slope, float* gx0, int C0,
+                             float* gx1, int C1, int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
+                             int pad_mode, void* workspace, size_t ws_bytes, int prepacked, void* stream,
+                             const nemar_conv_extras* extras);
+int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
+                               int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
+                               void* workspace, size_t ws_bytes, void* stream, const nemar_conv_extras* extras);
 /* Tuning switches for A/B measurements (tools/, tests/): not part of the operator contract, defaults = measured best.
  *   0  conv tile family for 128x128-capable shapes: 0 wave-specialised (default), 5 same without 16-byte B loads,
  *      6 one barrier per 32 reduction rows, 7 four loader waves, 4 first-generation wave-specialised, 1/2/3 generic
@@ -140,10 +169,15 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   16..19 loader / tile / ring-depth / narrow-kernel variants
  *   20 3x3 stride-1 layers with >= 128 output channels on the bf16 matrix pipe with three-way split operands (1, default;
  *      needs the scratch arena below; 0 = exact-fp32 MFMA kernels).  Packed weight images are per setting.
- *   21 operand split of those kernels: 4 fp16 x 3 (default), 3 bf16 x 6, 0 bf16 x 6 on the first-generation kernel
+ *   21 operand split of those kernels: 4 fp16 x 3 (default), 3 bf16 x 6
  *   23 smallest layer (million multiply-adds, default 2000) that takes the split-16 route
- *   24 every other convolution with >= 16 output channels on the 16-bit matrix pipe with the operand split INSIDE the kernel
- *      (csrc/conv_s16g*.hip; 1, default; 0 = exact-fp32 MFMA kernels)      25 its work threshold (million multiply-adds, 30) */
+ *   24 every other convolution with >= 5 output channels on the 16-bit matrix pipe with the operand split INSIDE the kernel
+ *      (csrc/conv_s16g*.hip; 1, default; 0 = exact-fp32 MFMA kernels)      25 its work threshold (million multiply-adds, 30)
+ *   26 the wide layers' weight gradient on the in-kernel-split kernel instead of wgrad_split16 (0, default: measured slower)
+ *   27 widest channel tile of s16g_kernel (1, 2, 4 x 32)                  28 prefer pixel tiles that leave LDS for two workgroups
+ *   29 weight gradients of the key-24 layers on s16g_wgrad_kernel (1)     30 stride-1 reflect 3x3 data gradients of those layers on
+ *                                                                            the padded domain + reflect_fold_kernel (1)
+ *   31 ablation bits of instnorm_planes_kernel (measurement only) */
 int nemar_tune(int key, int value);
 /* Which kernel family served the calling thread's last nemar_conv2d_* call: 0 exact-fp32 implicit GEMM, 1 narrow (<= 4 channel)
  * VALU kernels, 2 split-16 kernels of the wide residual-block layers, 3 general 16-bit-pipe kernels (tests / tools). */

@@ -63,6 +63,9 @@ SIGNATURES = {
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
     "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp]),
     "nemar_planes_hint": (_i, [_vp, _vp, _i, _i, _i, _i]),
+    "nemar_conv2d_fwd_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _vp, _sz, _i, _vp, _vp]),
+    "nemar_conv2d_bwd_data_ex": (_i, [_vp, _vp, _vp, _i, _fl, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp]),
+    "nemar_conv2d_bwd_weight_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "nemar_instnorm_bwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _i, _vp]),
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),
@@ -84,6 +87,12 @@ SIGNATURES = {
 
 class NemarHipError(RuntimeError):
     pass
+
+
+class ConvExtras(C.Structure):
+    """include/nemar_hip.h nemar_conv_extras"""
+    _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("src_max_words", C.c_void_p), ("src_max_count", C.c_int),
+                ("src2_max_words", C.c_void_p), ("src2_max_count", C.c_int), ("src_planes", C.c_void_p)]
 
 
 class Library:

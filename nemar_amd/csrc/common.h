@@ -15,6 +15,17 @@
 
 #define NEMAR_API extern "C" __attribute__((visibility("default")))
 
+// include/nemar_hip.h's nemar_conv_extras (the per-call side inputs of nemar_conv2d_*_ex), field for field
+struct nemar_conv_extras {
+    void* scratch;
+    size_t scratch_bytes;
+    const void* src_max_words;
+    int src_max_count;
+    const void* src2_max_words;
+    int src2_max_count;
+    const void* src_planes;
+};
+
 // thread-local so the message survives being raised on autograd's backward thread
 void nemar_set_error(const char* fmt, ...);
 

@@ -1090,8 +1090,12 @@ static int g_s16g_wgrad_first = 0;  // key 26: 1 = the in-kernel-split weight gr
 static int g_s16g_wgrad = 1;        // key 29: weight gradients on the in-kernel-split kernels (conv_s16g_wgrad.hip)
 static int g_s16g_fold = 1;         // key 30: stride-1 reflect data gradients on the padded domain + fold
 static long long g_s16g_min_mmac = 30;   // key 25: ... above this many million multiply-adds (tiny layers are launch-bound either way)
-static void* g_scratch = nullptr;
-static size_t g_scratch_bytes = 0;
+static void* g_scratch_reg = nullptr;        // nemar_set_scratch: the registered arena
+static size_t g_scratch_reg_bytes = 0;
+static thread_local void* t_scratch = nullptr;        // nemar_conv2d_*_ex: this call's own arena (takes precedence)
+static thread_local size_t t_scratch_bytes = 0;
+#define g_scratch (t_scratch ? t_scratch : g_scratch_reg)
+#define g_scratch_bytes (t_scratch ? t_scratch_bytes : g_scratch_reg_bytes)
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
 static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise
                                  // reproducible backward pass), 0 = fp32 atomics in the weight / bias gradients (round-1 scheme)
@@ -2305,9 +2309,59 @@ NEMAR_API int nemar_tune(int key, int value) {
 // caller owns it and keeps it alive while calls that may use it are in flight; bytes == 0 unregisters.
 NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
     ++g_config_epoch;
-    g_scratch = bytes ? scratch : nullptr;
-    g_scratch_bytes = scratch ? bytes : 0;
+    g_scratch_reg = bytes ? scratch : nullptr;
+    g_scratch_reg_bytes = scratch ? bytes : 0;
     return NEMAR_OK;
+}
+
+// ---- per-call form of the side inputs (scratch arena, max words, producer-written planes): what nemar_set_scratch /
+// nemar_absmax_hint / nemar_planes_hint register process-wide, passed with the call instead.  Same kernels, same results.
+namespace {
+struct ExtrasScope {
+    const void* t0 = nullptr;
+    const void* t1 = nullptr;
+    const void* tp = nullptr;
+    ExtrasScope(const nemar_conv_extras* ex, const void* src, const void* src2, int N, int C, int H, int W) {
+        if (!ex) return;
+        if (ex->scratch && ex->scratch_bytes) { t_scratch = ex->scratch; t_scratch_bytes = ex->scratch_bytes; }
+        if (ex->src_max_words && ex->src_max_count > 0) { nemar_split16_set_hint(src, ex->src_max_words, ex->src_max_count); t0 = src; }
+        if (src2 && ex->src2_max_words && ex->src2_max_count > 0) { nemar_split16_set_hint(src2, ex->src2_max_words, ex->src2_max_count); t1 = src2; }
+        if (ex->src_planes) { nemar_split16_set_planes_hint(src, ex->src_planes, N, C, H, W); tp = src; }
+    }
+    ~ExtrasScope() {
+        t_scratch = nullptr; t_scratch_bytes = 0;
+        if (t0) nemar_split16_set_hint(t0, nullptr, 0);
+        if (t1) nemar_split16_set_hint(t1, nullptr, 0);
+        if (tp) nemar_split16_set_planes_hint(tp, nullptr, 0, 0, 0, 0);
+    }
+};
+}  // namespace
+
+NEMAR_API int nemar_conv2d_fwd_ex(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias, float* y, int N,
+                                  int H, int W, int K, int R, int S, int stride, int pad, int pad_mode, int act, float slope,
+                                  void* workspace, size_t ws_bytes, int prepacked, void* stream, const nemar_conv_extras* extras) {
+    ExtrasScope scope(extras, x0, nullptr, N, C0 + C1, H, W);
+    return nemar_conv2d_fwd(x0, C0, x1, C1, w, bias, y, N, H, W, K, R, S, stride, pad, pad_mode, act, slope, workspace, ws_bytes, prepacked, stream);
+}
+
+NEMAR_API int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const float* bias, int act, float slope, float* gx0, int C0,
+                                       float* gx1, int C1, int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
+                                       int pad_mode, void* workspace, size_t ws_bytes, int prepacked, void* stream,
+                                       const nemar_conv_extras* extras) {
+    nemar_conv_extras e;
+    if (extras) { e = *extras; e.src_planes = nullptr; }
+    ExtrasScope scope(extras ? &e : nullptr, gy, nullptr, N, K, OH, OW);
+    return nemar_conv2d_bwd_data(gy, w, bias, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes,
+                                 prepacked, stream);
+}
+
+NEMAR_API int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
+                                         int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
+                                         void* workspace, size_t ws_bytes, void* stream, const nemar_conv_extras* extras) {
+    nemar_conv_extras e;
+    if (extras) { e = *extras; e.src_planes = nullptr; }
+    ExtrasScope scope(extras ? &e : nullptr, x0, gy, N, C0 + C1, H, W);
+    return nemar_conv2d_bwd_weight(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes, stream);
 }
 
 // max |t| (finite elements) per sample of a tensor, for callers that feed the same tensor to several split-16 convolution calls

@@ -608,12 +608,12 @@ unsigned* pack_max_word(void* packed, int M, int Cred, int KS) {
 
 // nemar_absmax_hint: max |t| words the caller has already computed for tensors the next calls take as sources (count words: one per
 // sample of the tensor, or 1 = one for the whole tensor)
-const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr};
-const unsigned* g_hint_word[4] = {nullptr, nullptr, nullptr, nullptr};
-int g_hint_count[4] = {0, 0, 0, 0};
+thread_local const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr};      // (per calling thread, like the route note)
+thread_local const unsigned* g_hint_word[4] = {nullptr, nullptr, nullptr, nullptr};
+thread_local int g_hint_count[4] = {0, 0, 0, 0};
 // nemar_planes_hint: the fp16 x 3 planes of a source already exist (a producer wrote them: norm_planes.hip) — reflect 3x3 layout only
 struct PlanesHint { const void* tensor; const void* planes; int N, C, H, W; };
-PlanesHint g_planes_hint[2] = {{nullptr, nullptr, 0, 0, 0, 0}, {nullptr, nullptr, 0, 0, 0, 0}};
+thread_local PlanesHint g_planes_hint[2] = {{nullptr, nullptr, 0, 0, 0, 0}, {nullptr, nullptr, 0, 0, 0, 0}};
 }  // namespace
 
 void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W) {

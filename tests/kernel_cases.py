@@ -560,6 +560,60 @@ def case_producer_max_words(be, seed=0):
     assert np.array_equal(be.np(y0), be.np(y1)) and words_of(w) == want(a)
 
 
+def case_conv_ex(be, N=3, C=128, H=8, W=32, K=128, seed=0):
+    """nemar_conv2d_*_ex: arena and max words passed with the call == the registered arena / hints, bit for bit, on the same route."""
+    import ctypes as C_
+    from nemar_amd._lib import ConvExtras
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    gy = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
+    assert need > 0
+    d_x, d_gy, d_w = be.dev(x), be.dev(gy), be.dev(w)
+
+    def run(ex):
+        outs = []
+        fwd = be.lib.conv2d_fwd_ex if ex is not None else be.lib.conv2d_fwd
+        bwd = be.lib.conv2d_bwd_data_ex if ex is not None else be.lib.conv2d_bwd_data
+        wgr = be.lib.conv2d_bwd_weight_ex if ex is not None else be.lib.conv2d_bwd_weight
+        tail = lambda e: (C_.byref(e),) if ex is not None else ()
+        d_y = be.full((N, K, H, W), np.nan)
+        ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, 3, 3, 1, 1))
+        fwd(be.ptr(d_x), C, None, 0, be.ptr(d_w), None, be.ptr(d_y), N, H, W, K, 3, 3, 1, 1, PAD_REFLECT, 0, 0.2, be.ptr(ws), wsb, 0,
+            be.stream, *tail(ex and ex[0]))
+        assert be.lib.last_route() == 2
+        d_gx = be.full((N, C, H, W), np.nan)
+        ws, wsb = _ws(be, be.lib.conv2d_bwd_data_workspace(N, C, H, W, K, 3, 3, 1, 1, PAD_REFLECT))
+        bwd(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gx), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1, PAD_REFLECT, be.ptr(ws), wsb, 0,
+            be.stream, *tail(ex and ex[1]))
+        assert be.lib.last_route() == 2
+        d_gw = be.full((K, C, 3, 3), 0.0)
+        ws, wsb = _ws(be, be.lib.conv2d_bwd_weight_workspace(N, C, H, W, K, H, W, 3, 3, 1, 1))
+        wgr(be.ptr(d_x), C, None, 0, be.ptr(d_gy), be.ptr(d_gw), None, N, H, W, K, H, W, 3, 3, 1, 1, PAD_REFLECT, be.ptr(ws), wsb,
+            be.stream, *tail(ex and ex[2]))
+        assert be.lib.last_route() == 2
+        be.sync()
+        return [be.np(t) for t in (d_y, d_gx, d_gw)]
+
+    with scratch_arena(be, need):
+        want = run(None)
+    # per call: an arena of its own, and the max words of x / gy computed once and handed to every call that takes the tensor
+    arena = be.bytes_buf(need)
+    xw, gw_ = be.bytes_buf(4 * N), be.bytes_buf(4 * N)
+    be.lib.absmax_samples(be.ptr(d_x), N, C * H * W, be.ptr(xw), be.stream)
+    be.lib.absmax_samples(be.ptr(d_gy), N, K * H * W, be.ptr(gw_), be.stream)
+    vp = lambda h: C_.cast(be.ptr(h), C_.c_void_p)
+    mk = lambda a, na, b, nb: ConvExtras(vp(arena), need, vp(a) if a is not None else None, na, vp(b) if b is not None else None, nb, None)
+    be.lib.tune(23, 0)
+    try:
+        got = run((mk(xw, N, None, 0), mk(gw_, N, None, 0), mk(xw, N, gw_, N)))
+    finally:
+        be.lib.tune(23, 2000)
+    for a, b, what in zip(want, got, ('fwd', 'dgrad', 'wgrad')):
+        assert np.array_equal(a, b), what
+
+
 def _decode_planes(raw, N, C, H, W):
     """conv_split16.hip's plane layout -> float64 [2 (hi, lo)][N][C][H+4][W+4]"""
     a = raw.view(np.float16).astype(np.float64).reshape(2, N, C // 8, H + 4, W + 4, 8)

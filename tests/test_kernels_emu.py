@@ -483,6 +483,10 @@ def test_instnorm_planes(be, act, res, drop):
     K.case_instnorm_planes(be, act, res, drop)
 
 
+def test_conv_ex_per_call_side_inputs(be):
+    K.case_conv_ex(be)
+
+
 def test_conv_from_producer_planes(be):
     K.case_conv_from_producer_planes(be)
 

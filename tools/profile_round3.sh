@@ -31,5 +31,7 @@ python $R/tools/microbench.py > $O/microbench.jsonl 2>/dev/null
 cd $R
 timeout 600 python tools/trace_convs.py > $O/conv_trace.jsonl 2> $O/trace.err
 timeout 900 python tools/microbench_trace.py $O/conv_trace.jsonl > $O/conv_layers.txt 2> $O/layers.err
+{ echo '# tools/timeline_s16g.py 64 128 256 3 2 16 (T.down1 forward, NEMAR_TIMELINE build)'; NEMAR_TL_LIB=$R/nemar_amd/lib/libnemar_hip_tl.so timeout 120 python tools/timeline_s16g.py 64 128 256 3 2 16; echo '# tools/timeline_s16g.py 32 32 256 3 1 8 (R.res 32->32)'; NEMAR_TL_LIB=$R/nemar_amd/lib/libnemar_hip_tl.so timeout 120 python tools/timeline_s16g.py 32 32 256 3 1 8; } > $O/s16g_timeline.txt 2>&1
+timeout 200 python tools/clock_trace.py 2>&1 | grep -v amdgpu.ids > $O/clock_trace.txt
 cat $O/bench.json
 rm -rf $O/stats/*/*.db $O/pmc_resblock16_* $O/pmc_tdown1_* $O/pmc_warp_*
