@@ -10,10 +10,14 @@ fused Adam steps) on one synthetic batch already resident in HBM.  Workload = BA
 N GPUs = N independent batch shards (weak scaling) + gradient all-reduce(avg) over RCCL.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline            dominant kernel = the fp32-MFMA implicit-GEMM conv (the 256->256 3x3 reflect layer of the
-                      translation net's residual blocks, 36 launches/step fwd): algorithmic FLOP / launch duration
-                      measured with HIP events on the launch stream in two extra steps right after the timed region, vs
-                      the 157.3 TF fp32 peak
+  roofline            dominant kernel = igemm_split16_kernel<2,2,3>: forward and data gradient of the 256->256 3x3 reflect
+                      layers of the translation net's residual blocks (36 batch-16 launches per step, 17 % of the step), fp32
+                      products as three fp16 partial products on the 16-bit MFMA.  achieved = algorithmic (fp32-equivalent) FLOP /
+                      launch duration, measured with HIP events on the launch stream inside the library (nemar_kernel_timer) in
+                      two extra steps right after the timed region; peak = 2500 TF dense fp16 MFMA / 3 products;
+                      traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same batch-16 launch from separate rocprofv3 --pmc passes
+                      (profiles/r3_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
+                      peak assumes (profiles/r3_clock_trace.txt)
   roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
   cpu_baseline        the CPU oracle (oracle/torch_ref.py, a proven-equal restatement of the reference's step) timed
                       on this box's host cores on a bounded sample (config-2 shape at batch 1)
@@ -32,7 +36,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense FP16/BF16 MFMA peak (32x32x16)
-PMC_FILE = "profiles/r2_pmc_traffic.json"
+PMC_FILE = "profiles/r3_pmc_traffic.json"
 
 
 def build_opt(batch, size, extra=()):
@@ -211,9 +215,9 @@ def main():
         "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32",
-        "dtype_note": "fp32 tensors and fp32 accumulation throughout; the >=128-channel stride-1 3x3 / 4x4 convolutions form each fp32 "
-                      "product from three fp16 partial products on the 16-bit MFMA (measured error vs float64 below the exact-fp32 MFMA "
-                      "kernels', DESIGN.md 4c); every other kernel is exact fp32",
+        "dtype_note": "fp32 tensors and fp32 accumulation throughout; convolutions with >= 5 output channels above 30 M multiply-adds form "
+                      "each fp32 product from three fp16 partial products on the 16-bit MFMA (per-sample / per-tile power-of-two scales; "
+                      "measured error vs float64 at or below the exact-fp32 MFMA kernels', DESIGN.md 4c/4d); every other kernel is exact fp32",
         "data": "synthetic U[-1,1) A/B pairs resident in HBM; reference-equivalent random init",
         "config": {"workload": "BASELINE configs[1]: --stn_type unet --stn_cfg A, resnet_9blocks T, basic PatchGAN D, "
                                "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32%s"
@@ -249,12 +253,14 @@ def main():
         peak = F16_MFMA_PEAK_TF / 3.0
         out["roofline"] = {"bound": "mfma", "achieved": flop / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": flop / sec / 1e12 / peak,
-                           # PMC passes ran the batch-8 launch (38.65 GFLOP); the step's launches carry T's two applications as one
-                           # batch of 16: same tiles, twice as many — traffic scales with the launch
-                           "traffic": (pmc["igemm_split16"]["traffic_bytes"] * flop / 38654705664.0) if std and pmc.get("igemm_split16") else None,
-                           "traffic_source": (PMC_FILE + " (batch-8 launch, scaled by flop per launch)") if std and pmc.get("igemm_split16") else None,
-                           "kernel": "igemm_split16_kernel<2,2,3> (conv2d_fwd / conv2d_bwd_data of the 256->256 3x3 reflect layers @%dx%d, batch %d; "
-                                     "fp32 operands as fp16 x 3 partial products, fp32 accumulate)" % (a.size // 4, a.size // 4, a.batch),
+                           # PMC passes ran the step's own batch-16 launch (77.3 GFLOP: T's two applications as one batch);
+                           # scaled by flop per launch should the timed launches differ
+                           "traffic": (pmc["igemm_split16"]["traffic_bytes"] * flop / 77309411328.0) if std and pmc.get("igemm_split16") else None,
+                           "algorithmic_bytes": (pmc["igemm_split16"]["algorithmic_bytes"] * flop / 77309411328.0) if std and pmc.get("igemm_split16") else None,
+                           "traffic_source": (PMC_FILE + " (batch-16 launch)") if std and pmc.get("igemm_split16") else None,
+                           "kernel": "igemm_split16_kernel<2,2,3> (conv2d_fwd / conv2d_bwd_data of the 256->256 3x3 reflect layers @%dx%d, %d images per "
+                                     "launch = T's two applications of the batch of %d as one; fp32 operands as fp16 x 3 partial products, fp32 "
+                                     "accumulate)" % (a.size // 4, a.size // 4, 2 * a.batch, a.batch),
                            "launches_timed": tk_n, "avg_launch_us": sec * 1e6,
                            "algorithmic_flop_per_launch": flop,
                            "peak_basis": "2500 TFLOP/s dense fp16 MFMA / 3 products per fp32 product",

@@ -111,6 +111,7 @@ class GradSync:
         self.works = []
         self.launched = []
         self._side = None
+        self._events = {}
         for p in opt.params:
             p._grad_sync = self
 
@@ -167,7 +168,9 @@ class GradSync:
         elif buf.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=buf.device)
-            ev = torch.cuda.Event()
+            if b not in self._events:                     # one event per bucket for the life of the optimizer, re-recorded every step
+                self._events[b] = torch.cuda.Event()
+            ev = self._events[b]
             ev.record()                                   # everything that wrote this bucket is ahead of this point
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)

@@ -55,6 +55,18 @@ class ScalarLog:
         if self.writer is not None:
             self.writer.add_scalar(tag, float(value), step)
 
+    def add_histogram(self, tag, tensor, step, bins=30):
+        """reference tb_visualizer.py:39 `writer.add_histogram(name, p.clone().cpu().data.numpy(), step)`: the SummaryWriter call
+        when tensorboard is importable; the JSON-lines file always gets a 30-bin histogram computed ON the device (one
+        torch.histc + min / max / mean: 33 floats cross PCIe instead of the whole parameter)."""
+        t = tensor.detach().float().reshape(-1)
+        lo, hi = float(t.min()), float(t.max())
+        counts = torch.histc(t, bins=bins, min=lo, max=hi if hi > lo else lo + 1.0).tolist()
+        with open(os.path.join(self.dir, 'histograms.jsonl'), 'a') as f:
+            f.write(json.dumps({'tag': tag, 'step': int(step), 'min': lo, 'max': hi, 'mean': float(t.mean()), 'counts': counts}) + '\n')
+        if self.writer is not None:
+            self.writer.add_histogram(tag, t.cpu().numpy(), step)
+
 
 class OffsetMeter:
     """Running mean of the deformation offsets per direction (reference tb_visualizer.py:59-74): update() adds the field's
@@ -91,6 +103,7 @@ class TrainingMonitor:
         self.model, self.opt = model, opt
         self.rate = int(getattr(opt, 'tbvis_iteration_update_rate', 1000))
         self.report_offsets = not getattr(opt, 'tbvis_disable_report_offsets', False)
+        self.report_weights = not getattr(opt, 'tbvis_disable_report_weights', False)
         self.log = ScalarLog(opt)
         self.meter = OffsetMeter(model.device)
         self.iteration_cnt = 0
@@ -105,6 +118,8 @@ class TrainingMonitor:
         if self.iteration_cnt == 0:
             for name, v in self.model.get_current_losses().items():
                 self.log.add_scalar('loss/{}'.format(name), v, self.save_count)
+            if self.report_weights:
+                self.save_current_weights()
             if self.report_offsets:
                 mx, my = self.meter.means()
                 self.log.add_scalar('offset/mean_x', mx, self.save_count)
@@ -112,11 +127,24 @@ class TrainingMonitor:
             self.save_count += 1
         self.iteration_cnt = (self.iteration_cnt + 1) % self.rate
 
+    def save_current_weights(self):
+        """'<net>/data/Weight|Bias/<parameter name>' histograms of every trainable parameter of T, R, D (reference
+        tb_visualizer.py:34-40; gated by --tbvis_disable_report_weights like there)."""
+        for net_name in ('netR', 'netT', 'netD'):             # the reference's list and order (models/nemar_model.py:58)
+            net = getattr(self.model, net_name, None)
+            if net is None:
+                continue
+            for n, p in net.named_parameters():
+                if p.requires_grad:
+                    self.log.add_histogram('{}/data/{}/{}'.format(net_name, 'Bias' if 'bias' in n else 'Weight', n), p, self.save_count)
+
     def epoch_step(self):
         if self.rate > 0:          # iteration-resolution reporting is on: nothing per epoch (reference :87-95)
             return
         for name, v in self.model.get_current_losses().items():
             self.log.add_scalar('loss/{}'.format(name), v, self.save_count)
+        if self.report_weights:
+            self.save_current_weights()
         if self.report_offsets:
             mx, my = self.meter.means()
             self.log.add_scalar('offset/mean_x', mx, self.save_count)

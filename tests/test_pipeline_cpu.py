@@ -27,3 +27,42 @@ def test_dataset_discovery_rule():
     assert cls.__name__ == 'GpuPairsDataset' and issubclass(cls, BaseDataset)
     with pytest.raises(ModuleNotFoundError):
         find_dataset_using_name('no_such')
+
+
+def test_training_monitor_reports_weight_histograms(tmp_path):
+    """reference util/tb_visualizer.py:34-40,79-80: '<net>/data/Weight|Bias/<name>' histograms of every trainable parameter with each
+    report, unless --tbvis_disable_report_weights."""
+    import argparse
+    import json
+    import torch
+    from nemar_amd.util import visualizer as V
+
+    class Model:
+        device = torch.device('cpu')
+        netT = torch.nn.Conv2d(2, 3, 1)
+        netR = torch.nn.Linear(4, 2)
+        netD = torch.nn.Conv2d(1, 1, 1, bias=False)
+
+        def get_current_losses(self):
+            return {'L1_TR': 1.5}
+
+    for p in Model.netD.parameters():
+        p.requires_grad_(False)
+    for disable in (False, True):
+        opt = argparse.Namespace(checkpoints_dir=str(tmp_path), name='h%d' % disable, tbvis_iteration_update_rate=2,
+                                 tbvis_disable_report_offsets=True, tbvis_disable_report_weights=disable)
+        mon = V.TrainingMonitor(Model(), opt)
+        for _ in range(3):
+            mon.iteration_step()
+        mon.end()
+        path = os.path.join(mon.log.dir, 'histograms.jsonl')
+        if disable:
+            assert not os.path.exists(path)
+            continue
+        rows = [json.loads(l) for l in open(path)]
+        tags = [r['tag'] for r in rows if r['step'] == 0]
+        assert tags == ['netR/data/Weight/weight', 'netR/data/Bias/bias', 'netT/data/Weight/weight', 'netT/data/Bias/bias']   # frozen D: none
+        assert {r['step'] for r in rows} == {0, 1}            # iterations 0 and 2
+        w = Model.netR.weight.detach()
+        r0 = rows[0]
+        assert sum(r0['counts']) == w.numel() and abs(r0['min'] - float(w.min())) < 1e-6 and abs(r0['max'] - float(w.max())) < 1e-6
