@@ -366,6 +366,13 @@ __global__ __launch_bounds__(TL_THREADS) void grid_sample_bwd_tiled_kernel(const
 // by far_scatter_kernel with 64-bit FIXED-POINT atomics — integer addition is associative, so that path is reproducible as
 // well: contributions are scaled by 2^(40 - e), e = exponent of max |gout| (found by the first pass), i.e. 40 bits below the
 // largest gradient, and far_fold_kernel adds the converted sums to grad_input and returns the accumulator to all-zero.
+// Round 3: the window FOLLOWS the field.  A smooth deformation of many pixels is locally a translation, so every destination tile T
+// gets an integer offset o_T = the displacement of the pixels that land in it (tile_offset_kernel: two fixed-point steps of
+// o <- d(centre(T) - o)), stages the pixels of (T - o_T) +- GT_R instead of T +- GT_R, and a texel scans the window around t - o_T.
+// "Near" becomes a property of a (pixel, corner) pair — corner k of pixel p is gathered iff d(p) - o_T(k) lies in the window, T(k) the
+// tile of that corner's texel — and only the other corners go through the fixed-point scatter (4-bit mask next to the pixel id in the
+// far list).  With o = 0 everywhere this is exactly the round-2 scheme; a smooth 3-pixel field at 1024^2 went from 872 us (most
+// pixels far) to the identity regime's cost.
 constexpr int GT_W = 64, GT_H = 16, GT_R = 3, GT_RW = GT_W + 2 * GT_R, GT_RH = GT_H + 2 * GT_R, GT_NP = GT_RW * GT_RH;
 constexpr int GT_CH = 4;
 constexpr int GT_KEY_NONE = 0x7fff7fff;
@@ -379,7 +386,60 @@ struct GatherWs {
     long long* acc;               // [N*C*H*W] fixed-point accumulator — ALL-ZERO between calls (far_fold_kernel restores it)
     unsigned* dirty;              // [N*tiles] tile touched by the far scatter — all-zero between calls
     float* gpart;                 // [N][tiles][6] per-workgroup sums of the affine grid gradient
+    const int* toff;              // [N*tiles][2] gather-window offset (ox, oy) of every destination tile (tile_offset_kernel)
 };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_offset_kernel(const float* __restrict__ gsrc, int* __restrict__ toff, int H, int W,
+                                                          int tiles_x, int tiles_y, int N, unsigned* __restrict__ any_shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * tiles_x * tiles_y) return;
+    const int n = i / (tiles_x * tiles_y), r = i - n * (tiles_x * tiles_y);
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    float th[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE == GRID_AFFINE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) th[k] = gsrc[n * 6 + k] + ((k == 0 || k == 4) ? 1.f : 0.f);
+    }
+    const int cx = min(tx * GT_W + GT_W / 2, W - 1), cy = min(ty * GT_H + GT_H / 2, H - 1);
+    int ox = 0, oy = 0;
+    for (int it = 0; it < 2; ++it) {
+        const int px = min(max(cx - ox, 0), W - 1), py = min(max(cy - oy, 0), H - 1);
+        float gx, gy;
+        make_grid<MODE>(gsrc, n, py, px, H, W, th, gx, gy);
+        const Sample s = locate(gx, gy, W, H);
+        ox = min(max(s.x0 - px, -16384), 16384);
+        oy = min(max(s.y0 - py, -16384), 16384);
+    }
+    // dead zone: the centred window already covers displacements of -GT_R .. GT_R - 1 pixels — identity, the linspace zoom and
+    // pixel-level noise keep o = 0, and then the gather pass takes its table-free path (*any_shift stays 0)
+    if (ox >= -1 && ox <= 0) ox = 0;
+    if (oy >= -1 && oy <= 0) oy = 0;
+    toff[2 * i] = ox;
+    toff[2 * i + 1] = oy;
+    if ((ox | oy) != 0 && *(volatile unsigned*)any_shift == 0u) *(volatile unsigned*)any_shift = 1u;
+}
+
+// corners of pixel (h, w) with corner base (x0, y0) that NO destination tile gathers: bit k = corner (x0 + (k & 1), y0 + (k >> 1))
+__device__ __forceinline__ unsigned far_corner_mask(const int* __restrict__ toff, int tiles_x, int x0, int y0, int h, int w, int H,
+                                                    int W, bool any_shift) {
+    if (!any_shift) {           // every window is centred on its tile: all four corners share the round-2 test
+        const int dx = x0 - w, dy = y0 - h;
+        return (dx >= -GT_R && dx <= GT_R - 1 && dy >= -GT_R && dy <= GT_R - 1) ? 0u : 15u;
+    }
+    unsigned mask = 0u;
+    int last_t = -1, lox = 0, loy = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+        if ((unsigned)cx >= (unsigned)W || (unsigned)cy >= (unsigned)H) continue;
+        const int t = (cy / GT_H) * tiles_x + cx / GT_W;
+        if (t != last_t) { last_t = t; lox = toff[2 * t]; loy = toff[2 * t + 1]; }
+        const int dx = x0 - w - lox, dy = y0 - h - loy;
+        if (!(dx >= -GT_R && dx <= GT_R - 1 && dy >= -GT_R && dy <= GT_R - 1)) mask |= 1u << k;
+    }
+    return mask;
+}
 
 // GG: the pass also computes d loss / d grid for the tile's own pixels (needs the 4-corner gathers of `in`); !GG: grid
 // gradient left to grid_sample_bwd_kernel<MODE, false>, this pass only streams gsrc + gout and writes grad_input.
@@ -410,12 +470,19 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     const float* goN = gout + (size_t)n * C * plane;
     if (tid == 0) s_nfar = 0u;
     __syncthreads();
+    const int tiles_x = gridDim.x, tiles_n = gridDim.x * gridDim.y;
+    const int* const toffN = ws.toff + 2 * (size_t)n * tiles_n;                 // this image's offset table
+    const bool any_shift = ws.count[2] != 0u;                                   // (uniform) some tile of the launch has o != 0
+    const int ox = any_shift ? toffN[2 * (blockIdx.y * tiles_x + blockIdx.x)] : 0;
+    const int oy = any_shift ? toffN[2 * (blockIdx.y * tiles_x + blockIdx.x) + 1] : 0;
+    const bool shifted = (ox | oy) != 0;       // the staged region is (tile - o) +- GT_R: the tile's own pixels are not (all) in it
+    const int rx0 = tx0 - ox - GT_R, ry0 = ty0 - oy - GT_R;                     // pixel at staged index (0, 0)
     float acc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gmax = 0.f;
     // Local arrays are only ever indexed by unrolled constants (a run-time channel index would put them in scratch memory).
     // ---- stage 1: the tile's own pixels (4 per thread, independent iterations: their loads overlap): geometry + gout -> LDS,
     //      d loss / d grid -> global, far pixels -> list ------------------------------------------------------------------------
-    constexpr int OWN_PT = GG ? GT_W * GT_H / GT_THREADS : 0;
+    constexpr int OWN_PT = GT_W * GT_H / GT_THREADS;
 #pragma unroll
     for (int i = 0; i < OWN_PT; ++i) {
         const int t = tid + i * GT_THREADS;
@@ -433,9 +500,13 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             const bool y0 = (unsigned)s.y0 < (unsigned)H, y1 = (unsigned)(s.y0 + 1) < (unsigned)H;
             const bool any = (x0 || x1) && (y0 || y1);
             const size_t it = (size_t)h * W + w;
-            const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;
+            // corners no tile's window reaches -> this tile's far list (the scatter pass handles exactly those corners)
+            if (any) {
+                const unsigned fm = far_corner_mask(toffN, tiles_x, s.x0, s.y0, h, w, H, W, any_shift);
+                if (fm) s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w) | (fm << 28);
+            }
+            const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;   // (o = 0 form)
             if (any && near) key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
-            if (any && !near) s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w);
             // d loss / d grid (same arithmetic as grid_sample_bwd_kernel)
             const int o = s.y0 * W + s.x0;
             const float ex = 1.f - s.tx, ey = 1.f - s.ty;
@@ -444,42 +515,49 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             for (int c = 0; c < GT_CH; ++c) {
                 if (c < C) {
                     g[c] = goN[(size_t)c * plane + it];
-                    const float* pch = inN + (size_t)c * plane;
-                    const float a = (x0 && y0) ? pch[o] : 0.f;
-                    const float b = (x1 && y0) ? pch[o + 1] : 0.f;
-                    const float cc = (x0 && y1) ? pch[o + W] : 0.f;
-                    const float d = (x1 && y1) ? pch[o + W + 1] : 0.f;
-                    gix += g[c] * ((b - a) * ey + (d - cc) * s.ty);
-                    giy += g[c] * ((cc - a) * ex + (d - b) * s.tx);
                     gmax = fmaxf(gmax, fabsf(g[c]));
+                    if (GG) {
+                        const float* pch = inN + (size_t)c * plane;
+                        const float a = (x0 && y0) ? pch[o] : 0.f;
+                        const float b = (x1 && y0) ? pch[o + 1] : 0.f;
+                        const float cc = (x0 && y1) ? pch[o + W] : 0.f;
+                        const float d = (x1 && y1) ? pch[o + W + 1] : 0.f;
+                        gix += g[c] * ((b - a) * ey + (d - cc) * s.ty);
+                        giy += g[c] * ((cc - a) * ex + (d - b) * s.tx);
+                    }
                 }
             }
-            const float ggx = gix * (0.5f * (float)W), ggy = giy * (0.5f * (float)H);
-            if (MODE == GRID_UNET) {
-                float* q = ggrid + (size_t)n * 2 * plane + it;
-                if (accum_ggrid) { q[0] += ggx; q[plane] += ggy; } else { q[0] = ggx; q[plane] = ggy; }
-            } else if (MODE == GRID_EXPLICIT) {
-                float2* q = reinterpret_cast<float2*>(ggrid + ((size_t)n * plane + it) * 2);
-                if (accum_ggrid) { float2 t2 = *q; t2.x += ggx; t2.y += ggy; *q = t2; } else { *q = make_float2(ggx, ggy); }
-            } else {
-                const float xb = affine_base(w, W), yb = affine_base(h, H);
-                acc6[0] += ggx * xb; acc6[1] += ggx * yb; acc6[2] += ggx;
-                acc6[3] += ggy * xb; acc6[4] += ggy * yb; acc6[5] += ggy;
+            if (GG) {
+                const float ggx = gix * (0.5f * (float)W), ggy = giy * (0.5f * (float)H);
+                if (MODE == GRID_UNET) {
+                    float* q = ggrid + (size_t)n * 2 * plane + it;
+                    if (accum_ggrid) { q[0] += ggx; q[plane] += ggy; } else { q[0] = ggx; q[plane] = ggy; }
+                } else if (MODE == GRID_EXPLICIT) {
+                    float2* q = reinterpret_cast<float2*>(ggrid + ((size_t)n * plane + it) * 2);
+                    if (accum_ggrid) { float2 t2 = *q; t2.x += ggx; t2.y += ggy; *q = t2; } else { *q = make_float2(ggx, ggy); }
+                } else {
+                    const float xb = affine_base(w, W), yb = affine_base(h, H);
+                    acc6[0] += ggx * xb; acc6[1] += ggx * yb; acc6[2] += ggx;
+                    acc6[3] += ggy * xb; acc6[4] += ggy * yb; acc6[5] += ggy;
+                }
             }
         }
-        s_key[idx] = key;
-        s_tx[idx] = ftx;
-        s_ty[idx] = fty;
+        if (GG && !shifted) {              // (an unshifted tile's own pixels ARE the centre of its staged region)
+            s_key[idx] = key;
+            s_tx[idx] = ftx;
+            s_ty[idx] = fty;
 #pragma unroll
-        for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
+            for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
+        }
     }
-    // ---- stage 2: the halo ring (pixels within GT_R of the tile that belong to neighbouring tiles): geometry + gout only -----
-    //      (!GG: every pixel of the region, own ones included — those also feed the far list and max |gout|)
-    constexpr int HALO_N = GG ? GT_NP - GT_W * GT_H : GT_NP;    // top / bottom bands of GT_R rows, then GT_R columns left / right
+    // ---- stage 2: the rest of the staged region: geometry + gout only.  Unshifted tile with the fused grid gradient: the halo ring
+    //      (GT_R rows above / below, GT_R columns left / right of the tile); otherwise every pixel of the region ---------------------
+    const bool whole = !GG || shifted;
+    const int halo_n = whole ? GT_NP : GT_NP - GT_W * GT_H;
 #pragma unroll 2
-    for (int e = tid; e < HALO_N; e += GT_THREADS) {
+    for (int e = tid; e < halo_n; e += GT_THREADS) {
         int ry, rx;
-        if (!GG) {
+        if (whole) {
             ry = e / GT_RW;
             rx = e - ry * GT_RW;
         } else if (e < 2 * GT_R * GT_RW) {
@@ -493,7 +571,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             rx = c2 < GT_R ? c2 : GT_W + c2;
         }
         const int idx = ry * GT_RW + rx;
-        const int h = ty0 - GT_R + ry, w = tx0 - GT_R + rx;
+        const int h = ry0 + ry, w = rx0 + rx;
         int key = GT_KEY_NONE;
         float ftx = 0.f, fty = 0.f, g[GT_CH] = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
@@ -503,19 +581,14 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
             ftx = s.tx; fty = s.ty;
             const bool anyx = (unsigned)s.x0 < (unsigned)W || (unsigned)(s.x0 + 1) < (unsigned)W;
             const bool anyy = (unsigned)s.y0 < (unsigned)H || (unsigned)(s.y0 + 1) < (unsigned)H;
-            const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;
-            const bool own = !GG && ry >= GT_R && ry < GT_R + GT_H && rx >= GT_R && rx < GT_R + GT_W;
-            if (anyx && anyy && (near || own)) {
+            const int dx = s.x0 - w - ox, dy = s.y0 - h - oy;                     // against THIS tile's window
+            const bool near = dx >= -GT_R && dx <= GT_R - 1 && dy >= -GT_R && dy <= GT_R - 1;
+            if (anyx && anyy && near) {
                 const size_t it = (size_t)h * W + w;
 #pragma unroll
                 for (int c = 0; c < GT_CH; ++c)
                     if (c < C) g[c] = goN[(size_t)c * plane + it];
-                if (near) key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
-                else s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w);
-                if (own) {
-#pragma unroll
-                    for (int c = 0; c < GT_CH; ++c) gmax = fmaxf(gmax, fabsf(g[c]));
-                }
+                key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
             }
         }
         s_key[idx] = key;
@@ -619,7 +692,8 @@ __global__ __launch_bounds__(256) void far_scatter_kernel(const float* __restric
     const size_t plane = (size_t)H * W;
     const int tiles_x = (W + GT_W - 1) / GT_W, tiles_y = (H + GT_H - 1) / GT_H;
     for (unsigned i = threadIdx.x; i < count; i += blockDim.x) {
-        const unsigned pid = ws.far_list[wgid * (GT_W * GT_H) + i];
+        const unsigned ent = ws.far_list[wgid * (GT_W * GT_H) + i];
+        const unsigned pid = ent & 0x0fffffffu, fmask = ent >> 28;          // pixel id | the corners no gather window reached
         const int w = (int)(pid % (unsigned)W);
         const unsigned t = pid / (unsigned)W;
         const int h = (int)(t % (unsigned)H), n = (int)(t / (unsigned)H);
@@ -635,6 +709,7 @@ __global__ __launch_bounds__(256) void far_scatter_kernel(const float* __restric
         const float wk[4] = {ex * ey, s.tx * ey, ex * s.ty, s.tx * s.ty};
         for (int k = 0; k < 4; ++k) {
             const int cx = s.x0 + (k & 1), cy = s.y0 + (k >> 1);
+            if (!((fmask >> k) & 1u)) continue;
             if ((unsigned)cx >= (unsigned)W || (unsigned)cy >= (unsigned)H) continue;
             ws.dirty[((size_t)n * tiles_y + cy / GT_H) * tiles_x + cx / GT_W] = 1u;
             for (int c = 0; c < C; ++c) {
@@ -704,9 +779,10 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
 // near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
 int g_tiled_scatter = 0;
 int g_gather_512 = 1;       // 512-thread workgroups in the gather pass (default: 170 vs 249 us at 8x3x1024^2); nemar_grid_sample_tune(16): 256
+int g_gather_follow = 1;    // gather windows follow the field (tile_offset_kernel); nemar_grid_sample_tune(32): centred on the tiles (round 2)
 int g_gather_fused = 1;     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
 
-struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, wgc_off, list_off, gpart_off, total; int tiles_x, tiles_y; };
+struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, wgc_off, list_off, gpart_off, toff_off, total; int tiles_x, tiles_y; };
 GatherLayout gather_layout(int N, int C, int H, int W) {
     GatherLayout L;
     L.tiles_x = nemar_cdiv(W, GT_W); L.tiles_y = nemar_cdiv(H, GT_H);
@@ -723,6 +799,8 @@ GatherLayout gather_layout(int N, int C, int H, int W) {
     const int nogin_blocks = nemar_cdiv((long long)H * W, 256);     // per-block sums of the affine kernels (either of them)
     const int nwg = L.tiles_x * L.tiles_y > nogin_blocks ? L.tiles_x * L.tiles_y : nogin_blocks;
     L.gpart_off = o; o += sizeof(float) * (size_t)N * nwg * 6;
+    o = (o + 15) & ~(size_t)15;
+    L.toff_off = o; o += sizeof(int) * 2 * (size_t)N * L.tiles_x * L.tiles_y;
     L.total = o;
     return L;
 }
@@ -739,15 +817,23 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
     const GatherLayout L = gather_layout(N, C, H, W);
     float* gpart = (workspace && MODE == GRID_AFFINE) ? (float*)(wsb + L.gpart_off) : nullptr;
     const bool gather = gin && workspace && H == Ho && W == Wo && C <= GT_CH && g_tiled_scatter == 0 && N <= 65535 &&
-                        (long long)N * H * W < (1ll << 32);
+                        (long long)N * H * W < (1ll << 28);        // (pixel id + 4-bit corner mask in one far-list word)
     if (gather) {
         GatherWs ws;
         ws.acc = (long long*)(wsb + L.acc_off); ws.dirty = (unsigned*)(wsb + L.dirty_off);
         ws.count = (unsigned*)(wsb + L.misc_off); ws.maxbits = ws.count + 1;
         ws.far_list = (unsigned*)(wsb + L.list_off); ws.gpart = (float*)(wsb + L.gpart_off);
         ws.wg_count = (unsigned*)(wsb + L.wgc_off);
-        (void)hipMemsetAsync(ws.count, 0, 8, st);
+        ws.toff = (const int*)(wsb + L.toff_off);
+        (void)hipMemsetAsync(ws.count, 0, 12, st);                // count, maxbits, any_shift
         const dim3 tg(L.tiles_x, L.tiles_y, N);
+        {
+            const int nt = N * L.tiles_x * L.tiles_y;
+            if (g_gather_follow)
+                hipLaunchKernelGGL((tile_offset_kernel<MODE>), dim3(nemar_cdiv(nt, 256)), dim3(256), 0, st, gsrc, (int*)(wsb + L.toff_off), H, W,
+                                   L.tiles_x, L.tiles_y, N, ws.count + 2);
+            // (else: any_shift stays 0 = windows centred on the tiles, the round-2 scheme, for A/B)
+        }
         if (g_gather_fused) {
             if (g_gather_512)
                 hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true, 512>), tg, dim3(512), 0, st, in, gsrc, gout, gin,
@@ -797,7 +883,8 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 NEMAR_API int nemar_grid_sample_tune(int variant) {
     g_gather_fused = (variant & 8) ? 0 : 1;
     g_gather_512 = (variant & 16) ? 0 : 1;
-    g_tiled_scatter = variant & ~24;
+    g_gather_follow = (variant & 32) ? 0 : 1;
+    g_tiled_scatter = variant & ~56;
     return NEMAR_OK;
 }
 

@@ -21,15 +21,26 @@ def _assert_close(got, want, atol, rtol=0.0, what=""):
 
 # ------------------------------------------------------------------------------------------------
 def case_grid_sample(be, mode, N, C, H, W, Ho, Wo, scale, seed=0, need_gin=True, accumulate=False, workspace=True,
-                     atomic=False):
+                     atomic=False, smooth_px=None):
+    """smooth_px = (shift_x, shift_y, wave) in pixels (GRID_UNET / GRID_EXPLICIT): a smooth LARGE deformation — a translation plus a
+    slow sinusoid — on top of the `scale` noise: the regime in which the gather windows of the backward pass follow the field."""
     rng = np.random.default_rng(seed)
     inp = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
     # The sampling coordinates are computed in float32 with the kernel's exact operation order, so that the
     # oracle makes the same floor() decisions (d out / d grid is discontinuous at integer coordinates);
     # everything downstream of the coordinates is evaluated in float64.
     f32 = np.float32
+    def offsets():
+        o = rng.standard_normal((N, 2, Ho, Wo)) * scale
+        if smooth_px is not None:
+            sx, sy, wave = smooth_px
+            yy, xx = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing='ij')
+            o[:, 0] += (sx + wave * np.sin(2 * np.pi * yy / Ho + 0.3) * np.cos(2 * np.pi * xx / Wo)) * 2.0 / Wo
+            o[:, 1] += (sy + wave * np.cos(2 * np.pi * xx / Wo + 0.7)) * 2.0 / Ho
+        return o.astype(f32)
+
     if mode == GRID_UNET:
-        src = (rng.standard_normal((N, 2, Ho, Wo)) * scale).astype(f32)
+        src = offsets()
         grid = O.unet_grid(src)                                   # float32, fma-exact linspace + offsets
     elif mode == GRID_AFFINE:
         src = (rng.standard_normal((N, 6)) * scale).astype(f32)
@@ -39,7 +50,7 @@ def case_grid_sample(be, mode, N, C, H, W, Ho, Wo, scale, seed=0, need_gin=True,
         T = lambda i: th[:, i][:, None, None]
         grid = np.stack([(T(0) * xb + T(1) * yb) + T(2), (T(3) * xb + T(4) * yb) + T(5)], axis=-1).astype(f32)
     else:
-        src = O.unet_grid((rng.standard_normal((N, 2, Ho, Wo)) * scale).astype(f32))
+        src = O.unet_grid(offsets())
         grid = src
     gout = rng.standard_normal((N, C, Ho, Wo)).astype(np.float32)
     want_out = O.grid_sample_fwd(inp.astype(np.float64), grid)

@@ -66,6 +66,15 @@ def test_grid_sample_bwd_gather_and_fixed_point_paths(be):
     K.case_grid_sample(be, K.GRID_AFFINE, N=2, C=1, H=36, W=70, Ho=36, Wo=70, scale=0.3, accumulate=True)
     K.case_grid_sample(be, K.GRID_EXPLICIT, N=1, C=3, H=20, W=66, Ho=20, Wo=66, scale=0.03)
     K.case_grid_sample(be, K.GRID_UNET, N=1, C=6, H=12, W=16, Ho=12, Wo=16, scale=0.1, atomic=True)   # C > 4: legacy kernels
+    # smooth LARGE deformations: the gather windows follow the field (tile offsets != 0), straddling tiles with different offsets
+    K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.001, smooth_px=(9.3, -4.6, 2.0))
+    K.case_grid_sample(be, K.GRID_UNET, N=1, C=3, H=48, W=200, Ho=48, Wo=200, scale=0.004, smooth_px=(-17.0, 6.2, 6.0), accumulate=True)
+    K.case_grid_sample(be, K.GRID_EXPLICIT, N=1, C=2, H=33, W=130, Ho=33, Wo=130, scale=0.0, smooth_px=(30.5, 12.0, 1.0))   # partly out of bounds
+    be.lib.grid_sample_tune(32)                 # A/B variant: windows centred on the tiles (round 2): same results
+    try:
+        K.case_grid_sample(be, K.GRID_UNET, N=2, C=3, H=40, W=150, Ho=40, Wo=150, scale=0.001, smooth_px=(9.3, -4.6, 2.0))
+    finally:
+        be.lib.grid_sample_tune(0)
 
 
 @pytest.mark.parametrize("Ci,alpha", [(0, 0.0), (3, 0.0), (3, 1.7), (1, 0.5)])
