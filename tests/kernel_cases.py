@@ -311,7 +311,11 @@ def case_conv_split16_dynamic_range(be, what, N=3, C=128, H=8, W=32, K=128, seed
     """The fp16 x 3 route of the wide layers (csrc/conv_split16*.hip) on adversarial magnitudes, through the C ABI: the scale is per
     SAMPLE, so every sample keeps fp32-class accuracy relative to its own magnitude.  what: 'samples' = per-sample magnitudes
     1 : 1e-6 : 1e4; 'outlier' = one 1e4 outlier in an otherwise O(1) sample; 'zero' = an all-zero sample next to a normal one;
-    'inf' = one infinity: only the outputs whose receptive field holds it are non-finite."""
+    'inf' = one infinity: only the outputs whose receptive field holds it are non-finite; 'channels' = heavy-tailed CHANNELS (x and gy
+    channel magnitudes spread over 1e-3 .. 1e3 inside every sample: the per-sample scale is set by the loudest channel, the quiet ones
+    live on the absolute term of the stated bound); 'subnormal' = a sample whose every element but one sits at 2^-27 of its maximum,
+    i.e. is an fp16 SUBNORMAL after scaling: the 16-bit MFMA must not flush its inputs (outputs away from the maximum stay non-zero
+    and accurate to the subnormal spacing)."""
     rng = np.random.default_rng(seed)
     x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
     gy = rng.standard_normal((N, K, H, W)).astype(np.float32)
@@ -327,6 +331,12 @@ def case_conv_split16_dynamic_range(be, what, N=3, C=128, H=8, W=32, K=128, seed
         gy[0] = 0.0
     elif what == 'inf':
         x[0, 5, 4, 10] = np.inf
+    elif what == 'channels':
+        x = x * (10.0 ** rng.permutation(np.linspace(-3, 3, C))).reshape(1, C, 1, 1)
+        gy = gy * (10.0 ** rng.permutation(np.linspace(-3, 3, K))).reshape(1, K, 1, 1)
+    elif what == 'subnormal':
+        x[0] = np.float32(2.0 ** -27) * np.sign(x[0])
+        x[0, 0, 0, 0] = 1.0
     x, gy = x.astype(np.float32), gy.astype(np.float32)
     need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
     assert need > 0
@@ -362,6 +372,16 @@ def case_conv_split16_dynamic_range(be, what, N=3, C=128, H=8, W=32, K=128, seed
         assert np.all(err <= 4e-6 * mag + 2e-11 * per), (err.max(),)
         return
     want = O.conv2d_fwd(x64, w64, None, 1, 1, 'reflect')
+    if what == 'subnormal':
+        # rows >= 3 of sample 0 see only the 2^-27 elements (2^-16 after scaling: subnormal in fp16, spacing 2^-24): not flushed to
+        # zero, and accurate to that spacing per term
+        far = want[0, :, 3:, :]
+        got = y[0, :, 3:, :]
+        assert np.all(far != 0) and np.all(got != 0), "fp16 subnormal operands were flushed"
+        spacing = 2.0 ** -24 / 2.0 ** 11                       # one subnormal step in units of x (scale 2^11 for max = 1)
+        assert np.all(np.abs(got - far) <= 1.0 * spacing * np.abs(w64).sum(axis=(1, 2, 3)).reshape(K, 1, 1) + 1e-30), \
+            float(np.abs(got - far).max())
+        return
     want_gx, want_gw, _ = O.conv2d_bwd(x64, w64, gy64, 1, 1, 'reflect')
     mag = O.conv2d_fwd(np.abs(x64), np.abs(w64), None, 1, 1, 'reflect')
     mag_gx, _, _ = O.conv2d_bwd(np.abs(x64), np.abs(w64), np.abs(gy64), 1, 1, 'reflect')

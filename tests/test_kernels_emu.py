@@ -481,7 +481,7 @@ def test_conv_s16g_weight_gradient_row_scales(be):
     K.case_conv_s16g_bwd_weight(be, 1, 64, 0, 4, 32, 64, 3, 1, 1, K.PAD_ZERO, gscale=10.0 ** np.linspace(-6, 6, 64))
 
 
-@pytest.mark.parametrize("what", ["samples", "outlier", "zero", "inf"])
+@pytest.mark.parametrize("what", ["samples", "outlier", "zero", "inf", "channels", "subnormal"])
 def test_conv_split16_dynamic_range(be, what):
     """The fp16 x 3 route of the wide layers on adversarial magnitudes (per-sample scales): see kernel_cases."""
     K.case_conv_split16_dynamic_range(be, what)

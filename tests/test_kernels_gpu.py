@@ -450,7 +450,7 @@ def test_conv_s16g_weight_gradient_row_scales(be):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("what", ["samples", "outlier", "zero", "inf"])
+@pytest.mark.parametrize("what", ["samples", "outlier", "zero", "inf", "channels", "subnormal"])
 def test_conv_split16_dynamic_range(be, what):
     """The fp16 x 3 route of the wide layers on adversarial magnitudes (per-sample scales): see kernel_cases."""
     K.case_conv_split16_dynamic_range(be, what, N=3, C=128, H=16, W=32, K=128)
