@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     // ---- loader role: waves 0, 1 fill k group 0 (channels 0..7 of the chunk), waves 2, 3 k group 1; thread = halo pixel ----
     const int kgl = wid >> 1;
     const int hpn = p.HR * p.HC;
+    const int ns = __builtin_amdgcn_readfirstlane((hpn + 127) >> 7);          // halo slots in use (of NSMAX)
     int soff[NSMAX], lpos[NSMAX];      // soff: source offset inside a channel image (always a valid address), < 0 flags in svalid
     bool svalid[NSMAX], sany[NSMAX];   // this lane's halo pixel is inside the image / some lane of the wave is not (wave-uniform)
 #pragma unroll
@@ -249,14 +250,19 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     // source values of chunk `ch_`: 8 channels (wave-uniform base pointers) x this thread's halo pixels
 #define S16G_LOAD(ch_)                                                                                                  \
     {                                                                                                                   \
+        const float* cb_[8];                                                                                            \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                 \
             const int c_ = (ch_) * 16 + kgl * 8 + j;                                                                    \
-            const float* cb_ = c_ < p.C0 ? p.src0 + ((size_t)n * p.C0 + c_) * HWs                                       \
-                                         : p.src1 + ((size_t)n * p.C1 + (c_ - p.C0)) * HWs;                             \
-            (void)cb_;                                                                                                  \
-            const float* cbs_ = c_ < C ? cb_ : p.src0;      /* beyond the last channel: any valid address, zeroed below */  \
-            if (p.dbg & 2) { _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) v[i][j] = 1.f; }                         \
-            else { _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) v[i][j] = cbs_[soff[i]]; }  /* unconditional: no branches */ \
+            const float* b_ = c_ < p.C0 ? p.src0 + ((size_t)n * p.C0 + c_) * HWs                                        \
+                                        : p.src1 + ((size_t)n * p.C1 + (c_ - p.C0)) * HWs;                              \
+            cb_[j] = c_ < C ? b_ : p.src0;      /* beyond the last channel: any valid address, zeroed below */          \
+        }                                                                                                               \
+        /* slots beyond the tile's halo (ns of NSMAX: wave-uniform) issue nothing — a 256-pixel stride-1 tile uses 4 of 7 */ \
+        _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) {                                                             \
+            if (i < ns) {                                                                                               \
+                if (p.dbg & 2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = 1.f; }                         \
+                else { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = cb_[j][soff[i]]; }  /* unconditional per lane */ \
+            }                                                                                                           \
         }                                                                                                               \
     }
     // what the unconditional loads fetched for padding pixels / channels beyond C becomes zero (wave-uniform tests: interior tiles
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     {                                                                                                                   \
         const int jlim_ = C - (ch_) * 16 - kgl * 8;                                                                     \
         _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) {                                                             \
-            if (sany[i] || jlim_ < 8) {                                                                                 \
+            if (i < ns && (sany[i] || jlim_ < 8)) {                                                                                 \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = (svalid[i] && j < jlim_) ? v[i][j] : 0.f;       \
             }                                                                                                           \
         }                                                                                                               \
@@ -315,17 +321,21 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             float mf = 0.f;
 #pragma unroll
             for (int i = 0; i < NSMAX; ++i)
+                if (i < ns) {
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) mf = fmaxf(mf, fmaxf(__builtin_fabsf(v[i][j]), __builtin_fabsf(v[i][j + 1])));
+                    for (int j = 0; j < 8; j += 2) mf = fmaxf(mf, fmaxf(__builtin_fabsf(v[i][j]), __builtin_fabsf(v[i][j + 1])));
+                }
             unsigned m = __builtin_bit_cast(unsigned, mf);
             if (m >= 0x7f800000u) {
                 m = 0;
 #pragma unroll
                 for (int i = 0; i < NSMAX; ++i)
+                    if (i < ns) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const unsigned u = __builtin_bit_cast(unsigned, v[i][j]) & 0x7fffffffu;
-                        m = max(m, u < 0x7f800000u ? u : 0u);
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned u = __builtin_bit_cast(unsigned, v[i][j]) & 0x7fffffffu;
+                            m = max(m, u < 0x7f800000u ? u : 0u);
+                        }
                     }
             }
             m = wave_max_to_lane63(m);
