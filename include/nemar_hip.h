@@ -177,7 +177,8 @@ int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x1, int C1,
  *   27 widest channel tile of s16g_kernel (1, 2, 4 x 32)                  28 prefer pixel tiles that leave LDS for two workgroups
  *   29 weight gradients of the key-24 layers on s16g_wgrad_kernel (1)     30 stride-1 reflect 3x3 data gradients of those layers on
  *                                                                            the padded domain + reflect_fold_kernel (1)
- *   31 ablation bits of instnorm_planes_kernel (measurement only) */
+ *   31 ablation bits of instnorm_planes_kernel (measurement only)
+ *   32 3-slot weight ring of the wide-layer kernel for the unfolded 3x3 launches (0, default: no gain) */
 int nemar_tune(int key, int value);
 /* Which kernel family served the calling thread's last nemar_conv2d_* call: 0 exact-fp32 implicit GEMM, 1 narrow (<= 4 channel)
  * VALU kernels, 2 split-16 kernels of the wide residual-block layers, 3 general 16-bit-pipe kernels (tests / tools). */

@@ -32,6 +32,7 @@
 #include "conv_split16.h"
 #include "conv_s16g.h"
 
+extern int g_split16_ring3;                      // conv_split16.hip
 void nemar_norm_planes_debug(int bits);          // norm_planes.hip: ablation bits of the fused producer (measurement only)
 
 // conv_narrow.hip: VALU + LDS-halo kernels for layers with <= 4 output channels
@@ -2288,6 +2289,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 27) { nemar_s16g_tune(0, value); return NEMAR_OK; }
     if (key == 29) { g_s16g_wgrad = value != 0; return NEMAR_OK; }
     if (key == 31) { nemar_norm_planes_debug(value); return NEMAR_OK; }
+    if (key == 32) { g_split16_ring3 = value != 0; return NEMAR_OK; }
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }

@@ -278,13 +278,22 @@ __device__ __forceinline__ void glds16u(const u32x4* ubase, unsigned lane_bytes,
 // Two chunks (18 taps) per loop iteration, so that the register-set parity is a compile-time constant of the tap position.
 // NPL = operand planes: 3 = bf16 x 6 products, 2 = fp16 x 3 products (scaled, see split2_f16)
 // KS = filter size (3x3, or the discriminator's 4x4 / pad 1 layers computed on the input-sized domain, last row / column masked)
-template <int NBW, int NPL, int KS = 3>   // NBW = halo copy slots per wave per tap on taps 3..NT-1 of a chunk (they carry the next chunk's halo)
+// RING = weight-stage slots: 4 (stage T + 4 issued during tap T), or 3 — with 3 slots and no folded border rows the 3x3 fp16 x 3 kernel
+// needs 76.8 KB of LDS and TWO workgroups share a CU (two waves per SIMD: while one sits at a barrier or waits for LDS the other issues
+// MFMAs).  LDS is dynamic: [RING weight stages][two halo buffers].  (RING = 3 needs NT % 3 == 0: the slot of a tap is then a
+// compile-time constant.)
+template <int NBW, int NPL, int KS = 3, int RING = 4>   // NBW = halo copy slots per wave per tap on taps 3..NT-1 of a chunk (they carry the next chunk's halo)
 __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
     constexpr int NT = KS * KS;                          // taps
-    constexpr int RING = 4, ASTAGE16 = 256 * NPL, KB = (NT - 3) * NBW, NREG = 2 * NPL, NP = NPL == 3 ? 6 : 3, NMFMA = 8 * NP;
+    constexpr int ASTAGE16 = 256 * NPL, KB = (NT - 3) * NBW, NREG = 2 * NPL, NP = NPL == 3 ? 6 : 3, NMFMA = 8 * NP;
     constexpr int ACOPY = NPL;                           // 1 KiB weight copies per wave per stage (a quarter of the stage)
-    constexpr int SMEM16 = 9728;
-    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM16];
+    static_assert(RING == 4 || (RING == 3 && NT % 3 == 0), "ring slot of a tap must be a compile-time constant");
+#define S16_SLOTOF(stage_, tap_) (RING == 4 ? ((stage_) & 3) : ((tap_) % 3))       /* tap_ == stage_ mod NT, up to a multiple of 3 */
+#ifdef NEMAR_HOST_EMULATION
+    __shared__ __attribute__((aligned(16))) u32x4 smem[9728];      // (the emulator has no dynamic LDS)
+#else
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+#endif
     u32x4* const As = smem;
     u32x4* const Bs = smem + RING * ASTAGE16;
     const int region16 = p.halo16 + p.aux16, bbuf16 = NREG * region16;
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
     {                                                                                                                   \
         const int st_ = min((stage_), nstage - 1);                   /* tail: harmless re-copies of the last stage */   \
         const u32x4* const a_ = wsrc0 + (size_t)st_ * wstage + lane;                                                    \
-        u32x4* const ad_ = As + ((stage_) & (RING - 1)) * ASTAGE16 + wid * (64 * ACOPY);                                \
+        u32x4* const ad_ = As + S16_SLOTOF(stage_, ti_) * ASTAGE16 + wid * (64 * ACOPY);                                \
         _Pragma("unroll") for (int q = 0; q < ACOPY; ++q) glds16(a_ + 64 * q, ad_ + 64 * q);                            \
         if ((ti_) >= 3) {                                                                                               \
             const int hc_ = min((ci_) + 1, nchunks - 1);             /* chunk whose halo travels with this stage */     \
@@ -408,8 +417,12 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
     S16_COPIES(0, 0, 0)
     S16_COPIES(1, 1, 0)
     S16_COPIES(2, 2, 0)
-    S16_COPIES(3, 3, 0)
-    S16_VMCNT(2 * ACOPY + NBW)                       // (stages 2 and 3 may be in flight) the first halo and stages 0, 1 have landed
+    if (RING == 4) {
+        S16_COPIES(3, 3, 0)
+        S16_VMCNT(2 * ACOPY + NBW)                   // (stages 2 and 3 may be in flight) the first halo and stages 0, 1 have landed
+    } else {
+        S16_VMCNT(ACOPY)                             // (stage 2 may be in flight)
+    }
     __builtin_amdgcn_s_barrier();                     // ... for all four waves
     int z = 0;
     S16_READ(0, 0, 0, 0, 0)
@@ -444,8 +457,8 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
                 const int ntap = tap == NT - 1 ? 0 : tap + 1;
                 const int nhb = tap == NT - 1 ? hb ^ 1 : hb;
                 const int nr = ntap / KS, nsx = ntap % KS;
-                const int iti = tap + 4 >= NT ? tap + 4 - NT : tap + 4;
-                const int ici = tap + 4 >= NT ? chunk + 1 : chunk;
+                const int iti = tap + RING >= NT ? tap + RING - NT : tap + RING;        // tap position / chunk of stage T + RING
+                const int ici = tap + RING >= NT ? chunk + 1 : chunk;
 #define S16_MFMAS(beg_, end_)                 /* MFMAs [beg_, end_) of the tap's NMFMA: m = 8 q + 2 mt + nt */        \
                 _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < NMFMA; ++m_) {                              \
                     const int q_ = m_ >> 3, mt_ = (m_ & 7) >> 1, nt_ = m_ & 1;                                          \
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
                     baddr[nt] = ra_ + sl_;
                 }
                 const u32x4* const Bn_ = Bs + nhb * bbuf16 + lhi * region16;
-                const u32x4* const An_ = As + ((T + 1) & (RING - 1)) * ASTAGE16 + lhi * 128 + l31;
+                const u32x4* const An_ = As + S16_SLOTOF(T + 1, tap + 1) * ASTAGE16 + lhi * 128 + l31;
                 S16_SLOT(0)
 #pragma unroll
                 for (int i = 0; i < 2 * NPL; ++i) {           // the B fragments
@@ -486,10 +499,10 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
                     af[nxt][i / NPL][i % NPL] = An_[(i % NPL) * 256 + (i / NPL) * 32];
                     S16_SLOT(1 + 2 * NPL + i)
                 }
-                {                                             // the copies of stage T + 4
-                    const int st_ = min(T + 4, nstage - 1);   // (tail: harmless re-copies of the last stage)
+                {                                             // the copies of stage T + RING
+                    const int st_ = min(T + RING, nstage - 1);   // (tail: harmless re-copies of the last stage)
                     const u32x4* const a_ = wsrc0 + (size_t)st_ * wstage + lane;
-                    u32x4* const ad_ = As + (T & (RING - 1)) * ASTAGE16 + wid * (64 * ACOPY);
+                    u32x4* const ad_ = As + S16_SLOTOF(T, tap) * ASTAGE16 + wid * (64 * ACOPY);
 #pragma unroll
                     for (int q = 0; q < ACOPY; ++q) {
                         glds16(a_ + 64 * q, ad_ + 64 * q);
@@ -513,9 +526,12 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 #undef S16_MFMAS
                 // this wave's copies of stage T + 2 have landed; those of T + 3 and T + 4 may still be in flight
                 const int t3 = tap + 3 >= NT ? tap + 3 - NT : tap + 3;
-                const int nfl = S16_COUNT(t3) + S16_COUNT(iti);     // compile-time after unrolling: one of three values
+                // (a 3-slot ring has only stage T + 3 = T + RING in flight behind the one that must have landed)
+                const int nfl = RING == 4 ? S16_COUNT(t3) + S16_COUNT(iti) : S16_COUNT(iti);     // compile-time after unrolling
                 S16_STAMP(1)
-                if (nfl == 2 * ACOPY) S16_VMCNT(2 * ACOPY)
+                if (nfl == ACOPY) S16_VMCNT(ACOPY)
+                else if (nfl == ACOPY + NBW) S16_VMCNT(ACOPY + NBW)
+                else if (nfl == 2 * ACOPY) S16_VMCNT(2 * ACOPY)
                 else if (nfl == 2 * ACOPY + NBW) S16_VMCNT(2 * ACOPY + NBW)
                 else S16_VMCNT(2 * ACOPY + 2 * NBW)
                 S16_STAMP(2)
@@ -532,6 +548,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
 #undef S16_VMCNT
 #undef S16_COUNT
 #undef S16_COPIES
+#undef S16_SLOTOF
 
     const size_t HW = (size_t)p.OH * p.OW;
     // fp16 form: take the two power-of-two operand scales out again (exact)
@@ -748,6 +765,10 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int 
                        (const unsigned*)nullptr, NT);
 }
 
+int g_split16_ring3 = 0;         // nemar_tune(32, 1): 3-slot weight ring (76.8 KB of LDS) for the unfolded 3x3 launches.  Measured: same time
+                                 // (287.6 vs 292.3 us per call, bench 37.5 vs 37.2-37.5 ms) — the kernel needs 332 VGPRs (two fragment sets), so a
+                                 // SIMD still holds ONE wave and the second workgroup never becomes resident; kept for the experiment only
+
 void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
                          int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
                          long long* tl, hipStream_t st) {
@@ -802,16 +823,38 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (p.mblks * p.ksplit) == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
     const dim3 g(grid);
+    // dynamic LDS: [RING weight stages][two halo buffers]; above 64 KiB the attribute is needed (set once per instantiation)
+#ifdef NEMAR_HOST_EMULATION
+#define S16_GO(NBW_, NPL_, KS_, RING_) { hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), g, dim3(256), 0, st, p); }
+#else
+#define S16_GO(NBW_, NPL_, KS_, RING_)                                                                                  \
+    {                                                                                                                   \
+        static bool attr_ = false;                                                                                      \
+        if (!attr_) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_split16_kernel<NBW_, NPL_, KS_, RING_>),     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);                     \
+            attr_ = true;                                                                                               \
+        }                                                                                                               \
+        const size_t lds_ = ((size_t)(RING_) * 256 * (NPL_) + (size_t)2 * 2 * (NPL_) * (p.halo16 + p.aux16)) * 16;      \
+        hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), g, dim3(256), lds_, st, p);                  \
+    }
+#endif
     if (variant == 4) {                 // fp16 x 3 (nemar_split16_eligible checked the LDS budget)
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), KS * KS - 3);
+        // 3-slot weight ring where that lets two workgroups share a CU (<= 80 KiB each: 3x3 layers without the folded border rows)
+        const bool ring3 = g_split16_ring3 && KS == 3 && ((size_t)3 * 512 + (size_t)8 * (p.halo16 + p.aux16)) * 16 <= 80 * 1024 - 512;
         S16_TIMED_LAUNCH(
             if (KS == 4) {
-                if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2, 4>), g, dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((igemm_split16_kernel<2, 2, 4>), g, dim3(256), 0, st, p);
-            } else if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 2>), g, dim3(256), 0, st, p);
-            else if (nbw == 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 2>), g, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((igemm_split16_kernel<3, 2>), g, dim3(256), 0, st, p);)
+                if (nbw <= 1) S16_GO(1, 2, 4, 4)
+                else S16_GO(2, 2, 4, 4)
+            } else if (ring3) {
+                if (nbw <= 1) S16_GO(1, 2, 3, 3)
+                else if (nbw == 2) S16_GO(2, 2, 3, 3)
+                else S16_GO(3, 2, 3, 3)
+            } else if (nbw <= 1) S16_GO(1, 2, 3, 4)
+            else if (nbw == 2) S16_GO(2, 2, 3, 4)
+            else S16_GO(3, 2, 3, 4))
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
         return;
     }
@@ -819,12 +862,13 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), KS * KS - 3);
         if (KS == 4) {
-            if (nbw <= 1) hipLaunchKernelGGL((igemm_split16_kernel<1, 3, 4>), g, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((igemm_split16_kernel<2, 3, 4>), g, dim3(256), 0, st, p);
-        } else if (nbw <= 2) hipLaunchKernelGGL((igemm_split16_kernel<2, 3>), g, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((igemm_split16_kernel<3, 3>), g, dim3(256), 0, st, p);
+            if (nbw <= 1) S16_GO(1, 3, 4, 4)
+            else S16_GO(2, 3, 4, 4)
+        } else if (nbw <= 2) S16_GO(2, 3, 3, 4)
+        else S16_GO(3, 3, 3, 4)
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
         return;
     }
+#undef S16_GO
     (void)region;
 }
