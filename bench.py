@@ -36,6 +36,8 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense FP16/BF16 MFMA peak (32x32x16)
+F16_MFMA_SUSTAINED_TF = 1423.0   # measured on the MI355X of this pool: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, no LDS / memory —
+                                 # the clock falls to 1.39 GHz at 100 % issue (tools/probes/mfma_f16_clock.hip, profiles/r3_mfma_f16_clock.txt)
 PMC_FILE = "profiles/r3_pmc_traffic.json"
 
 
@@ -265,7 +267,11 @@ def main():
                            "algorithmic_flop_per_launch": flop,
                            "peak_basis": "2500 TFLOP/s dense fp16 MFMA / 3 products per fp32 product",
                            "issued_mfma_TFLOPs": 3.0 * flop / sec / 1e12, "issued_frac_of_fp16_peak": 3.0 * flop / sec / 1e12 / F16_MFMA_PEAK_TF,
-                           "vs_fp32_mfma_peak_157": flop / sec / 1e12 / FP32_MFMA_PEAK_TF}
+                           "vs_fp32_mfma_peak_157": flop / sec / 1e12 / FP32_MFMA_PEAK_TF,
+                           # the nominal peak assumes 2.4 GHz; a pure MFMA loop on this chip sustains 1423 TFLOP/s (power-limited clock)
+                           "sustained_mfma_TFLOPs_measured": F16_MFMA_SUSTAINED_TF,
+                           "frac_of_sustained_mfma": 3.0 * flop / sec / 1e12 / F16_MFMA_SUSTAINED_TF,
+                           "sustained_source": "profiles/r3_mfma_f16_clock.txt"}
     if 'igemm_fwd_resblock' in spans:       # the whole operator call (max pass + split pass + main kernel), for the record
         n, sec = spans['igemm_fwd_resblock']
         out["conv2d_fwd_resblock_call"] = {"avg_us": sec * 1e6, "calls_timed": n,
