@@ -124,7 +124,7 @@ struct S16gParams {
 
 // max |w| of a weight tensor as a bit pattern, stage 1: ABSMAX_WGS workgroups, one partial each (plain stores — no zero-fill, no
 // atomics); the pack kernel and the convolution take the maximum of the partials themselves
-constexpr int ABSMAX_WGS = 16;
+constexpr int ABSMAX_WGS = 64;       // (16 workgroups took 20-32 us on the 300-500 K element tensors: latency-bound)
 __global__ __launch_bounds__(256) void s16g_absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
     __shared__ unsigned red[4];
     unsigned m = 0;
@@ -583,11 +583,11 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
 }
 
 size_t nemar_s16g_pack_bytes(const S16gProblem& q, const S16gPlan& pl) {
-    return pl.pack_words_per_class * 16 * (size_t)q.ncls + 64;
+    return pl.pack_words_per_class * 16 * (size_t)q.ncls + 4 * ABSMAX_WGS;
 }
 
 namespace {
-// layout of the packed buffer: [class 0 words][class 1 words]...[max word, 64 bytes]
+// layout of the packed buffer: [class 0 words][class 1 words]...[max partial words, 4 ABSMAX_WGS bytes]
 unsigned* pack_max_word(const S16gProblem& q, const S16gPlan& pl, void* packed) {
     return (unsigned*)((char*)packed + pl.pack_words_per_class * 16 * (size_t)q.ncls);
 }
