@@ -174,7 +174,7 @@ int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x1, int C1,
  *   24 every other convolution with >= 5 output channels on the 16-bit matrix pipe with the operand split INSIDE the kernel
  *      (csrc/conv_s16g*.hip; 1, default; 0 = exact-fp32 MFMA kernels)      25 its work threshold (million multiply-adds, 30)
  *   26 the wide layers' weight gradient on the in-kernel-split kernel instead of wgrad_split16 (0, default: measured slower)
- *   27 widest channel tile of s16g_kernel (1, 2, 4 x 32)                  28 prefer pixel tiles that leave LDS for two workgroups
+ *   27 widest channel tile of s16g_kernel (1, 2 = default, 4 x 32)                28 prefer pixel tiles that leave LDS for two workgroups
  *   29 weight gradients of the key-24 layers on s16g_wgrad_kernel (1)     30 stride-1 reflect 3x3 data gradients of those layers on
  *                                                                            the padded domain + reflect_fold_kernel (1)
  *   31 ablation bits of instnorm_planes_kernel (measurement only)

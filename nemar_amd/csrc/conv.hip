@@ -1538,9 +1538,22 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     const int c = blockIdx.x, n = blockIdx.y;
     const int beg = blockIdx.z * chunk, end = min(HW, beg + chunk);
     const float* q = g + ((size_t)n * C + c) * HW;
-    float acc = 0.f;
-    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) acc += q[i];
-    const float t = block_sum(acc, red);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if ((((uintptr_t)(q + beg)) & 15) == 0) {
+        // 16-byte loads, four independent sums, two loads in flight per thread (the one-dword-one-accumulator loop ran at 1.7 TB/s)
+        const float4* q4 = reinterpret_cast<const float4*>(q + beg);
+        const int n4 = (end - beg) >> 2;
+        int i = threadIdx.x;
+        for (; i + 256 < n4; i += 512) {
+            const float4 u = q4[i], v = q4[i + 256];
+            a0 += u.x + v.x; a1 += u.y + v.y; a2 += u.z + v.z; a3 += u.w + v.w;
+        }
+        if (i < n4) { const float4 u = q4[i]; a0 += u.x; a1 += u.y; a2 += u.z; a3 += u.w; }
+        for (int k = beg + (n4 << 2) + threadIdx.x; k < end; k += 256) a0 += q[k];
+    } else {
+        for (int i = beg + threadIdx.x; i < end; i += blockDim.x) a0 += q[i];
+    }
+    const float t = block_sum((a0 + a1) + (a2 + a3), red);
     if (threadIdx.x == 0) part[((size_t)n * gridDim.z + blockIdx.z) * C + c] = t;
 }
 
@@ -1555,17 +1568,21 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         const int h = (int)(t % H);
         const long long nc = t / H;
         const float* q = gp + nc * (long long)Hp * Wp;
-        // padded rows that map to h: h+pad always; pad-h if 1<=h<=pad; 2(H-1)-h+pad if H-1-pad<=h<=H-2
-        int ys[3], xs[3], ny = 0, nx = 0;
-        ys[ny++] = h + pad;
-        if (h >= 1 && h <= pad) ys[ny++] = pad - h;
-        if (h <= H - 2 && h >= H - 1 - pad) ys[ny++] = 2 * (H - 1) - h + pad;
-        xs[nx++] = w + pad;
-        if (w >= 1 && w <= pad) xs[nx++] = pad - w;
-        if (w <= W - 2 && w >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - w + pad;
-        float s = 0.f;
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) s += q[ys[a] * Wp + xs[b]];
+        // padded rows that map to h: h+pad always; pad-h if 1<=h<=pad; 2(H-1)-h+pad if H-1-pad<=h<=H-2 (columns likewise).  No index
+        // lists in private arrays (dynamically indexed ones live in scratch memory): up to three rows x three columns, spelled out
+        const int y0 = h + pad, x0 = w + pad;
+        const int y1 = (h >= 1 && h <= pad) ? pad - h : -1, y2 = (h <= H - 2 && h >= H - 1 - pad) ? 2 * (H - 1) - h + pad : -1;
+        const int x1 = (w >= 1 && w <= pad) ? pad - w : -1, x2 = (w <= W - 2 && w >= W - 1 - pad) ? 2 * (W - 1) - w + pad : -1;
+        auto rowsum = [&](int y) {
+            const float* r = q + (long long)y * Wp;
+            float v = r[x0];
+            if (x1 >= 0) v += r[x1];
+            if (x2 >= 0) v += r[x2];
+            return v;
+        };
+        float s = rowsum(y0);
+        if (y1 >= 0) s += rowsum(y1);
+        if (y2 >= 0) s += rowsum(y2);
         gx[idx] = s;
     }
 }

@@ -506,10 +506,11 @@ int nemar_s16g_timer_read(double* total_ms, double* total_flop) {
     return n;
 }
 
-static int g_s16g_maxmt = 4;      // widest channel tile (x 32): nemar_s16g_tune(0, v)
+static int g_s16g_maxmt = 2;      // widest channel tile (x 32): nemar_s16g_tune(0, v).  64 channels: the step is 1.3 % faster than with 128-channel
+                                   // tiles (36.4-36.7 vs 37.0-37.2 ms, A/B on one box) — their fragment sets leave no room for latency hiding
 static int g_s16g_lds_pref = 0;   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
 void nemar_s16g_tune(int key, int value) {
-    if (key == 0) g_s16g_maxmt = value == 1 || value == 2 ? value : 4;
+    if (key == 0) g_s16g_maxmt = value == 1 || value == 4 ? value : 2;
     if (key == 1) g_s16g_lds_pref = value;
 }
 
@@ -547,7 +548,8 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     // pixel tile: 128 NT pixels as RT rows x TW columns; the smallest halo that fits wins
     const int sx = q.sstride, ey = dymax - dymin, ex = dxmax - dxmin;
     long long best = -1;
-    for (int NT = (sx == 2 ? 1 : 2); NT >= 1; --NT) {
+    // (128 channels x 256 pixels per workgroup — MT 4, NT 2 — needs 280 VGPRs: 144 of them spilled to scratch; that tile is not offered)
+    for (int NT = (sx == 2 || pl.MT == 4 ? 1 : 2); NT >= 1; --NT) {
         const int NP = 128 * NT;
         for (int TW = 32; TW <= NP; TW *= 2) {
             if (TW > 32 && TW / 2 >= OW) break;              // wider than the rows: pure waste
