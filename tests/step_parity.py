@@ -181,7 +181,7 @@ def run(name, report=None, check=True):
                 continue                  # conv biases in front of InstanceNorm: exactly-zero gradient + noise
             knife = _maxabs(alt.numpy(), v.numpy()) / vmax          # 0 unless a pre-activation sits on the knife edge
             e = _maxabs(mine, v.numpy()) / vmax
-            errs.append(e)
+            errs.append(max(e - 1.5 * knife, 0.0))                  # (what the knife edge can account for is not an error)
             if e / (1e-3 + 1.5 * knife) > worst[0]:
                 worst = (e / (1e-3 + 1.5 * knife), k, e, knife)
         # Typical tensor 2e-4, worst tensor 1e-3 of the tensor's max, + 1.5 x what the oracle's own knife-edge re-evaluation moves
@@ -189,7 +189,7 @@ def run(name, report=None, check=True):
         # weight gradient by ~1 % (measured: tools/diag_dgrad.py, profiles/r3_knife_edge.txt — the exact-fp32 route and the 16-bit
         # route give the SAME 1.04e-2 on mr0.model.8.weight in the second step of unet256, bitwise reproducibly); which seeded
         # state contains one changes with any rounding-level change of the previous step's update.
-        add(pre + 'grad/D on identical fakes, median tensor', float(np.median(errs)), 2e-4 if ref.knife_count == 0 else 1e-3)
+        add(pre + 'grad/D on identical fakes, median tensor (beyond the knife-edge allowance)', float(np.median(errs)), 2e-4)
         add(pre + 'grad/D on identical fakes, worst tensor (%s: %.2e, knife-edge allowance %.2e, %d elements in the band)'
             % (worst[1], worst[2], 1.5 * worst[3], ref.knife_count), worst[0], 1.0)
         # full-step gradients (own forward values): direction agreement with the fp64 oracle per network / tensor
