@@ -124,6 +124,11 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (weak scaling)')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
+                    help='replay the step as ONE captured hipGraph in the timed region (NEMARModel.enable_step_graph: every kernel of the '
+                         'step, dropout offsets and Adam scalars in device memory; bit-identical to eager launches, tests/test_step_gpu.py). '
+                         'auto = on a single GPU, eager if the capture fails; the per-kernel roofline pass after the timed region is eager '
+                         'either way (event records cannot sit inside a graph)')
     ap.add_argument('--opt', action='append', default=[], metavar='FLAG',
                     help='extra reference-style option for other BASELINE configs, e.g. --opt=--multi_resolution --opt=2')
     a = ap.parse_args()
@@ -167,6 +172,19 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    graph_on, graph_note = False, None
+    if a.graph != 'off' and world == 1 and not dist.is_distributed():
+        try:
+            model.set_input(data)
+            model.enable_step_graph()
+            graph_on = True
+        except Exception as e:  # noqa: BLE001  (bench only: fall back to eager launches and say so in the JSON line)
+            if a.graph == 'on':
+                raise
+            graph_note = '%s: %s' % (type(e).__name__, e)
+            model._graph = None
+    elif a.graph == 'on':
+        raise SystemExit('--graph on: single GPU only')
 
     multi = dist.is_distributed()        # world > 1 (or the one-rank RCCL smoke configuration, NEMAR_DIST_SINGLE=1)
 
@@ -183,6 +201,7 @@ def main():
     dt = time.perf_counter() - t0
     # per-launch durations of the roofline kernels: HIP events on the launch stream in a SEPARATE pass of two steps, after
     # the timed region (the event records would otherwise sit inside it)
+    model._graph = None                  # the roofline pass needs eager launches (step parameters stay in device memory)
     timer.enabled = True
     from nemar_amd import _lib
     lib = _lib.load()
@@ -225,7 +244,9 @@ def main():
                                "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32%s"
                                % (a.size, a.size, a.batch, (" + " + " ".join(a.opt)) if a.opt else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world, "stn_cfg": opt.stn_cfg,
-                   "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"},
+                   "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"
+                           + (" — the timed steps are replays of ONE captured hipGraph of the step" if graph_on else "")},
+        "launch": "hipGraph replay" if graph_on else ("eager" + (" (capture failed: %s)" % graph_note if graph_note else "")),
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
         "rank_ms_per_step": rank_ms,                      # one entry per rank: the N > 1 run cannot degrade to one rank unnoticed
         "dist": {"backend": "nccl (RCCL)" if multi else None, "buckets_launched_last_step": buckets,

@@ -293,6 +293,15 @@ int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long 
 int nemar_dropout_max(const float* x, float* y, int samples, long long per_sample, float p, unsigned long long seed,
                       unsigned offset, void* max_words, void* stream);
 
+/* Replaying a step as a captured hipGraph: launch arguments are frozen at capture time, so what changes from step to step must live in
+ * device memory.  nemar_set_dropout_base registers a device word that every dropout-type launch (nemar_dropout, nemar_dropout_max,
+ * nemar_instnorm_fwd_planes) adds to its `offset` at run time (NULL = none, the default); the caller rewrites the word before each replay.
+ * nemar_adam_step_dev is nemar_adam_step with hyper[0] = lr / (1 - beta1^step) and hyper[1] = sqrt(1 - beta2^step) read from device memory
+ * (computed by the caller in double, rounded to float — exactly what nemar_adam_step passes to its kernel). */
+int nemar_set_dropout_base(const void* device_word);
+int nemar_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, double beta1,
+                        double beta2, double eps, void* stream);
+
 /* Input pipeline, on the GPU: random crop + horizontal flip + ToTensor/Normalize(0.5, 0.5) of a pool of images resident in
  * HBM — reference data/base_dataset.py:63-78 (get_params: ONE crop position / flip per A-B pair) and :81-112
  * (get_transform; Normalize :111).  pool [M,C,H,W] with values in [0, 1/scale]; params [B,4] int32 device array

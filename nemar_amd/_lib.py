@@ -63,6 +63,8 @@ SIGNATURES = {
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
     "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp]),
     "nemar_planes_hint": (_i, [_vp, _vp, _i, _i, _i, _i]),
+    "nemar_set_dropout_base": (_i, [_vp]),
+    "nemar_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "nemar_conv2d_fwd_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _vp, _sz, _i, _vp, _vp]),
     "nemar_conv2d_bwd_data_ex": (_i, [_vp, _vp, _vp, _i, _fl, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp]),
     "nemar_conv2d_bwd_weight_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),

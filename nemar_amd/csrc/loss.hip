@@ -98,6 +98,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// the same update with the two step-dependent scalars (lr / bias-correction-1, sqrt(bias-correction-2)) read from device memory: a captured
+// hipGraph replays this launch every step, the host refreshes the two floats before each replay
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long long n, float w1, float beta2,
+                                                       float one_m_beta2, const float* __restrict__ hyper, float eps) {
+    const float step_size = hyper[0], bc2_sqrt = hyper[1];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        const float diff = gi - mi;
+        mi = (w1 < 0.5f) ? mi + w1 * diff : gi - diff * (1.f - w1);
+        vi = vi * beta2 + (one_m_beta2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + (-step_size) * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
 int red_blocks(long long n) {
     int b = nemar_cdiv(n, 256 * 4);
     if (b < 1) b = 1;
@@ -174,5 +194,18 @@ NEMAR_API int nemar_adam_step(float* p, const float* g, float* m, float* v, long
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2),
                        (float)eps);
     NEMAR_CHECK_LAUNCH("adam_step");
+    return NEMAR_OK;
+}
+
+// nemar_adam_step with its step-dependent scalars in device memory: hyper[0] = lr / (1 - beta1^step), hyper[1] = sqrt(1 - beta2^step),
+// both computed by the caller in double and rounded to float (what nemar_adam_step does internally) — the form a captured hipGraph
+// can replay (the launch arguments are frozen at capture, the two floats are refreshed before every replay).
+NEMAR_API int nemar_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, double beta1,
+                                  double beta2, double eps, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(p && g && m && v && hyper && n > 0, "adam_step_dev: bad arguments");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(nemar_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), hyper, (float)eps);
+    NEMAR_CHECK_LAUNCH("adam_step_dev");
     return NEMAR_OK;
 }

@@ -80,6 +80,7 @@ struct NormPlanesParams {
     unsigned thresh;
     float dscale;
     unsigned seed_lo, seed_hi, offset;
+    const unsigned* obase;     // nemar_set_dropout_base word (added to offset) or null
     int dbg;                   // measurement only (nemar_tune(31, bits)): 1 no plane stores, 2 no LDS transpose, 4 no statistics, 8 no fp32 stores
 };
 
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
         if (p.dropout) {
             const unsigned long long q = ((unsigned long long)n * p.C + (unsigned long long)cg * 8 + j) * (unsigned long long)(HW >> 2) + t;
             unsigned r[4];
-            np_philox((unsigned)q, (unsigned)(q >> 32), p.offset, 0u, p.seed_lo, p.seed_hi, r);
+            np_philox((unsigned)q, (unsigned)(q >> 32), p.offset + (p.obase ? *p.obase : 0u), 0u, p.seed_lo, p.seed_hi, r);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = r[e] >= p.thresh ? o[e] * p.dscale : 0.f;
         }
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
 int g_norm_planes_dbg = 0;
 }  // namespace
 
+extern const unsigned* g_dropout_base;          // pointwise.hip
+
 void nemar_norm_planes_debug(int bits) { g_norm_planes_dbg = bits; }
 
 // y (optional) = [residual +] dropout(act(InstanceNorm(x))), stats, AND the fp16 x 3 planes of y for a 3x3 / pad-1 reflect convolution
@@ -279,6 +282,7 @@ NEMAR_API int nemar_instnorm_fwd_planes(const float* x, const float* residual, c
     p.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     p.dscale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     p.dbg = g_norm_planes_dbg;
+    p.obase = g_dropout_base;
     p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32); p.offset = offset;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(instnorm_planes_kernel, dim3(N * (C / 8)), dim3(1024), 0, st, p);

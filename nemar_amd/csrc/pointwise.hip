@@ -250,7 +250,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 // masks are those of the one-sample launch over the whole tensor)
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
                                                       unsigned thresh, float scale, unsigned seed_lo, unsigned seed_hi,
-                                                      unsigned offset, unsigned* maxw) {
+                                                      unsigned offset, unsigned* maxw, const unsigned* obase) {
+    if (obase) offset += *obase;             // (nemar_set_dropout_base: the per-step part of the offset lives in device memory)
     __shared__ unsigned red[4];
     const long long n4 = (n + 3) >> 2;
     const long long q0 = (long long)blockIdx.y * n4;
@@ -394,6 +395,15 @@ NEMAR_API int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, 
     return NEMAR_OK;
 }
 
+// A device word added to the `offset` of every dropout-type launch (nemar_dropout, nemar_dropout_max, nemar_instnorm_fwd_planes) at run
+// time; NULL (default) = none.  A captured hipGraph freezes launch arguments: with the per-step part of the Philox offset in this word the
+// replayed step still draws fresh masks (the caller rewrites the word before every replay).
+const unsigned* g_dropout_base = nullptr;
+NEMAR_API int nemar_set_dropout_base(const void* device_word) {
+    g_dropout_base = (const unsigned*)device_word;
+    return NEMAR_OK;
+}
+
 // y = x * mask / (1 - p) with mask ~ Bernoulli(1 - p) drawn from Philox(seed, offset); call it again with the same
 // (seed, offset) on the upstream gradient for the backward pass.
 NEMAR_API int nemar_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned offset,
@@ -404,7 +414,7 @@ NEMAR_API int nemar_dropout(const float* x, float* y, long long n, float p, unsi
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     hipLaunchKernelGGL(dropout_kernel, dim3(nemar_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n,
-                       thresh, 1.f / (1.f - p), (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)nullptr);
+                       thresh, 1.f / (1.f - p), (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)nullptr, g_dropout_base);
     NEMAR_CHECK_LAUNCH("dropout");
     return NEMAR_OK;
 }
@@ -423,7 +433,7 @@ NEMAR_API int nemar_dropout_max(const float* x, float* y, int samples, long long
     int gx = nemar_stream_grid(per_sample / 4, 256);
     if (gx * samples > 8192) gx = (8192 + samples - 1) / samples;
     hipLaunchKernelGGL(dropout_kernel, dim3(gx, samples), dim3(256), 0, (hipStream_t)stream, x, y, per_sample, thresh, 1.f / (1.f - p),
-                       (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)max_words);
+                       (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), offset, (unsigned*)max_words, g_dropout_base);
     max_words_finalize((unsigned*)max_words, samples, gx, (hipStream_t)stream);
     NEMAR_CHECK_LAUNCH("dropout_max");
     return NEMAR_OK;

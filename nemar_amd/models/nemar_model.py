@@ -290,7 +290,63 @@ class NEMARModel(BaseModel):
         return _LazyLoss([(r, 1.0) for r in roots[:len(roots) - (1 if opt.lambda_smooth != 0.0 else 0)]] +
                          [(self.stn_reg_term, float(opt.lambda_smooth))])
 
+    # ---- the step as a captured hipGraph (launch-bound small configurations: BASELINE config 1) ---------------------------------
+    def enable_step_graph(self, warmup=3):
+        """Capture optimize_parameters() for the CURRENT input shapes into a hipGraph and replay it from then on: one graph launch
+        instead of ~1100 kernel launches per step.  Single process only (the gradient all-reduce is not captured).  Inputs are copied
+        into static buffers; dropout offsets and Adam's step-dependent scalars live in device memory (ops.step_params), so every
+        replay is a fresh step; an eager run in that mode produces the same bits (tests/test_step_gpu.py)."""
+        if dist.is_distributed():
+            raise RuntimeError('enable_step_graph: single-process only')
+        if self.tb_visualizer is not None:
+            raise RuntimeError('enable_step_graph: disable the tensorboard visualiser (it reads tensors between launches)')
+        ops.step_params(True, self.device)
+        self._static_A, self._static_B = self.real_A.clone(), self.real_B.clone()
+        opts = [self.optimizer_D, self.optimizer_R, self.optimizer_T]
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # warm-up on a side stream (allocator pools, lazy attributes, packs)
+            for _ in range(warmup):
+                self.real_A, self.real_B = self._static_A, self._static_B
+                ops.begin_step()
+                self._optimize_parameters_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        self.real_A, self.real_B = self._static_A, self._static_B
+        ops.begin_step()
+        for o in opts:
+            o.prepare_step(o.step_count + 1)
+        ops._step_params["capturing"] = True
+        try:
+            with torch.cuda.graph(self._graph):
+                self._optimize_parameters_eager()
+        finally:
+            ops._step_params["capturing"] = False
+        # (the capture itself executed nothing: the step it describes is run by the first replay; undo its host book-keeping)
+        for o in opts:
+            o.step_count -= 1
+        ops._step_params["step"] -= 1
+
+    def _replay_step(self):
+        if self.real_A is not self._static_A:
+            self._static_A.copy_(self.real_A)
+            self._static_B.copy_(self.real_B)
+            self.real_A, self.real_B = self._static_A, self._static_B
+        ops.begin_step()
+        for o in (self.optimizer_D, self.optimizer_R, self.optimizer_T):
+            o.prepare_step(o.step_count + 1)
+        self._graph.replay()
+        for o in (self.optimizer_D, self.optimizer_R, self.optimizer_T):
+            o.replayed_step()
+
     def optimize_parameters(self):
+        if getattr(self, '_graph', None) is not None:
+            return self._replay_step()
+        ops.begin_step()
+        return self._optimize_parameters_eager()
+
+    def _optimize_parameters_eager(self):
         # data parallel: how many gradient contributions each parameter will receive is COUNTED while the forward passes run
         # (T: once batched / twice; every discriminator: once batched / three times) — GradSync launches a bucket's all-reduce when
         # its last contribution has been issued

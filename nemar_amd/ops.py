@@ -612,6 +612,37 @@ def resize_bilinear(x, Ho, Wo):
 
 _dropout_state = {"seed": 0x5EED5EED, "offset": 0}
 
+# ---- step parameters in device memory (hipGraph replay: nemar_amd/models/nemar_model.py enable_step_graph) -----------------------
+# A captured graph replays the launches of ONE step with frozen arguments.  What changes from step to step — the dropout offsets
+# and Adam's bias-corrected step size — then has to be read from device memory: `step_params(True)` switches the dropout launches to
+# "offset within the step (frozen) + a device word the host rewrites before every step" and FlatAdam.step() to nemar_adam_step_dev.
+# The same arithmetic as the by-value forms: an eager run in this mode and a graph replay are bit-identical.
+_step_params = {"on": False, "base": None, "capturing": False, "step": 0}
+DROPOUT_STEP_STRIDE = 4096           # offsets per step (dropout launches per step must stay below it)
+
+
+def step_params(on, device=None):
+    _step_params["on"] = bool(on)
+    if on:
+        if _step_params["base"] is None:
+            _step_params["base"] = torch.zeros(1, dtype=torch.int32, device=device)
+        L.set_dropout_base(_p(_step_params["base"]))
+    else:
+        L.set_dropout_base(None)
+
+
+def begin_step():
+    """Before every step in step_params mode (eager or graph replay, NOT inside a capture): the dropout offsets of this step are
+    base + 1 .. base + calls, base = step index x DROPOUT_STEP_STRIDE in the device word."""
+    if not _step_params["on"]:
+        return
+    if _dropout_state["offset"] >= DROPOUT_STEP_STRIDE:
+        raise RuntimeError("more than %d dropout launches in one step" % DROPOUT_STEP_STRIDE)
+    _step_params["step"] += 1
+    base = (_step_params["step"] * DROPOUT_STEP_STRIDE) & 0x7FFFFFFF
+    _step_params["base"].copy_(torch.tensor([base], dtype=torch.int32))
+    _dropout_state["offset"] = 0
+
 
 def manual_seed(seed):
     """Seed of the counter-based dropout generator.  NEMARModel seeds it from torch.initial_seed() + rank, so that
@@ -867,8 +898,30 @@ class FlatAdam:
         self._epoch.n += 1
         self.step_count += 1
         g = self.param_groups[0]
+        if _step_params["on"]:
+            # the two step-dependent scalars in device memory (written by prepare_step() before a graph replay; here when eager)
+            if not _step_params["capturing"]:
+                self.prepare_step(self.step_count)
+            L.adam_step_dev(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, _p(self.hyper),
+                            self.betas[0], self.betas[1], self.eps, _stream())
+            return
         L.adam_step(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, float(g["lr"]),
                     self.betas[0], self.betas[1], self.eps, self.step_count, _stream())
+
+    def prepare_step(self, step):
+        """hyper <- (lr / (1 - beta1^step), sqrt(1 - beta2^step)) for the step about to run: nemar_adam_step's own arithmetic (double,
+        rounded to float once)."""
+        if getattr(self, 'hyper', None) is None:
+            self.hyper = torch.zeros(2, dtype=torch.float32, device=self.flat_p.device)
+        lr = float(self.param_groups[0]["lr"])
+        bc1 = 1.0 - self.betas[0] ** step
+        bc2 = 1.0 - self.betas[1] ** step
+        self.hyper.copy_(torch.tensor([lr / bc1, bc2 ** 0.5], dtype=torch.float64).to(torch.float32))
+
+    def replayed_step(self):
+        """book-keeping of a step that ran inside a graph replay (the launches were the graph's)"""
+        self._epoch.n += 1
+        self.step_count += 1
 
     def state_dict(self):
         return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone()}

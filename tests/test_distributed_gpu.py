@@ -107,7 +107,7 @@ def test_rccl_code_path_with_a_world_of_one_rank():
         env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                    NEMAR_DIST_SINGLE=forced, NEMAR_BENCH_DUMP_LOSSES="1")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                            "--no-cpu-baseline", "--batch", "2", "--opt=--no_dropout"], env=env, capture_output=True, text=True,
+                            "--no-cpu-baseline", "--batch", "2", "--opt=--no_dropout", "--graph", "off"], env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]

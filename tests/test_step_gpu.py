@@ -76,3 +76,61 @@ def test_batched_passes_match_reference_call_order(name, monkeypatch):
     for g in ('gd', 'gt', 'gr'):
         scale = y[g].abs().max().item()
         assert (x[g] - y[g]).abs().max().item() <= 2e-3 * scale, (g, (x[g] - y[g]).abs().max().item(), scale)
+
+
+def test_step_graph_replay_equals_eager():
+    """optimize_parameters() captured as a hipGraph (NEMARModel.enable_step_graph) and replayed == the same steps launched eagerly with
+    the step parameters in device memory (ops.step_params): bit-identical weights, Adam moments and losses after four steps, with
+    dropout ON (fresh masks every replay: the Philox offset's per-step part is a device word) and Adam's bias corrections advancing."""
+    import torch
+    import seeded
+    from nemar_amd import ops
+    from nemar_amd.models import create_model
+    from step_configs import make_opt
+    name = 'affine128'
+    cfg = STEP_CONFIGS[name]
+    a, b = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    data = {'A': torch.from_numpy(a), 'B': torch.from_numpy(b), 'A_paths': [''], 'B_paths': ['']}
+
+    def build():
+        opt = make_opt(cfg, gpu_ids=[0])
+        opt.no_dropout = False
+        m = create_model(opt)
+        m.setup(opt)
+        step_parity.load_seeded_into(m.netT, cfg['seed'] + 1, cfg.get('overrides_T'))
+        step_parity.load_seeded_into(m.netR, cfg['seed'] + 2, cfg.get('overrides_R'))
+        step_parity.load_seeded_into(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
+        ops.manual_seed(1234)
+        ops._step_params["step"] = 0
+        return m
+
+    def snap(m):
+        torch.cuda.synchronize()
+        return ([o.flat_p.detach().cpu().clone() for o in m.optimizers], [o.m.detach().cpu().clone() for o in m.optimizers],
+                [o.v.detach().cpu().clone() for o in m.optimizers], dict(m.get_current_losses()))
+
+    try:
+        ops.step_params(True, torch.device('cuda:0'))
+        m = build()
+        first = None
+        for i in range(4):
+            m.set_input(data)
+            m.optimize_parameters()
+            if i == 0:
+                first = snap(m)
+        eager = snap(m)
+        assert not all(torch.equal(x, y) for x, y in zip(first[0], eager[0]))          # (the steps do move the weights)
+        m = build()
+        m.set_input(data)
+        m.enable_step_graph(warmup=2)
+        for _ in range(2):
+            m.set_input(data)
+            m.optimize_parameters()
+        graph = snap(m)
+        assert [o.step_count for o in m.optimizers] == [4, 4, 4]
+    finally:
+        ops.step_params(False)
+    for k in range(3):
+        for x, y in zip(eager[k], graph[k]):
+            assert torch.equal(x, y)
+    assert eager[3] == graph[3], (eager[3], graph[3])

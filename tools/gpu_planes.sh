@@ -5,7 +5,7 @@ cd $R
 timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "planes or producer or norm" 2>&1 | tail -3
 timeout 900 python -m pytest tests/test_step_full_gpu.py tests/test_nets_gpu.py -q -x 2>&1 | tail -3
 for v in 1 0 1 0; do
-  NEMAR_PLANES=$v timeout 600 python bench.py --no-cpu-baseline > $O/bench_planes$v.json 2>/dev/null
+  NEMAR_PLANES=$v timeout 600 python bench.py --no-cpu-baseline --graph off > $O/bench_planes$v.json 2>/dev/null
   python -c "
 import json
 d = json.load(open('$O/bench_planes$v.json')); print('NEMAR_PLANES=$v %.2f img/s  %.2f ms/step' % (d['value'], d['ms_per_step']))"
