@@ -645,6 +645,42 @@ def case_conv_ex(be, N=3, C=128, H=8, W=32, K=128, seed=0):
         assert np.array_equal(a, b), what
 
 
+def case_step_params_in_device_memory(be, seed=0):
+    """What a captured hipGraph needs: nemar_adam_step_dev (the two step-dependent scalars read from device memory) == nemar_adam_step,
+    and a dropout launch with base word b and offset k == the launch with offset b + k and no base — bit for bit."""
+    rng = np.random.default_rng(seed)
+    n = 5003
+    p0 = rng.standard_normal(n).astype(np.float32)
+    g = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    m0 = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    v0 = (rng.random(n) * 1e-3).astype(np.float32)
+    lr, b1, b2, eps, step = 2e-4, 0.5, 0.999, 1e-8, 7
+    outs = []
+    for dev in (False, True):
+        d_p, d_g, d_m, d_v = be.dev(p0.copy()), be.dev(g.copy()), be.dev(m0.copy()), be.dev(v0.copy())     # (the host backend aliases)
+        if dev:
+            hyper = be.dev(np.array([lr / (1.0 - b1 ** step), (1.0 - b2 ** step) ** 0.5], dtype=np.float64).astype(np.float32))
+            be.lib.adam_step_dev(be.ptr(d_p), be.ptr(d_g), be.ptr(d_m), be.ptr(d_v), n, be.ptr(hyper), b1, b2, eps, be.stream)
+        else:
+            be.lib.adam_step(be.ptr(d_p), be.ptr(d_g), be.ptr(d_m), be.ptr(d_v), n, lr, b1, b2, eps, step, be.stream)
+        be.sync()
+        outs.append((be.np(d_p), be.np(d_m), be.np(d_v)))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    x = rng.standard_normal((2, 16, 6, 10)).astype(np.float32)
+    d_x = be.dev(x)
+    y0, y1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
+    be.lib.dropout(be.ptr(d_x), be.ptr(y0), x.size, 0.5, 99, 1000 + 7, be.stream)
+    base = be.dev_i32(np.array([1000], dtype=np.int32))
+    be.lib.set_dropout_base(be.ptr(base))
+    try:
+        be.lib.dropout(be.ptr(d_x), be.ptr(y1), x.size, 0.5, 99, 7, be.stream)
+        be.sync()
+    finally:
+        be.lib.set_dropout_base(None)
+    assert np.array_equal(be.np(y0), be.np(y1)) and (be.np(y0) == 0).any() and (be.np(y0) != 0).any()
+
+
 def _decode_planes(raw, N, C, H, W):
     """conv_split16.hip's plane layout -> float64 [2 (hi, lo)][N][C][H+4][W+4]"""
     a = raw.view(np.float16).astype(np.float64).reshape(2, N, C // 8, H + 4, W + 4, 8)

@@ -492,6 +492,10 @@ def test_instnorm_planes(be, act, res, drop):
     K.case_instnorm_planes(be, act, res, drop)
 
 
+def test_step_params_in_device_memory(be):
+    K.case_step_params_in_device_memory(be)
+
+
 def test_conv_ex_per_call_side_inputs(be):
     K.case_conv_ex(be)
 
