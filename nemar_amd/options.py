@@ -106,6 +106,9 @@ class TrainOptions(BaseOptions):
                                    ('--niter_decay', int, 100), ('--pool_size', int, 50), ('--lr_decay_iters', int, 50)):
             a(flag, type=typ, default=default)
         a('--no_html', action='store_true')
+        a('--step_graph', action='store_true',
+          help='(MI355X build) capture optimize_parameters() into a hipGraph after the first batch and replay it: for launch-bound '
+               'shapes (small images, batch 1); single process, fixed batch shape, no --enable_tbvis')
         a('--save_by_iter', action='store_true')
         a('--continue_train', action='store_true')
         a('--phase', type=str, default='train')

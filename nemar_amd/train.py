@@ -67,6 +67,8 @@ def main(argv=None):
             total_iters += opt.batch_size
             epoch_iter += opt.batch_size
             model.set_input(data)
+            if getattr(opt, 'step_graph', False) and world == 1 and getattr(model, '_graph', None) is None:
+                model.enable_step_graph()                              # this batch and every later one: graph replays
             model.optimize_parameters()
             if total_iters % opt.print_freq == 0:
                 losses = model.get_current_losses()                    # the only host synchronisation of the loop

@@ -58,6 +58,24 @@ def test_train_loop_writes_the_loss_line_and_offset_scalars(tmp_path, capsys):
     assert {'offset/mean_x', 'offset/mean_y', 'loss/L1_TR', 'loss/D'} <= tags
 
 
+def test_train_loop_with_the_step_as_a_graph(tmp_path, capsys):
+    """--step_graph: the loop's steps are replays of one captured hipGraph; the reference's loss line comes out as before."""
+    from nemar_amd import ops, train
+    try:
+        train.main(['--model', 'nemar', '--stn_type', 'affine', '--netG', 'resnet_3blocks', '--ngf', '8', '--ndf', '8',
+                    '--dataset_mode', 'gpupairs', '--dataroot', 'synthetic', '--img_height', '128', '--img_width', '128',
+                    '--crop_size', '128', '--load_size', '128', '--batch_size', '2', '--pool_size_pairs', '8', '--checkpoints_dir',
+                    str(tmp_path), '--name', 'graph', '--print_freq', '4', '--niter', '1', '--niter_decay', '0', '--save_epoch_freq',
+                    '100', '--gpu_ids', '0', '--step_graph'])
+    finally:
+        ops.step_params(False)
+    out = capsys.readouterr().out
+    line = [l for l in out.splitlines() if l.startswith('(epoch: 1, iters: 4, time: ')]
+    assert line and ' L1_TR: ' in line[0] and ' D: ' in line[0]
+    vals = [float(t) for t in line[0].replace(',', ' ').split() if t.replace('.', '', 1).replace('-', '', 1).isdigit()]
+    assert all(v == v for v in vals)
+
+
 def test_offset_meter_matches_the_reference_arithmetic():
     """reference tb_visualizer.py:71-74: mean over iterations of np.mean(offset[:, c])."""
     from nemar_amd.util.visualizer import OffsetMeter
