@@ -116,6 +116,105 @@ def cpu_baseline():
                         "sample": "%d steps of BASELINE config 1 (affine STN, resnet_6blocks, 128x128, batch 1, no dropout)" % n1}}
 
 
+OTHER_CONFIGS = (
+    # (name, batch per GPU, size, steps, warmup, extra flags): the per-GPU shards of the other BASELINE.json configs (parity cases with
+    # full-width fixtures in tests/; here only their step time, eager and as a hipGraph replay)
+    ("C1 affine, resnet_6blocks, 128x128, batch 1", 1, 128, 20, 5, ['--stn_type', 'affine', '--netG', 'resnet_6blocks']),
+    ("C3 shard: C2 + multi-resolution D, 256x256, batch 8", 8, 256, 5, 2, ['--multi_resolution', '2']),
+    ("C4 shard: 512x512, bilateral smoothness, multi-resolution regulariser, batch 4", 4, 512, 5, 2,
+     ['--stn_bilateral_alpha', '1.5', '--stn_multires_reg', '2']),
+    ("C5 shard: 1024x1024, deep stn cfg, batch 1", 1, 1024, 5, 2, ['--stn_cfg', 'deep']),
+)
+
+
+def _make(batch, size, extra, dev, seed=0):
+    import contextlib
+    import io
+    from nemar_amd.models import create_model
+    opt = build_opt(batch, size, extra)
+    opt.gpu_ids = [dev.index]
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+        model.setup(opt)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    A = torch.rand(batch, 3, size, size, device=dev, generator=g) * 2 - 1
+    B = torch.rand(batch, 3, size, size, device=dev, generator=g) * 2 - 1
+    return model, {'A': A, 'B': B, 'A_paths': ['synthetic'], 'B_paths': ['synthetic']}
+
+
+def _time_steps(model, data, steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.set_input(data)
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def other_configs(dev):
+    """Step time of the other BASELINE shapes on this GPU (their per-GPU shard), eager launches and hipGraph replay."""
+    import gc
+    out = []
+    for name, batch, size, steps, warmup, extra in OTHER_CONFIGS:
+        row = {"config": name}
+        try:
+            model, data = _make(batch, size, extra, dev)
+            for _ in range(warmup):
+                model.set_input(data)
+                model.optimize_parameters()
+            row["eager_ms_per_step"] = _time_steps(model, data, steps)
+            try:
+                model.set_input(data)
+                model.enable_step_graph()
+                row["graph_ms_per_step"] = _time_steps(model, data, steps)
+            except Exception as e:  # noqa: BLE001
+                row["graph_error"] = '%s: %s' % (type(e).__name__, e)
+            best = min(v for k, v in row.items() if k.endswith('_ms_per_step'))
+            row["images_per_sec"] = batch / best * 1e3
+        except Exception as e:  # noqa: BLE001  (a side measurement must not take the bench line down)
+            row["error"] = '%s: %s' % (type(e).__name__, e)
+        finally:
+            from nemar_amd import ops
+            ops.pin_workspaces(False)
+            ops.step_params(False)
+            model = data = None
+            gc.collect()
+            torch.cuda.empty_cache()
+        out.append(row)
+    return out
+
+
+def route_agreement(dev):
+    """How far the fp16 x 3 routes move the step's GRADIENTS: one full-width config-2-shaped step (batch 1, no dropout, same seeded weights
+    and inputs) on the default routes and with every 16-bit-pipe kernel off (nemar_tune 20=0, 24=0: exact-fp32 MFMA / VALU), compared
+    per network as 1 - cos of the whole flat gradient and as relative L2 distance."""
+    import gc
+    from nemar_amd import ops
+    grads = {}
+    for tag, keys in (("default", ()), ("exact", (20, 24))):
+        for k in keys:
+            ops.tune(k, 0)
+        try:
+            model, data = _make(1, 256, ['--no_dropout'], dev, seed=7)
+            model.set_input(data)
+            model.optimize_parameters()
+            torch.cuda.synchronize()
+            grads[tag] = {n: getattr(model, 'optimizer_' + n).flat_g.double().clone() for n in ('T', 'R', 'D')}
+        finally:
+            for k in keys:
+                ops.tune(k, 1)
+            model = None
+            gc.collect()
+    out = {}
+    for n in ('T', 'R', 'D'):
+        a, b = grads["default"][n], grads["exact"][n]
+        out[n] = {"one_minus_cos": float(1.0 - (a * b).sum() / (a.norm() * b.norm())), "rel_l2": float((a - b).norm() / b.norm())}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,6 +223,8 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (weak scaling)')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the side measurements of the default run (exact-route A/B, the other BASELINE shapes, route agreement)')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='replay the step as ONE captured hipGraph in the timed region (NEMARModel.enable_step_graph: every kernel of the '
                          'step, dropout offsets and Adam scalars in device memory; bit-identical to eager launches, tests/test_step_gpu.py). '
@@ -148,12 +249,17 @@ def main():
 
     from nemar_amd import ops
     from nemar_amd.models import create_model
+    import contextlib
+    import io
+    cpu_base = None
+    if world == 1 and not a.no_cpu_baseline:
+        # the CPU leg runs FIRST: the GPU phase is then one contiguous block at the end of the run (the driver samples GPU activity)
+        with contextlib.redirect_stdout(sys.stderr):     # the net constructors print; stdout carries the JSON line only
+            cpu_base = cpu_baseline()
     opt = build_opt(a.batch, a.size, a.opt)
     opt.gpu_ids = [local]
     torch.manual_seed(0)      # identical initial weights on every rank (also broadcast at setup); NEMARModel seeds the
                               # dropout stream with torch.initial_seed() + rank
-    import contextlib
-    import io
     with contextlib.redirect_stdout(io.StringIO()):
         model = create_model(opt)
         model.setup(opt)
@@ -217,6 +323,7 @@ def main():
     tk_ms, tk_flop, tk_n = tk_ms_c.value, tk_fl_c.value, tk_n_c.value
     rank_ms = [dt / a.steps * 1e3]
     buckets = sum(len(getattr(model, n).launched) for n in ("sync_T", "sync_D", "sync_R"))
+    stn_cfg = opt.stn_cfg
     if multi:
         t = torch.zeros(world, device=dev, dtype=torch.float64)
         t[rank] = dt
@@ -224,6 +331,39 @@ def main():
         rank_ms = [float(x) / a.steps * 1e3 for x in t.tolist()]
         dt = float(t.max().item())
     losses = model.get_current_losses()
+    extras = {}
+    if world == 1 and not multi and not a.no_extras:
+        # side measurements of the default single-GPU run — after the timed region, never inside it
+        try:
+            ms_default = _time_steps(model, data, 5)
+            for k in (20, 24):
+                ops.tune(k, 0)                     # every 16-bit-pipe kernel off: all convolutions on the exact-fp32 MFMA / VALU kernels
+            try:
+                for _ in range(2):
+                    step()
+                ms_exact = _time_steps(model, data, 5)
+            finally:
+                for k in (20, 24):
+                    ops.tune(k, 1)
+            extras["exact_route"] = {"ms_per_step_eager": ms_exact, "images_per_sec": a.batch / ms_exact * 1e3,
+                                     "default_route_ms_per_step_eager": ms_default,
+                                     "speedup_from_fp16x3_routes": ms_exact / ms_default,
+                                     "how": "same model and batch, nemar_tune 20=0 and 24=0 (no fp16 x 3 kernel anywhere), 5 eager steps each"}
+        except Exception as e:  # noqa: BLE001
+            extras["exact_route"] = {"error": '%s: %s' % (type(e).__name__, e)}
+        import gc
+        ops.pin_workspaces(False)
+        ops.step_params(False)
+        ops.set_kernel_timer(None)
+        model = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        if a.size == 256 and not a.opt:
+            try:
+                extras["route_agreement"] = route_agreement(dev)
+            except Exception as e:  # noqa: BLE001
+                extras["route_agreement"] = {"error": '%s: %s' % (type(e).__name__, e)}
+            extras["other_configs"] = other_configs(dev)
     if multi:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -243,7 +383,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: --stn_type unet --stn_cfg A, resnet_9blocks T, basic PatchGAN D, "
                                "%dx%d, batch %d per GPU, dropout on, lambda_smooth 10, fp32%s"
                                % (a.size, a.size, a.batch, (" + " + " ".join(a.opt)) if a.opt else ""),
-                   "global_batch": a.batch * world, "parallelism": "dp%d" % world, "stn_cfg": opt.stn_cfg,
+                   "global_batch": a.batch * world, "parallelism": "dp%d" % world, "stn_cfg": stn_cfg,
                    "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"
                            + (" — the timed steps are replays of ONE captured hipGraph of the step" if graph_on else "")},
         "launch": "hipGraph replay" if graph_on else ("eager" + (" (capture failed: %s)" % graph_note if graph_note else "")),
@@ -312,9 +452,9 @@ def main():
                                        "traffic": sum(pmc.get(t, {}).get("traffic_bytes", 0) for t in gs)
                                        if std and pmc else None,
                                        "kernels": gs}
-    if world == 1 and not a.no_cpu_baseline:
-        with contextlib.redirect_stdout(sys.stderr):     # the net constructors print; stdout carries the JSON line only
-            out["cpu_baseline"] = cpu_baseline()
+    out.update(extras)
+    if cpu_base is not None:
+        out["cpu_baseline"] = cpu_base
     print(json.dumps(out), flush=True)
 
 

@@ -42,9 +42,10 @@ def world_size():
     return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, device=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun's
-    contract).  Returns (rank, world_size, local_rank).  No-op for a single process."""
+    contract).  Returns (rank, world_size, local_rank).  No-op for a single process.  `device`: the GPU index this rank uses (default
+    LOCAL_RANK) — selected BEFORE the communicator is created, so that no stray context is opened on another GPU."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,7 +55,7 @@ def init_from_env(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(lr)
+            torch.cuda.set_device(lr if device is None else int(device))
         td.init_process_group(backend=backend, rank=rk, world_size=ws)
     return rk, ws, lr
 

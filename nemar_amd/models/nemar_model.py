@@ -303,13 +303,29 @@ class NEMARModel(BaseModel):
         ops.step_params(True, self.device)
         self._static_A, self._static_B = self.real_A.clone(), self.real_B.clone()
         opts = [self.optimizer_D, self.optimizer_R, self.optimizer_T]
+        # The warm-up steps must not train: they run with lr = 0 (Adam leaves every parameter bit-unchanged: p - 0 * x) and the
+        # moments, step counts and the dropout step counter are put back afterwards — the first replay is then step 1 of the same
+        # schedule an eager loop would follow, on untouched weights.  (The packed-weight images are rebuilt from the same values, so
+        # the state the capture sees — T and R to be re-packed, D's forward images valid — is the steady state of every later step.)
+        saved = [(o.m.clone(), o.v.clone(), o.step_count, o.param_groups[0]["lr"]) for o in opts]
+        saved_step = ops._step_params["step"]
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                         # warm-up on a side stream (allocator pools, lazy attributes, packs)
-            for _ in range(warmup):
-                self.real_A, self.real_B = self._static_A, self._static_B
-                ops.begin_step()
-                self._optimize_parameters_eager()
+            try:
+                for o in opts:
+                    o.param_groups[0]["lr"] = 0.0
+                for _ in range(warmup):
+                    self.real_A, self.real_B = self._static_A, self._static_B
+                    ops.begin_step()
+                    self._optimize_parameters_eager()
+            finally:
+                for o, (m, v, n, lr) in zip(opts, saved):
+                    o.m.copy_(m)
+                    o.v.copy_(v)
+                    o.step_count = n
+                    o.param_groups[0]["lr"] = lr
+                ops._step_params["step"] = saved_step
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
@@ -327,8 +343,15 @@ class NEMARModel(BaseModel):
         for o in opts:
             o.step_count -= 1
         ops._step_params["step"] -= 1
+        self._graph_losses = {k: v for k, v in self.__dict__.items() if k.startswith('_lazy_loss_')}
+        ops.pin_workspaces(True)          # the graph holds their addresses: from now on they may grow but are never freed
 
     def _replay_step(self):
+        if self.real_A.shape != self._static_A.shape or self.real_B.shape != self._static_B.shape:
+            # a batch of another shape (the ragged last batch of an epoch): the captured launches do not describe it — run this step
+            # eagerly, in the same device-parameter mode (bit-identical arithmetic), and keep the graph for the next full batch
+            ops.begin_step()
+            return self._optimize_parameters_eager()
         if self.real_A is not self._static_A:
             self._static_A.copy_(self.real_A)
             self._static_B.copy_(self.real_B)
@@ -339,6 +362,11 @@ class NEMARModel(BaseModel):
         self._graph.replay()
         for o in (self.optimizer_D, self.optimizer_R, self.optimizer_T):
             o.replayed_step()
+        # the loss_* attributes were created during the capture: their term buffers hold THIS step's values now, any sum formed by an
+        # earlier read is stale
+        for k, v in self._graph_losses.items():
+            v._v = None
+            self.__dict__[k] = v          # (an eager step in between — a ragged batch — had replaced them)
 
     def optimize_parameters(self):
         if getattr(self, '_graph', None) is not None:

@@ -1,43 +1,49 @@
-"""STN factory and command-line flags — mirror of reference models/stn/__init__.py (flags :10-25, define_stn :28-48)."""
+"""STN factory and command-line flags of the registration network: the drop-in contract of reference models/stn/__init__.py
+(flag names and defaults :10-25, `define_stn(opt, stn_type)` :28-48).  Names / types / defaults are the interface and are identical;
+everything else is this build's own."""
 from .affine_stn import AffineSTN
 from .unet_stn import UnetSTN
 
 sampling_align_corners = False
 sampling_mode = 'bilinear'
 
+# (flag, argparse keywords, train-only) — the reference's five --stn_* options
+_FLAGS = (
+    ('--stn_cfg', dict(type=str, default='A',
+                       help="layer table of the registration net: 'A' (the reference's), 'deep' (9 levels, for 1024x1024 inputs)"), False),
+    ('--stn_type', dict(type=str, default='affine',
+                        help='registration model: affine (6 parameters per pair) | unet (dense deformation field)'), False),
+    ('--stn_bilateral_alpha', dict(type=float, default=0.0,
+                                   help='unet only: edge-aware weight exp(-alpha |dI|) on the smoothness penalty; 0 switches it off'), True),
+    ('--stn_no_identity_init', dict(action='store_true',
+                                    help='unet only: start from a random field instead of the near-identity initialisation'), True),
+    ('--stn_multires_reg', dict(type=int, default=1,
+                                help='unet only: apply the smoothness penalty at this many resolutions (1 = full resolution only)'), True),
+)
+_BUILDERS = {
+    'affine': lambda a, b, h, w, opt: AffineSTN(a, b, h, w, opt.stn_cfg, opt.init_type),
+    'unet': lambda a, b, h, w, opt: UnetSTN(a, b, h, w, opt.stn_cfg, opt.init_type, opt.stn_bilateral_alpha,
+                                            not opt.stn_no_identity_init, opt.stn_multires_reg),
+}
+
 
 def modify_commandline_options(parser, is_train=True):
-    parser.add_argument('--stn_cfg', type=str, default='A', help='Set the configuration used to build the STN.')
-    parser.add_argument('--stn_type', type=str, default='affine',
-                        help='The type of STN to use. Currently supported are [unet, affine]')
-    if is_train:
-        parser.add_argument('--stn_bilateral_alpha', type=float, default=0.0,
-                            help='The bilateral filtering coefficient used in the the smoothness loss.'
-                                 'This is relevant for unet stn only.')
-        parser.add_argument('--stn_no_identity_init', action='store_true',
-                            help='Whether to start the transformation from identity transformation or some random'
-                                 'transformation. This is only relevant for unet stn (for affine the model'
-                                 'doesn\'t converge).')
-        parser.add_argument('--stn_multires_reg', type=int, default=1,
-                            help='In multi-resolution smoothness, the regularization is applied on multiple resolution.'
-                                 '(default : 1, means no multi-resolution)')
+    for flag, kw, train_only in _FLAGS:
+        if is_train or not train_only:
+            parser.add_argument(flag, **kw)
     return parser
 
 
 def define_stn(opt, stn_type='affine'):
-    """Create the STN for `opt` on its device.  One process drives one GPU (no nn.DataParallel wrap, so there is
-    no `.module` indirection); returns None for an unknown type, like the reference."""
+    """The STN for `opt`, on this process's GPU.  One process drives one GPU (no nn.DataParallel wrap, hence no `.module`
+    indirection); an unknown type gives None, as the reference's factory does."""
     import torch
-    nc_a = opt.input_nc if opt.direction == 'AtoB' else opt.output_nc
-    nc_b = opt.output_nc if opt.direction == 'AtoB' else opt.input_nc
-    height, width, cfg = opt.img_height, opt.img_width, opt.stn_cfg
-    stn = None
-    if stn_type == 'affine':
-        stn = AffineSTN(nc_a, nc_b, height, width, cfg, opt.init_type)
-    if stn_type == 'unet':
-        stn = UnetSTN(nc_a, nc_b, height, width, cfg, opt.init_type, opt.stn_bilateral_alpha,
-                      (not opt.stn_no_identity_init), opt.stn_multires_reg)
-    if stn is not None and len(opt.gpu_ids) > 0:
+    make = _BUILDERS.get(stn_type)
+    if make is None:
+        return None
+    a_to_b = opt.direction == 'AtoB'
+    net = make(opt.input_nc if a_to_b else opt.output_nc, opt.output_nc if a_to_b else opt.input_nc, opt.img_height, opt.img_width, opt)
+    if len(opt.gpu_ids) > 0:
         assert torch.cuda.is_available()
-        stn.to(torch.device('cuda', opt.gpu_ids[0]))
-    return stn
+        net.to(torch.device('cuda', opt.gpu_ids[0]))
+    return net

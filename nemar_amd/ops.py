@@ -63,12 +63,28 @@ def _span(tag):
 
 
 _ws_cache = {}
+_pinned = [False]      # a captured hipGraph holds the addresses of the buffers below: they may still grow, the old ones are kept alive
+_retired = []
+
+
+def pin_workspaces(on):
+    """While a captured step graph is live (NEMARModel.enable_step_graph) a regrown workspace / scratch arena must not FREE the buffer
+    the graph's launches point at: the replaced buffers are parked instead of released."""
+    _pinned[0] = bool(on)
+    if not on:
+        _retired.clear()
+
+
+def _retire(buf):
+    if _pinned[0] and buf is not None:
+        _retired.append(buf)
 
 
 def _workspace(nbytes, device):
     """Grow-only scratch buffer per device.  Kernels are stream-ordered, so one buffer serves consecutive ops."""
     buf = _ws_cache.get(device)
     if buf is None or buf.numel() * 4 < nbytes:
+        _retire(buf)
         buf = torch.empty(max(int(nbytes) // 4 + 64, 1 << 20), dtype=torch.float32, device=device)
         _ws_cache[device] = buf
     return buf
@@ -90,6 +106,7 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
         return False
     buf = _arena.get(device)
     if buf is None or buf.numel() * 4 < need:
+        _retire(buf)
         buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
         _arena[device] = buf
     live = (buf.data_ptr(), buf.numel() * 4)
@@ -134,6 +151,12 @@ def _absmax_word_compute(t):
     a power of two derived from its own maximum).  Computed once per tensor and shared by the calls that take it as a source.
     Words come out of a pre-zeroed pool: one fill launch per 4096 of them instead of one per tensor."""
     n = int(t.shape[0])
+    if _step_params["on"]:
+        # device-parameter mode (a step that is, or may become, a captured graph): the words must be zeroed IN-STREAM by every
+        # execution — a pooled word zeroed once at allocation would carry a running maximum from replay to replay
+        word = torch.zeros(n, dtype=torch.int32, device=t.device)
+        L.absmax_samples(_p(t), n, t.numel() // n, _p(word), _stream())
+        return word
     pool = _absmax_pool.get(t.device)
     if pool is None or pool[1] + n > pool[0].numel():
         pool = [torch.zeros(4096, dtype=torch.int32, device=t.device), 0]

@@ -109,6 +109,8 @@ class TrainOptions(BaseOptions):
         a('--step_graph', action='store_true',
           help='(MI355X build) capture optimize_parameters() into a hipGraph after the first batch and replay it: for launch-bound '
                'shapes (small images, batch 1); single process, fixed batch shape, no --enable_tbvis')
+        a('--seed', type=int, default=None,
+          help='(MI355X build) seed torch + the dropout generator for a repeatable run; default: unseeded, as the reference')
         a('--save_by_iter', action='store_true')
         a('--continue_train', action='store_true')
         a('--phase', type=str, default='train')

@@ -5,6 +5,7 @@ console + loss_log.txt line.  Out of scope by SURVEY.md §2: visdom / HTML image
     python -m nemar_amd.train --model nemar --stn_type unet --dataset_mode gpupairs --dataroot synthetic \\
         --img_height 256 --img_width 256 --crop_size 256 --load_size 286 --batch_size 8 --lambda_smooth 10
 """
+import os
 import sys
 import time
 
@@ -27,12 +28,14 @@ def main(argv=None):
     (nemar_amd/launch.py); under torchrun the ranks are already there.  `--batch_size` stays the GLOBAL batch, each rank takes
     batch_size / world of every batch (equal shards: mean of means == full-batch mean), gradients are averaged over RCCL inside
     optimize_parameters(), and rank 0 alone writes checkpoints and logs."""
-    quiet = int(__import__('os').environ.get('RANK', '0')) != 0
+    quiet = int(os.environ.get('RANK', '0')) != 0
     opt = _Options().parse(argv, quiet=quiet)
     ids = list(opt.gpu_ids)
     if len(ids) > 1 and not launch.under_launcher():
         raise SystemExit(launch.spawn_local_ranks(len(ids), argv=sys.argv[1:] if argv is None else list(argv), module='nemar_amd.train'))
-    rank, world, local = dist.init_from_env()
+    env_world, env_local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+    # this rank's GPU comes from --gpu_ids when it lists one per rank; it is selected before the RCCL communicator exists
+    rank, world, local = dist.init_from_env(device=ids[env_local] if (env_world > 1 and len(ids) == env_world) else None)
     if world > 1:
         if len(ids) not in (1, world):
             raise SystemExit('--gpu_ids lists %d GPUs but WORLD_SIZE=%d' % (len(ids), world))
@@ -47,7 +50,11 @@ def main(argv=None):
     if rank == 0:
         print('The number of training images = %d' % dataset_size)
     opt.batch_size = global_batch // world                   # what the model sees per step on this rank
-    torch.manual_seed(0)                                     # identical initial weights on every rank (also broadcast in setup)
+    # The reference is unseeded.  --seed S makes a run repeatable (weights, dropout masks, loader order); data-parallel ranks always
+    # start from one seed so that they build identical replicas (setup() also broadcasts rank 0's parameters).
+    seed = getattr(opt, 'seed', None)
+    if seed is not None or world > 1:
+        torch.manual_seed(0 if seed is None else int(seed))
     model = create_model(opt)
     model.setup(opt)
     opt.batch_size = global_batch
@@ -55,6 +62,8 @@ def main(argv=None):
     if rank != 0:
         model.tb_visualizer = None                           # scalar / offset reports: rank 0 only
     total_iters = 0
+    if hasattr(dataset, 'epoch'):
+        dataset.epoch = int(opt.epoch_count) - 1             # --continue_train resumes the shuffle sequence where it stopped
     for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
         epoch_start_time = time.time()
         iter_data_time = time.time()

@@ -56,3 +56,37 @@ def full_step_record(m, A, B, seed):
 def _cropc(t):
     h, w = t.shape[2] // 2, t.shape[3] // 2
     return t[:, :, h - 4:h + 4, w - 4:w + 4].double().cpu().numpy().copy()
+
+
+def registration_record(netR, l1, A, B, seed, lambda_recon=100.0, lambda_smooth=10.0):
+    """The registration SUB-MODEL of a step — deformation field, warp of A, smoothness term, and the gradients of
+    lambda_recon * L1(warp(A), B) + lambda_smooth * reg w.r.t. every parameter of the registration net — reduced to scalars and
+    small crops.  Small enough to run the REFERENCE's UnetSTN in fp64 at 1024x1024 (the full step there needs > 60 GB), so BASELINE
+    config 5's stress path (large-field grid_sample + smoothness + the deep registration net) has an fp64 truth of its own.
+    `l1(a, b, weight)` -> weight * mean|a - b| (torch's L1Loss for the reference, ops.l1_loss for the build)."""
+    out = {}
+    p0 = next(netR.parameters())
+    a, b = torch.from_numpy(A).to(p0.device, p0.dtype), torch.from_numpy(B).to(p0.device, p0.dtype)
+    for p in netR.parameters():
+        p.grad = None if getattr(p, '_flat_grad', None) is None else p.grad
+    warped, reg = netR(a, b, apply_on=[a])
+    w = warped[0]
+    rec = l1(w, b, lambda_recon)
+    out['loss/recon'], out['reg'] = float(rec), float(reg)
+    torch.autograd.backward([rec, reg], [torch.ones_like(rec), torch.full_like(reg, lambda_smooth)])
+    with torch.no_grad():
+        off = netR.offset_map(a, b)
+    out['offsets/mean'], out['offsets/absmean'] = off.double().mean().item(), off.double().abs().mean().item()
+    out['offsets/proj'] = proj(off, seed, 900)
+    out['offsets/cropc'] = _cropc(off)
+    t = w.detach()
+    out['mean/warped'], out['absmean/warped'] = t.double().mean().item(), t.double().abs().mean().item()
+    out['proj/warped'] = proj(t, seed, 901)
+    out['crop0/warped'] = t[:, :, :8, :8].double().cpu().numpy().copy()
+    out['cropc/warped'] = _cropc(t)
+    for j, (k, p) in enumerate(netR.named_parameters()):
+        if p.grad is not None:
+            out['gradnorm/R/' + k] = p.grad.double().norm().item()
+            out['gradproj/R/' + k] = proj(p.grad, seed, 1000 + j)
+            out['gradmax/R/' + k] = p.grad.double().abs().max().item()
+    return out

@@ -26,7 +26,7 @@ import torch  # noqa: E402
 
 import seeded  # noqa: E402
 from full_record import full_step_record  # noqa: E402
-from step_configs import STEP_CONFIGS, FULL_CONFIGS, DEEP_STN_CFG, make_opt  # noqa: E402
+from step_configs import STEP_CONFIGS, FULL_CONFIGS, DEEP_STN_CFG, make_opt, hw  # noqa: E402
 
 
 KEYS = {}
@@ -53,7 +53,7 @@ def run_step_config(name, cfg):
     load_seeded(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
     for i, d in enumerate(m.netD_multiresolution):
         load_seeded(d, cfg['seed'] + 10 + i, cfg.get('overrides_D'))
-    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     out = {}
     KEYS[name] = {nm: [[k, list(v.shape)] for k, v in net.state_dict().items()]
                   for nm, net in (('T', m.netT), ('R', m.netR), ('D', m.netD))}
@@ -87,7 +87,7 @@ def run_full_config(name, cfg):
     import models.stn.unet_stn as ref_unet
     for key, val in DEEP_STN_CFG.items():            # the 'deep' cfg: new entries in the reference's own dicts
         getattr(ref_unet, key)['deep'] = val
-    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     out = {}
     for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
         if tag == 'f64' and not cfg.get('f64', True):
@@ -114,6 +114,37 @@ def run_full_config(name, cfg):
               flush=True)
         del m
     np.savez_compressed(os.path.join(HERE, 'step_%s.npz' % name), **out)
+
+
+def run_registration_submodel(name='c5_full'):
+    """fp32 AND fp64 runs of the reference's UnetSTN sub-model (tests/full_record.registration_record) at a full configuration's
+    geometry — for BASELINE config 5 (1024x1024, 'deep' cfg) the fp64 truth the full step cannot have in this container."""
+    import time
+    from models import stn as ref_stn
+    import models.stn.unet_stn as ref_unet
+    from full_record import registration_record
+    for key, val in DEEP_STN_CFG.items():
+        getattr(ref_unet, key)['deep'] = val
+    cfg = FULL_CONFIGS[name]
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
+    out = {}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        t0 = time.time()
+        torch.set_default_dtype(dt)
+        try:
+            torch.manual_seed(0)
+            net = ref_stn.define_stn(make_opt(cfg), 'unet')
+            load_seeded(net, cfg['seed'] + 2, cfg.get('overrides_R'))
+            l1 = lambda x, y, wgt: torch.nn.functional.l1_loss(x, y) * wgt
+            rec = registration_record(net, l1, A, B, cfg['seed'], 100.0, cfg['lambda_smooth'])
+        finally:
+            torch.set_default_dtype(torch.float32)
+        for k, v in rec.items():
+            out['%s/%s' % (tag, k)] = np.asarray(v, dtype=np.float64)
+        print(name, 'registration sub-model', tag, '%.1fs' % (time.time() - t0),
+              {k: round(v, 6) for k, v in rec.items() if k in ('loss/recon', 'reg')}, flush=True)
+        del net
+    np.savez_compressed(os.path.join(HERE, 'regsub_%s.npz' % name), **out)
 
 
 def run_op_fixtures():
@@ -213,6 +244,8 @@ if __name__ == '__main__':
         run_init_stats()
     if a.only in (None, 'unet_generator'):
         run_unet_generator()
+    if a.only in (None, 'regsub', 'full'):
+        run_registration_submodel('c5_full')
     for name, cfg in STEP_CONFIGS.items():
         if a.only in (None, name):
             run_step_config(name, cfg)

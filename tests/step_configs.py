@@ -43,6 +43,14 @@ FULL_CONFIGS = {
     # C5: 1024x1024, the deeper registration net (stn_cfg 'deep': 9 levels -> 2x2 bottleneck at 1024x1024).  fp32 reference run
     # only: the fp64 run of the reference needs more host memory than the build container has (a 26 GB single allocation failed
     # under a 56 GB limit, /tmp/make_golden_c5.log of round 3), so C5's tolerances are the fixed bases of compare().
+    # The reference's DEFAULT geometry and nets (options/base_options.py:34,47-48: --img_height 288 --img_width 384, resnet_9blocks;
+    # models/stn/__init__.py:12: --stn_type affine) — non-square, not a power of two: 72x96 residual-block maps, 36x48 / 35x47 D maps
+    'default_full': dict(stn_type='affine', netG='resnet_9blocks', ngf=64, ndf=64, height=288, width=384, size=None, batch=1,
+                         seed=61, lambda_smooth=0.5, steps=1,
+                         overrides_R={'net.local.2.weight': 0.02, 'net.local.2.bias': 0.05}),
+    # a non-square dense-field case: unet cfg 'A' at 256x384 (2x3 bottleneck), batch 1
+    'c2_256x384': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, height=256, width=384, size=None, batch=1,
+                       seed=67, lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
     'c5_full': dict(stn_type='unet', stn_cfg='deep', netG='resnet_9blocks', ngf=64, ndf=64, size=1024, batch=1,
                     seed=53, lambda_smooth=10.0, steps=1, f64=False, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
 }
@@ -55,12 +63,17 @@ DEEP_STN_CFG = dict(ndf=[32, 64, 64, 64, 64, 64, 64, 64, 64], nuf=[64, 64, 64, 6
                     up_activation='leaky_relu')
 
 
+def hw(cfg):
+    """(height, width) of a configuration: 'size' for the square ones, 'height' / 'width' otherwise."""
+    return (cfg['height'], cfg['width']) if cfg.get('size') is None else (cfg['size'], cfg['size'])
+
+
 def make_opt(cfg, gpu_ids=()):
     return argparse.Namespace(
         gpu_ids=list(gpu_ids), isTrain=True, checkpoints_dir='/tmp/nemar_ck', name='golden', preprocess='none',
         input_nc=3, output_nc=3, ngf=cfg['ngf'], ndf=cfg['ndf'], netG=cfg['netG'], netD='basic', n_layers_D=3,
         norm='instance', init_type='normal', init_gain=0.02, no_dropout=True, direction='AtoB',
-        img_height=cfg['size'], img_width=cfg['size'], lr=2e-4, beta1=0.5, gan_mode=cfg.get('gan_mode', 'vanilla'),
+        img_height=hw(cfg)[0], img_width=hw(cfg)[1], lr=2e-4, beta1=0.5, gan_mode=cfg.get('gan_mode', 'vanilla'),
         lambda_GAN=1.0, lambda_recon=100.0, lambda_smooth=cfg.get('lambda_smooth', 0.0), enable_tbvis=False,
         multi_resolution=cfg.get('multi_resolution', 1), stn_cfg=cfg.get('stn_cfg', 'A'), stn_type=cfg['stn_type'],
         stn_bilateral_alpha=cfg.get('stn_bilateral_alpha', 0.0), stn_no_identity_init=False,

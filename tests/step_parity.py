@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 import seeded
-from step_configs import STEP_CONFIGS, make_opt
+from step_configs import STEP_CONFIGS, make_opt, hw
 from test_oracle_golden import GOLD, build_ref_model
 
 LR = 2e-4
@@ -25,6 +25,7 @@ LR = 2e-4
 N_PERTURBED = 2
 PERTURB_ULPS = 4.0
 KNIFE_BAND = 2e-6
+KNIFE_CAP = 2e-2          # the most a knife edge may excuse on one tensor (the measured case: 1.04e-2 x 1.5)
 
 
 def load_seeded_into(net, seed, overrides):
@@ -90,7 +91,7 @@ def run(name, report=None, check=True):
     ref64 = build_ref_model(name, dtype=torch.float64)
     refp = [build_ref_model(name) for _ in range(N_PERTURBED)]
     hip = build_hip_model(name)
-    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     tA, tB = torch.from_numpy(A), torch.from_numpy(B)
     eps = PERTURB_ULPS * 2.0 ** -24
     pert = [(torch.from_numpy(A * (1 + eps * seeded.uniform(A.shape, cfg['seed'], 7000 + 2 * i)).astype(np.float32)),
@@ -171,7 +172,7 @@ def run(name, report=None, check=True):
             2e-6 + 4 * _maxabs(ref.offsets.detach().numpy(), off))
         # D step on identical inputs: per-tensor max-abs error relative to the tensor's max (fp32 oracle)
         gmax = max(float(v.abs().max()) for v in ref.grads_D.values())
-        worst, errs = (0.0, None, 0.0, 0.0), []
+        worst, errs, worst_plain = (0.0, None, 0.0, 0.0), [], (0.0, None)
         pairs = [(k, v, gD_forced[k], ref.grads_D_knife[k]) for k, v in ref.grads_D.items()]
         for i, (gref, gmine) in enumerate(zip(ref.grads_D_mr, gDmr_forced)):     # reduced-resolution discriminators too
             pairs += [('mr%d.%s' % (i, k), v, gmine[k], ref.grads_D_mr_knife[i][k]) for k, v in gref.items()]
@@ -181,9 +182,12 @@ def run(name, report=None, check=True):
                 continue                  # conv biases in front of InstanceNorm: exactly-zero gradient + noise
             knife = _maxabs(alt.numpy(), v.numpy()) / vmax          # 0 unless a pre-activation sits on the knife edge
             e = _maxabs(mine, v.numpy()) / vmax
-            errs.append(max(e - 1.5 * knife, 0.0))                  # (what the knife edge can account for is not an error)
-            if e / (1e-3 + 1.5 * knife) > worst[0]:
-                worst = (e / (1e-3 + 1.5 * knife), k, e, knife)
+            allow = min(1.5 * knife, KNIFE_CAP)                     # (what the knife edge can account for is not an error — capped)
+            errs.append(max(e - allow, 0.0))
+            if e / (1e-3 + allow) > worst[0]:
+                worst = (e / (1e-3 + allow), k, e, knife)
+            if knife == 0.0 and e > worst_plain[0]:                 # tensors no knife edge reaches keep the plain 1e-3 bound
+                worst_plain = (e, k)
         # Typical tensor 2e-4, worst tensor 1e-3 of the tensor's max, + 1.5 x what the oracle's own knife-edge re-evaluation moves
         # that tensor by.  One LeakyReLU pre-activation of these tiny discriminators at rounding distance of 0 moves a layer's
         # weight gradient by ~1 % (measured: tools/diag_dgrad.py, profiles/r3_knife_edge.txt — the exact-fp32 route and the 16-bit
@@ -191,7 +195,8 @@ def run(name, report=None, check=True):
         # state contains one changes with any rounding-level change of the previous step's update.
         add(pre + 'grad/D on identical fakes, median tensor (beyond the knife-edge allowance)', float(np.median(errs)), 2e-4)
         add(pre + 'grad/D on identical fakes, worst tensor (%s: %.2e, knife-edge allowance %.2e, %d elements in the band)'
-            % (worst[1], worst[2], 1.5 * worst[3], ref.knife_count), worst[0], 1.0)
+            % (worst[1], worst[2], min(1.5 * worst[3], KNIFE_CAP), ref.knife_count), worst[0], 1.0)
+        add(pre + 'grad/D on identical fakes, worst tensor without a knife edge (%s)' % worst_plain[1], worst_plain[0], 1e-3)
         # full-step gradients (own forward values): direction agreement with the fp64 oracle per network / tensor
         for nm, mine, g64 in (('T', gT, ref64.grads_T), ('R', gR, ref64.grads_R), ('D', gD, ref64.grads_D)):
             gmax = max(float(v.abs().max()) for v in g64.values())

@@ -10,14 +10,14 @@ import torch
 
 import seeded
 import step_parity
-from step_configs import STEP_CONFIGS
+from step_configs import STEP_CONFIGS, hw
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def _inputs(cfg):
-    a, b = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    a, b = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     return {'A': torch.from_numpy(a), 'B': torch.from_numpy(b), 'A_paths': ['a'], 'B_paths': ['b']}
 
 

@@ -11,7 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 import seeded
-from step_configs import STEP_CONFIGS
+from step_configs import STEP_CONFIGS, hw
 
 
 def _free_port():
@@ -160,7 +160,7 @@ def test_mean_of_shard_gradients_equals_full_batch_gradient():
     """Oracle-level check of the data-parallel identity on the affine128 step (batch 2 -> two shards of 1)."""
     from test_oracle_golden import build_ref_model
     cfg = STEP_CONFIGS['affine128']
-    A, B = seeded.seeded_images(2, 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(2, 3, *hw(cfg), cfg['seed'])
     A, B = torch.from_numpy(A), torch.from_numpy(B)
     full = build_ref_model('affine128', dtype=torch.float64)
     full.optimize_parameters(A, B)

@@ -14,7 +14,7 @@ import torch
 import torch.multiprocessing as mp
 
 import seeded
-from step_configs import STEP_CONFIGS, make_opt
+from step_configs import STEP_CONFIGS, make_opt, hw
 
 pytestmark = pytest.mark.gpu
 NAME = 'affine128'
@@ -53,7 +53,7 @@ def _rank(rank, world, port, out):
     from nemar_amd import distributed as dist
     dist.init_from_env(backend='gloo')
     cfg = STEP_CONFIGS[NAME]
-    A, B = seeded.seeded_images(world, 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(world, 3, *hw(cfg), cfg['seed'])
     lo, hi = dist.shard_range(world)
     m = _build(hi - lo)
     m.set_input({'A': torch.from_numpy(A[lo:hi]), 'B': torch.from_numpy(B[lo:hi]), 'A_paths': [''], 'B_paths': ['']})
@@ -78,7 +78,7 @@ def test_two_ranks_equal_one_process_on_the_full_batch():
         for a, b in zip(got[0][k], got[1][k]):
             assert np.array_equal(a, b), k
     cfg = STEP_CONFIGS[NAME]
-    A, B = seeded.seeded_images(2, 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(2, 3, *hw(cfg), cfg['seed'])
     full = _build(2)
     full.set_input({'A': torch.from_numpy(A), 'B': torch.from_numpy(B), 'A_paths': [''], 'B_paths': ['']})
     full.optimize_parameters()
@@ -107,7 +107,7 @@ def test_rccl_code_path_with_a_world_of_one_rank():
         env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                    NEMAR_DIST_SINGLE=forced, NEMAR_BENCH_DUMP_LOSSES="1")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                            "--no-cpu-baseline", "--batch", "2", "--opt=--no_dropout", "--graph", "off"], env=env, capture_output=True, text=True,
+                            "--no-cpu-baseline", "--no-extras", "--batch", "2", "--opt=--no_dropout", "--graph", "off"], env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]

@@ -15,7 +15,7 @@ import torch
 import seeded
 from oracle import ops_np as O
 from oracle import torch_ref as R
-from step_configs import STEP_CONFIGS
+from step_configs import STEP_CONFIGS, hw
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -72,7 +72,7 @@ def test_step_oracle_reproduces_reference(name):
     g = np.load(os.path.join(GOLD, 'step_%s.npz' % name))
     torch.set_num_threads(8)
     m = build_ref_model(name)
-    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     A, B = torch.from_numpy(A), torch.from_numpy(B)
     for step in range(cfg.get('steps', 1)):
         losses = m.optimize_parameters(A, B)

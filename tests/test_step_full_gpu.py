@@ -30,7 +30,7 @@ import torch
 
 import seeded
 from full_record import full_step_record
-from step_configs import FULL_CONFIGS, make_opt
+from step_configs import FULL_CONFIGS, make_opt, hw
 from step_parity import load_seeded_into
 
 pytestmark = pytest.mark.gpu
@@ -148,13 +148,54 @@ def compare(name, rec, report=None):
     return rows
 
 
+ROUTE_NAMES = {0: 'exact', 1: 'narrow', 2: 'split16', 3: 's16g'}
+
+
+class _RouteLog:
+    """Which kernel family every convolution-type C-ABI call of a step took (nemar_last_route()), written into the test report:
+    the reference's default geometry (288 x 384) and the non-square unet case land on route combinations no square fixture exercises."""
+
+    def __init__(self):
+        from nemar_amd import ops
+        self.L, self.rows, self.saved = ops.L, {}, {}
+
+    def __enter__(self):
+        L = self.L
+        for nm, dims in (('conv2d_fwd', (7, 8, 9, 10, 11, 13, 14)), ('conv2d_bwd_data', (9, 10, 11, 12, 15, 17, 18)),
+                         ('conv2d_bwd_weight', (7, 8, 9, 10, 13, 15, 16))):
+            f = getattr(L, nm)
+            self.saved[nm] = f
+
+            def wrapped(*a, _f=f, _nm=nm, _dims=dims):
+                r = _f(*a)
+                key = (_nm,) + tuple(a[i] for i in _dims) + (ROUTE_NAMES.get(L.last_route(), '?'),)
+                self.rows[key] = self.rows.get(key, 0) + 1
+                return r
+            setattr(L, nm, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for nm, f in self.saved.items():
+            setattr(self.L, nm, f)
+
+    def write(self, name, report):
+        if not report:
+            return
+        with open(report, 'a') as f:
+            f.write('== %s: routes of the convolution calls (op, N, H, W, K, R|OH, stride, pad -> route x count)\n' % name)
+            for k, c in sorted(self.rows.items(), key=lambda kv: (kv[0][0], -kv[0][2] * kv[0][3], kv[0][4])):
+                f.write('   %-18s N=%-3d H=%-4d W=%-4d K=%-4d R=%-3d stride=%d pad=%d  -> %-8s x %d\n' % (k[:8] + (k[8], c)))
+
+
 @pytest.mark.parametrize("name", list(FULL_CONFIGS))
 def test_full_width_step_vs_reference(name):
     cfg = FULL_CONFIGS[name]
     m = build(name)
-    A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
-    rec = full_step_record(m, A, B, cfg['seed'])
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
+    with _RouteLog() as routes:
+        rec = full_step_record(m, A, B, cfg['seed'])
     torch.cuda.synchronize()
+    routes.write(name, os.environ.get('NEMAR_FULL_REPORT'))
     rows = compare(name, rec, report=os.environ.get('NEMAR_FULL_REPORT'))
     assert len(rows) > (200 if cfg['stn_type'] == 'affine' else 300), len(rows)     # (the affine STN has 8 parameter tensors)
     bad = [r for r in rows if not r[3]]
@@ -171,7 +212,7 @@ def test_full_width_step_on_the_exact_fp32_route():
     ops.tune(24, 0)
     try:
         m = build(name)
-        A, B = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+        A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
         rec = full_step_record(m, A, B, cfg['seed'])
         torch.cuda.synchronize()
     finally:
@@ -180,3 +221,53 @@ def test_full_width_step_on_the_exact_fp32_route():
     rows = compare(name, rec)
     bad = [r for r in rows if not r[3]]
     assert len(rows) > 300 and not bad, (len(bad), bad[:8])
+
+
+def test_registration_submodel_of_config5_vs_fp64():
+    """BASELINE config 5's stress path with an fp64 truth of its own: the deep registration net + large-field warp + smoothness at
+    1024 x 1024 (tests/golden/regsub_c5_full.npz: the reference's UnetSTN run in fp32 and fp64 by make_golden.py --only regsub), same
+    bound as the full-width steps:  |build - ref64| <= base + 4 |ref32 - ref64|, gradients with the net's 90th-percentile gap."""
+    from full_record import registration_record
+    from nemar_amd import ops
+    from nemar_amd.models import stn
+    path = os.path.join(GOLD, 'regsub_c5_full.npz')
+    if not os.path.exists(path):
+        pytest.skip('regsub_c5_full.npz not generated')
+    g = np.load(path)
+    cfg = FULL_CONFIGS['c5_full']
+    net = stn.define_stn(make_opt(cfg, gpu_ids=[0]), 'unet')
+    load_seeded_into(net, cfg['seed'] + 2, cfg.get('overrides_R'))
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
+    rec = registration_record(net, ops.l1_loss, A, B, cfg['seed'], 100.0, cfg['lambda_smooth'])
+    torch.cuda.synchronize()
+    net_gap = _net_grad_gap(g, 'R')
+    gmax = _net_gmax(g, 'R', 'f64')
+    base = dict(BASE)
+    rows = []
+    for k in sorted(g.files):
+        if not k.startswith('f64/'):
+            continue
+        q = k[4:]
+        want, got = g[k], np.asarray(rec[q], dtype=np.float64)
+        cls = _class_of(q)
+        rel, ab = base[cls]
+        if cls.startswith('grad'):
+            scale = float(g['f64/gradnorm/' + q.split('/', 1)[1]])
+            if scale < 1e-5 * gmax:
+                continue
+        else:
+            scale = float(np.abs(want).max())
+        gap = float(np.abs(g['f32/' + q] - want).max())
+        if cls.startswith('grad'):
+            gap = max(gap, net_gap * scale)
+        tol = rel * scale + ab + 4.0 * gap
+        err = float(np.abs(got - want).max())
+        rows.append((q, err, tol, err <= tol))
+    report = os.environ.get('NEMAR_FULL_REPORT')
+    if report:
+        with open(report, 'a') as f:
+            f.write('== registration sub-model of c5_full (%d rows, truth = reference f64)\n' % len(rows))
+            for r in rows:
+                f.write('%-86s err=%.3e tol=%.1e %s\n' % (r[0], r[1], r[2], 'ok' if r[3] else 'FAIL'))
+    bad = [r for r in rows if not r[3]]
+    assert len(rows) > 150 and not bad, (len(rows), len(bad), bad[:8])

@@ -4,7 +4,7 @@ Tolerances are written row by row in tests/step_parity.py (fp32, a different sum
 by the oracle's own fp32-vs-fp64 gap)."""
 import pytest
 
-from step_configs import STEP_CONFIGS
+from step_configs import STEP_CONFIGS, hw
 import step_parity
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +28,7 @@ def test_step_is_bitwise_reproducible():
     import seeded
     name = 'unet256'
     cfg = STEP_CONFIGS[name]
-    a, b = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    a, b = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     snaps = []
     for _ in range(2):
         m = step_parity.build_hip_model(name)
@@ -55,7 +55,7 @@ def test_batched_passes_match_reference_call_order(name, monkeypatch):
         monkeypatch.setenv("NEMAR_BATCHED_PASSES", flag)
         m = step_parity.build_hip_model(name)
         assert m._batched == (flag == "1")
-        a, b = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+        a, b = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
         m.set_input({'A': torch.from_numpy(a), 'B': torch.from_numpy(b), 'A_paths': [''], 'B_paths': ['']})
         m.forward()
         m.set_requires_grad([m.netT, m.netR], False)
@@ -80,7 +80,7 @@ def test_batched_passes_match_reference_call_order(name, monkeypatch):
 
 def test_step_graph_replay_equals_eager():
     """optimize_parameters() captured as a hipGraph (NEMARModel.enable_step_graph) and replayed == the same steps launched eagerly with
-    the step parameters in device memory (ops.step_params): bit-identical weights, Adam moments and losses after four steps, with
+    the step parameters in device memory (ops.step_params): bit-identical weights, Adam moments and the losses read after EVERY one of four steps (one of them a ragged batch), with
     dropout ON (fresh masks every replay: the Philox offset's per-step part is a device word) and Adam's bias corrections advancing."""
     import torch
     import seeded
@@ -89,7 +89,7 @@ def test_step_graph_replay_equals_eager():
     from step_configs import make_opt
     name = 'affine128'
     cfg = STEP_CONFIGS[name]
-    a, b = seeded.seeded_images(cfg['batch'], 3, cfg['size'], cfg['size'], cfg['seed'])
+    a, b = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     data = {'A': torch.from_numpy(a), 'B': torch.from_numpy(b), 'A_paths': [''], 'B_paths': ['']}
 
     def build():
@@ -109,28 +109,41 @@ def test_step_graph_replay_equals_eager():
         return ([o.flat_p.detach().cpu().clone() for o in m.optimizers], [o.m.detach().cpu().clone() for o in m.optimizers],
                 [o.v.detach().cpu().clone() for o in m.optimizers], dict(m.get_current_losses()))
 
+    # a ragged batch in the middle of the sequence (the last batch of an epoch): the graph cannot describe it — that step runs eagerly
+    small = {'A': data['A'][:1], 'B': data['B'][:1], 'A_paths': [''], 'B_paths': ['']}
+    seq = [data, data, small, data]
     try:
         ops.step_params(True, torch.device('cuda:0'))
         m = build()
-        first = None
-        for i in range(4):
-            m.set_input(data)
+        eager_losses = []
+        for i, d in enumerate(seq):
+            m.set_input(d)
             m.optimize_parameters()
+            eager_losses.append(dict(m.get_current_losses()))
             if i == 0:
                 first = snap(m)
         eager = snap(m)
         assert not all(torch.equal(x, y) for x, y in zip(first[0], eager[0]))          # (the steps do move the weights)
+        assert eager_losses[0] != eager_losses[1]
         m = build()
+        before = [o.flat_p.detach().cpu().clone() for o in m.optimizers]
         m.set_input(data)
         m.enable_step_graph(warmup=2)
-        for _ in range(2):
-            m.set_input(data)
+        # the warm-up steps do not train: weights, moments, step counts and the dropout step counter are where they were
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, o.flat_p.detach().cpu()) for x, o in zip(before, m.optimizers))
+        assert all(float(o.m.abs().max()) == 0.0 and float(o.v.abs().max()) == 0.0 and o.step_count == 0 for o in m.optimizers)
+        graph_losses = []
+        for d in seq:
+            m.set_input(d)
             m.optimize_parameters()
+            graph_losses.append(dict(m.get_current_losses()))       # read after EVERY replay: a stale cached sum would show here
         graph = snap(m)
         assert [o.step_count for o in m.optimizers] == [4, 4, 4]
     finally:
         ops.step_params(False)
+        ops.pin_workspaces(False)
     for k in range(3):
         for x, y in zip(eager[k], graph[k]):
             assert torch.equal(x, y)
-    assert eager[3] == graph[3], (eager[3], graph[3])
+    assert eager_losses == graph_losses, (eager_losses, graph_losses)

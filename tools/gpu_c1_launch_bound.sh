@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$1; mkdir -p $O
 for g in on off; do
   mkdir -p $O/$g
   cd /tmp && export TMPDIR=/tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/$g/stats -- python $R/bench.py --batch 1 --size 128 --steps 50 --warmup 5 --no-cpu-baseline --graph $g --opt=--stn_type --opt=affine --opt=--netG --opt=resnet_6blocks > $O/$g/bench.json 2>/dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/$g/stats -- python $R/bench.py --batch 1 --size 128 --steps 50 --warmup 5 --no-cpu-baseline --no-extras --graph $g --opt=--stn_type --opt=affine --opt=--netG --opt=resnet_6blocks > $O/$g/bench.json 2>/dev/null
   cd $R; python tools/prof_summary.py $O/$g/stats $O/$g/kernel_stats.csv > /dev/null 2>&1
   python - <<PY
 import csv, json

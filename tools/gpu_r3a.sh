@@ -18,8 +18,8 @@ for b in 8 16; do
   timeout 300 python tools/microbench_conv.py --iters 20 --batch $b --tune 24 0 2>/dev/null | python -c "$fmt" >> $O/mb.txt
 done
 cat $O/mb.txt
-timeout 600 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
-NEMAR_TUNE="24=0" timeout 600 python bench.py --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
+timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+NEMAR_TUNE="24=0" timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_exact.json 2> $O/bench_exact.err
 python -c "
 import json
 for f in ('bench.json','bench_exact.json'):
@@ -28,6 +28,6 @@ for f in ('bench.json','bench_exact.json'):
     except Exception as e: print(f, 'failed', e)
 "
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 cd $R; python tools/prof_summary.py $O/stats $O/kernel_stats.csv > /dev/null 2>&1
 head -40 $O/kernel_stats.csv | cut -c1-170

@@ -16,13 +16,13 @@ for b in 8 16; do
 done
 cat $O/mb.txt
 if [ "$2" == "bench" ]; then
-timeout 600 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
 python -c "
 import json
 d = json.load(open('$O/bench.json')); print('bench %.2f img/s  %.2f ms/step' % (d['value'], d['ms_per_step']))
 "
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 cd $R; python tools/prof_summary.py $O/stats $O/kernel_stats.csv > /dev/null 2>&1
 head -45 $O/kernel_stats.csv | cut -c1-150
 fi

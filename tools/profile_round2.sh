@@ -7,7 +7,7 @@ O=$R/gpurun_out/$1
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 python $R/tools/prof_summary.py $O/stats $O/kernel_stats.csv > /dev/null 2>&1
 G1="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
 for which in fwd dgrad wgrad; do
