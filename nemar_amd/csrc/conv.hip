@@ -31,6 +31,7 @@
 #include "common.h"
 #include "conv_split16.h"
 #include "conv_s16g.h"
+#include "conv_k7.h"
 
 extern int g_split16_ring3;                      // conv_split16.hip
 void nemar_norm_planes_debug(int bits);          // norm_planes.hip: ablation bits of the fused producer (measurement only)
@@ -1085,6 +1086,7 @@ static int g_split16_variant = 4;   // key 21: 4 fp16 x 3 products (default), 3 
 // 1 narrow (<= 4 channel) VALU kernels, 2 split-16 kernel of the wide residual-block layers, 3 general 16-bit-pipe kernels
 static thread_local int g_last_route = 0;
 static int g_config_epoch = 0;      // bumped by every nemar_tune / nemar_set_scratch: routes (and packed-weight formats) may have changed
+static int g_k7 = 1;               // key 33: the 7x7 stem / head layers (<= 4 channels on one side) on the 16-bit matrix pipe (conv_k7.hip)
 static int g_s16g = 1;             // key 24: general layers on the 16-bit matrix pipe with the in-kernel operand split (conv_s16g.hip)
 static int g_s16g_wgrad_first = 0;  // key 26: 1 = the in-kernel-split weight gradient also takes the wide residual-block layers (stand-alone 374 vs
                                     // 393 us per call, but 44.3 vs 41.8 ms per step inside the bench: off)
@@ -1772,6 +1774,10 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     L.aux_cols_off = o;
     if (L.ring && pad == 1 && R == 3 && S == 3) o += 8ull * N * K * H;
     L.total = o;
+    if (C > 4 && nemar_k7_fm_eligible(K, C, R, S, stride, pad)) {       // 7x7 head (<= 4 output channels): [packed weights | padded-domain gradient]
+        const size_t k7 = ((nemar_k7_fm_pack_floats(C) + 3) & ~(size_t)3) + (refl ? (size_t)N * C * (H + 6) * (W + 6) : 0);
+        if (k7 > L.total) L.total = k7;
+    }
     return L;
 }
 
@@ -1795,6 +1801,7 @@ FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride
             if (b > L.pack) L.pack = b;
         }
     }
+    if (nemar_k7_fm_eligible(C, K, R, S, stride, pad) && nemar_k7_fm_pack_floats(K) > L.pack) L.pack = nemar_k7_fm_pack_floats(K);
     L.ksplit = 1;
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (g_ksplit && OH > 0 && OW > 0 && K > 4) L.ksplit = normalize_ksplit(C * R * S, small_problem_split(K, N * OH * OW, C * R * S));
@@ -1834,6 +1841,14 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         return NEMAR_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (g_k7 && C1 == 0 && act != ACT_TANH && nemar_k7_fm_eligible(C, K, R, S, stride, pad)) {
+        // 7x7 stem (<= 4 input channels): row-expanded source on the 16-bit matrix pipe, weights in registers (conv_k7.hip)
+        if (!prepacked) nemar_k7_fm_pack(w, (long long)C * 49, 49, 0, K, C, workspace, st);
+        nemar_k7_fm_conv(x0, C, H, W, 3, pad_mode == BORDER_REFLECT, workspace, bias, y, K, N, H, W, act, slope, st);
+        g_last_route = 4;
+        NEMAR_CHECK_LAUNCH("conv2d_fwd (7x7, 16-bit pipe)");
+        return NEMAR_OK;
+    }
     if (nemar_narrow_eligible(K, C1, R, S, stride, N, OH, OW) && g_narrow) {
         // the narrow kernels read the weights in place: the packed-weight workspace doubles as the slab space of their
         // channel-split mode (the split count is capped to what fits, see nemar_narrow_fwd)
@@ -1931,6 +1946,23 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                   "conv2d_bwd_data: problem too large for 32-bit tile indexing");
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)workspace;
+    if (g_k7 && C1 == 0 && gx0 && !bias && act == ACT_NONE && C > 4 && nemar_k7_fm_eligible(K, C, R, S, stride, pad)) {
+        // 7x7 head (<= 4 output channels): the data gradient is a few -> many convolution of gy with flipped, transposed weights
+        // (conv_k7.hip).  Reflect border: on the padded (H + 6) x (W + 6) domain (gy through a 6-texel zero border), then the fold.
+        if (!prepacked) nemar_k7_fm_pack(w, 49, (long long)C * 49, 1, C, K, workspace, st);
+        if (refl) {
+            float* padded = wsf + ((nemar_k7_fm_pack_floats(C) + 3) & ~(size_t)3);
+            nemar_k7_fm_conv(gy, K, OH, OW, 6, 0, workspace, nullptr, padded, C, N, H + 6, W + 6, ACT_NONE, 0.f, st);
+            const long long total = (long long)N * C * H * W;
+            hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded, gx0, H, W, pad,
+                               total);
+        } else {
+            nemar_k7_fm_conv(gy, K, OH, OW, 3, 0, workspace, nullptr, gx0, C, N, H, W, ACT_NONE, 0.f, st);
+        }
+        g_last_route = 4;
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_data (7x7, 16-bit pipe)");
+        return NEMAR_OK;
+    }
     {
         // 3x3 stride-1 layers: the data gradient is the same convolution with flipped, transposed weights (conv_split16.hip)
         const int mode = refl ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO;
@@ -2160,6 +2192,10 @@ NEMAR_API size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, i
         const size_t f6 = (size_t)nemar_s16g_wgrad_slabs_max(N, C, K, OH, W, stride) * ((size_t)K * J + K);
         if (f6 > fl) fl = f6;
     }
+    if (nemar_k7_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {            // 7x7 stem / head: slabs + max words + bias partials
+        const size_t f7 = nemar_k7_wgrad_floats(N, C, H, W, K) + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
+        if (f7 > fl) fl = f7;
+    }
     if (nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad)) {       // slabs of the split-16 route + bias partials
         const size_t f5 = (size_t)nemar_split16_wgrad_splits(N, C, H, W, K, R) * K * J + (size_t)N * nemar_cdiv(OH * OW, BIAS_CHUNK) * K;
         if (f5 > fl) fl = f5;
@@ -2190,6 +2226,18 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
     }
     hipStream_t st = (hipStream_t)stream;
     const int J = (C0 + C1) * R * S;
+    if (g_k7 && part && C1 == 0 && nemar_k7_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad)) {
+        // 7x7 stem / head (<= 4 channels on one side): reduction over pixels on the 16-bit matrix pipe (conv_k7.hip)
+        if (!nemar_k7_wgrad(x0, gy, gw, gb, N, C0, H, W, K, pad_mode, part, st)) {      // (head: K <= 4 planes of gy, its own small reduction)
+            const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
+            float* pb = part + nemar_k7_wgrad_floats(N, C0, H, W, K);
+            hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, pb, N, K, OH * OW, BIAS_CHUNK);
+            nemar_sum_partials(pb, K, N * chunks, gb, K, true, st);
+        }
+        g_last_route = 4;
+        NEMAR_CHECK_LAUNCH("conv2d_bwd_weight (7x7, 16-bit pipe)");
+        return NEMAR_OK;
+    }
     if (nemar_narrow_eligible(K, C1, R, S, stride, N, OH, OW) && g_narrow) {
         nemar_narrow_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad, pad_mode, part, st);
         if (gb) {
@@ -2307,6 +2355,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 29) { g_s16g_wgrad = value != 0; return NEMAR_OK; }
     if (key == 31) { nemar_norm_planes_debug(value); return NEMAR_OK; }
     if (key == 32) { g_split16_ring3 = value != 0; return NEMAR_OK; }
+    if (key == 33) { g_k7 = value != 0; return NEMAR_OK; }
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }

@@ -258,13 +258,15 @@ def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False,
         assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
 
 
-def case_conv_s16g_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, seed=0, gscale=None):
+def case_conv_s16g_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, seed=0, gscale=None, route=3, xscale=None):
     """Weight + bias gradient through nemar_conv2d_bwd_weight on the general 16-bit-pipe route (csrc/conv_s16g_wgrad.hip);
     `gscale` [K] multiplies the gradient rows (per-row running scales: rows of very different magnitude keep their accuracy)."""
     rng = np.random.default_rng(seed)
     C = C0 + C1
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
     x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    if xscale is not None:                      # per-sample magnitudes of the source
+        x = (x * np.asarray(xscale, dtype=np.float32)[:, None, None, None]).astype(np.float32)
     gy = (rng.standard_normal((N, K, OH, OW)) / np.sqrt(N * OH * OW)).astype(np.float32)
     if gscale is not None:
         gy = (gy * np.asarray(gscale, dtype=np.float32)[None, :, None, None]).astype(np.float32)
@@ -282,7 +284,7 @@ def case_conv_s16g_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, 
             ws, wsb = _ws(be, be.lib.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, R, stride, pad))
             be.lib.conv2d_bwd_weight(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_gy), be.ptr(d_gw), be.ptr(d_gb), N, H, W, K,
                                      OH, OW, R, R, stride, pad, pad_mode, be.ptr(ws), wsb, be.stream)
-            assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
+            assert be.lib.last_route() == route, "the shape took route %d, not %d" % (be.lib.last_route(), route)
             outs.append((be.np(d_gw), be.np(d_gb)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), "not bitwise reproducible"
     for got, want, mag, what in ((outs[0][0], want_gw, mag_gw, "gw"), (outs[0][1], want_gb, mag_gb, "gb")):
@@ -292,6 +294,68 @@ def case_conv_s16g_bwd_weight(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, 
             i = np.unravel_index(np.argmax(err / lim), err.shape)
             raise AssertionError("conv2d_bwd_weight (s16g) %s: err %.3e > %.3e at %s (got %.6g want %.6g)" %
                                  (what, err[i], lim[i], i, got[i], want[i]))
+
+
+ROUTE_K7 = 4
+
+
+def case_conv_k7_bwd_weight(be, N, C, H, W, K, pad_mode, seed=0, gscale=None, xscale=None):
+    """Weight + bias gradient of the 7x7 / pad-3 stem (C <= 4 -> K = 32 n) and head (C = 32 n -> K <= 4) layers on the 16-bit matrix pipe
+    (csrc/conv_k7.hip): route 4, bitwise reproducible, 2e-6 of sum |gy| |x| against the float64 oracle."""
+    case_conv_s16g_bwd_weight(be, N, C, 0, H, W, K, 7, 1, 3, pad_mode, seed=seed, gscale=gscale, route=ROUTE_K7, xscale=xscale)
+
+
+def case_conv_k7_fwd(be, N, C, H, W, K, pad_mode, act=O.ACT_NONE, bias=True, seed=0, xscale=None):
+    """Forward of the 7x7 / pad-3 stem (C <= 4 -> K = 32 n) on the 16-bit matrix pipe (csrc/conv_k7.hip, few -> many): route 4,
+    2e-6 of sum |w| |x| against the float64 oracle.  xscale: per-(sample, channel, row-block) magnitudes — the scale is per tile."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    if xscale is not None:
+        x = (x * np.asarray(xscale, dtype=np.float32).reshape(N, 1, 1, 1)).astype(np.float32)
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32) if bias else None
+    want = O.act_fwd(O.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), None if b is None else b.astype(np.float64), 1, 3,
+                                  _PM[pad_mode]), act)
+    mag = O.conv2d_fwd(np.abs(x).astype(np.float64), np.abs(w).astype(np.float64), None, 1, 3, _PM[pad_mode])
+    d_x, d_w, d_b = be.dev(x), be.dev(w), (be.dev(b) if bias else None)
+    d_y = be.full((N, K, H, W), np.nan)
+    ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, 7, 7, 1, 3))
+    for prepacked in (0, 1):              # the second call reuses the packed weights
+        d_y = be.full((N, K, H, W), np.nan)
+        be.lib.conv2d_fwd(be.ptr(d_x), C, None, 0, be.ptr(d_w), be.ptr(d_b), be.ptr(d_y), N, H, W, K, 7, 7, 1, 3, pad_mode, act, 0.2,
+                          be.ptr(ws), wsb, prepacked, be.stream)
+        assert be.lib.last_route() == ROUTE_K7, "route %d" % be.lib.last_route()
+        got = be.np(d_y)
+        err = np.abs(got - want)
+        lim = 2e-6 * mag + 1e-6 * (np.abs(want) + (0 if b is None else np.abs(b)[None, :, None, None])) + 1e-30
+        if not np.all(err <= lim):
+            i = np.unravel_index(np.argmax(err / lim), err.shape)
+            raise AssertionError("conv2d_fwd (k7, prepacked %d): err %.3e > %.3e at %s (got %.6g want %.6g)" %
+                                 (prepacked, err[i], lim[i], i, got[i], want[i]))
+
+
+def case_conv_k7_bwd_data(be, N, C, H, W, K, pad_mode, seed=0):
+    """Data gradient of the 7x7 / pad-3 head (C = 32 n -> K <= 4): few -> many with flipped, transposed weights; reflect border on the
+    padded domain + fold."""
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(K * 49)).astype(np.float32)
+    gy = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    want, _, _ = O.conv2d_bwd(np.zeros((N, C, H, W)), w.astype(np.float64), gy.astype(np.float64), 1, 3, _PM[pad_mode])
+    mag, _, _ = O.conv2d_bwd(np.zeros((N, C, H, W)), np.abs(w).astype(np.float64), np.abs(gy).astype(np.float64), 1, 3, _PM[pad_mode])
+    d_gy, d_w = be.dev(gy), be.dev(w)
+    ws, wsb = _ws(be, be.lib.conv2d_bwd_data_workspace(N, C, H, W, K, 7, 7, 1, 3, pad_mode))
+    for prepacked in (0, 1):
+        d_gx = be.full((N, C, H, W), np.nan)
+        be.lib.conv2d_bwd_data(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gx), C, None, 0, N, H, W, K, H, W, 7, 7, 1, 3, pad_mode,
+                               be.ptr(ws), wsb, prepacked, be.stream)
+        assert be.lib.last_route() == ROUTE_K7, "route %d" % be.lib.last_route()
+        got = be.np(d_gx)
+        err = np.abs(got - want)
+        lim = 2e-6 * mag + 1e-6 * np.abs(want) + 1e-30
+        if not np.all(err <= lim):
+            i = np.unravel_index(np.argmax(err / lim), err.shape)
+            raise AssertionError("conv2d_bwd_data (k7, prepacked %d): err %.3e > %.3e at %s (got %.6g want %.6g)" %
+                                 (prepacked, err[i], lim[i], i, got[i], want[i]))
 
 
 def case_conv_split16(be, N, C, H, W, K, pad_mode, dgrad, seed=0, R=3):

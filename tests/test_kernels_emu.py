@@ -513,3 +513,46 @@ def test_conv_s16g_reflect_data_gradient(be):
     gradient of the padded input on the general 16-bit-pipe kernel, then the fold of the mirrored border."""
     K.case_conv_s16g_bwd_data(be, 2, 32, 0, 8, 32, 32, 3, 1, 1, pad_mode=K.PAD_REFLECT)
     K.case_conv_s16g_bwd_data(be, 1, 64, 0, 6, 40, 48, 3, 1, 1, pad_mode=K.PAD_REFLECT)
+
+
+# ---- 7x7 stem / head layers on the 16-bit matrix pipe (csrc/conv_k7.hip) ----
+@pytest.mark.parametrize("case", [
+    (2, 3, 12, 40, 64, K.PAD_REFLECT),       # stem: 3 -> 64, ragged strip (40 = 32 + 8), one row block
+    (1, 3, 70, 32, 32, K.PAD_ZERO),          # stem with 32 outputs (second row tile masked), two row blocks (70 > 64)
+    (2, 64, 10, 36, 3, K.PAD_REFLECT),       # head: 64 -> 3, Big seen through its reflect border (42 columns: ragged strip)
+    (1, 32, 8, 8, 2, K.PAD_ZERO),            # head with 32 inputs / 2 outputs, zero border
+    (1, 32, 6, 64, 3, K.PAD_REFLECT),        # head, source-aligned strips: the mirrored border as the edge word of the first / last strip
+    (1, 64, 5, 32, 2, K.PAD_ZERO),           # ... zero border: no edge word
+])
+def test_conv_k7_weight_gradient(be, case):
+    N, C, H, W, Kc, pm = case
+    K.case_conv_k7_bwd_weight(be, N, C, H, W, Kc, pm)
+
+
+def test_conv_k7_weight_gradient_scales(be):
+    """rows of gy spread over 1e-6 .. 1e6 (running scale of the many-channel operand, accumulator rescale) and samples of x of very
+    different magnitude (per-sample scale of the few-channel operand)"""
+    K.case_conv_k7_bwd_weight(be, 3, 3, 9, 32, 64, K.PAD_REFLECT, xscale=[1.0, 1e-4, 1e3])
+    K.case_conv_k7_bwd_weight(be, 2, 64, 9, 32, 3, K.PAD_REFLECT, xscale=[1e-3, 1e2])
+
+
+@pytest.mark.parametrize("case", [
+    (2, 3, 9, 70, 64, K.PAD_REFLECT, K.O.ACT_NONE),      # stem: ragged tile rows (9 = 2 x 4 + 1) and columns (70 = 64 + 6)
+    (1, 4, 8, 16, 32, K.PAD_ZERO, K.O.ACT_RELU),         # 4 input channels (28 (c, dy) pairs: the 4th operand word), 32 outputs, zero border
+    (1, 1, 4, 8, 96, K.PAD_REFLECT, K.O.ACT_LRELU),      # one input channel, 96 outputs (two channel blocks, the second half full)
+])
+def test_conv_k7_forward(be, case):
+    N, C, H, W, Kc, pm, act = case
+    K.case_conv_k7_fwd(be, N, C, H, W, Kc, pm, act=act)
+
+
+def test_conv_k7_forward_tile_scales(be):
+    K.case_conv_k7_fwd(be, 3, 3, 8, 64, 64, K.PAD_REFLECT, xscale=[1.0, 1e-5, 1e4])
+
+
+@pytest.mark.parametrize("case", [
+    (2, 64, 9, 40, 3, K.PAD_REFLECT), (1, 32, 8, 16, 2, K.PAD_ZERO), (1, 64, 4, 70, 1, K.PAD_REFLECT),
+])
+def test_conv_k7_data_gradient(be, case):
+    N, C, H, W, Kc, pm = case
+    K.case_conv_k7_bwd_data(be, N, C, H, W, Kc, pm)
