@@ -153,6 +153,22 @@ int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const float* bias,
 int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                                int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
                                void* workspace, size_t ws_bytes, void* stream, const nemar_conv_extras* extras);
+/* Weight-pack plans.  Every convolution family reads its weights from a packed operand image in the `workspace` of the call
+ * (prepacked = 0: the call rebuilds it first — a max reduction and a pack launch per weight and direction, ~240 launches of 4-6 us per
+ * training step).  A plan batches them: while nemar_pack_plan_record(plan) is in effect on the calling thread, the pack launches the
+ * convolution entry points issue are ALSO recorded as jobs of `plan` (record(-1) stops); nemar_pack_plan_commit copies the recorded
+ * job arguments into a caller-owned device buffer of nemar_pack_plan_bytes(plan) bytes (once per change: nemar_pack_plan_dirty);
+ * nemar_pack_plan_run re-runs every job — the same images, bit for bit — in at most five launches (one multi-job kernel per family,
+ * job arguments read from that buffer), after which the owners of those workspaces may call with prepacked = 1.  The caller keeps the
+ * weights, the workspaces and the device buffer alive and unmoved while the plan is in use, and uses one plan per group of weights
+ * that change together (an optimizer).  nemar_pack_plan_jobs -> pack jobs recorded; nemar_pack_plan_reset forgets the plan. */
+int nemar_pack_plan_record(int plan);
+int nemar_pack_plan_jobs(int plan);
+size_t nemar_pack_plan_bytes(int plan);
+int nemar_pack_plan_dirty(int plan);
+int nemar_pack_plan_commit(int plan, void* device_buffer, size_t bytes, void* stream);
+int nemar_pack_plan_run(int plan, void* stream);
+int nemar_pack_plan_reset(int plan);
 /* Tuning switches for A/B measurements (tools/, tests/): not part of the operator contract, defaults = measured best.
  *   0  conv tile family for 128x128-capable shapes: 0 wave-specialised (default), 5 same without 16-byte B loads,
  *      6 one barrier per 32 reduction rows, 7 four loader waves, 4 first-generation wave-specialised, 1/2/3 generic
@@ -299,6 +315,10 @@ int nemar_dropout_max(const float* x, float* y, int samples, long long per_sampl
  * nemar_adam_step_dev is nemar_adam_step with hyper[0] = lr / (1 - beta1^step) and hyper[1] = sqrt(1 - beta2^step) read from device memory
  * (computed by the caller in double, rounded to float — exactly what nemar_adam_step passes to its kernel). */
 int nemar_set_dropout_base(const void* device_word);
+/* dst[0..n) = the n <= 8 four-byte words at host_words, stream-ordered: the values travel as KERNEL ARGUMENTS (read from host memory
+ * during the call), so the host buffer may be reused at once — unlike an asynchronous copy from pageable memory, whose source may be
+ * read later.  How the step's device-resident parameters (dropout base word, Adam's two scalars) are rewritten before a graph replay. */
+int nemar_store_words(void* dst, const void* host_words, int n, void* stream);
 int nemar_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, double beta1,
                         double beta2, double eps, void* stream);
 

@@ -64,6 +64,14 @@ SIGNATURES = {
     "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp]),
     "nemar_planes_hint": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "nemar_set_dropout_base": (_i, [_vp]),
+    "nemar_store_words": (_i, [_vp, _vp, _i, _vp]),
+    "nemar_pack_plan_record": (_i, [_i]),
+    "nemar_pack_plan_jobs": (_i, [_i]),
+    "nemar_pack_plan_bytes": (_sz, [_i]),
+    "nemar_pack_plan_dirty": (_i, [_i]),
+    "nemar_pack_plan_commit": (_i, [_i, _vp, _sz, _vp]),
+    "nemar_pack_plan_run": (_i, [_i, _vp]),
+    "nemar_pack_plan_reset": (_i, [_i]),
     "nemar_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "nemar_conv2d_fwd_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _vp, _sz, _i, _vp, _vp]),
     "nemar_conv2d_bwd_data_ex": (_i, [_vp, _vp, _vp, _i, _fl, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp]),
@@ -129,7 +137,7 @@ class Library:
         if full not in fns:
             raise AttributeError(name)
         fn = fns[full]
-        if SIGNATURES[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_config_epoch"):
+        if SIGNATURES[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

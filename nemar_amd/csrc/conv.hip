@@ -32,6 +32,7 @@
 #include "conv_split16.h"
 #include "conv_s16g.h"
 #include "conv_k7.h"
+#include "pack_plan.h"
 
 extern int g_split16_ring3;                      // conv_split16.hip
 void nemar_norm_planes_debug(int bits);          // norm_planes.hip: ablation bits of the fused producer (measurement only)
@@ -1231,11 +1232,47 @@ constexpr int ZERO_PAGE = 64;   // floats of zeros appended to every packed-weig
 size_t packed_core_floats(int M, int Kred) { return (size_t)nemar_cdiv(Kred, BK) * BK * (size_t)igemm_mpad(M); }
 size_t packed_floats(int M, int Kred) { return packed_core_floats(M, Kred) + ZERO_PAGE; }
 
+// the same pack as a job of a weight-pack plan (pack_plan.h): arguments from device memory, grid.z = job
+struct ExactPackArgs {
+    const float* w; float* wp;
+    int M, Mpad, Cs, Kred, KredPad, wsm, wsc, zero_tail;
+    int gx, gy;
+    int wofs[MAX_TAPS];
+};
+__device__ __forceinline__ void exact_pack_body(const ExactPackArgs& a, int bx, int, int gx) {
+    const int core = a.KredPad * a.Mpad, total = core + a.zero_tail;
+    for (int idx = bx * 256 + threadIdx.x; idx < total; idx += gx * 256) {
+        const int blk = idx / (a.Mpad * 4), within = idx - blk * (a.Mpad * 4);
+        const int m = within >> 2, s = within & 3;
+        const int kk = 8 * (blk >> 1) + 2 * s + (blk & 1);
+        float v = 0.f;
+        if (idx < core && m < a.M && kk < a.Kred) {
+            const int t = kk / a.Cs, ch = kk - t * a.Cs;
+            v = a.w[(size_t)m * a.wsm + (size_t)ch * a.wsc + a.wofs[t]];
+        }
+        a.wp[idx] = v;
+    }
+}
+NEMAR_PACK_MULTI(exact_pack_multi_kernel, ExactPackArgs, exact_pack_body, 256)
+void exact_pack_multi(const void* jobs, int njobs, int gx, int gy, hipStream_t st) {
+    hipLaunchKernelGGL(exact_pack_multi_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, (const ExactPackArgs*)jobs);
+}
+struct RegExactPack {
+    RegExactPack() { nemar_pack_register(PACK_FAM_EXACT, sizeof(ExactPackArgs), exact_pack_multi); }
+} g_reg_exact_pack;
+
 void launch_pack(const float* w, float* wp, int M, int Cs, int wsm, int wsc, const TapTable& taps, hipStream_t st) {
     const int Kred = taps.n * Cs;
     const int KredPad = nemar_cdiv(Kred, BK) * BK;
     const int Mpad = igemm_mpad(M);
     const int total = KredPad * Mpad + ZERO_PAGE;
+    if (nemar_pack_recording()) {
+        ExactPackArgs a;
+        a.w = w; a.wp = wp; a.M = M; a.Mpad = Mpad; a.Cs = Cs; a.Kred = Kred; a.KredPad = KredPad; a.wsm = wsm; a.wsc = wsc;
+        a.zero_tail = ZERO_PAGE; a.gx = nemar_stream_grid(total, 256); a.gy = 1;
+        for (int i = 0; i < MAX_TAPS; ++i) a.wofs[i] = i < taps.n ? taps.wofs[i] : 0;
+        nemar_pack_record_job(PACK_FAM_EXACT, &a, a.gx, 1);
+    }
     hipLaunchKernelGGL(pack_weights_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, wp, M, Mpad, Cs,
                        Kred, KredPad, wsm, wsc, ZERO_PAGE, taps);
 }
@@ -1518,6 +1555,27 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __rest
         w2[idx] = w[(((size_t)k * C + c) * R + (R - 1 - r)) * S + (S - 1 - s)];
     }
 }
+
+// ... as a job of a weight-pack plan (pack_plan.h)
+struct FlipTArgs {
+    const float* w; float* w2;
+    int K, C, R, S;
+    int gx, gy;
+};
+__device__ __forceinline__ void flipt_body(const FlipTArgs& a, int bx, int, int gx) {
+    const int total = a.K * a.C * a.R * a.S;
+    for (int idx = bx * 256 + threadIdx.x; idx < total; idx += gx * 256) {
+        const int s = idx % a.S, r = (idx / a.S) % a.R, k = (idx / (a.S * a.R)) % a.K, c = idx / (a.S * a.R * a.K);
+        a.w2[idx] = a.w[(((size_t)k * a.C + c) * a.R + (a.R - 1 - r)) * a.S + (a.S - 1 - s)];
+    }
+}
+NEMAR_PACK_MULTI(flipt_multi_kernel, FlipTArgs, flipt_body, 256)
+void flipt_multi(const void* jobs, int njobs, int gx, int gy, hipStream_t st) {
+    hipLaunchKernelGGL(flipt_multi_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, (const FlipTArgs*)jobs);
+}
+struct RegFlipT {
+    RegFlipT() { nemar_pack_register(PACK_FAM_FLIPT, sizeof(FlipTArgs), flipt_multi); }
+} g_reg_flipt;
 
 // round-1 form (nemar_tune(14, 0)): one atomic per workgroup
 __global__ __launch_bounds__(256) void bias_grad_atomic_kernel(const float* __restrict__ g, float* __restrict__ gb, int N, int C,
@@ -2062,9 +2120,14 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             bool ring_done = false;
             if (narrow) {
                 float* w2 = wsf + L.w2_off;
-                if (!prepacked)
+                if (!prepacked) {
+                    if (nemar_pack_recording()) {
+                        FlipTArgs a{w, w2, K, C, R, S, nemar_stream_grid((long long)K * C * R * S, 256), 1};
+                        nemar_pack_record_job(PACK_FAM_FLIPT, &a, a.gx, 1);
+                    }
                     hipLaunchKernelGGL(flip_transpose_kernel, dim3(nemar_stream_grid((long long)K * C * R * S, 256)),
                                        dim3(256), 0, st, w, w2, K, C, R, S);
+                }
                 nemar_narrow_fwd(gy, w2, nullptr, gx0, N, K, OH, OW, C, R, R - 1 - pad, BORDER_ZERO, ACT_NONE, 0.f, nullptr, 0, st);
             } else {
                 // split reductions (see dgrad_layout): each split stores its partial gradient to its own slab, summed in order

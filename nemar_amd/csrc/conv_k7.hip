@@ -23,6 +23,7 @@
 // results go to slabs (plain stores) summed in order: bitwise reproducible, like every other weight gradient of the library.
 #include "common.h"
 #include "conv_k7.h"
+#include "pack_plan.h"
 
 namespace {
 
@@ -422,8 +423,18 @@ struct K7FmParams {
 };
 
 
-__global__ __launch_bounds__(1024) void k7_fm_pack_kernel(const float* __restrict__ w, long long wsm, long long wsc, int flip, int M,
-                                                          int Cs, u32x4* __restrict__ out, unsigned* __restrict__ maxword) {
+// pack (one workgroup: the tensors have <= 4 x 49 x M elements): max |w|, then the scaled hi / lo operand words.  Also a job type of the
+// weight-pack plans (pack_plan.h).
+struct K7PackArgs {
+    const float* w; long long wsm, wsc; int flip, M, Cs; u32x4* out; unsigned* maxword;
+    int gx, gy;
+};
+__device__ __forceinline__ void k7_fm_pack_body(const K7PackArgs& a, int, int, int) {
+    const float* __restrict__ w = a.w;
+    const long long wsm = a.wsm, wsc = a.wsc;
+    const int flip = a.flip, M = a.M, Cs = a.Cs;
+    u32x4* __restrict__ out = a.out;
+    unsigned* __restrict__ maxword = a.maxword;
     __shared__ unsigned red[16];
     __shared__ unsigned mx;
     const int total = M * Cs * 49;
@@ -464,6 +475,14 @@ __global__ __launch_bounds__(1024) void k7_fm_pack_kernel(const float* __restric
         out[i] = pl ? lo : hi;
     }
 }
+__global__ __launch_bounds__(1024) void k7_fm_pack_kernel(K7PackArgs a) { k7_fm_pack_body(a, 0, 0, 1); }
+NEMAR_PACK_MULTI(k7_fm_pack_multi_kernel, K7PackArgs, k7_fm_pack_body, 1024)
+void k7_fm_pack_multi(const void* jobs, int njobs, int gx, int gy, hipStream_t st) {
+    hipLaunchKernelGGL(k7_fm_pack_multi_kernel, dim3(gx, gy, njobs), dim3(1024), 0, st, (const K7PackArgs*)jobs);
+}
+struct RegK7Pack {
+    RegK7Pack() { nemar_pack_register(PACK_FAM_K7, sizeof(K7PackArgs), k7_fm_pack_multi); }
+} g_reg_k7_pack;
 
 template <int Cs>
 __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
@@ -729,7 +748,9 @@ size_t nemar_k7_fm_pack_floats(int M) { return (size_t)nemar_cdiv(M, 64) * 2 * 7
 
 void nemar_k7_fm_pack(const float* w, long long wsm, long long wsc, int flip, int M, int Cs, void* packed, hipStream_t st) {
     unsigned* maxword = (unsigned*)((float*)packed + nemar_k7_fm_pack_floats(M) - 4);
-    hipLaunchKernelGGL(k7_fm_pack_kernel, dim3(1), dim3(1024), 0, st, w, wsm, wsc, flip, M, Cs, (u32x4*)packed, maxword);
+    K7PackArgs a{w, wsm, wsc, flip, M, Cs, (u32x4*)packed, maxword, 1, 1};
+    if (nemar_pack_recording()) nemar_pack_record_job(PACK_FAM_K7, &a, 1, 1);
+    hipLaunchKernelGGL(k7_fm_pack_kernel, dim3(1), dim3(1024), 0, st, a);
 }
 
 void nemar_k7_fm_conv(const float* src, int Cs, int Hs, int Ws, int pad, int reflect, const void* packed, const float* bias, float* dst,

@@ -34,6 +34,7 @@
 // fragment reads + MFMAs, no memory waits; the NEXT chunk's source loads are in flight] barrier.
 #include "common.h"
 #include "conv_s16g.h"
+#include "pack_plan.h"
 
 namespace {
 
@@ -183,6 +184,51 @@ __global__ __launch_bounds__(256) void s16g_pack_kernel(const float* __restrict_
         o[2 * MB] = lo;
     }
 }
+
+// the same pack as a job of a weight-pack plan (pack_plan.h): arguments from device memory, grid (blocks, class, job)
+struct S16gPackArgs {
+    const float* w; u32x4* out;
+    int M, Cred, MB, mblks, nchunks;
+    long long wsm, wsc, cls_words;
+    const unsigned* maxbits;
+    int gx, gy;
+    int ntaps[S16G_MAX_CLS];
+    int wofs[S16G_MAX_CLS][S16G_MAX_TAPS];
+};
+__device__ __forceinline__ void s16g_pack_body(const S16gPackArgs& a, int bx, int cls, int gx) {
+    const int ntaps = a.ntaps[cls];
+    const float scale = weight_scale(absmax_of_partials(a.maxbits));
+    u32x4* const out = a.out + (size_t)cls * a.cls_words;
+    const long long total = (long long)a.nchunks * a.mblks * ntaps * 2 * a.MB;
+    for (long long t = (long long)bx * 256 + threadIdx.x; t < total; t += (long long)gx * 256) {
+        const int m = (int)(t % a.MB);
+        long long r = t / a.MB;
+        const int kg = (int)(r & 1);
+        r >>= 1;
+        const int tap = (int)(r % ntaps);
+        r /= ntaps;
+        const int mblk = (int)(r % a.mblks), chunk = (int)(r / a.mblks);
+        const int mg = mblk * a.MB + m;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cr = chunk * 16 + kg * 8 + j;
+            v[j] = (mg < a.M && cr < a.Cred) ? a.w[(long long)mg * a.wsm + (long long)cr * a.wsc + a.wofs[cls][tap]] : 0.f;
+        }
+        u32x4 hi, lo;
+        split8(v, scale, hi, lo);
+        u32x4* const o = out + ((((long long)chunk * a.mblks + mblk) * ntaps + tap) * 4 + kg) * a.MB + m;
+        o[0] = hi;
+        o[2 * a.MB] = lo;
+    }
+}
+NEMAR_PACK_MULTI(s16g_pack_multi_kernel, S16gPackArgs, s16g_pack_body, 256)
+void s16g_pack_multi(const void* jobs, int njobs, int gx, int gy, hipStream_t st) {
+    hipLaunchKernelGGL(s16g_pack_multi_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, (const S16gPackArgs*)jobs);
+}
+struct RegS16gPack {
+    RegS16gPack() { nemar_pack_register(PACK_FAM_S16G, sizeof(S16gPackArgs), s16g_pack_multi); }
+} g_reg_s16g_pack;
 
 // MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride.
 // LDS (dynamic: exactly what the layer needs, so that narrow layers keep several workgroups per CU): [weights of one chunk,
@@ -610,6 +656,20 @@ void nemar_s16g_pack(const S16gProblem& q, const S16gPlan& pl, const float* w, l
     const long long n = (long long)(q.M - 1) * wsm + (long long)(C - 1) * wsc + maxofs + 1;
     hipLaunchKernelGGL(s16g_absmax_kernel, dim3(ABSMAX_WGS), dim3(256), 0, st, w, n, mw);
     const long long total = (long long)pl.nchunks * pl.mblks * maxtaps * 2 * MB;
+    if (nemar_pack_recording()) {
+        static_assert(ABSMAX_WGS == NEMAR_PACK_MAX_PARTS, "plan max jobs write the same partial words");
+        NemarPackMaxArgs ma{w, n, mw, ABSMAX_WGS, 1};
+        nemar_pack_record_job(PACK_FAM_MAX, &ma, ma.gx, 1);
+        S16gPackArgs a;
+        a.w = w; a.out = (u32x4*)packed; a.M = q.M; a.Cred = C; a.MB = MB; a.mblks = pl.mblks; a.nchunks = pl.nchunks;
+        a.wsm = wsm; a.wsc = wsc; a.cls_words = (long long)pl.pack_words_per_class; a.maxbits = mw;
+        a.gx = nemar_stream_grid(total, 256); a.gy = q.ncls;
+        for (int c = 0; c < S16G_MAX_CLS; ++c) {
+            a.ntaps[c] = c < q.ncls ? q.ntaps[c] : 0;
+            for (int t = 0; t < S16G_MAX_TAPS; ++t) a.wofs[c][t] = (c < q.ncls && t < q.ntaps[c]) ? q.wofs[c][t] : 0;
+        }
+        nemar_pack_record_job(PACK_FAM_S16G, &a, a.gx, a.gy);
+    }
     S16gProblem qq = q;                      // (pointers unused by the kernel)
     hipLaunchKernelGGL(s16g_pack_kernel, dim3(nemar_stream_grid(total, 256), q.ncls), dim3(256), 0, st, w, (u32x4*)packed, q.M, C, MB,
                        pl.mblks, pl.nchunks, wsm, wsc, (long long)pl.pack_words_per_class, (const unsigned*)mw, qq);

@@ -39,6 +39,7 @@
 // [128][8]: a stage is one contiguous run.
 #include "common.h"
 #include "conv_split16.h"
+#include "pack_plan.h"
 
 namespace {
 
@@ -222,6 +223,49 @@ __global__ __launch_bounds__(256) void split16_pack_kernel(const float* __restri
         if (NPL == 3) o[512] = pack8(b2);
     }
 }
+
+// the fp16 x 3 pack as a job of a weight-pack plan (pack_plan.h): the scale comes from the NEMAR_PACK_MAX_PARTS partial maxima a stage-1
+// job wrote (no zero fill, no atomics); block 0 also leaves the final max word where the convolution kernels read it
+struct Split16PackArgs {
+    const float* w; u32x4* out;
+    int M, Cred, dgrad, NT;
+    const unsigned* parts; unsigned* maxword;
+    int gx, gy;
+};
+__device__ __forceinline__ void split16_pack_body(const Split16PackArgs& a, int bx, int, int gx) {
+    unsigned mb = 0;
+#pragma unroll
+    for (int i = 0; i < NEMAR_PACK_MAX_PARTS; ++i) mb = max(mb, a.parts[i]);
+    if (bx == 0 && threadIdx.x == 0) *a.maxword = mb;
+    const int mblks = a.M >> 7, NT = a.NT, M = a.M, Cred = a.Cred;
+    const long long total = (long long)(Cred >> 4) * NT * mblks * 256;
+    const float scale = pow2_scale(mb);
+    for (long long t = (long long)bx * 256 + threadIdx.x; t < total; t += (long long)gx * 256) {
+        const int m = (int)(t & 127), kg = (int)((t >> 7) & 1);
+        long long q = t >> 8;
+        const int mblk = (int)(q % mblks);
+        q /= mblks;
+        const int tap = (int)(q % NT), chunk = (int)(q / NT);
+        const int mg = mblk * 128 + m;
+        unsigned short b0[8], b1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cr = chunk * 16 + kg * 8 + j;
+            const float v = a.dgrad ? a.w[((size_t)cr * M + mg) * NT + (NT - 1 - tap)] : a.w[((size_t)mg * Cred + cr) * NT + tap];
+            split2_f16(v * scale, b0[j], b1[j]);
+        }
+        u32x4* o = a.out + (((size_t)(chunk * NT + tap) * mblks + mblk) * 2) * 256 + kg * 128 + m;
+        o[0] = pack8(b0);
+        o[256] = pack8(b1);
+    }
+}
+NEMAR_PACK_MULTI(split16_pack_multi_kernel, Split16PackArgs, split16_pack_body, 256)
+void split16_pack_multi(const void* jobs, int njobs, int gx, int gy, hipStream_t st) {
+    hipLaunchKernelGGL(split16_pack_multi_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, (const Split16PackArgs*)jobs);
+}
+struct RegSplit16Pack {
+    RegSplit16Pack() { nemar_pack_register(PACK_FAM_SPLIT16, sizeof(Split16PackArgs), split16_pack_multi); }
+} g_reg_split16_pack;
 
 struct Split16Params {
     const u32x4* planes;       // split source, see split_planes_kernel
@@ -755,6 +799,13 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int 
     const long long total = (long long)(Cred / 16) * NT * (M / 128) * 256;
     if (variant == 4) {
         unsigned* mw = pack_max_word(packed, M, Cred, KS);
+        if (nemar_pack_recording()) {                        // (partial words: in the slack behind the image, 1 KiB before its end)
+            unsigned* parts = (unsigned*)((char*)packed + nemar_split16_pack_bytes(M, Cred, KS) - 1024);
+            NemarPackMaxArgs ma{w, (long long)K * C * NT, parts, NEMAR_PACK_MAX_PARTS, 1};
+            nemar_pack_record_job(PACK_FAM_MAX, &ma, ma.gx, 1);
+            Split16PackArgs a{w, (u32x4*)packed, M, Cred, dgrad, NT, parts, mw, nemar_stream_grid(total, 256), 1};
+            nemar_pack_record_job(PACK_FAM_SPLIT16, &a, a.gx, 1);
+        }
         (void)hipMemsetAsync(mw, 0, sizeof(unsigned), st);
         nemar_split16_absmax(w, 1, (long long)K * C * NT, mw, st);
         hipLaunchKernelGGL((split16_pack_kernel<2>), dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, w, (u32x4*)packed, M, Cred, dgrad, mw,

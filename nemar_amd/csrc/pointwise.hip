@@ -399,6 +399,23 @@ NEMAR_API int nemar_bilinear_bwd(const float* gy, float* gx, int planes, int H, 
 // time; NULL (default) = none.  A captured hipGraph freezes launch arguments: with the per-step part of the Philox offset in this word the
 // replayed step still draws fresh masks (the caller rewrites the word before every replay).
 const unsigned* g_dropout_base = nullptr;
+namespace {
+struct Words8 { unsigned w[8]; };
+__global__ void store_words_kernel(unsigned* dst, Words8 v, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+}  // namespace
+
+NEMAR_API int nemar_store_words(void* dst, const void* host_words, int n, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(dst && host_words && n >= 1 && n <= 8, "store_words: bad arguments");
+    Words8 v;
+    for (int i = 0; i < 8; ++i) v.w[i] = i < n ? ((const unsigned*)host_words)[i] : 0u;
+    hipLaunchKernelGGL(store_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned*)dst, v, n);
+    NEMAR_CHECK_LAUNCH("store_words");
+    return NEMAR_OK;
+}
+
 NEMAR_API int nemar_set_dropout_base(const void* device_word) {
     g_dropout_base = (const unsigned*)device_word;
     return NEMAR_OK;

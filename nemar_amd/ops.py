@@ -189,19 +189,45 @@ def _zeroed_workspace(nbytes, key):
 # update does not re-pack the translation / registration nets), invalidate_packed_weights() bumps the global one, in-place
 # torch ops bump tensor._version.
 class PackEpoch:
-    """Value generation of a group of weights: bumped when their values change outside torch's version counter."""
-    __slots__ = ('n',)
+    """Value generation of a group of weights: bumped when their values change outside torch's version counter.  `plan`: the
+    weight-pack plan of the optimizer that owns them (None: none)."""
+    __slots__ = ('n', 'plan')
 
     def __init__(self):
         self.n = 0
+        self.plan = None
 
 
 _param_epoch = PackEpoch()      # everything (re-initialisation through .data, checkpoint loads)
 _pack_cache = {}
 
+# ---- weight-pack plans (include/nemar_hip.h: nemar_pack_plan_*) ---------------------------------------------------------------------
+# Lazily, every (weight, direction) re-packs itself at its first use after its optimizer stepped: ~240 launches of 4-6 us per training
+# step.  With plans the pack jobs of an optimizer's weights are RECORDED the first time they run (the library notes the launches its
+# convolution entry points issue while nemar_pack_plan_record is in effect) and from then on FlatAdam.step() re-runs all of them right
+# behind the Adam kernel in <= 5 launches; the convolutions then find their images ready (prepacked = 1).  The packed images are the
+# same bits either way.  NEMAR_PACK_PLAN=0 switches plans off (A/B, tests).
+_plans_on = [os.environ.get("NEMAR_PACK_PLAN", "1") != "0"]
+_plan_gen = [0]                 # bumped when every plan is forgotten (route switches, re-initialised weights): recorded entries lapse
+_plan_owners = weakref.WeakSet()
+_plan_ids = [0]
+
+
+def pack_plans(on):
+    """Switch weight-pack plans on / off (off: every weight packs itself at first use, as before); forgets the recorded plans."""
+    _plans_on[0] = bool(on)
+    _reset_plans()
+
+
+def _reset_plans():
+    _plan_gen[0] += 1
+    for o in list(_plan_owners):
+        L.pack_plan_reset(o._plan)
+
 
 def invalidate_packed_weights():
     _param_epoch.n += 1
+    _reset_plans()
 
 
 def tune(key, value):
@@ -211,23 +237,59 @@ def tune(key, value):
     invalidate_packed_weights()
 
 
+class _PackEntry:
+    __slots__ = ('buf', 'token', 'ref', 'plan_gen')
+
+    def __init__(self, buf, token, ref):
+        self.buf, self.token, self.ref, self.plan_gen = buf, token, ref, -1
+
+
+class _record:
+    """`with _record(plan):` — the pack launches of the library call inside are recorded as jobs of `plan` (None: nothing happens)"""
+    __slots__ = ('plan',)
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        if self.plan is not None:
+            L.pack_plan_record(self.plan)
+
+    def __exit__(self, *a):
+        if self.plan is not None:
+            L.pack_plan_record(-1)
+
+
 def _packed(weight, kind, nbytes):
-    """-> (workspace tensor, prepacked flag) for `weight` used in direction `kind`."""
+    """-> (workspace tensor, prepacked flag, plan to record the pack into or None) for `weight` used in direction `kind`."""
     key = (id(weight), kind)
     own = getattr(weight, '_pack_epoch', None)
     # (the library's config epoch: which kernel family a shape routes to — and so the format of its packed image — depends on the
     # nemar_tune switches and on the registered arena, whoever changed them)
-    token = (_param_epoch.n, own.n if own is not None else 0, weight._version, weight.data_ptr(), tuple(weight.shape),
-             L.config_epoch())
+    static = (_param_epoch.n, weight._version, weight.data_ptr(), tuple(weight.shape), L.config_epoch())
+    token = (static, own.n if own is not None else 0)
     ent = _pack_cache.get(key)
     # id() and device addresses are recycled once a tensor dies: an entry is only valid for the very object it was
     # made for (weak reference), with unchanged values (epoch, _version) at an unchanged address
-    if ent is not None and ent[2]() is weight and ent[1] == token and ent[0].numel() * 4 >= nbytes:
-        return ent[0], 1
-    buf = ent[0] if (ent is not None and ent[2]() is weight and ent[0].numel() * 4 >= nbytes) else \
-        torch.empty(int(nbytes) // 4 + 64, dtype=torch.float32, device=weight.device)
-    _pack_cache[key] = (buf, token, weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None)))
-    return buf, 0
+    mine = ent is not None and ent.ref() is weight and ent.buf.numel() * 4 >= nbytes
+    if mine and ent.token == token:
+        return ent.buf, 1, None
+    # an image that is a job of its optimizer's plan was rebuilt right behind the optimizer's last step
+    if mine and ent.plan_gen == _plan_gen[0] and ent.token[0] == static:
+        return ent.buf, 1, None
+    buf = ent.buf if mine else torch.empty(int(nbytes) // 4 + 64, dtype=torch.float32, device=weight.device)
+    new = _PackEntry(buf, token, weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None)))
+    plan = None
+    # record the pack as a plan job: once per (image buffer, plan generation), not while a captured graph holds an older image of the
+    # plan (its replays would not rebuild the newcomer), not for weights without an optimizer
+    if _plans_on[0] and own is not None and own.plan is not None and not _pinned[0]:
+        if mine and ent.plan_gen == _plan_gen[0]:
+            new.plan_gen = ent.plan_gen                     # (already a job: same buffer)
+        else:
+            plan = own.plan
+            new.plan_gen = _plan_gen[0]
+    _pack_cache[key] = new
+    return buf, 0, plan
 
 
 def grad_ready(param):
@@ -279,7 +341,7 @@ class _Conv2d(Function):
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
-        ws, hit = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
+        ws, hit, plan = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
         split16 = _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device) and x2 is None
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
@@ -293,8 +355,9 @@ class _Conv2d(Function):
                     xmax = _absmax_word(x)
                 L.absmax_hint(_p(x), _p(xmax), xmax.numel())
             try:
-                L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
-                             slope, _p(ws), wsb, hit, _stream())
+                with _record(plan):
+                    L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
+                                 slope, _p(ws), wsb, hit, _stream())
             finally:
                 if split16:
                     L.absmax_hint(_p(x), None, 0)
@@ -365,10 +428,11 @@ class _Conv2d(Function):
             else:
                 Nd, gd, gxd = N, g, gx
             wsb = L.conv2d_bwd_data_workspace(Nd, C, H, W, K, R, S, stride, pad, pad_mode)
-            ws, hit = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, Nd, H, W), wsb)
+            ws, hit, plan = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, Nd, H, W), wsb)
             _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
-            L.conv2d_bwd_data(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
-                              stride, pad, pad_mode, _p(ws), wsb, hit, st)
+            with _record(plan):
+                L.conv2d_bwd_data(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
+                                  stride, pad, pad_mode, _p(ws), wsb, hit, st)
             if not need_x2:
                 gx2 = None
         want_b = need_b and ctx.bias is not None
@@ -412,9 +476,10 @@ class _ConvTranspose2d(Function):
         Wo = (W - 1) * stride - 2 * pad + S + out_pad
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO)
-        ws, hit = _packed(weight, ('convT_fwd', stride, pad, N, Ho, Wo), wsb)
-        L.conv2d_bwd_data(_p(x), _p(w), _p(b), act, slope, _p(y), Co, None, 0, N, Ho, Wo, Ci, H, W, R, S, stride, pad,
-                          PAD_ZERO, _p(ws), wsb, hit, _stream())
+        ws, hit, plan = _packed(weight, ('convT_fwd', stride, pad, N, Ho, Wo), wsb)
+        with _record(plan):
+            L.conv2d_bwd_data(_p(x), _p(w), _p(b), act, slope, _p(y), Co, None, 0, N, Ho, Wo, Ci, H, W, R, S, stride, pad,
+                              PAD_ZERO, _p(ws), wsb, hit, _stream())
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
         _note_use(weight)
@@ -442,9 +507,10 @@ class _ConvTranspose2d(Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             wsb = L.conv2d_fwd_workspace(N, Ho, Wo, Ci, Co, R, S, stride, pad)
-            ws, hit = _packed(ctx.weight, ('convT_bwd', stride, pad, N, Ho, Wo), wsb)
-            L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
-                         0.0, _p(ws), wsb, hit, st)
+            ws, hit, plan = _packed(ctx.weight, ('convT_bwd', stride, pad, N, Ho, Wo), wsb)
+            with _record(plan):
+                L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
+                             0.0, _p(ws), wsb, hit, st)
         if ctx.needs_input_grad[1]:
             wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
             L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
@@ -663,7 +729,9 @@ def begin_step():
         raise RuntimeError("more than %d dropout launches in one step" % DROPOUT_STEP_STRIDE)
     _step_params["step"] += 1
     base = (_step_params["step"] * DROPOUT_STEP_STRIDE) & 0x7FFFFFFF
-    _step_params["base"].copy_(torch.tensor([base], dtype=torch.int32))
+    # (the value travels as a kernel argument: an asynchronous copy from a temporary, pageable host tensor may read its source AFTER the
+    # tensor has been freed and its memory reused — seen as forward and backward masks of one step drawn from different bases)
+    L.store_words(_p(_step_params["base"]), ctypes.byref(ctypes.c_uint32(base)), 1, _stream())
     _dropout_state["offset"] = 0
 
 
@@ -903,6 +971,10 @@ class FlatAdam:
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_count = 0
         self._epoch = PackEpoch()
+        _plan_ids[0] += 1
+        self._plan, self._plan_buf = _plan_ids[0], None
+        self._epoch.plan = self._plan
+        _plan_owners.add(self)
         invalidate_packed_weights()
         with torch.no_grad():
             for p, o in zip(self.params, offs):
@@ -927,9 +999,25 @@ class FlatAdam:
                 self.prepare_step(self.step_count)
             L.adam_step_dev(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, _p(self.hyper),
                             self.betas[0], self.betas[1], self.eps, _stream())
+            self._repack()
             return
         L.adam_step(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_numel, float(g["lr"]),
                     self.betas[0], self.betas[1], self.eps, self.step_count, _stream())
+        self._repack()
+
+    def _repack(self):
+        """Right behind the Adam kernel: every recorded pack job of this optimizer's weights, in <= 5 launches (weight-pack plans)."""
+        if not _plans_on[0] or L.pack_plan_jobs(self._plan) == 0:
+            return
+        if L.pack_plan_dirty(self._plan):
+            if _step_params["capturing"]:
+                raise RuntimeError("a weight was packed for the first time inside a graph capture: run the step eagerly first")
+            need = int(L.pack_plan_bytes(self._plan))
+            if self._plan_buf is None or self._plan_buf.numel() < need:
+                _retire(self._plan_buf)
+                self._plan_buf = torch.empty(need + 4096, dtype=torch.uint8, device=self.flat_p.device)
+            L.pack_plan_commit(self._plan, _p(self._plan_buf), self._plan_buf.numel(), _stream())
+        L.pack_plan_run(self._plan, _stream())
 
     def prepare_step(self, step):
         """hyper <- (lr / (1 - beta1^step), sqrt(1 - beta2^step)) for the step about to run: nemar_adam_step's own arithmetic (double,
@@ -939,7 +1027,8 @@ class FlatAdam:
         lr = float(self.param_groups[0]["lr"])
         bc1 = 1.0 - self.betas[0] ** step
         bc2 = 1.0 - self.betas[1] ** step
-        self.hyper.copy_(torch.tensor([lr / bc1, bc2 ** 0.5], dtype=torch.float64).to(torch.float32))
+        words = (ctypes.c_float * 2)(lr / bc1, bc2 ** 0.5)            # (double -> float, rounded once; as kernel arguments: see begin_step)
+        L.store_words(_p(self.hyper), ctypes.byref(words), 2, _stream())
 
     def replayed_step(self):
         """book-keeping of a step that ran inside a graph replay (the launches were the graph's)"""

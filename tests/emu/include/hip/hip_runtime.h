@@ -50,10 +50,11 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)1; ret
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }      // the emulator runs launches synchronously
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
-static const int hipMemcpyDeviceToDevice = 3;
+static const int hipMemcpyDeviceToDevice = 3, hipMemcpyHostToDevice = 1;
 
 // ---- vector types -------------------------------------------------------------------------
 struct float2 { float x, y; };
