@@ -1747,6 +1747,144 @@ bool s16g_dgrad_problem(S16gProblem& q, S16gPlan& pl, int N, int C, int mskip, i
     return pl.ok != 0;
 }
 
+// ---- 7x7 / pad-3 layers with <= 4 channels on the OUTPUT side (the translation net's RGB head; the data gradient of its stem) -------
+// out[k][y][x] = sum_{c, dy, dx} w[k][c][dy][dx] src[c][y + dy][x + dx] with 3 rows would waste 29 of 32 MFMA rows.  Instead the rows of the
+// GEMM are the (k, dx) PAIRS (4 x 8 = 32 pseudo-channels): P[(k, dx)][y][x'] = sum_{c, dy} w[k][c][dy][dx] src[c][y + dy][x'] is a SEVEN-TAP
+// VERTICAL convolution with 32 output channels — the general 16-bit-pipe kernel (conv_s16g.hip) takes it as it is, over the halo columns
+// x' as well — and out[k][y][x] = sum_dx P[(k, dx)][y][x + dx] is a horizontal shift-sum (k7_mf_sum_kernel: + bias, activation, and
+// for a reflect-padded data gradient the fold of the padded domain).  Workspace: [re-arranged weights][their packed image][P].
+__global__ __launch_bounds__(256) void k7_mf_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Ks, int Cb, int dgrad) {
+    // wt[(ks * 8 + dx)][cb][dy]: forward w[ks][cb][dy][dx] (w = [Ks][Cb][7][7]); data gradient w[cb][ks][6 - dy][6 - dx] (w = [Cb][Ks][7][7])
+    const int total = 32 * Cb * 7;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int dy = i % 7, cb = (i / 7) % Cb, m = i / (7 * Cb), ks = m >> 3, dx = m & 7;
+        float v = 0.f;
+        if (ks < Ks && dx < 7)
+            v = dgrad ? w[(((size_t)cb * Ks + ks) * 7 + (6 - dy)) * 7 + (6 - dx)] : w[(((size_t)ks * Cb + cb) * 7 + dy) * 7 + dx];
+        wt[i] = v;
+    }
+}
+struct K7MfWtArgs {
+    const float* w; float* wt;
+    int Ks, Cb, dgrad;
+    int gx, gy;
+};
+__device__ __forceinline__ void k7_mf_wt_body(const K7MfWtArgs& a, int bx, int, int gx) {
+    const int total = 32 * a.Cb * 7;
+    for (int i = bx * 256 + threadIdx.x; i < total; i += gx * 256) {
+        const int dy = i % 7, cb = (i / 7) % a.Cb, m = i / (7 * a.Cb), ks = m >> 3, dx = m & 7;
+        float v = 0.f;
+        if (ks < a.Ks && dx < 7)
+            v = a.dgrad ? a.w[(((size_t)cb * a.Ks + ks) * 7 + (6 - dy)) * 7 + (6 - dx)] : a.w[(((size_t)ks * a.Cb + cb) * 7 + dy) * 7 + dx];
+        a.wt[i] = v;
+    }
+}
+NEMAR_PACK_MULTI(k7_mf_wt_multi_kernel, K7MfWtArgs, k7_mf_wt_body, 256)
+void k7_mf_wt_multi(const void* jobs, int njobs, int gx, int gy, hipStream_t st) {
+    hipLaunchKernelGGL(k7_mf_wt_multi_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, (const K7MfWtArgs*)jobs);
+}
+struct RegK7MfWt {
+    RegK7MfWt() { nemar_pack_register(PACK_FAM_PRE, sizeof(K7MfWtArgs), k7_mf_wt_multi); }
+} g_reg_k7_mf_wt;
+
+// out[n][k][y][x] = act(bias[k] + sum over the P positions (Y, X) that belong to (y, x) of sum_dx P[n][k * 8 + dx][Y][X + dx]).
+// fold == 0: (Y, X) = (y, x).  fold == 1 (reflect-padded data gradient, P on the padded domain): every padded position that mirrors onto
+// (y, x): rows y + 3, 3 - y (1 <= y <= 3), 2 (H - 1) - y + 3 (H - 4 <= y <= H - 2), columns likewise — fixed order, no atomics.
+__global__ __launch_bounds__(256) void k7_mf_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ out,
+                                                        int Ks, int H, int W, int PH, int PW, int fold, int act, float slope, long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        long long t = idx / W;
+        const int y = (int)(t % H);
+        t /= H;
+        const int k = (int)(t % Ks);
+        const long long n = t / Ks;
+        const float* Pk = P + ((size_t)n * 32 + (size_t)k * 8) * PH * PW;
+        const size_t pplane = (size_t)PH * PW;
+        auto at = [&](int Y, int X) {
+            const float* r = Pk + (size_t)Y * PW + X;
+            float s = 0.f;
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) s += r[(size_t)dx * pplane + dx];
+            return s;
+        };
+        float v;
+        if (!fold) {
+            v = at(y, x);
+        } else {
+            const int y0 = y + 3, x0 = x + 3;
+            const int y1 = (y >= 1 && y <= 3) ? 3 - y : -1, y2 = (y <= H - 2 && y >= H - 4) ? 2 * (H - 1) - y + 3 : -1;
+            const int x1 = (x >= 1 && x <= 3) ? 3 - x : -1, x2 = (x <= W - 2 && x >= W - 4) ? 2 * (W - 1) - x + 3 : -1;
+            auto row = [&](int Y) {
+                float s = at(Y, x0);
+                if (x1 >= 0) s += at(Y, x1);
+                if (x2 >= 0) s += at(Y, x2);
+                return s;
+            };
+            v = row(y0);
+            if (y1 >= 0) v += row(y1);
+            if (y2 >= 0) v += row(y2);
+        }
+        if (bias) v += bias[k];
+        out[idx] = apply_act(v, act, slope);
+    }
+}
+
+// geometry of the vertical convolution: P = [N][32][PH][PW]; src = [N][Cb][Hs][Ws] seen through a border of `spad` (3: forward / zero-padded
+// gradient; 6, zero: reflect gradient on the padded domain)
+struct K7MfPlan {
+    S16gProblem q;
+    S16gPlan pl;
+    size_t wt_off, pack_off, p_off, total;      // floats
+    int PH, PW;
+    bool ok;
+};
+K7MfPlan k7_mf_plan(int N, int Cb, int Hs, int Ws, int spad, int border) {
+    K7MfPlan m;
+    m.ok = false;
+    m.PH = Hs + 2 * spad - 6;
+    m.PW = Ws + 2 * spad;
+    S16gProblem& q = m.q;
+    q = S16gProblem();
+    q.C0 = Cb; q.C1 = 0; q.Hs = Hs; q.Ws = Ws; q.N = N; q.M = 32; q.M0 = 32;
+    q.act = ACT_NONE; q.slope = 0.f; q.border = border; q.sstride = 1;
+    q.OHf = m.PH; q.OWf = m.PW; q.osy = 1; q.osx = 1; q.ncls = 1;
+    TapTable t;
+    t.n = 7;
+    for (int i = 0; i < 7; ++i) { t.dy[i] = (short)(i - spad); t.dx[i] = (short)(-spad); t.dyx[i] = ((i - spad) << 16) | ((-spad) & 0xffff); t.wofs[i] = i; }
+    s16g_set_class(q, 0, t, m.PH, m.PW, 0, 0);
+    m.pl = nemar_s16g_plan(q);
+    if (!m.pl.ok) return m;
+    m.wt_off = 0;
+    m.pack_off = ((size_t)32 * Cb * 7 + 3) & ~(size_t)3;
+    m.p_off = (m.pack_off + (nemar_s16g_pack_bytes(q, m.pl) + 3) / 4 + 3) & ~(size_t)3;
+    m.total = m.p_off + (size_t)N * 32 * m.PH * m.PW;
+    m.ok = true;
+    return m;
+}
+bool k7_mf_eligible(int Cb, int Ks, int R, int S, int stride, int pad) {
+    return g_k7 && R == 7 && S == 7 && stride == 1 && pad == 3 && Ks >= 1 && Ks <= 4 && Cb >= 16 && Cb % 16 == 0;
+}
+// src -> out through the three launches (weights re-arranged + packed first unless prepacked)
+void k7_mf_run(const K7MfPlan& m_, const float* src, const float* w, int Ks, int Cb, int dgrad, const float* bias, float* out, int N, int H, int W,
+               int fold, int act, float slope, float* wsf, int prepacked, hipStream_t st) {
+    K7MfPlan m = m_;
+    float* wt = wsf + m.wt_off;
+    void* packed = wsf + m.pack_off;
+    float* P = wsf + m.p_off;
+    if (!prepacked) {
+        K7MfWtArgs a{w, wt, Ks, Cb, dgrad, nemar_stream_grid(32 * Cb * 7, 256), 1};
+        if (nemar_pack_recording()) nemar_pack_record_job(PACK_FAM_PRE, &a, a.gx, 1);
+        hipLaunchKernelGGL(k7_mf_weights_kernel, dim3(a.gx), dim3(256), 0, st, w, wt, Ks, Cb, dgrad);
+        nemar_s16g_pack(m.q, m.pl, wt, (long long)Cb * 7, 7, packed, st);
+    }
+    m.q.src0 = src; m.q.src1 = nullptr; m.q.dst0 = P; m.q.dst1 = nullptr; m.q.bias = nullptr; m.q.dbg = 0; m.q.tl = nullptr;
+    nemar_s16g_conv(m.q, m.pl, packed, st);
+    const long long total = (long long)N * Ks * H * W;
+    hipLaunchKernelGGL(k7_mf_sum_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)P, bias, out, Ks, H, W, m.PH, m.PW, fold,
+                       act, slope, total);
+}
+
 // Workspace layout of nemar_conv2d_bwd_data (floats), shared by the size query and the operator:
 //   [packed weights x stride^2 parity classes][padded-domain scratch (strided reflect)][flipped weights (C <= 4)]
 //   [compact border-ring gradient (stride-1 reflect)][ksplit slabs of the gradient (split reductions)]
@@ -1832,6 +1970,10 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     L.aux_cols_off = o;
     if (L.ring && pad == 1 && R == 3 && S == 3) o += 8ull * N * K * H;
     L.total = o;
+    if (k7_mf_eligible(K, C, R, S, stride, pad)) {                       // 7x7 stem (<= 4 input channels): [re-arranged weights | packed image | P]
+        const K7MfPlan m = k7_mf_plan(N, K, H, W, refl ? 6 : 3, BORDER_ZERO);
+        if (m.ok && m.total > L.total) L.total = m.total;
+    }
     if (C > 4 && nemar_k7_fm_eligible(K, C, R, S, stride, pad)) {       // 7x7 head (<= 4 output channels): [packed weights | padded-domain gradient]
         const size_t k7 = ((nemar_k7_fm_pack_floats(C) + 3) & ~(size_t)3) + (refl ? (size_t)N * C * (H + 6) * (W + 6) : 0);
         if (k7 > L.total) L.total = k7;
@@ -1865,6 +2007,10 @@ FwdLayout fwd_layout(int N, int H, int W, int K, int C, int R, int S, int stride
     if (g_ksplit && OH > 0 && OW > 0 && K > 4) L.ksplit = normalize_ksplit(C * R * S, small_problem_split(K, N * OH * OW, C * R * S));
     L.slab_off = (L.pack + 3) & ~(size_t)3;
     L.total = L.slab_off + (L.ksplit > 1 ? (size_t)L.ksplit * N * K * OH * OW : 0);
+    if (k7_mf_eligible(C, K, R, S, stride, pad)) {           // 7x7 head: [re-arranged weights | packed image | P] (either border)
+        const K7MfPlan m = k7_mf_plan(N, C, H, W, 3, BORDER_ZERO);
+        if (m.ok && m.total > L.total) L.total = m.total;
+    }
     return L;
 }
 
@@ -1899,6 +2045,17 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
         return NEMAR_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (C1 == 0 && k7_mf_eligible(C, K, R, S, stride, pad)) {
+        // 7x7 head (<= 4 output channels): vertical 7-tap convolution with (k, dx) pseudo-channels on the general 16-bit-pipe kernel, then
+        // the horizontal shift-sum with bias and activation (tanh included)
+        const K7MfPlan m = k7_mf_plan(N, C, H, W, 3, pad_mode);
+        if (m.ok) {
+            k7_mf_run(m, x0, w, K, C, 0, bias, y, N, H, W, 0, act, slope, (float*)workspace, prepacked, st);
+            g_last_route = 4;
+            NEMAR_CHECK_LAUNCH("conv2d_fwd (7x7 many -> few, 16-bit pipe)");
+            return NEMAR_OK;
+        }
+    }
     if (g_k7 && C1 == 0 && act != ACT_TANH && nemar_k7_fm_eligible(C, K, R, S, stride, pad)) {
         // 7x7 stem (<= 4 input channels): row-expanded source on the 16-bit matrix pipe, weights in registers (conv_k7.hip)
         if (!prepacked) nemar_k7_fm_pack(w, (long long)C * 49, 49, 0, K, C, workspace, st);
@@ -2004,6 +2161,17 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                   "conv2d_bwd_data: problem too large for 32-bit tile indexing");
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)workspace;
+    if (C1 == 0 && gx0 && !bias && act == ACT_NONE && k7_mf_eligible(K, C, R, S, stride, pad)) {
+        // 7x7 stem (<= 4 input channels): gx = the many -> few correlation of gy with flipped, transposed weights; reflect border: on the
+        // padded domain (gy through a 6-texel zero border), folded back inside the shift-sum pass
+        const K7MfPlan m = k7_mf_plan(N, K, OH, OW, refl ? 6 : 3, BORDER_ZERO);
+        if (m.ok) {
+            k7_mf_run(m, gy, w, C, K, 1, nullptr, gx0, N, H, W, refl ? 1 : 0, ACT_NONE, 0.f, wsf, prepacked, st);
+            g_last_route = 4;
+            NEMAR_CHECK_LAUNCH("conv2d_bwd_data (7x7 many -> few, 16-bit pipe)");
+            return NEMAR_OK;
+        }
+    }
     if (g_k7 && C1 == 0 && gx0 && !bias && act == ACT_NONE && C > 4 && nemar_k7_fm_eligible(K, C, R, S, stride, pad)) {
         // 7x7 head (<= 4 output channels): the data gradient is a few -> many convolution of gy with flipped, transposed weights
         // (conv_k7.hip).  Reflect border: on the padded (H + 6) x (W + 6) domain (gy through a 6-texel zero border), then the fold.

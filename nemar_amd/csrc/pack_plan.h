@@ -8,13 +8,14 @@
 #include <stddef.h>
 
 enum {
-    PACK_FAM_MAX = 0,           // stage 1: NEMAR_PACK_MAX_PARTS partial maxima of |w| per tensor (pack_plan.hip)
-    PACK_FAM_EXACT = 1,         // stage 2: the packs (conv.hip, conv_s16g.hip, conv_split16.hip, conv_k7.hip)
-    PACK_FAM_S16G = 2,
-    PACK_FAM_SPLIT16 = 3,
-    PACK_FAM_K7 = 4,
-    PACK_FAM_FLIPT = 5,         //          flipped + transposed weights of the narrow (<= 4 channel) data gradients (conv.hip)
-    PACK_FAMS = 6
+    PACK_FAM_PRE = 0,           // stage 0: re-arranged weight tensors that later stages read (conv.hip: the 7x7 many -> few layers)
+    PACK_FAM_MAX = 1,           // stage 1: NEMAR_PACK_MAX_PARTS partial maxima of |w| per tensor (pack_plan.hip)
+    PACK_FAM_EXACT = 2,         // stage 2: the packs (conv.hip, conv_s16g.hip, conv_split16.hip, conv_k7.hip)
+    PACK_FAM_S16G = 3,
+    PACK_FAM_SPLIT16 = 4,
+    PACK_FAM_K7 = 5,
+    PACK_FAM_FLIPT = 6,         //          flipped + transposed weights of the narrow (<= 4 channel) data gradients (conv.hip)
+    PACK_FAMS = 7
 };
 constexpr int NEMAR_PACK_MAX_PARTS = 64;
 // stage-1 job: out[b] = largest finite |x[i]| (bit pattern) over block b's share of x[0, n), b < NEMAR_PACK_MAX_PARTS — plain stores

@@ -24,10 +24,10 @@ Family g_fam[PACK_FAMS];
 
 struct Plan {
     std::vector<unsigned char> args[PACK_FAMS];     // host copies of the job arguments, per family
-    int njobs[PACK_FAMS] = {0, 0, 0, 0, 0, 0};
-    int gx[PACK_FAMS] = {0, 0, 0, 0, 0, 0}, gy[PACK_FAMS] = {0, 0, 0, 0, 0, 0};
+    int njobs[PACK_FAMS] = {0, 0, 0, 0, 0, 0, 0};
+    int gx[PACK_FAMS] = {0, 0, 0, 0, 0, 0, 0}, gy[PACK_FAMS] = {0, 0, 0, 0, 0, 0, 0};
     const unsigned char* dev = nullptr;             // committed image: the families' argument arrays back to back (256-byte aligned)
-    size_t dev_off[PACK_FAMS] = {0, 0, 0, 0, 0, 0};
+    size_t dev_off[PACK_FAMS] = {0, 0, 0, 0, 0, 0, 0};
     bool dirty = true;
 };
 std::map<int, Plan> g_plans;

@@ -104,30 +104,37 @@ __global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __res
         }
         Sample s[VEC];
         float wnw[VEC], wne[VEC], wsw[VEC], wse[VEC];
-        int onw[VEC];
-        bool vx0[VEC], vx1[VEC], vy0[VEC], vy1[VEC];
+        int o00[VEC], o01[VEC], o10[VEC], o11[VEC];
+        bool v00[VEC], v01[VEC], v10[VEC], v11[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             s[v] = locate(gx[v], gy[v], W, H);
             const float ex = 1.f - s[v].tx, ey = 1.f - s[v].ty;
             wnw[v] = ex * ey; wne[v] = s[v].tx * ey; wsw[v] = ex * s[v].ty; wse[v] = s[v].tx * s[v].ty;
-            vx0[v] = (unsigned)s[v].x0 < (unsigned)W;
-            vx1[v] = (unsigned)(s[v].x0 + 1) < (unsigned)W;
-            vy0[v] = (unsigned)s[v].y0 < (unsigned)H;
-            vy1[v] = (unsigned)(s[v].y0 + 1) < (unsigned)H;
-            onw[v] = s[v].y0 * W + s[v].x0;
+            const bool vx0 = (unsigned)s[v].x0 < (unsigned)W, vx1 = (unsigned)(s[v].x0 + 1) < (unsigned)W;
+            const bool vy0 = (unsigned)s[v].y0 < (unsigned)H, vy1 = (unsigned)(s[v].y0 + 1) < (unsigned)H;
+            v00[v] = vx0 && vy0; v01[v] = vx1 && vy0; v10[v] = vx0 && vy1; v11[v] = vx1 && vy1;
+            // corner addresses CLAMPED into the image: the loads below are unconditional (a conditional load makes hipcc branch around
+            // it and wait for every load separately — 48 serialized gathers per thread), zeros are selected afterwards
+            const int xa = min(max(s[v].x0, 0), W - 1), xb = min(max(s[v].x0 + 1, 0), W - 1);
+            const int ya = min(max(s[v].y0, 0), H - 1), yb = min(max(s[v].y0 + 1, 0), H - 1);
+            o00[v] = ya * W + xa; o01[v] = ya * W + xb; o10[v] = yb * W + xa; o11[v] = yb * W + xb;
         }
         for (int c = 0; c < C; ++c) {
             const float* p = inN + (size_t)c * iplane;
-            float r[VEC];
+            float a[VEC], b[VEC], cc[VEC], d[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const float a = (vx0[v] && vy0[v]) ? p[onw[v]] : 0.f;
-                const float b = (vx1[v] && vy0[v]) ? p[onw[v] + 1] : 0.f;
-                const float cc = (vx0[v] && vy1[v]) ? p[onw[v] + W] : 0.f;
-                const float d = (vx1[v] && vy1[v]) ? p[onw[v] + W + 1] : 0.f;
-                r[v] = a * wnw[v] + b * wne[v] + cc * wsw[v] + d * wse[v];
+                a[v] = p[o00[v]];
+                b[v] = p[o01[v]];
+                cc[v] = p[o10[v]];
+                d[v] = p[o11[v]];
             }
+            float r[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                r[v] = (v00[v] ? a[v] : 0.f) * wnw[v] + (v01[v] ? b[v] : 0.f) * wne[v] + (v10[v] ? cc[v] : 0.f) * wsw[v] +
+                       (v11[v] ? d[v] : 0.f) * wse[v];
             float* q = outN + (size_t)c * oplane + (size_t)h * Wo + w0;
             if (VEC == 4) {
                 *reinterpret_cast<float4*>(q) = make_float4(r[0], r[1], r[2], r[3]);
@@ -759,8 +766,9 @@ __global__ __launch_bounds__(64) void affine_ggrid_fold_kernel(const float* __re
 template <int MODE>
 int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int H, int W, int Ho, int Wo,
                hipStream_t st) {
+    extern int g_fwd_vec1;
     const bool vec4 = (Wo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (((uintptr_t)gsrc & 15) == 0) &&
-                      (MODE != GRID_EXPLICIT);
+                      (MODE != GRID_EXPLICIT) && !g_fwd_vec1;
     const long long items = (long long)Ho * (vec4 ? Wo / 4 : Wo);
     int gx = nemar_cdiv(items, 256);
     const int cap = nemar_cdiv(256 * 8, N);
@@ -780,6 +788,9 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
 int g_tiled_scatter = 0;
 int g_gather_512 = 1;       // 512-thread workgroups in the gather pass (default: 170 vs 249 us at 8x3x1024^2); nemar_grid_sample_tune(16): 256
 int g_gather_follow = 1;    // gather windows follow the field (tile_offset_kernel); nemar_grid_sample_tune(32): centred on the tiles (round 2)
+int g_fwd_vec1 = 1;         // forward: one pixel per lane (default: every gather / store instruction of a wave covers whole cache lines;
+                            // 8x3x1024^2 identity 92 -> 71 us, smooth 3-px field 104 -> 74 us, profiles/r4_gs_fwd_vec.txt); nemar_grid_sample_tune(64):
+                            // the round-1 form, 4 pixels per lane with 16-byte stores
 int g_gather_fused = 1;     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
 
 struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, wgc_off, list_off, gpart_off, toff_off, total; int tiles_x, tiles_y; };
@@ -881,6 +892,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 }  // namespace
 
 NEMAR_API int nemar_grid_sample_tune(int variant) {
+    g_fwd_vec1 = (variant & 64) ? 0 : 1;
     g_gather_fused = (variant & 8) ? 0 : 1;
     g_gather_512 = (variant & 16) ? 0 : 1;
     g_gather_follow = (variant & 32) ? 0 : 1;

@@ -556,3 +556,27 @@ def test_conv_k7_forward_tile_scales(be):
 def test_conv_k7_data_gradient(be, case):
     N, C, H, W, Kc, pm = case
     K.case_conv_k7_bwd_data(be, N, C, H, W, Kc, pm)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 32, 8, 24, 3, K.PAD_REFLECT, K.O.ACT_TANH),      # the RGB head: 32 -> 3, reflect border, tanh in the shift-sum pass
+    (1, 16, 5, 40, 1, K.PAD_ZERO, K.O.ACT_NONE),         # one output channel, zero border
+    (1, 48, 6, 30, 4, K.PAD_REFLECT, K.O.ACT_RELU),      # four outputs: all 32 (k, dx) rows in use
+])
+def test_conv_k7_many_to_few_forward(be, case):
+    """7x7 layers with <= 4 OUTPUT channels: vertical 7-tap convolution with (k, dx) pseudo-channels on the general 16-bit-pipe kernel +
+    horizontal shift-sum (csrc/conv.hip k7_mf_*), against the float64 oracle."""
+    N, C, H, W, Kc, pm, act = case
+    K.case_conv_fwd(be, N, C, 0, H, W, Kc, 7, 1, 3, pm, act=act)
+    assert be.lib.last_route() == K.ROUTE_K7
+
+
+@pytest.mark.parametrize("case", [
+    (2, 3, 9, 20, 32, K.PAD_REFLECT), (1, 2, 6, 26, 16, K.PAD_ZERO), (1, 4, 12, 18, 48, K.PAD_REFLECT),
+])
+def test_conv_k7_many_to_few_data_gradient(be, case):
+    """data gradient of a 7x7 layer with <= 4 INPUT channels (the stem): the same two passes with flipped, transposed weights; reflect
+    border folded inside the shift-sum pass"""
+    N, C, H, W, Kc, pm = case
+    K.case_conv_bwd_data(be, N, C, 0, H, W, Kc, 7, 1, 3, pm)
+    assert be.lib.last_route() == K.ROUTE_K7
