@@ -2059,7 +2059,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     if (g_k7 && C1 == 0 && act != ACT_TANH && nemar_k7_fm_eligible(C, K, R, S, stride, pad)) {
         // 7x7 stem (<= 4 input channels): row-expanded source on the 16-bit matrix pipe, weights in registers (conv_k7.hip)
         if (!prepacked) nemar_k7_fm_pack(w, (long long)C * 49, 49, 0, K, C, workspace, st);
-        nemar_k7_fm_conv(x0, C, H, W, 3, pad_mode == BORDER_REFLECT, workspace, bias, y, K, N, H, W, act, slope, st);
+        nemar_k7_fm_conv(x0, C, H, W, 3, pad_mode == BORDER_REFLECT, workspace, bias, y, K, N, H, W, act, slope, 0, st);
         g_last_route = 4;
         NEMAR_CHECK_LAUNCH("conv2d_fwd (7x7, 16-bit pipe)");
         return NEMAR_OK;
@@ -2176,14 +2176,16 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         // 7x7 head (<= 4 output channels): the data gradient is a few -> many convolution of gy with flipped, transposed weights
         // (conv_k7.hip).  Reflect border: on the padded (H + 6) x (W + 6) domain (gy through a 6-texel zero border), then the fold.
         if (!prepacked) nemar_k7_fm_pack(w, 49, (long long)C * 49, 1, C, K, workspace, st);
-        if (refl) {
+        if (refl && nemar_k7_fm_fold_ok(H, W)) {             // mirrored contributions accumulated in the kernel: no padded tensor, no fold pass
+            nemar_k7_fm_conv(gy, K, OH, OW, 6, 0, workspace, nullptr, gx0, C, N, H, W, ACT_NONE, 0.f, 1, st);
+        } else if (refl) {
             float* padded = wsf + ((nemar_k7_fm_pack_floats(C) + 3) & ~(size_t)3);
-            nemar_k7_fm_conv(gy, K, OH, OW, 6, 0, workspace, nullptr, padded, C, N, H + 6, W + 6, ACT_NONE, 0.f, st);
+            nemar_k7_fm_conv(gy, K, OH, OW, 6, 0, workspace, nullptr, padded, C, N, H + 6, W + 6, ACT_NONE, 0.f, 0, st);
             const long long total = (long long)N * C * H * W;
             hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded, gx0, H, W, pad,
                                total);
         } else {
-            nemar_k7_fm_conv(gy, K, OH, OW, 3, 0, workspace, nullptr, gx0, C, N, H, W, ACT_NONE, 0.f, st);
+            nemar_k7_fm_conv(gy, K, OH, OW, 3, 0, workspace, nullptr, gx0, C, N, H, W, ACT_NONE, 0.f, 0, st);
         }
         g_last_route = 4;
         NEMAR_CHECK_LAUNCH("conv2d_bwd_data (7x7, 16-bit pipe)");

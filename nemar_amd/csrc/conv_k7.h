@@ -24,4 +24,7 @@ size_t nemar_k7_fm_pack_floats(int M);
 void nemar_k7_fm_pack(const float* w, long long wsm, long long wsc, int flip, int M, int Cs, void* packed, hipStream_t st);
 // src [N][Cs][Hs][Ws] seen through a border of `pad` texels (reflect: mirrored, else zero); dst [N][M][Hv][Wv], view = (Hv + 6) x (Wv + 6)
 void nemar_k7_fm_conv(const float* src, int Cs, int Hs, int Ws, int pad, int reflect, const void* packed, const float* bias, float* dst,
-                      int M, int N, int Hv, int Wv, int act, float slope, hipStream_t st);
+                      int M, int N, int Hv, int Wv, int act, float slope, int fold, hipStream_t st);
+// fold = 1: dst is the IMAGE-domain gradient of a reflect-padded layer (Hv x Wv = the image, src through a 6-texel zero border): the
+// mirrored contributions are accumulated inside the kernel.  Needs nemar_k7_fm_fold_ok(Hv, Wv).
+static inline bool nemar_k7_fm_fold_ok(int H, int W) { return H % 4 == 0 && H >= 8 && W % 64 == 0; }

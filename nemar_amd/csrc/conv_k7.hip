@@ -484,11 +484,17 @@ struct RegK7Pack {
     RegK7Pack() { nemar_pack_register(PACK_FAM_K7, sizeof(K7PackArgs), k7_fm_pack_multi); }
 } g_reg_k7_pack;
 
-template <int Cs>
+// FOLD (the data gradient of a REFLECT-padded layer, W % 64 == 0, H % 4 == 0, H >= 8): the tile is a tile of the IMAGE; the gradient of
+// the padded input at every padded position that mirrors onto one of its pixels is accumulated into the SAME accumulator — more taps
+// over other rows / columns of the row-expanded source, no padded-domain tensor, no fold pass.  Padded row of image row y: y + 3, plus
+// 3 - y (1 <= y <= 3) / 2 (H - 1) - y + 3 (H - 4 <= y <= H - 2): the first / last tile stage 7 rows (padded rows 0..6 / H-1..H+5) instead
+// of 4; columns likewise through per-lane operand addresses (lanes without a mirror read a column that stays zero).
+template <int Cs, bool FOLD>
 __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
-    constexpr int NR = FM_RT + 6;
-    __shared__ __attribute__((aligned(16))) u32x4 Bs[2][FM_G][FM_RT][FM_HCP];
-    __shared__ unsigned Raw[4][NR][FM_HCP];
+    constexpr int NRB = FOLD ? 7 : FM_RT, NR = NRB + 6;      // operand rows / halo rows a tile may stage
+    constexpr int HC = FOLD ? 76 : FM_HC, HCP = FOLD ? 84 : FM_HCP, GW = (7 * Cs + 7) / 8;      // valid / allocated columns (FOLD: 76..83 stay zero)
+    __shared__ __attribute__((aligned(16))) u32x4 Bs[2][GW][NRB][HCP];
+    __shared__ unsigned Raw[Cs][NR][HCP];
     __shared__ unsigned red[4];
     __shared__ float bias_s[64];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
@@ -507,13 +513,19 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
     const int ntiles = p.N * p.tiles_y * p.tiles_x, tstep = (int)gridDim.x / p.mblks;
     const size_t splane = (size_t)p.small.H * p.small.W, dplane = (size_t)p.Hv * p.Wv;
 
-    constexpr int NSL = (4 * NR * FM_HCP + 255) / 256;
-    constexpr int nsl = (Cs * NR * FM_HCP + 255) >> 8;
+    constexpr int NSL = (Cs * NR * HCP + 255) / 256, nsl = NSL;
+    if (FOLD) {                                              // the always-zero columns
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * GW * NRB * (HCP - HC); i += 256) {
+            const int col = HC + i % (HCP - HC), rest = i / (HCP - HC);
+            Bs[rest / (GW * NRB)][(rest / NRB) % GW][rest % NRB][col] = zero;
+        }
+    }
     int s_crx[NSL];                                          // loader slot = element (c, halo row r, halo column xi): c << 16 | r << 8 | xi
 #pragma unroll
     for (int i = 0; i < NSL; ++i) {
-        const int idx = tid + 256 * i, c = idx / (NR * FM_HCP), rem = idx - c * (NR * FM_HCP), r = rem / FM_HCP;
-        s_crx[i] = (c << 16) | (r << 8) | (rem - r * FM_HCP);
+        const int idx = tid + 256 * i, c = idx / (NR * HCP), rem = idx - c * (NR * HCP), r = rem / HCP;
+        s_crx[i] = (c << 16) | (r << 8) | (rem - r * HCP);
     }
 #define K7_SC(i_) (s_crx[i_] >> 16)
 #define K7_SR(i_) ((s_crx[i_] >> 8) & 0xff)
@@ -521,6 +533,8 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
     // the halo of a tile, one element per slot — UNCONDITIONAL loads from clamped addresses (a conditional load, or a select right
     // behind a load, makes hipcc wait for every load separately), zeros selected when the values are consumed.  Issued one tile AHEAD.
     float v[NSL];
+    // view row of operand row 0 of tile row ty: the tile's first row; FOLD: padded rows y0 + 3 .. (the first tile starts at padded row 0)
+    auto ybase_of = [&](int ty) { return FOLD ? (ty == 0 ? 0 : ty * FM_RT + 3) : ty * FM_RT; };
     auto issue_loads = [&](int t) {
         const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
         const float* const sbase = p.small.p + (size_t)n * Cs * splane;
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
         for (int i = 0; i < NSL; ++i) {
             if (i < nsl) {
                 const int c = K7_SC(i) < Cs ? K7_SC(i) : Cs - 1;
-                const int ry = view_index(ty * FM_RT + K7_SR(i), p.small.pad, p.small.H, p.small.mode);
+                const int ry = view_index(ybase_of(ty) + K7_SR(i), p.small.pad, p.small.H, p.small.mode);
                 const int cx = view_index(tx * FM_TW + K7_SX(i), p.small.pad, p.small.W, p.small.mode);
                 v[i] = sbase[(size_t)c * splane + (size_t)(ry < 0 ? 0 : ry) * p.small.W + (cx < 0 ? 0 : cx)];
             }
@@ -538,14 +552,16 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
     if (t_first < ntiles) issue_loads(t_first);
     for (int t = t_first; t < ntiles; t += tstep) {
         const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
-        const int y0 = ty * FM_RT, x0 = tx * FM_TW;
+        const int y0 = ty * FM_RT, x0 = tx * FM_TW, Yb = ybase_of(ty);
+        const bool top = FOLD && ty == 0, bot = FOLD && ty == p.tiles_y - 1;      // tiles with mirrored rows: 7 operand rows
+        const int nrb = (top || bot) ? NRB : FM_RT;
         unsigned mloc = 0;
 #pragma unroll
         for (int i = 0; i < NSL; ++i) {
             if (i < nsl) {
-                const int ry = view_index(y0 + K7_SR(i), p.small.pad, p.small.H, p.small.mode);
+                const int ry = view_index(Yb + K7_SR(i), p.small.pad, p.small.H, p.small.mode);
                 const int cx = view_index(x0 + K7_SX(i), p.small.pad, p.small.W, p.small.mode);
-                v[i] = (K7_SC(i) < Cs && K7_SX(i) < FM_HC && ry >= 0 && cx >= 0) ? v[i] : 0.f;
+                v[i] = (K7_SC(i) < Cs && K7_SX(i) < HC && ry >= 0 && cx >= 0) ? v[i] : 0.f;
                 const unsigned u = __builtin_bit_cast(unsigned, v[i]) & 0x7fffffffu;
                 mloc = max(mloc, u < 0x7f800000u ? u : 0u);
             }
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
         const float scale = pow2f(127 + TEXP + 127 - E);
 #pragma unroll
         for (int i = 0; i < NSL; ++i) {
-            if (i < nsl && K7_SC(i) < 4) {
+            if (i < nsl && K7_SC(i) < Cs) {
                 const _Float16 h = (_Float16)(v[i] * scale);
                 const _Float16 l = (_Float16)__builtin_fmaf(v[i], scale, -(float)h);
                 f16x2 hl;
@@ -572,13 +588,13 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
         __builtin_amdgcn_s_barrier();
 
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < (NRB * HC + 255) / 256; ++pass) {
             const int q = tid + 256 * pass;
-            if (q < FM_RT * FM_HC) {
-                const int y = q / FM_HC, xi = q - y * FM_HC;
+            if (q < nrb * HC) {
+                const int y = q / HC, xi = q - y * HC;
 #pragma unroll
-                for (int g = 0; g < FM_G; ++g) {
-                    if (g * 8 < 7 * Cs) {
+                for (int g = 0; g < GW; ++g) {
+                    {
                         unsigned reg[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -594,10 +610,6 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
                         }
                         Bs[0][g][y][xi] = hi;
                         Bs[1][g][y][xi] = lo;
-                    } else if (t == t_first) {
-                        const u32x4 zero = {0u, 0u, 0u, 0u};
-                        Bs[0][g][y][xi] = zero;
-                        Bs[1][g][y][xi] = zero;
                     }
                 }
             }
@@ -614,18 +626,38 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            // operand rows / columns of this wave's pixels: the pixel's own padded position, and (FOLD) its mirrors
+            const int rm = FOLD ? yl + 3 - (Yb - y0) : yl;                              // main row (Yb - y0 = 3, or 0 in the first tile)
+            const int rr = top ? (yl >= 1 ? 3 - yl : -1) : (bot ? (yl <= 2 ? 6 - yl : -1) : -1);      // mirrored row or none (wave-uniform)
 #pragma unroll
-            for (int dx = 0; dx < 7; ++dx)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const u32x4 bh = Bs[0][2 * s + lhi][yl][32 * i + l31 + dx], bl = Bs[1][2 * s + lhi][yl][32 * i + l31 + dx];
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[dx][s][1]), __builtin_bit_cast(f16x8, bh), acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[dx][s][0]), __builtin_bit_cast(f16x8, bl), acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[dx][s][0]), __builtin_bit_cast(f16x8, bh), acc[i], 0, 0, 0);
-                    }
+            for (int i = 0; i < 2; ++i) {
+                const int xl = 32 * i + l31, cm = FOLD ? xl + 3 : xl;                   // main column
+                int cx = HC;                                                            // mirrored column (a zero column: none)
+                bool anyc = false;                                                      // (wave-uniform: this pixel tile has border columns)
+                if (FOLD) {
+                    if (x0 == 0 && i == 0) { anyc = true; if (xl >= 1 && xl <= 3) cx = 3 - xl; }
+                    if (x0 + FM_TW == p.Wv && i == 1) { anyc = true; if (xl >= 60 && xl <= 62) cx = 2 * 63 - xl + 3; }
                 }
+#pragma unroll
+                for (int var = 0; var < (FOLD ? 4 : 1); ++var) {
+                    const int row = (var & 1) ? rr : rm;
+                    if ((var & 1) && rr < 0) continue;
+                    if ((var & 2) && !anyc) continue;
+                    const int col = (var & 2) ? cx : cm;
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            if (2 * s >= GW) continue;
+                            const u32x4 zero = {0u, 0u, 0u, 0u};
+                            const bool on = 2 * s + lhi < GW;                           // (Cs <= 2: the second k word does not exist)
+                            const u32x4 bh = on ? Bs[0][on ? 2 * s + lhi : 0][row][col + dx] : zero, bl = on ? Bs[1][on ? 2 * s + lhi : 0][row][col + dx] : zero;
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[dx][s][1]), __builtin_bit_cast(f16x8, bh), acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[dx][s][0]), __builtin_bit_cast(f16x8, bl), acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[dx][s][0]), __builtin_bit_cast(f16x8, bh), acc[i], 0, 0, 0);
+                        }
+                }
+            }
 
             const float u12 = u1 * u2;
             const bool one_mul = u12 != 0.f && u12 < 3.0e38f;
@@ -754,7 +786,7 @@ void nemar_k7_fm_pack(const float* w, long long wsm, long long wsc, int flip, in
 }
 
 void nemar_k7_fm_conv(const float* src, int Cs, int Hs, int Ws, int pad, int reflect, const void* packed, const float* bias, float* dst,
-                      int M, int N, int Hv, int Wv, int act, float slope, hipStream_t st) {
+                      int M, int N, int Hv, int Wv, int act, float slope, int fold, hipStream_t st) {
     K7FmParams p;
     p.small = K7View{src, Cs, Hs, Ws, pad, reflect ? MODE_REFLECT : MODE_ZERO};
     p.wp = (const u32x4*)packed;
@@ -763,8 +795,8 @@ void nemar_k7_fm_conv(const float* src, int Cs, int Hs, int Ws, int pad, int ref
     p.tiles_x = nemar_cdiv(Wv, FM_TW); p.tiles_y = nemar_cdiv(Hv, FM_RT); p.mblks = nemar_cdiv(M, 64);
     const long long ntiles = (long long)N * p.tiles_x * p.tiles_y;
     const int wgs = (int)(ntiles < 512 ? ntiles : 512) * p.mblks;
-    if (Cs == 1) hipLaunchKernelGGL(k7_fm_kernel<1>, dim3(wgs), dim3(256), 0, st, p);
-    else if (Cs == 2) hipLaunchKernelGGL(k7_fm_kernel<2>, dim3(wgs), dim3(256), 0, st, p);
-    else if (Cs == 3) hipLaunchKernelGGL(k7_fm_kernel<3>, dim3(wgs), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k7_fm_kernel<4>, dim3(wgs), dim3(256), 0, st, p);
+#define K7_FM(C_, F_) hipLaunchKernelGGL((k7_fm_kernel<C_, F_>), dim3(wgs), dim3(256), 0, st, p)
+    if (fold) { if (Cs == 1) K7_FM(1, true); else if (Cs == 2) K7_FM(2, true); else if (Cs == 3) K7_FM(3, true); else K7_FM(4, true); }
+    else { if (Cs == 1) K7_FM(1, false); else if (Cs == 2) K7_FM(2, false); else if (Cs == 3) K7_FM(3, false); else K7_FM(4, false); }
+#undef K7_FM
 }

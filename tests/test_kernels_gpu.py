@@ -521,6 +521,8 @@ def test_conv_k7_forward_tile_scales(be):
 
 @pytest.mark.parametrize("case", [
     (2, 64, 9, 40, 3, K.PAD_REFLECT), (1, 32, 8, 16, 2, K.PAD_ZERO), (1, 64, 4, 70, 1, K.PAD_REFLECT),
+    (1, 32, 8, 64, 3, K.PAD_REFLECT),       # in-kernel fold: first and last row tile, one column tile holding both mirrored borders
+    (1, 64, 12, 128, 2, K.PAD_REFLECT),     # ... an interior row tile, the two borders in different column tiles
     (2, 64, 128, 96, 3, K.PAD_REFLECT),
 ])
 def test_conv_k7_data_gradient(be, case):
