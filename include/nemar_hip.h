@@ -8,8 +8,9 @@
  *   - plain C: pointers + sizes, no torch types.  Every pointer is DEVICE memory owned by the caller;
  *     tensors are contiguous NCHW float32.  The library never allocates, frees or synchronises.
  *   - every launch goes on `stream` (a hipStream_t passed as void*; NULL = the null stream), so the caller's
- *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream.  The only process-global
- *     state are the nemar_tune* measurement switches and the scratch arena registered with nemar_set_scratch (below).
+ *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream: every input of an operator —
+ *     including the side inputs of the wide-layer route (scratch arena, max words, planes: nemar_conv_extras) — travels with
+ *     the call.  The only process-global state are the nemar_tune* measurement switches and the recorded weight-pack plans.
  *   - return value: 0 on success, negative on error (NEMAR_EINVAL bad shape/pointer/unsupported,
  *     NEMAR_ELAUNCH HIP launch error, NEMAR_EWORKSPACE workspace too small); nemar_last_error() returns the
  *     message of the calling thread's last failure.  Python glue raises on non-zero.
@@ -124,9 +125,9 @@ size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, int K, int 
 int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
                             int N, int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad,
                             int pad_mode, void* workspace, size_t ws_bytes, void* stream);
-/* The same three entry points with their SIDE INPUTS passed per call instead of registered process-wide (nemar_set_scratch,
- * nemar_absmax_hint, nemar_planes_hint below — those remain and are what a thin autograd binding uses; the registered hints are
- * per calling thread).  Any member may be NULL / 0 = "not given".  Same kernels, bit-identical results.
+/* The same three entry points with the SIDE INPUTS of the wide-layer fp16 x 3 route (below) passed with the call — the only way to
+ * hand them over (rounds 2-3 also had process-wide registrations: nemar_set_scratch / nemar_absmax_hint / nemar_planes_hint; they are
+ * gone).  Any member may be NULL / 0 = "not given"; extras == NULL is the plain entry point.  Same kernels, bit-identical results.
  *   scratch / scratch_bytes     transient arena of the wide-layer fp16 x 3 route for THIS call (nemar_conv2d_scratch bytes)
  *   src_max_words / _count      per-sample max |source| words (source = x0 for fwd / bwd_weight, gy for bwd_data); count = N or 1
  *   src2_max_words / _count     bwd_weight only: the same for gy
@@ -199,7 +200,7 @@ int nemar_tune(int key, int value);
 /* Which kernel family served the calling thread's last nemar_conv2d_* call: 0 exact-fp32 implicit GEMM, 1 narrow (<= 4 channel)
  * VALU kernels, 2 split-16 kernels of the wide residual-block layers, 3 general 16-bit-pipe kernels (tests / tools). */
 int nemar_last_route(void);
-/* Counter bumped by every nemar_tune / nemar_set_scratch call.  The route a shape takes — and with it the FORMAT of the packed
+/* Counter bumped by every nemar_tune call.  The route a shape takes — and with it the FORMAT of the packed
  * weight image a `prepacked` call finds in its workspace — is a function of (shape, these settings): a caller that caches packed
  * workspaces keys them with this value. */
 int nemar_config_epoch(void);
@@ -209,12 +210,10 @@ int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycl
  * :576-597; >= 128 channels, >= 2 G multiply-adds) run on the 16-bit matrix pipe at fp32 accuracy: each fp32 operand is split into
  * two power-of-two-scaled fp16 terms and three partial products are accumulated in fp32 (csrc/conv_split16*.hip; measured error
  * against float64 below that of the exact-fp32 MFMA kernels).  The split copies of the source tensors live in this
- * arena for the duration of the call.  nemar_conv2d_scratch -> bytes the layer wants (0: never uses it); nemar_set_scratch
- * registers a caller-owned device buffer (process-global like the tune switches: one stream at a time may run operators that use
- * it; bytes = 0 unregisters).  A layer whose need exceeds the registered arena, or with no arena at all, runs on the exact-fp32
- * MFMA kernels instead — same results within fp32 rounding. */
+ * arena for the duration of the call.  nemar_conv2d_scratch -> bytes the layer wants (0: never uses it); the caller passes a device
+ * buffer of at least that size as nemar_conv_extras.scratch (one stream at a time per buffer).  A layer called without an arena, or
+ * with one that is too small, runs on the exact-fp32 MFMA kernels instead — same results within fp32 rounding. */
 size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad);
-int nemar_set_scratch(void* scratch, size_t bytes);
 /* The fp16 form of those kernels scales every SAMPLE of a source tensor by its own power of two, derived from the largest finite
  * magnitude of the sample (so samples of very different magnitude in one batch — the batched real / fake passes — do not share a
  * scale).  Error bound of the fp16 x 3 form, per product v w: |error| <= 3 * 2^-22 |v w| as long as |v| >= 2^-14 max_sample|v|
@@ -223,12 +222,10 @@ int nemar_set_scratch(void* scratch, size_t bytes);
  * is per workgroup tile and 16-channel chunk, or per channel row in the weight gradient — csrc/conv_s16g*.hip.)
  * A caller that feeds one tensor to several calls (x: forward and weight gradient; gy: data and weight gradient) computes the words
  * once with nemar_absmax_samples (out_words: `samples` 4-byte words that are ZERO on entry — the kernel takes an atomic max of the bit
- * patterns into them; nemar_absmax = one sample) and registers them with nemar_absmax_hint(tensor, words, count) for the calls that
- * follow (count = the tensor's batch size, or 1 = one word for the whole tensor); nemar_absmax_hint(tensor, NULL, 0) withdraws it.
- * Without a hint every call runs its own max pass.  (Process-global like the scratch arena; at most four hints.) */
+ * patterns into them; nemar_absmax = one sample) and passes them as nemar_conv_extras.src_max_words / src2_max_words (count = the
+ * tensor's batch size, or 1 = one word for the whole tensor).  Without them every call runs its own max pass. */
 int nemar_absmax(const float* t, long long n, void* out_word, void* stream);
 int nemar_absmax_samples(const float* t, int samples, long long per_sample, void* out_words, void* stream);
-int nemar_absmax_hint(const void* tensor, const void* words, int count);
 /* Measurement hook for bench.py's roofline entry: while enabled, HIP events are recorded on the launch stream around the main
  * kernel (igemm_split16_kernel) of every forward / data-gradient call of those layers; read -> summed duration, summed algorithmic
  * (fp32-equivalent) flop 2 N OH OW K C R S of the timed launches, and their count (synchronises on the recorded events, resets). */
@@ -249,8 +246,8 @@ int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* s
 int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                        int act, float slope, void* stream);
 /* The same, and max |output| (finite elements) of every SAMPLE into max_words[sample]: what nemar_absmax_samples would compute in a
- * pass of its own — the producer has the values in registers.  The words are what nemar_absmax_hint takes (the fp16 x 3
- * convolutions consume them).  max_words is a buffer of NEMAR_MAX_WORDS(samples) 4-byte words, no initialisation needed: the first
+ * pass of its own — the producer has the values in registers.  The words are what nemar_conv_extras.src_max_words takes (the
+ * fp16 x 3 convolutions consume them).  max_words is a buffer of NEMAR_MAX_WORDS(samples) 4-byte words, no initialisation needed: the first
  * `samples` words are the result, the rest is scratch for the per-workgroup partials a second tiny launch reduces (no atomics —
  * thousands of workgroups' device-scope atomicMax on a handful of words cost more than the pass they replaced).
  * planes_per_sample <= NEMAR_MAX_PARTIALS. */
@@ -264,12 +261,12 @@ int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, 
 /* InstanceNorm (+ activation, + Dropout(p) drawn exactly as nemar_dropout draws it over the [N,C,H,W] tensor, + residual) that ALSO
  * writes its output as the fp16 x 3 planes a following 3x3 / pad-1 REFLECT convolution of the wide-layer route consumes
  * (reference: the conv -> InstanceNorm -> ReLU -> [Dropout] -> ReflectionPad2d(1) -> conv chain of ResnetBlock,
- * models/networks.py:418-446) — the consumer then skips its max and split passes (nemar_planes_hint + nemar_absmax_hint below).
+ * models/networks.py:418-446) — the consumer then skips its max and split passes (nemar_conv_extras.src_planes + .src_max_words).
  *   y          fp32 output or NULL (planes only: nothing else reads it)
  *   planes     2 * N * (C/8) * (H+4) * (W+4) 16-byte words (hi plane, lo plane), layout of conv_split16.hip
  *   scale_words[N]  out: the a-priori BOUND each sample was scaled by, sqrt(HW) [/ (1-p)] [+ max |residual| of the sample] —
- *              InstanceNorm's output cannot exceed it, so the scale is known before the first element exists; pass these words to
- *              nemar_absmax_hint for the consuming convolution (its epilogue unscales with them).  A bound 2^k above the actual
+ *              InstanceNorm's output cannot exceed it, so the scale is known before the first element exists; pass these words as
+ *              src_max_words of the consuming convolution (its epilogue unscales with them).  A bound 2^k above the actual
  *              maximum costs nothing for k <= 8: elements above 2^(k-14) x max keep the split's 22 bits, smaller ones are off by
  *              <= 2^(k-36) x max (norm_planes.hip).
  *   residual_max_words[N]  required with a residual: its per-sample maxima (a producer's max words)
@@ -279,11 +276,6 @@ int nemar_instnorm_fwd_planes(const float* x, const float* residual, const void*
                               int N, int C, int H, int W, float eps, int act, float slope, float dropout_p,
                               unsigned long long seed, unsigned offset, void* planes, void* scale_words, void* max_words,
                               void* stream);
-/* "the planes of `tensor` ([N,C,H,W], reflect 3x3 layout) already exist at `planes`": consumed by the next nemar_conv2d_fwd whose
- * source is `tensor` when that layer runs on the fp16 x 3 wide-layer route AND an nemar_absmax_hint with N words is registered for
- * the same tensor (the words the planes were scaled by); ignored otherwise.  planes = NULL clears. */
-int nemar_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W);
-
 /* ---- K5/K6/K7: pointwise, pooling, resize, dropout -----------------------------------------------------------------
  * act_bwd: gx = gy * f'(.) expressed with the activation OUTPUT y (f fused into a conv epilogue):
  *     nn.LeakyReLU / nn.ReLU / nn.Tanh — reference models/networks.py:377,576 ; models/stn/layers.py:61-64. */

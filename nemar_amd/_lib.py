@@ -45,10 +45,8 @@ SIGNATURES = {
     "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz,
                                      _vp]),
     "nemar_conv2d_scratch": (_sz, [_i] * 9),
-    "nemar_set_scratch": (_i, [_vp, _sz]),
     "nemar_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "nemar_absmax_samples": (_i, [_vp, _i, _ll, _vp, _vp]),
-    "nemar_absmax_hint": (_i, [_vp, _vp, _i]),
     "nemar_kernel_timer": (_i, [_i]),
     "nemar_kernel_timer_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
@@ -62,7 +60,6 @@ SIGNATURES = {
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
     "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp]),
-    "nemar_planes_hint": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "nemar_set_dropout_base": (_i, [_vp]),
     "nemar_store_words": (_i, [_vp, _vp, _i, _vp]),
     "nemar_pack_plan_record": (_i, [_i]),

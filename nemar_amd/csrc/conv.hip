@@ -1094,12 +1094,10 @@ static int g_s16g_wgrad_first = 0;  // key 26: 1 = the in-kernel-split weight gr
 static int g_s16g_wgrad = 1;        // key 29: weight gradients on the in-kernel-split kernels (conv_s16g_wgrad.hip)
 static int g_s16g_fold = 1;         // key 30: stride-1 reflect data gradients on the padded domain + fold
 static long long g_s16g_min_mmac = 30;   // key 25: ... above this many million multiply-adds (tiny layers are launch-bound either way)
-static void* g_scratch_reg = nullptr;        // nemar_set_scratch: the registered arena
-static size_t g_scratch_reg_bytes = 0;
-static thread_local void* t_scratch = nullptr;        // nemar_conv2d_*_ex: this call's own arena (takes precedence)
+static thread_local void* t_scratch = nullptr;        // nemar_conv2d_*_ex: this call's scratch arena (nemar_conv_extras.scratch)
 static thread_local size_t t_scratch_bytes = 0;
-#define g_scratch (t_scratch ? t_scratch : g_scratch_reg)
-#define g_scratch_bytes (t_scratch ? t_scratch_bytes : g_scratch_reg_bytes)
+#define g_scratch t_scratch
+#define g_scratch_bytes t_scratch_bytes
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
 static int g_deterministic = 1;  // tuning switch (key 14): 1 = split reductions go through per-split slabs summed in order (bitwise
                                  // reproducible backward pass), 0 = fp32 atomics in the weight / bias gradients (round-1 scheme)
@@ -2606,17 +2604,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     return NEMAR_EINVAL;
 }
 
-// Transient scratch arena shared by the operators of one stream (split source planes of the bf16 x 6 convolutions).  The
-// caller owns it and keeps it alive while calls that may use it are in flight; bytes == 0 unregisters.
-NEMAR_API int nemar_set_scratch(void* scratch, size_t bytes) {
-    ++g_config_epoch;
-    g_scratch_reg = bytes ? scratch : nullptr;
-    g_scratch_reg_bytes = scratch ? bytes : 0;
-    return NEMAR_OK;
-}
-
-// ---- per-call form of the side inputs (scratch arena, max words, producer-written planes): what nemar_set_scratch /
-// nemar_absmax_hint / nemar_planes_hint register process-wide, passed with the call instead.  Same kernels, same results.
+// ---- the side inputs of the wide-layer route (scratch arena, per-sample max words, producer-written planes) travel WITH the call
+// (nemar_conv_extras): nothing is registered process-wide.  Inside the library they are thread-local for the duration of the call.
 namespace {
 struct ExtrasScope {
     const void* t0 = nullptr;
@@ -2694,18 +2683,6 @@ NEMAR_API int nemar_kernel_timer(int enable) {
 NEMAR_API int nemar_kernel_timer_read(double* total_ms, double* total_flop, int* launches) {
     NEMAR_REQUIRE(total_ms && total_flop && launches, "kernel_timer_read: null pointer");
     *launches = nemar_split16_timer_read(total_ms, total_flop);
-    return NEMAR_OK;
-}
-
-NEMAR_API int nemar_absmax_hint(const void* tensor, const void* words, int count) {
-    NEMAR_REQUIRE(tensor && (!words || count >= 1), "absmax_hint: null tensor / bad count");
-    nemar_split16_set_hint(tensor, words, count);
-    return NEMAR_OK;
-}
-
-NEMAR_API int nemar_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W) {
-    NEMAR_REQUIRE(tensor && (!planes || (N > 0 && C > 0 && H > 0 && W > 0)), "planes_hint: null tensor / bad shape");
-    nemar_split16_set_planes_hint(tensor, planes, N, C, H, W);
     return NEMAR_OK;
 }
 

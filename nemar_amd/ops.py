@@ -91,29 +91,41 @@ def _workspace(nbytes, device):
 
 
 _scratch_need = {}     # layer shape -> nemar_conv2d_scratch bytes (depends on the nemar_tune switches: ops.tune clears it)
-_arena = {}            # device -> tensor registered with nemar_set_scratch
-_arena_live = [None]   # (data_ptr, bytes) the library currently holds
+_arena = {}            # device -> the transient scratch arena handed to the wide-layer calls (nemar_conv_extras.scratch)
 
 
 def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
-    """Make sure the library's transient scratch arena (split source planes of the wide 3x3 layers, csrc/conv_split16.hip) covers
-    this layer.  Grow-only per device; stream-ordered like _workspace."""
+    """-> the scratch arena (tensor) this layer's fp16 x 3 route wants (split source planes of the wide 3x3 layers, csrc/conv_split16.hip),
+    or None.  Grow-only per device; stream-ordered like _workspace.  Handed to the library WITH THE CALL (nemar_conv2d_*_ex): nothing is
+    registered process-wide."""
     key = (N, H, W, K, C, R, S, stride, pad)
     need = _scratch_need.get(key)
     if need is None:                      # (a host-bound small config pays for every ctypes call: ask once per shape)
         need = _scratch_need[key] = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
     if not need:
-        return False
+        return None
     buf = _arena.get(device)
     if buf is None or buf.numel() * 4 < need:
         _retire(buf)
         buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
         _arena[device] = buf
-    live = (buf.data_ptr(), buf.numel() * 4)
-    if _arena_live[0] != live:
-        L.set_scratch(_p(buf), live[1])
-        _arena_live[0] = live
-    return True
+    return buf
+
+
+def _extras(arena=None, src_max=None, src2_max=None, planes=None):
+    """nemar_conv_extras for one call: the side inputs of the wide-layer route, or None when there are none"""
+    if arena is None and src_max is None and src2_max is None and planes is None:
+        return None
+    e = _lib.ConvExtras()
+    if arena is not None:
+        e.scratch, e.scratch_bytes = arena.data_ptr(), arena.numel() * 4
+    if src_max is not None:
+        e.src_max_words, e.src_max_count = src_max.data_ptr(), src_max.numel()
+    if src2_max is not None:
+        e.src2_max_words, e.src2_max_count = src2_max.data_ptr(), src2_max.numel()
+    if planes is not None:
+        e.src_planes = planes.data_ptr()
+    return ctypes.byref(e)
 
 
 _absmax_pool = {}      # device -> [zero-filled int32 tensor, next free word]: nemar_absmax wants its output word zero on entry
@@ -342,27 +354,16 @@ class _Conv2d(Function):
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
         wsb = L.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
         ws, hit, plan = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
-        split16 = _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device) and x2 is None
+        arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device) if x2 is None else None
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
         with (_span(tag) if tag else contextlib.nullcontext()):
             xmax = ready = None
-            if split16:           # max |x| once: this call and the weight gradient in backward both scale x by it
+            if arena is not None:     # max |x| once: this call and the weight gradient in backward both scale x by it
                 ready = _planes_of(x) if (pad_mode == PAD_REFLECT and R == 3 and S == 3 and stride == 1 and pad == 1) else None
-                if ready is not None:             # the producer wrote x's planes, scaled by its a-priori bound words
-                    xmax = ready[1]
-                    L.planes_hint(_p(x), _p(ready[0]), N, C, H, W)
-                else:
-                    xmax = _absmax_word(x)
-                L.absmax_hint(_p(x), _p(xmax), xmax.numel())
-            try:
-                with _record(plan):
-                    L.conv2d_fwd(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
-                                 slope, _p(ws), wsb, hit, _stream())
-            finally:
-                if split16:
-                    L.absmax_hint(_p(x), None, 0)
-                    if ready is not None:
-                        L.planes_hint(_p(x), None, 0, 0, 0, 0)
+                xmax = ready[1] if ready is not None else _absmax_word(x)     # (planes from the producer: scaled by its a-priori bound words)
+            with _record(plan):
+                L.conv2d_fwd_ex(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
+                                slope, _p(ws), wsb, hit, _stream(), _extras(arena, xmax, None, ready[0] if ready is not None else None))
         ctx.xmax = xmax
         ctx.grad_from = int(getattr(x, '_nemar_grad_from', 0)) if x2 is None else 0
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
@@ -391,23 +392,13 @@ class _Conv2d(Function):
             g = gy
         need_x, need_x2, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
             ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        gx = gx2 = None
-        hinted = []
-        if ctx.xmax is not None:      # split-16 layer: max |gy| once for the data and the weight gradient, max |x| from the forward
-            gmax = _absmax_word(g)
-            L.absmax_hint(_p(g), _p(gmax), gmax.numel())
-            L.absmax_hint(_p(x), _p(ctx.xmax), ctx.xmax.numel())
-            hinted = [g, x]
-        try:
-            return _Conv2d._backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st,
-                                          need_x, need_x2, need_w, need_b)
-        finally:
-            for t in hinted:
-                L.absmax_hint(_p(t), None, 0)
+        gmax = _absmax_word(g) if ctx.xmax is not None else None      # wide layer: max |gy| once for the data and the weight gradient
+        return _Conv2d._backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st,
+                                      need_x, need_x2, need_w, need_b, gmax)
 
     @staticmethod
     def _backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st, need_x, need_x2, need_w,
-                       need_b):
+                       need_b, gmax):
         gx = gx2 = None
         if need_x or need_x2:
             gx = torch.empty_like(x) if need_x else None
@@ -429,19 +420,21 @@ class _Conv2d(Function):
                 Nd, gd, gxd = N, g, gx
             wsb = L.conv2d_bwd_data_workspace(Nd, C, H, W, K, R, S, stride, pad, pad_mode)
             ws, hit, plan = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, Nd, H, W), wsb)
-            _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
+            arena = _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
             with _record(plan):
-                L.conv2d_bwd_data(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
-                                  stride, pad, pad_mode, _p(ws), wsb, hit, st)
+                L.conv2d_bwd_data_ex(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
+                                     stride, pad, pad_mode, _p(ws), wsb, hit, st,
+                                     _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax))
             if not need_x2:
                 gx2 = None
         want_b = need_b and ctx.bias is not None
         if need_w:
             gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
             wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
-            _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
-            L.conv2d_bwd_weight(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
-                                R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st)
+            arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
+            L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
+                                   R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st,
+                                   _extras(arena, ctx.xmax, gmax))
             grad_ready(ctx.weight)
             if want_b:
                 grad_ready(ctx.bias)
@@ -555,7 +548,7 @@ def conv_transpose2d(x, weight, bias=None, stride=2, pad=1, out_pad=1, act=ACT_N
 def _planes_ok(x, residual):
     """InstanceNorm output -> fp16 x 3 planes in the same pass (norm_planes.hip): shapes the kernel covers and the wide-layer route takes"""
     N, C, H, W = x.shape
-    return _planes_on[0] and _wants_max(x) and W % 4 == 0 and H >= 4 and H * W <= 4096 and _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, x.device)
+    return _planes_on[0] and _wants_max(x) and W % 4 == 0 and H >= 4 and H * W <= 4096 and _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, x.device) is not None
 
 
 _planes_on = [os.environ.get("NEMAR_PLANES", "1") != "0"]       # A/B switch for the fused producer (NEMAR_PLANES=0, ops.tune_planes)

@@ -4,13 +4,15 @@
 import ctypes
 import numpy as np
 
+from tools.side_inputs import SideInputs
+
 
 class EmuBackend:
     name = "emu"
     stream = None
 
     def __init__(self, lib):
-        self.lib = lib
+        self.lib = SideInputs(lib)      # (registered side inputs -> the per-call form of the C ABI)
 
     def dev(self, a):
         return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
@@ -47,7 +49,7 @@ class HipBackend:
     def __init__(self, lib):
         import torch
         self.torch = torch
-        self.lib = lib
+        self.lib = SideInputs(lib)      # (registered side inputs -> the per-call form of the C ABI)
         self.device = torch.device("cuda:0")
 
     @property

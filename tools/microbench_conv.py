@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from nemar_amd import _lib
+from tools.side_inputs import SideInputs
 from tools.microbench import timeit
 
 SHAPES = [  # name, C0, C1, K, R, stride, pad, pad_mode, H
@@ -36,7 +37,7 @@ def main():
     ap.add_argument("--arena", action='store_true', help="register a scratch arena (split-16 kernels for the wide 3x3 layers); "
                                                          "forward is then timed without the fused activation, as the resblocks run it")
     a = ap.parse_args()
-    lib = _lib.load()
+    lib = SideInputs(_lib.load())
     for k, v in a.tune:
         lib.tune(k, v)
     dev = torch.device("cuda:0")

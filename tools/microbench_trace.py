@@ -3,9 +3,10 @@ import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib
+from tools.side_inputs import SideInputs
 from tools.microbench import timeit
 
-lib = _lib.load(); dev = torch.device('cuda:0')
+lib = SideInputs(_lib.load()); dev = torch.device('cuda:0')
 for kv in sys.argv[2:]:
     k, v = kv.split('='); lib.tune(int(k), int(v))
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

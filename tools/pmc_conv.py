@@ -4,9 +4,10 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib
+from tools.side_inputs import SideInputs
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-lib = _lib.load(); dev = torch.device('cuda:0')
+lib = SideInputs(_lib.load()); dev = torch.device('cuda:0')
 for kv in sys.argv[3:]:          # nemar_tune switches as key=value
     k, v = kv.split('='); lib.tune(int(k), int(v))
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
