@@ -187,6 +187,52 @@ def other_configs(dev):
     return out
 
 
+def grid_sample_hbm_stress(dev):
+    """BASELINE's second metric at the HBM-stress shape of config 5 (8 x 3 x 1024 x 1024; the bench config's 256 x 256 launches are
+    8-30 us: latency-sized): the four grid_sample launches of a step — forward of real_A and fake_B, backward with grad_input (fake_B) and
+    without (real_A) — through the C ABI on a near-identity field (what the registration net emits early in training) and on a smooth
+    3-pixel field, algorithmic bytes (32 / 52 / 40 B per pixel) over event-timed duration."""
+    import ctypes
+    from nemar_amd import _lib
+    lib = _lib.load()
+    N, C, H, W = 8, 3, 1024, 1024
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    g = torch.Generator(device=dev).manual_seed(5)
+    img = torch.rand(N, C, H, W, device=dev, generator=g) * 2 - 1
+    go = torch.randn(N, C, H, W, device=dev, generator=g)
+    res, gin = torch.empty_like(img), torch.empty_like(img)
+    wsb = lib.grid_sample_bwd_workspace(N, C, H, W)
+    ws = torch.zeros(wsb // 4 + 16, device=dev)
+    out = {}
+    for name, off in (("near_identity", torch.randn(N, 2, H, W, device=dev, generator=g) * 1e-4),
+                      ("smooth_3px", torch.nn.functional.interpolate(torch.randn(N, 2, H // 32, W // 32, device=dev, generator=g), size=(H, W),
+                                                                     mode='bilinear', align_corners=False) * (6.0 / W))):
+        gd = torch.empty_like(off)
+
+        def t(fn, iters=10):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e-3
+        fwd = t(lambda: lib.grid_sample_fwd(P(img), P(off), 1, P(res), N, C, H, W, H, W, st()))
+        bgi = t(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), P(gin), 0, P(gd), 0, N, C, H, W, H, W, P(ws), wsb, st()))
+        bng = t(lambda: lib.grid_sample_bwd(P(img), P(off), 1, P(go), None, 0, P(gd), 0, N, C, H, W, H, W, P(ws), wsb, st()))
+        px = N * H * W
+        tot_b, tot_t = px * (32 * 2 + 52 + 40), 2 * fwd + bgi + bng
+        out[name] = {"fwd_us": fwd * 1e6, "fwd_GBps": px * 32 / fwd / 1e9, "bwd_gin_us": bgi * 1e6, "bwd_gin_GBps": px * 52 / bgi / 1e9,
+                     "bwd_nogin_us": bng * 1e6, "bwd_nogin_GBps": px * 40 / bng / 1e9,
+                     "step_mix_GBps": tot_b / tot_t / 1e9, "frac_of_hbm_peak": tot_b / tot_t / 1e9 / HBM_PEAK_GBS}
+    out["shape"] = [N, C, H, W]
+    out["peak"] = HBM_PEAK_GBS
+    return out
+
+
 def route_agreement(dev):
     """How far the fp16 x 3 routes move the step's GRADIENTS: one full-width config-2-shaped step (batch 1, no dropout, same seeded weights
     and inputs) on the default routes and with every 16-bit-pipe kernel off (nemar_tune 20=0, 24=0: exact-fp32 MFMA / VALU), compared
@@ -323,7 +369,6 @@ def main():
     tk_ms, tk_flop, tk_n = tk_ms_c.value, tk_fl_c.value, tk_n_c.value
     rank_ms = [dt / a.steps * 1e3]
     buckets = sum(len(getattr(model, n).launched) for n in ("sync_T", "sync_D", "sync_R"))
-    stn_cfg = opt.stn_cfg
     if multi:
         t = torch.zeros(world, device=dev, dtype=torch.float64)
         t[rank] = dt
@@ -331,6 +376,34 @@ def main():
         rank_ms = [float(x) / a.steps * 1e3 for x in t.tolist()]
         dt = float(t.max().item())
     losses = model.get_current_losses()
+    bucket_rows = []
+    if multi:
+        # one more step with events around every bucket's all-reduce (compute stream at launch, side stream at completion): achieved
+        # bus bandwidth per bucket and how long finish() had to wait — the part of the exchange that is NOT hidden behind backward
+        evs = []
+        for nm in ("D", "R", "T"):
+            s_ = getattr(model, "sync_" + nm)
+
+            def launch(b, s_=s_, nm=nm, orig=s_._launch):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(b)
+                e1 = torch.cuda.Event(enable_timing=True)
+                if s_._side is not None:
+                    with torch.cuda.stream(s_._side):
+                        e1.record()
+                else:
+                    e1.record()
+                lo, hi = s_.buckets[b]
+                evs.append((nm, b, (hi - lo) * 4, e0, e1))
+            s_._launch = launch
+        step()
+        torch.cuda.synchronize()
+        for nm, b, nbytes, e0, e1 in evs:
+            ms = e0.elapsed_time(e1)
+            bucket_rows.append({"optimizer": nm, "bucket": b, "MB": nbytes / 1e6, "ms_ready_to_reduced": ms,
+                                "ring_GBps_per_rank": nbytes * 2.0 * (world - 1) / world / max(ms, 1e-6) / 1e6})
+    stn_cfg = opt.stn_cfg
     extras = {}
     if world == 1 and not multi and not a.no_extras:
         # side measurements of the default single-GPU run — after the timed region, never inside it
@@ -364,6 +437,10 @@ def main():
             except Exception as e:  # noqa: BLE001
                 extras["route_agreement"] = {"error": '%s: %s' % (type(e).__name__, e)}
             extras["other_configs"] = other_configs(dev)
+            try:
+                extras["roofline_grid_sample_1024"] = grid_sample_hbm_stress(dev)
+            except Exception as e:  # noqa: BLE001
+                extras["roofline_grid_sample_1024"] = {"error": '%s: %s' % (type(e).__name__, e)}
     if multi:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -389,7 +466,7 @@ def main():
         "launch": "hipGraph replay" if graph_on else ("eager" + (" (capture failed: %s)" % graph_note if graph_note else "")),
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
         "rank_ms_per_step": rank_ms,                      # one entry per rank: the N > 1 run cannot degrade to one rank unnoticed
-        "dist": {"backend": "nccl (RCCL)" if multi else None, "buckets_launched_last_step": buckets,
+        "dist": {"backend": "nccl (RCCL)" if multi else None, "buckets_launched_last_step": buckets, "buckets": bucket_rows or None,
                  "launcher": "self-spawned ranks" if os.environ.get("NEMAR_SPAWNED") else ("torchrun" if multi else None)},
     }
     if os.environ.get("NEMAR_BENCH_DUMP_LOSSES"):       # tests: the losses of the last step + how many gradient buckets went out

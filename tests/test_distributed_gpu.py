@@ -117,3 +117,64 @@ def test_rccl_code_path_with_a_world_of_one_rank():
     assert a["n_gpus"] == 1 and a["losses_finite"] and a["dist_buckets_launched"] > 0 and b["dist_buckets_launched"] == 0
     for k, v in a["losses"].items():
         assert abs(v - b["losses"][k]) <= 1e-6 * max(1.0, abs(v)), (k, v, b["losses"][k])
+
+
+def _rccl_rank(rank, world, port, out):
+    """one rank of the REAL configuration: its own GPU, backend "nccl" (= RCCL), bucketed all-reduce(AVG) on the side stream behind events"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from nemar_amd import distributed as dist
+    dist.init_from_env(backend='nccl', device=rank)
+    torch.cuda.set_device(rank)
+    import step_parity
+    from nemar_amd.models import create_model
+    cfg = dict(STEP_CONFIGS[NAME], batch=1)
+    A, B = seeded.seeded_images(world, 3, *hw(cfg), cfg['seed'])
+    res = {}
+    for mode in ('overlapped', 'plain'):
+        opt = make_opt(cfg, gpu_ids=[rank])
+        m = create_model(opt)
+        m.setup(opt)
+        step_parity.load_seeded_into(m.netT, cfg['seed'] + 1, cfg.get('overrides_T'))
+        step_parity.load_seeded_into(m.netR, cfg['seed'] + 2, cfg.get('overrides_R'))
+        step_parity.load_seeded_into(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
+        if mode == 'plain':
+            # the simple form: no bucket launches during backward, one all_reduce_gradients() per optimizer phase
+            for s in (m.sync_T, m.sync_D, m.sync_R):
+                s.begin = lambda expected=None: None
+                s.finish = (lambda o: (lambda: dist.all_reduce_gradients([o])))(s.opt)
+        m.set_input({'A': torch.from_numpy(A[rank:rank + 1]), 'B': torch.from_numpy(B[rank:rank + 1]), 'A_paths': [''], 'B_paths': ['']})
+        m.optimize_parameters()
+        torch.cuda.synchronize()
+        if mode == 'overlapped':
+            assert m.sync_T.launched and len(m.sync_T.launched) == len(m.sync_T.buckets)
+        res[mode] = {k: [getattr(o, k).detach().cpu().numpy().copy() for o in m.optimizers] for k in ('flat_p', 'flat_g', 'm')}
+    out.put((rank, res))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: real RCCL ranks over xGMI")
+def test_two_rccl_ranks_overlapped_buckets_equal_plain_all_reduce():
+    """Two REAL RCCL ranks (one GPU each): the bucketed all-reduce(AVG) issued on the side stream behind events while backward is still
+    running (GradSync, nemar_amd/distributed.py) leaves bit-identical gradients, parameters and moments to one plain
+    all_reduce_gradients() per optimizer phase — and the two replicas are bit-identical to each other.  (The one-GPU boxes of the
+    build skip this; it is the first thing to run on a multi-GPU node.)"""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for k in ('flat_p', 'flat_g', 'm'):
+        for r in range(2):
+            for a, b in zip(got[r]['overlapped'][k], got[r]['plain'][k]):
+                assert np.array_equal(a, b), (k, r)
+        for a, b in zip(got[0]['overlapped'][k], got[1]['overlapped'][k]):
+            assert np.array_equal(a, b), k

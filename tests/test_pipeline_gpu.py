@@ -39,6 +39,35 @@ def test_gpupairs_batches_follow_the_reference_contract(tmp_path):
     assert seen == 3
 
 
+def test_gpupairs_whole_non_square_images_and_resize_modes(tmp_path):
+    """--preprocess none feeds whole NON-SQUARE images (the reference's default geometry 288 x 384); scale_width / resize_and_crop resize
+    the pool once (reference data/base_dataset.py:81-113) and then behave like the crop path."""
+    from nemar_amd.data import create_dataset
+    opt = _opt(tmp_path, ['--preprocess', 'none', '--img_height', '288', '--img_width', '384', '--no_flip'])
+    ds = create_dataset(opt)
+    data = next(iter(ds))
+    assert data['A'].shape == (2, 3, 288, 384)
+    for b, (i, y0, x0, flip) in enumerate(ds.dataset._last_params):
+        assert (y0, x0, flip) == (0, 0, 0)
+        assert torch.allclose(data['A'][b], (ds.dataset.pool_A[i] - 0.5) / 0.5, atol=1e-6)
+        assert torch.allclose(data['B'][b], (ds.dataset.pool_B[i] - 0.5) / 0.5, atol=1e-6)
+    # a pool on disk at another size: scale_width resizes it to width load_size, the height follows
+    root = tmp_path / 'pairs'
+    root.mkdir()
+    rng = np.random.default_rng(0)
+    np.save(root / 'A.npy', (rng.random((4, 60, 90, 3)) * 255).astype(np.uint8))
+    np.save(root / 'B.npy', (rng.random((4, 60, 90, 3)) * 255).astype(np.uint8))
+    opt = _opt(tmp_path, ['--dataroot', str(root), '--preprocess', 'scale_width', '--load_size', '120'])
+    ds = create_dataset(opt)
+    data = next(iter(ds))
+    assert data['A'].shape == (2, 3, 80, 120) and float(data['A'].abs().max()) <= 1.0
+    opt = _opt(tmp_path, ['--dataroot', str(root), '--preprocess', 'resize_and_crop', '--load_size', '72', '--crop_size', '64'])
+    ds = create_dataset(opt)
+    assert ds.dataset.pool_A.shape == (4, 3, 72, 72)
+    data = next(iter(ds))
+    assert data['A'].shape == (2, 3, 64, 64)
+
+
 def test_train_loop_writes_the_loss_line_and_offset_scalars(tmp_path, capsys):
     import json
     import os
