@@ -16,8 +16,9 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                       launch duration, measured with HIP events on the launch stream inside the library (nemar_kernel_timer) in
                       two extra steps right after the timed region; peak = 2500 TF dense fp16 MFMA / 3 products;
                       traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same batch-16 launch from separate rocprofv3 --pmc passes
-                      (profiles/r3_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
-                      peak assumes (profiles/r3_clock_trace.txt)
+                      (profiles/r4_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
+                      peak assumes (profiles/r3_clock_trace.txt); a pure MFMA loop on random operands sustains 1730 TFLOP/s,
+                      on all-zero operands 2530 (profiles/r4_mfma_peak_modes.txt): `frac_of_sustained_mfma` is priced on the former
   roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
   cpu_baseline        the CPU oracle (oracle/torch_ref.py, a proven-equal restatement of the reference's step) timed
                       on this box's host cores on a bounded sample (config-2 shape at batch 1)
@@ -36,9 +37,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense FP16/BF16 MFMA peak (32x32x16)
-F16_MFMA_SUSTAINED_TF = 1423.0   # measured on the MI355X of this pool: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, no LDS / memory —
-                                 # the clock falls to 1.39 GHz at 100 % issue (tools/probes/mfma_f16_clock.hip, profiles/r3_mfma_f16_clock.txt)
-PMC_FILE = "profiles/r3_pmc_traffic.json"
+F16_MFMA_SUSTAINED_TF = 1730.0   # measured on the MI355X of this pool: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, no LDS / memory,
+                                 # RANDOM operands, 2 waves / SIMD: the clock settles at ~1.75 GHz.  The same loop on all-zero / all-one
+                                 # operands holds 2.37-2.43 GHz = 2450-2530 TFLOP/s — the guide's peak is a trivial-operand figure, the
+                                 # power limit depends on the data (tools/probes/mfma_peak_modes.hip, profiles/r4_mfma_peak_modes.txt)
+PMC_FILE = "profiles/r4_pmc_traffic.json"
 
 
 def build_opt(batch, size, extra=()):
@@ -506,10 +509,11 @@ def main():
                            "peak_basis": "2500 TFLOP/s dense fp16 MFMA / 3 products per fp32 product",
                            "issued_mfma_TFLOPs": 3.0 * flop / sec / 1e12, "issued_frac_of_fp16_peak": 3.0 * flop / sec / 1e12 / F16_MFMA_PEAK_TF,
                            "vs_fp32_mfma_peak_157": flop / sec / 1e12 / FP32_MFMA_PEAK_TF,
-                           # the nominal peak assumes 2.4 GHz; a pure MFMA loop on this chip sustains 1423 TFLOP/s (power-limited clock)
+                           # the nominal peak assumes 2.4 GHz; a pure MFMA loop on random operands sustains 1730 TFLOP/s on this chip
+                           # (power-limited clock; 2450-2530 on all-zero / all-one operands)
                            "sustained_mfma_TFLOPs_measured": F16_MFMA_SUSTAINED_TF,
                            "frac_of_sustained_mfma": 3.0 * flop / sec / 1e12 / F16_MFMA_SUSTAINED_TF,
-                           "sustained_source": "profiles/r3_mfma_f16_clock.txt"}
+                           "sustained_source": "profiles/r4_mfma_peak_modes.txt (f16, random operands, 2 waves/SIMD, long run)"}
     if 'igemm_fwd_resblock' in spans:       # the whole operator call (max pass + split pass + main kernel), for the record
         n, sec = spans['igemm_fwd_resblock']
         out["conv2d_fwd_resblock_call"] = {"avg_us": sec * 1e6, "calls_timed": n,

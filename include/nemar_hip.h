@@ -31,7 +31,7 @@ extern "C" {
 #define NEMAR_EWORKSPACE (-3)
 
 /* library */
-int nemar_version(void);              /* major*10000 + minor*100 + patch */
+int nemar_version(void);              /* major*10000 + minor*100 + patch; 400 = this header (0.3.x had nemar_set_scratch / *_hint) */
 const char* nemar_last_error(void);   /* thread-local message of the last failing call */
 
 /* ---- K9/K10/K11: sampling-grid generation fused into bilinear grid_sample ------------------------------
@@ -133,6 +133,11 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   src2_max_words / _count     bwd_weight only: the same for gy
  *   src_planes                  fwd only: the source's operand planes written by its producer (nemar_instnorm_fwd_planes), scaled by
  *                               src_max_words
+ *   gy_planes_out / _bytes      bwd_data only: a buffer of nemar_conv2d_gy_planes_bytes(...) bytes.  When given together with
+ *                               src_max_words (count = N) on a layer of the wide route, the pass that splits gy for the data gradient
+ *                               ALSO writes the operand planes the weight gradient of the same layer needs (gy is read once) ...
+ *   src2_planes                 ... and bwd_weight takes them here (with the SAME words as src2_max_words) instead of splitting gy again.
+ *                               The buffer must stay untouched between the two calls.
  * A packed-weight workspace (prepacked = 1) must be reused under the same route conditions it was written under (arena present or
  * not, nemar_config_epoch unchanged). */
 typedef struct nemar_conv_extras {
@@ -143,7 +148,14 @@ typedef struct nemar_conv_extras {
     const void* src2_max_words;
     int src2_max_count;
     const void* src_planes;
+    void* gy_planes_out;
+    size_t gy_planes_bytes;
+    const void* src2_planes;
 } nemar_conv_extras;
+/* bytes of the gy planes a bwd_data call can leave behind for the bwd_weight call of the same layer (0: this layer does not take them) */
+size_t nemar_conv2d_gy_planes_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode);
+/* 1 when the last nemar_conv2d_bwd_data_ex call on this thread filled its gy_planes_out buffer (check before passing it on as src2_planes) */
+int nemar_last_gy_planes(void);
 int nemar_conv2d_fwd_ex(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias, float* y, int N,
                         int H, int W, int K, int R, int S, int stride, int pad, int pad_mode, int act, float slope,
                         void* workspace, size_t ws_bytes, int prepacked, void* stream, const nemar_conv_extras* extras);

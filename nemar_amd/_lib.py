@@ -45,6 +45,7 @@ SIGNATURES = {
     "nemar_conv2d_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz,
                                      _vp]),
     "nemar_conv2d_scratch": (_sz, [_i] * 9),
+    "nemar_conv2d_gy_planes_bytes": (_sz, [_i] * 10),
     "nemar_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "nemar_absmax_samples": (_i, [_vp, _i, _ll, _vp, _vp]),
     "nemar_kernel_timer": (_i, [_i]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "nemar_tune": (_i, [_i, _i]),
     "nemar_last_route": (_i, []),
+    "nemar_last_gy_planes": (_i, []),
     "nemar_config_epoch": (_i, []),
     "nemar_grid_sample_tune": (_i, [_i]),
     "nemar_tune_ptr": (_i, [_vp]),
@@ -99,7 +101,8 @@ class NemarHipError(RuntimeError):
 class ConvExtras(C.Structure):
     """include/nemar_hip.h nemar_conv_extras"""
     _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("src_max_words", C.c_void_p), ("src_max_count", C.c_int),
-                ("src2_max_words", C.c_void_p), ("src2_max_count", C.c_int), ("src_planes", C.c_void_p)]
+                ("src2_max_words", C.c_void_p), ("src2_max_count", C.c_int), ("src_planes", C.c_void_p),
+                ("gy_planes_out", C.c_void_p), ("gy_planes_bytes", C.c_size_t), ("src2_planes", C.c_void_p)]
 
 
 class Library:
@@ -134,7 +137,7 @@ class Library:
         if full not in fns:
             raise AttributeError(name)
         fn = fns[full]
-        if SIGNATURES[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty"):
+        if SIGNATURES[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

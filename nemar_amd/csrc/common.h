@@ -24,6 +24,9 @@ struct nemar_conv_extras {
     const void* src2_max_words;
     int src2_max_count;
     const void* src_planes;
+    void* gy_planes_out;
+    size_t gy_planes_bytes;
+    const void* src2_planes;
 };
 
 // thread-local so the message survives being raised on autograd's backward thread

@@ -1096,6 +1096,11 @@ static int g_s16g_fold = 1;         // key 30: stride-1 reflect data gradients o
 static long long g_s16g_min_mmac = 30;   // key 25: ... above this many million multiply-adds (tiny layers are launch-bound either way)
 static thread_local void* t_scratch = nullptr;        // nemar_conv2d_*_ex: this call's scratch arena (nemar_conv_extras.scratch)
 static thread_local size_t t_scratch_bytes = 0;
+static thread_local void* t_gy_planes_out = nullptr;  // bwd_data_ex: where the pass that splits gy also leaves the weight gradient's planes
+static thread_local size_t t_gy_planes_bytes = 0;
+static thread_local const void* t_src2_planes = nullptr;      // bwd_weight_ex: those planes
+static int g_dual_gy = 1;            // key 35: the data-gradient call's split pass also writes the weight gradient's gy planes
+static thread_local int t_gy_planes_written = 0;      // did the last bwd_data_ex call on this thread fill gy_planes_out?
 #define g_scratch t_scratch
 #define g_scratch_bytes t_scratch_bytes
 static int g_reflect_aux = 1;    // tuning switch (key 8): 3x3 reflect data gradient folds the border into the main launch (1) / ring launch (0)
@@ -2078,7 +2083,7 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, K, C, OH, OW)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 0, g_split16_variant, st);
             nemar_split16_conv(x0, workspace, bias, y, N, H, W, K, C, R, 1, H, W, OH, OW, mode, g_scratch, g_xcd_map, g_split16_variant,
-                               g_tl, st);
+                               g_tl, nullptr, st);
             g_last_route = 2;
             NEMAR_CHECK_LAUNCH("conv2d_fwd (split-16)");
             return NEMAR_OK;
@@ -2196,8 +2201,13 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode, g_split16_variant) &&
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, C, K, H, W)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 1, g_split16_variant, st);
+            void* dual = nullptr;      // the weight gradient of the same layer follows and takes its gy planes from this call's split pass
+            if (R == 3 && t_gy_planes_out && t_gy_planes_bytes >= nemar_split16_wgrad_g_bytes(N, H, W, K, R) &&
+                nemar_split16_wgrad_g_bytes(N, H, W, K, R) > 0 && nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad))
+                dual = t_gy_planes_out;
+            t_gy_planes_written = dual ? 1 : 0;
             nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch, g_xcd_map,
-                               g_split16_variant, g_tl, st);
+                               g_split16_variant, g_tl, dual, st);
             g_last_route = 2;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (split-16)");
             return NEMAR_OK;
@@ -2500,7 +2510,8 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
         (R == 3 || pad_mode == BORDER_ZERO) && g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K, R)) {
         // wide 3x3 stride-1 layers: fp16 x 3 on the 16-bit matrix pipe (conv_split16_wgrad.hip); bias gradient as its own reduction
-        nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map, st);
+        nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map,
+                            R == 3 ? t_src2_planes : nullptr, st);
         if (gb) {
             const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
             float* pb = part + (size_t)nemar_split16_wgrad_splits(N, C0, H, W, K, R) * K * J;
@@ -2587,6 +2598,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 31) { nemar_norm_planes_debug(value); return NEMAR_OK; }
     if (key == 32) { g_split16_ring3 = value != 0; return NEMAR_OK; }
     if (key == 33) { g_k7 = value != 0; return NEMAR_OK; }
+    if (key == 35) { g_dual_gy = value != 0; return NEMAR_OK; }
+    if (key == 34) { nemar_split16_wgrad_tune(value); return NEMAR_OK; }      // wide weight gradient: 1 one gy copy (default), 0 KS shifted copies
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
@@ -2617,9 +2630,12 @@ struct ExtrasScope {
         if (ex->src_max_words && ex->src_max_count > 0) { nemar_split16_set_hint(src, ex->src_max_words, ex->src_max_count); t0 = src; }
         if (src2 && ex->src2_max_words && ex->src2_max_count > 0) { nemar_split16_set_hint(src2, ex->src2_max_words, ex->src2_max_count); t1 = src2; }
         if (ex->src_planes) { nemar_split16_set_planes_hint(src, ex->src_planes, N, C, H, W); tp = src; }
+        t_gy_planes_out = ex->gy_planes_out; t_gy_planes_bytes = ex->gy_planes_bytes;
+        t_src2_planes = ex->src2_planes;
     }
     ~ExtrasScope() {
         t_scratch = nullptr; t_scratch_bytes = 0;
+        t_gy_planes_out = nullptr; t_gy_planes_bytes = 0; t_src2_planes = nullptr;
         if (t0) nemar_split16_set_hint(t0, nullptr, 0);
         if (t1) nemar_split16_set_hint(t1, nullptr, 0);
         if (tp) nemar_split16_set_planes_hint(tp, nullptr, 0, 0, 0, 0);
@@ -2627,10 +2643,27 @@ struct ExtrasScope {
 };
 }  // namespace
 
+// bytes of the gy planes the data-gradient call of a layer can leave behind for its weight-gradient call (nemar_conv_extras.gy_planes_out /
+// .src2_planes); 0 = the layer's gradients do not both run on the wide route
+NEMAR_API size_t nemar_conv2d_gy_planes_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
+    if (!g_dual_gy || !g_split16 || g_split16_variant != 4 || R != 3 || S != 3 || stride != 1 || pad != 1) return 0;
+    const int mode = pad_mode == BORDER_REFLECT ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO;
+    if (!split16_worth_it(N, H, W, K, C, R, S) || !nemar_split16_eligible(N, H, W, C, K, R, S, stride, pad, mode, g_split16_variant) ||
+        !nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad))
+        return 0;
+    return nemar_split16_wgrad_g_bytes(N, H, W, K, R);
+}
+
+// 1 when the last nemar_conv2d_bwd_data_ex call on this thread filled its gy_planes_out buffer (the route it took supports it): only then
+// may the buffer be handed to nemar_conv2d_bwd_weight_ex as src2_planes
+NEMAR_API int nemar_last_gy_planes(void) { return t_gy_planes_written; }
+
 NEMAR_API int nemar_conv2d_fwd_ex(const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias, float* y, int N,
                                   int H, int W, int K, int R, int S, int stride, int pad, int pad_mode, int act, float slope,
                                   void* workspace, size_t ws_bytes, int prepacked, void* stream, const nemar_conv_extras* extras) {
-    ExtrasScope scope(extras, x0, nullptr, N, C0 + C1, H, W);
+    nemar_conv_extras e;
+    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.src2_planes = nullptr; }
+    ExtrasScope scope(extras ? &e : nullptr, x0, nullptr, N, C0 + C1, H, W);
     return nemar_conv2d_fwd(x0, C0, x1, C1, w, bias, y, N, H, W, K, R, S, stride, pad, pad_mode, act, slope, workspace, ws_bytes, prepacked, stream);
 }
 
@@ -2639,8 +2672,9 @@ NEMAR_API int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const fl
                                        int pad_mode, void* workspace, size_t ws_bytes, int prepacked, void* stream,
                                        const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.src_planes = nullptr; }
+    if (extras) { e = *extras; e.src_planes = nullptr; e.src2_planes = nullptr; }
     ExtrasScope scope(extras ? &e : nullptr, gy, nullptr, N, K, OH, OW);
+    t_gy_planes_written = 0;
     return nemar_conv2d_bwd_data(gy, w, bias, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes,
                                  prepacked, stream);
 }
@@ -2649,7 +2683,7 @@ NEMAR_API int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x
                                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
                                          void* workspace, size_t ws_bytes, void* stream, const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.src_planes = nullptr; }
+    if (extras) { e = *extras; e.src_planes = nullptr; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; }
     ExtrasScope scope(extras ? &e : nullptr, x0, gy, N, C0 + C1, H, W);
     return nemar_conv2d_bwd_weight(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes, stream);
 }

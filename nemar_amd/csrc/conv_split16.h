@@ -21,15 +21,22 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int 
 // correlation of gy [H-1, W-1]): Hs = H - 1, OH = H, src_pad = 2.  `scratch` >= nemar_split16_scratch_bytes
 void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
                          int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
-                         long long* tl, hipStream_t st);
+                         long long* tl, void* dual_g_out, hipStream_t st);
 
 // ---- weight gradient of the same layers (conv_split16_wgrad.hip) ----
 bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
 size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K, int KS);     // split gy (KS shifts) and padded x planes
 int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS);               // slabs of K C KS KS floats the caller provides
 // gw [K][C][KS][KS] += dW from x [N,C,H,W] and gy [N,K,H+3-KS,W+3-KS]; slabs summed in order (bitwise reproducible)
+void nemar_split16_wgrad_tune(int one_copy);          // nemar_tune(34): 1 (default) one gy copy + in-register shifts, 0 KS copies
+// g_planes != NULL: the G_0 planes of gy already exist (nemar_split16_dual_split wrote them, scaled by the max words hinted for gy)
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
-                         void* scratch, float* part, int xcd_map, hipStream_t st);
+                         void* scratch, float* part, int xcd_map, const void* g_planes, hipStream_t st);
+size_t nemar_split16_wgrad_g_bytes(int N, int H, int W, int K, int KS);      // bytes of the G_0 planes (two 16-bit planes)
+// one pass over gy [N, K, H, W] (3x3 / pad 1 layers): the data gradient's channel-blocked padded planes (mode SPLIT16_ZERO or
+// SPLIT16_DGRAD_REFLECT, bit-identical to split_planes_kernel's) into `dplanes` AND the weight gradient's G_0 planes into `gplanes`
+void nemar_split16_dual_split(const float* gy, void* dplanes, void* gplanes, int N, int K, int H, int W, int mode, const unsigned* maxbits,
+                              int mstride, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
 
 // ---- max |t| of a source tensor (the fp16 form's power-of-two scale follows from it) ----

@@ -822,7 +822,7 @@ int g_split16_ring3 = 0;         // nemar_tune(32, 1): 3-slot weight ring (76.8 
 
 void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
                          int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
-                         long long* tl, hipStream_t st) {
+                         long long* tl, void* dual_g_out, hipStream_t st) {
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
     const unsigned* xmax = xmw;
@@ -835,7 +835,11 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
     }
     if (variant == 4) {
         xmax = nemar_split16_source_max(src, N, (long long)Cred * Hs * Ws_src, xmw, &xstride, st);
-        if (!ready)
+        if (!ready && dual_g_out && KS == 3 && src_pad == 1 && Hs == H && Ws_src == W && Cred % 64 == 0 &&
+            (mode == SPLIT16_DGRAD_REFLECT || mode == SPLIT16_ZERO))
+            // data gradient of a 3x3 layer whose weight gradient follows: both operand layouts of gy from one read (conv_split16_wgrad.hip)
+            nemar_split16_dual_split(src, scratch, dual_g_out, N, Cred, H, W, mode, xmax, xstride, st);
+        else if (!ready)
             hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
                                mode, total, xmax, xstride, src_pad, Hs, Ws_src);
     } else {

@@ -10,7 +10,11 @@
 //   G_s[n][k][y][x'] = gy[n][k][y][x' - s]   for s = 0, 1, 2 (zero where x' - s falls outside the row),   x' = 0 .. 8 CPR - 1
 //   X  [n][c][yp][x'] = xpad[n][c][yp][x']                    (padding materialised, zero beyond column W + 1)
 // with CPR = ceil((W + 2) / 8) 8-pixel chunks per row, so that   dW[k][c][r][s] = sum_{n,y,x'} G_s[k][y][x'] X[c][y + r][x']
-// reads BOTH operands at the same aligned chunk: flat chunk f = y CPR + q of G_s against flat chunk f + r CPR of X.  Both are
+// reads BOTH operands at the same aligned chunk: flat chunk f = y CPR + q of G_s against flat chunk f + r CPR of X.
+// Round 4: only G_0 goes through HBM (one copy, 74 instead of 221 MB per batch-16 layer).  Every row of G_0 ends in >= KS - 1 zero
+// pixels, so the shifted operand of chunk f is the funnel shift of chunks f - 1 and f of G_0: the kernel keeps the last dword(s) of
+// the previous chunk (v_permlane32_swap_b32 moves them between the two 32-lane halves = the two chunks of a stage) and builds
+// G_1 .. G_(KS-1) with v_alignbit_b32 in the shadow of the MFMAs (first generation, three HBM copies: nemar_tune(34, 0)).  Both are
 // stored tile-ordered — [64-channel block][flat chunk][64 channels][8 pixels] fp16, high and low plane — so a stage of the
 // reduction is a run of contiguous 1 KiB copies and an LDS fragment read is conflict-free (32 lanes = 32 consecutive channels).
 //
@@ -68,7 +72,7 @@ __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
 constexpr int SPLIT_MAXW = 256;
 // gy is [N, K, H, W] (H x W = ITS extents: one less than the layer's input for the 4x4 layers); the planes have Hg >= H rows (zero
 // below row H: the row count is rounded up to a whole number of row blocks) and KS shifted versions.
-template <int TW, int KS>
+template <int TW, int KS>          // KS = number of shifted copies written (1: G_0 only)
 __global__ __launch_bounds__(256) void split_wgrad_g_kernel(const float* __restrict__ gy, u32x4* __restrict__ out, int N, int K, int H,
                                                             int W, int Hg, int CPR, long long total, const unsigned* maxbits,
                                                             int mstride) {
@@ -144,6 +148,70 @@ __global__ __launch_bounds__(256) void split_wgrad_x_kernel(const float* __restr
     }
 }
 
+// One pass over gy for BOTH gradients of a 3x3 / pad-1 layer (round 4: gy was read twice, by split_planes_kernel and by
+// split_wgrad_g_kernel).  Workgroup = one row of the data gradient's padded planes (rows 0 .. H + 3) of one 64-channel block: the
+// image row (or, for the reflect fold rows H + 2 / H + 3, the sum of the two image rows that fold together) goes to LDS once, then
+//   * the data gradient's words [n][k / 8][row][slot 0 .. W + 3][8 channels] of that row — the same values, bit for bit, as
+//     split_planes_kernel's (scaling by a power of two commutes with the fold sums), and
+//   * for image rows, the weight gradient's G_0 words of that row (the three border rows also write the <= 3 zero rows below the image).
+template <int TW>
+__global__ __launch_bounds__(256) void split_dual_kernel(const float* __restrict__ gy, u32x4* __restrict__ dpl, u32x4* __restrict__ gpl,
+                                                         int N, int K, int H, int W, int Hg, int CPR, int reflect, long long dtotal,
+                                                         long long gtotal, const unsigned* maxbits, int mstride) {
+    __shared__ float tile[64][TW + 1];
+    const int Hp = H + 4, Ws = W + 4, KBLK = K >> 6, CG = K >> 3, F = Hg * CPR;
+    const int prow = blockIdx.x % Hp, kblk = (blockIdx.x / Hp) % KBLK, n = blockIdx.x / (Hp * KBLK);
+    const float scale = pow2_scale(maxbits[n * mstride]);        // per sample
+    const bool img = prow >= 1 && prow <= H;
+    int ya = 0, yb = -1;
+    bool any = img;
+    if (img) ya = prow - 1;
+    else if (reflect && prow == H + 2) { ya = 0; yb = 2; any = true; }
+    else if (reflect && prow == H + 3) { ya = H - 3; yb = H - 1; any = true; }
+    const float* src = gy + ((size_t)n * K + kblk * 64) * H * W;
+    for (int i = threadIdx.x; i < 64 * W; i += 256) {
+        const int kk = i / W, x = i - kk * W;
+        const float a = src[((size_t)kk * H + ya) * W + x];
+        const float b = src[((size_t)kk * H + max(yb, 0)) * W + x];
+        tile[kk][x] = any ? (yb >= 0 ? a + b : a) * scale : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * Ws; i += 256) {            // data-gradient planes: 8 channel groups x (W + 4) slots of row `prow`
+        const int cgl = i / Ws, slot = i - cgl * Ws;
+        int xa = -1, xb = -1;
+        if (slot >= 1 && slot <= W) xa = slot - 1;
+        else if (reflect && slot == W + 2) { xa = 0; xb = 2; }
+        else if (reflect && slot == W + 3) { xa = W - 3; xb = W - 1; }
+        unsigned short h[8], l[8];
+        float va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                            // (unconditional, clamped LDS reads; masks afterwards)
+            va[j] = tile[cgl * 8 + j][max(xa, 0)];
+            vb[j] = tile[cgl * 8 + j][max(xb, 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split2_f16(xa >= 0 ? (xb >= 0 ? va[j] + vb[j] : va[j]) : 0.f, h[j], l[j]);
+        const size_t t = (((size_t)n * CG + kblk * 8 + cgl) * Hp + prow) * Ws + slot;
+        dpl[t] = pack8(h);
+        dpl[dtotal + t] = pack8(l);
+    }
+    const int grow = img ? prow - 1 : (prow == 0 ? H : prow);              // border rows 0, H + 1, H + 2 -> the zero rows H, H + 1, H + 2
+    if (grow < Hg && (img || prow <= H + 2)) {
+        const int kk = threadIdx.x & 63;
+        for (int q = threadIdx.x >> 6; q < CPR; q += 4) {
+            unsigned short h[8], l[8];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[kk][min(q * 8 + e, W - 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2_f16((img && q * 8 + e < W) ? v[e] : 0.f, h[e], l[e]);
+            const size_t t = (((size_t)n * KBLK + kblk) * F + (size_t)grow * CPR + q) * 64 + kk;
+            gpl[t] = pack8(h);
+            gpl[gtotal + t] = pack8(l);
+        }
+    }
+}
+
 struct WgParams {
     const u32x4* G;            // [3 s][2 planes] blocks of gplane16 words
     const u32x4* X;            // [2 planes] blocks of xplane16 words
@@ -158,11 +226,14 @@ struct WgParams {
     int xcd;
 };
 
-template <int KS>        // 3x3 layers, or the discriminator's 4x4 / pad 1 layers (16 taps: 16 accumulators per wave)
+// 3x3 layers, or the discriminator's 4x4 / pad 1 layers (16 taps: 16 accumulators per wave).  ONEG: G_0 only comes from HBM.
+template <int KS, bool ONEG>
 __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
-    constexpr int RING = 4, NCP = 2 * KS;              // copies per wave per stage: 4 KS of G + 4 KS of X over four waves
-    constexpr int STAGE16 = 8 * KS * 64;               // 4 KS G columns + 4 KS X columns: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
-    constexpr int NMF = 3 * KS * KS, NSL = 2 * 2 * KS + NCP;       // MFMAs and slots per step
+    constexpr int GC = ONEG ? 1 : KS;                  // copies of G staged per chunk
+    constexpr int RING = 4, NCOL = 4 * GC + 4 * KS, NCP = NCOL / 4;     // copies per wave per stage: NCOL columns over four waves
+    constexpr int STAGE16 = NCOL * 64;                 // 4 GC G columns + 4 KS X columns: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
+    constexpr int NMF = 3 * KS * KS, NSL = 2 * GC + 2 * KS + NCP;       // MFMAs and slots per step
+    constexpr int NPV = KS / 2;                        // dwords of the previous chunk a shift by <= KS - 1 pixels reaches into
     __shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int tiles = p.KBLK * p.CBLK;
@@ -178,11 +249,11 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #pragma unroll
     for (int q = 0; q < NCP; ++q) {
         const int i = NCP * wid + q;
-        if (i < 4 * KS) {
+        if (i < 4 * GC) {
             const int s = i >> 2, pl = (i >> 1) & 1, ch = i & 1;
             csrc[q] = p.G + (size_t)(s * 2 + pl) * p.gplane16 + (((size_t)n * p.KBLK + kblk) * p.F + f0 + ch) * 64 + lane;
         } else {
-            const int j = i - 4 * KS, r = j >> 2, pl = (j >> 1) & 1, ch = j & 1;
+            const int j = i - 4 * GC, r = j >> 2, pl = (j >> 1) & 1, ch = j & 1;
             csrc[q] = p.X + (size_t)pl * p.xplane16 + (((size_t)n * p.CBLK + cblk) * p.FX + f0 + r * p.CPR + ch) * 64 + lane;
         }
     }
@@ -203,16 +274,39 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
         for (int r = 0; r < KS; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[s][r][e] = 0.f;
-    u32x4 af[2][KS][2], bf[2][KS][2];                  // [register set][s | r][plane]
-    const int a_off = lhi * 64 + wk * 32 + l31, b_off = 4 * KS * 64 + lhi * 64 + wc * 32 + l31;
+    u32x4 af[2][GC][2], bf[2][KS][2];                  // [register set][s | r][plane]
+    u32x4 sh[2][ONEG ? KS : 1][2];                     // ONEG: [register set][s][plane] = G_s built from G_0 (sh[.][0] unused)
+    const int a_off = lhi * 64 + wk * 32 + l31, b_off = 4 * GC * 64 + lhi * 64 + wc * 32 + l31;
 #define WG_READ(set_, slot_)                                                                                            \
     {                                                                                                                   \
         const u32x4* const S_ = smem + (slot_) * STAGE16;                                                               \
-        _Pragma("unroll") for (int i = 0; i < 2 * KS; ++i) af[set_][i >> 1][i & 1] = S_[a_off + i * 128];               \
+        _Pragma("unroll") for (int i = 0; i < 2 * GC; ++i) af[set_][i >> 1][i & 1] = S_[a_off + i * 128];               \
         _Pragma("unroll") for (int i = 0; i < 2 * KS; ++i) bf[set_][i >> 1][i & 1] = S_[b_off + i * 128];               \
+    }
+    // G_s of the stage in register set `set_` from its G_0 words and the last NPV dwords of the chunk before: lanes 0..31 hold chunk
+    // 0 of the stage (previous chunk = chunk 1 of the stage before: lanes 32..63 of `pv_`), lanes 32..63 chunk 1 (previous = this
+    // stage's chunk 0).  in(j) = dword j of the chunk, in(-1), in(-2) = the previous chunk's last dwords; a shift by s pixels takes
+    // dword i from in(i - s / 2) (even s) or from the 16-bit funnel of in(i - s / 2), in(i - s / 2 - 1) (odd s).
+#define WG_SHIFT(set_, pv_)                                                                                             \
+    if (ONEG) {                                                                                                         \
+        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                              \
+            const u32x4 a_ = af[set_][0][pl];                                                                           \
+            unsigned in_[4 + NPV];                                 /* in_[NPV + j] = in(j) */                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) in_[NPV + j] = a_[j];                                         \
+            _Pragma("unroll") for (int j = 0; j < NPV; ++j) {                                                           \
+                const auto sw_ = __builtin_amdgcn_permlane32_swap(pv_[pl][j], a_[4 - NPV + j], false, false);           \
+                in_[j] = lhi ? sw_[0] : sw_[1];                                                                         \
+            }                                                                                                           \
+            _Pragma("unroll") for (int s = 1; s < KS; ++s)                                                              \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+                    const int j_ = NPV + i - (s >> 1);                                                                  \
+                    sh[set_][s][pl][i] = (s & 1) ? __builtin_amdgcn_alignbit(in_[j_], in_[j_ - 1], 16) : in_[j_];       \
+                }                                                                                                       \
+        }                                                                                                               \
     }
     // partial products, smallest first: (l h') (h l') (h h')
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#define WG_A(set_, s_, pl_) ((ONEG && (s_) > 0) ? sh[set_][(ONEG ? (s_) : 0)][pl_] : af[set_][ONEG ? 0 : (s_)][pl_])
 
     WG_COPIES(0)
     WG_COPIES(1)
@@ -222,6 +316,14 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     __builtin_amdgcn_s_barrier();
     WG_READ(0, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    {
+        unsigned zero_[2][NPV > 0 ? NPV : 1];          // the chunk before a slab's first one is the zero tail of the row above
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < NPV; ++j) zero_[pl][j] = 0u;
+        WG_SHIFT(0, zero_)
+    }
     __builtin_amdgcn_s_barrier();                      // every wave holds the fragments of step 0: slot 0 may be refilled
     for (int T0 = 0; T0 < nsteps; T0 += 2) {
 #pragma unroll
@@ -231,7 +333,7 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #define WG_MFMAS(beg_, end_)                              /* m = KS KS q + KS s + r */                                      \
             _Pragma("unroll") for (int m_ = (beg_); m_ < (end_) && m_ < NMF; ++m_) {                                    \
                 const int q_ = m_ / (KS * KS), s_ = (m_ % (KS * KS)) / KS, r_ = m_ % KS;                                \
-                acc[s_][r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[cur][s_][PA[q_]]),    \
+                acc[s_][r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, WG_A(cur, s_, PA[q_])),  \
                                                                      __builtin_bit_cast(f16x8, bf[cur][r_][PB[q_]]),    \
                                                                      acc[s_][r_], 0, 0, 0);                             \
             }                                                                                                           \
@@ -239,14 +341,25 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #define WG_SLOT(i_) WG_MFMAS((i_) * NMF / NSL, ((i_) + 1) * NMF / NSL)
             const u32x4* const S_ = smem + ((T + 1) & (RING - 1)) * STAGE16;
 #pragma unroll
-            for (int i = 0; i < 2 * KS; ++i) {
+            for (int i = 0; i < 2 * GC; ++i) {
                 af[nxt][i >> 1][i & 1] = S_[a_off + i * 128];
                 WG_SLOT(i)
             }
 #pragma unroll
             for (int i = 0; i < 2 * KS; ++i) {
                 bf[nxt][i >> 1][i & 1] = S_[b_off + i * 128];
-                WG_SLOT(2 * KS + i)
+                WG_SLOT(2 * GC + i)
+            }
+            if (ONEG) {
+                // the 2 G_0 words of step T + 1 have landed once at most the 2 KS X reads are outstanding (LDS returns in order):
+                // build its shifted operands now, between this step's MFMAs
+                __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * KS) << 8));
+                unsigned pv_[2][NPV > 0 ? NPV : 1];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int j = 0; j < NPV; ++j) pv_[pl][j] = af[cur][0][pl][4 - NPV + j];
+                WG_SHIFT(nxt, pv_)
             }
             {
                 const int st_ = min(T + 4, nsteps - 1);
@@ -254,7 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 #pragma unroll
                 for (int q = 0; q < NCP; ++q) {
                     glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
-                    WG_SLOT(4 * KS + q)
+                    WG_SLOT(2 * GC + 2 * KS + q)
                 }
             }
 #undef WG_SLOT
@@ -266,6 +379,8 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     }
     wait_vmem();                                       // (the tail's re-copies)
 #undef WG_READ
+#undef WG_SHIFT
+#undef WG_A
 #undef WG_VMCNT
 #undef WG_COPIES
 
@@ -326,23 +441,49 @@ int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS) {
 }
 
 // gw [K][C][KS][KS] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C KS KS floats.  x [N, C, H, W], gy [N, K, H + 3 - KS, W + 3 - KS]
+static int g_one_g = 1;        // nemar_tune(34): 1 = one copy of the gy planes, shifted operands built in registers; 0 = KS copies in HBM
+void nemar_split16_wgrad_tune(int v) { g_one_g = v ? 1 : 0; }
+
+size_t nemar_split16_wgrad_g_bytes(int N, int H, int W, int K, int KS) {
+    return g_one_g ? (size_t)2 * N * K * g_rows(H, KS) * ((W + 2 + 7) / 8) * 16 : 0;
+}
+
+void nemar_split16_dual_split(const float* gy, void* dplanes, void* gplanes, int N, int K, int H, int W, int mode, const unsigned* maxbits,
+                              int mstride, hipStream_t st) {
+    const int CPR = (W + 2 + 7) / 8, Hg = g_rows(H, 3);
+    const long long dtotal = (long long)N * (K / 8) * (H + 4) * (W + 4), gtotal = (long long)N * K * Hg * CPR;
+    const int reflect = mode == SPLIT16_DGRAD_REFLECT ? 1 : 0;
+    const dim3 grid(N * (K / 64) * (H + 4));
+#define WG_DUAL(TW_)                                                                                                               \
+    hipLaunchKernelGGL((split_dual_kernel<TW_>), grid, dim3(256), 0, st, gy, (u32x4*)dplanes, (u32x4*)gplanes, N, K, H, W, Hg, CPR, reflect, \
+                       dtotal, gtotal, maxbits, mstride);
+    if (W <= 64) { WG_DUAL(64) } else if (W <= 128) { WG_DUAL(128) } else { WG_DUAL(256) }
+#undef WG_DUAL
+}
+
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
-                         void* scratch, float* part, int xcd_map, hipStream_t st) {
+                         void* scratch, float* part, int xcd_map, const void* g_planes, hipStream_t st) {
     const int CPR = (W + 2 + 7) / 8, KBLK = K / 64, CBLK = C / 64;
     const int OHg = H + 3 - KS, OWg = W + 3 - KS, Hg = g_rows(H, KS), Hx = Hg + KS - 1;
     const long long gtotal = (long long)N * K * Hg * CPR, xtotal = (long long)N * C * Hx * CPR;      // words per plane block
-    u32x4* const G = (u32x4*)scratch;
-    u32x4* const X = G + 2 * KS * gtotal;
+    const bool oneg = g_one_g != 0;
+    const bool have_g = oneg && g_planes != nullptr;
+    const u32x4* const G = have_g ? (const u32x4*)g_planes : (const u32x4*)scratch;
+    u32x4* const X = (u32x4*)scratch + 2 * (oneg ? 1 : KS) * gtotal;
     unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K, KS) - 2048);    // 2 x 256 words
     int gstride = 0, xstride = 0;
     const unsigned* const gmax = nemar_split16_source_max(gy, N, (long long)K * OHg * OWg, mw, &gstride, st);
     const unsigned* const xmax = nemar_split16_source_max(x, N, (long long)C * H * W, mw + 256, &xstride, st);
 #define WG_SPLIT(TW_)                                                                                                              \
-    if (KS == 3)                                                                                                                   \
-        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 3>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, G, N, K, OHg, OWg, Hg, CPR, gtotal, \
+    if (have_g) {                                                                                                                  \
+    } else if (oneg)                                                                                                               \
+        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 1>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
+                           gmax, gstride);                                                                                         \
+    else if (KS == 3)                                                                                                              \
+        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 3>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
                            gmax, gstride);                                                                                         \
     else                                                                                                                           \
-        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 4>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, G, N, K, OHg, OWg, Hg, CPR, gtotal, \
+        hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 4>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
                            gmax, gstride);                                                                                         \
     hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * Hx), dim3(256), 0, st, x, X, N, C, H, W, Hx, CPR, reflect, xtotal, \
                        xmax, xstride);
@@ -359,7 +500,9 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     p.gmax = gmax; p.xmax = xmax; p.gstride = gstride; p.xstride = xstride;
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
-    if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wgrad_split16_kernel<4>), dim3(grid), dim3(256), 0, st, p);
+    if (KS == 3 && oneg) hipLaunchKernelGGL((wgrad_split16_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
+    else if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
+    else if (oneg) hipLaunchKernelGGL((wgrad_split16_kernel<4, true>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_split16_kernel<4, false>), dim3(grid), dim3(256), 0, st, p);
     nemar_sum_partials(part, (long long)K * C * KS * KS, splits, gw, (long long)K * C * KS * KS, true, st);
 }

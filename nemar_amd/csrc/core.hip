@@ -2,7 +2,8 @@
 #include "common.h"
 #include <stdarg.h>
 
-#define NEMAR_HIP_VERSION 300  // major*10000 + minor*100 + patch  (0.3.0: round 3 — general 16-bit-pipe kernels, per-sample scales, route / epoch queries)
+#define NEMAR_HIP_VERSION 400  // major*10000 + minor*100 + patch  (0.4.0: round 4 — side inputs per call only (set_scratch / *_hint removed),
+                               // weight-pack plans, nemar_store_words, 7x7 layers on the 16-bit pipe (route 4))
 
 static thread_local char g_err[512] = "";
 

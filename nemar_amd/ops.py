@@ -112,7 +112,28 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
     return buf
 
 
-def _extras(arena=None, src_max=None, src2_max=None, planes=None):
+_garena = {}           # device -> the buffer a layer's data-gradient call leaves the weight gradient's gy planes in
+_gplanes_need = {}
+
+
+def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
+    """-> the buffer (tensor) in which the data-gradient call of this layer leaves the operand planes of gy its weight-gradient call
+    takes (nemar_conv_extras.gy_planes_out -> .src2_planes: gy is split once for both), or None.  Grow-only per device, stream-ordered."""
+    key = (N, C, H, W, K, R, S, stride, pad, pad_mode)
+    need = _gplanes_need.get(key)
+    if need is None:
+        need = _gplanes_need[key] = L.conv2d_gy_planes_bytes(N, C, H, W, K, R, S, stride, pad, pad_mode)
+    if not need:
+        return None
+    buf = _garena.get(device)
+    if buf is None or buf.numel() * 4 < need:
+        _retire(buf)
+        buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
+        _garena[device] = buf
+    return buf
+
+
+def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None):
     """nemar_conv_extras for one call: the side inputs of the wide-layer route, or None when there are none"""
     if arena is None and src_max is None and src2_max is None and planes is None:
         return None
@@ -125,6 +146,10 @@ def _extras(arena=None, src_max=None, src2_max=None, planes=None):
         e.src2_max_words, e.src2_max_count = src2_max.data_ptr(), src2_max.numel()
     if planes is not None:
         e.src_planes = planes.data_ptr()
+    if gy_out is not None:
+        e.gy_planes_out, e.gy_planes_bytes = gy_out.data_ptr(), gy_out.numel() * 4
+    if src2_planes is not None:
+        e.src2_planes = src2_planes.data_ptr()
     return ctypes.byref(e)
 
 
@@ -399,7 +424,7 @@ class _Conv2d(Function):
     @staticmethod
     def _backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st, need_x, need_x2, need_w,
                        need_b, gmax):
-        gx = gx2 = None
+        gx = gx2 = gpl = None
         if need_x or need_x2:
             gx = torch.empty_like(x) if need_x else None
             gx2 = torch.empty_like(x2) if (need_x2 and x2 is not None) else None
@@ -421,10 +446,15 @@ class _Conv2d(Function):
             wsb = L.conv2d_bwd_data_workspace(Nd, C, H, W, K, R, S, stride, pad, pad_mode)
             ws, hit, plan = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, Nd, H, W), wsb)
             arena = _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
+            if arena is not None and need_w and Nd == N and gmax is not None and x2 is None:
+                # wide layer whose weight gradient follows: the pass that splits gy for this call leaves its planes for that one too
+                gpl = _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, g.device)
             with _record(plan):
                 L.conv2d_bwd_data_ex(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
                                      stride, pad, pad_mode, _p(ws), wsb, hit, st,
-                                     _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax))
+                                     _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax, gy_out=gpl))
+            if gpl is not None and not L.last_gy_planes():
+                gpl = None
             if not need_x2:
                 gx2 = None
         want_b = need_b and ctx.bias is not None
@@ -434,7 +464,7 @@ class _Conv2d(Function):
             arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
             L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
                                    R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st,
-                                   _extras(arena, ctx.xmax, gmax))
+                                   _extras(arena, ctx.xmax, gmax, src2_planes=gpl))
             grad_ready(ctx.weight)
             if want_b:
                 grad_ready(ctx.bias)

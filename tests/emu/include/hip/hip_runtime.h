@@ -205,6 +205,23 @@ static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address
 }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 
+// ---- v_permlane32_swap_b32 (gfx950): lanes 32..63 of vdst <-> lanes 0..31 of src; returns {new vdst, new src} -------------
+typedef unsigned emu_u32x2 __attribute__((ext_vector_type(2)));
+static inline emu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
+    unsigned mine[2] = {vdst, src};
+    unsigned all[64][2];
+    emu_wave_exchange(mine, sizeof(mine), all);
+    const int l = emu_lane_id();
+    emu_u32x2 r;
+    r[0] = l < 32 ? vdst : all[l - 32][1];
+    r[1] = l < 32 ? all[l + 32][0] : src;
+    return r;
+}
+// v_alignbit_b32: low 32 bits of ({hi, lo} >> shift)
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
+    return (unsigned)((((unsigned long long)hi << 32) | lo) >> (sh & 31));
+}
+
 // ---- scalar/uniform builtins ------------------------------------------------------------------
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline void __builtin_amdgcn_s_setprio(int) {}

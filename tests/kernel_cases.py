@@ -519,6 +519,80 @@ def case_conv_split16_wgrad(be, N, C, H, W, K, pad_mode, seed=0, R=3):
         case_conv_bwd_weight(be, N, C, 0, H, W, K, R, 1, 1, pad_mode, seed=seed)
 
 
+def case_conv_split16_dual_gy(be, N, C, H, W, K, pad_mode, seed=0):
+    """The data-gradient call of a wide 3x3 layer leaves the weight gradient's operand planes of gy behind (nemar_conv_extras.gy_planes_out ->
+    .src2_planes, csrc/conv_split16_wgrad.hip split_dual_kernel: gy is read and split once for both calls).  Both gradients must be
+    BIT-IDENTICAL to those of the calls that split gy on their own, and the handshake (nemar_last_gy_planes) must say what happened."""
+    from nemar_amd._lib import ConvExtras
+    import ctypes
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
+    assert need > 0, "shape is not eligible for the split-16 kernels"
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    gy = (rng.standard_normal((N, K, H, W)) / np.sqrt(N * H * W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    d_x, d_gy, d_w = be.dev(x), be.dev(gy), be.dev(w)
+    arena = be.bytes_buf(need)
+    lib = be.lib
+    lib.tune(23, 0)
+    try:
+        gbytes = lib.conv2d_gy_planes_bytes(N, C, H, W, K, 3, 3, 1, 1, pad_mode)
+        assert gbytes > 0, "layer does not take producer-written gy planes"
+        gbuf = be.bytes_buf(gbytes)
+        words = be.bytes_buf(4 * N)
+        lib.absmax_samples(be.ptr(d_gy), N, K * H * W, be.ptr(words), be.stream)
+        wsd, wsdb = _ws(be, lib.conv2d_bwd_data_workspace(N, C, H, W, K, 3, 3, 1, 1, pad_mode))
+        wsw, wswb = _ws(be, lib.conv2d_bwd_weight_workspace(N, C, H, W, K, H, W, 3, 3, 1, 1))
+
+        def extras(gy_out=None, src2_planes=None, with_words=True, weight_call=False):
+            e = ConvExtras()
+            e.scratch, e.scratch_bytes = be.ptr(arena).value, need
+            if with_words and not weight_call:
+                e.src_max_words, e.src_max_count = be.ptr(words).value, N
+            if with_words and weight_call:
+                e.src2_max_words, e.src2_max_count = be.ptr(words).value, N
+            if gy_out is not None:
+                e.gy_planes_out, e.gy_planes_bytes = be.ptr(gy_out).value, gbytes
+            if src2_planes is not None:
+                e.src2_planes = be.ptr(src2_planes).value
+            return ctypes.byref(e)
+
+        def run(dual, with_words):
+            d_gx = be.full((N, C, H, W), np.nan)
+            d_gw = be.full((K, C, 3, 3), 0.5)
+            lib.conv2d_bwd_data_ex(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gx), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1,
+                                   pad_mode, be.ptr(wsd), wsdb, 0, be.stream, extras(gy_out=gbuf if dual else None, with_words=with_words))
+            assert lib.last_route() == 2
+            assert lib.last_gy_planes() == (1 if dual else 0)
+            lib.conv2d_bwd_weight_ex(be.ptr(d_x), C, None, 0, be.ptr(d_gy), be.ptr(d_gw), None, N, H, W, K, H, W, 3, 3, 1, 1, pad_mode,
+                                     be.ptr(wsw), wswb, be.stream,
+                                     extras(src2_planes=gbuf if dual else None, with_words=with_words, weight_call=True))
+            assert lib.last_route() == 2
+            be.sync()
+            return be.raw(d_gx), be.raw(d_gw)
+
+        for with_words in (True, False):
+            gx_a, gw_a = run(False, with_words)
+            gx_b, gw_b = run(True, with_words)
+            assert np.array_equal(gx_a, gx_b), "data gradient differs when its split pass also writes the weight gradient's planes"
+            assert np.array_equal(gw_a, gw_b), "weight gradient from the data-gradient call's gy planes differs"
+        # and against float64
+        want_gx, want_gw, _ = O.conv2d_bwd(x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64), 1, 1, _PM[pad_mode])
+        _assert_close(gw_b.view(np.float32).reshape(K, C, 3, 3).astype(np.float64), want_gw + 0.5, atol=2e-5, rtol=2e-5,
+                      what="conv2d_bwd_weight (gy planes from the data-gradient call)")
+        # a buffer that is too small is not written
+        d_gx = be.full((N, C, H, W), np.nan)
+        e = ConvExtras()
+        e.scratch, e.scratch_bytes = be.ptr(arena).value, need
+        e.gy_planes_out, e.gy_planes_bytes = be.ptr(gbuf).value, gbytes - 16
+        lib.conv2d_bwd_data_ex(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gx), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1, pad_mode,
+                               be.ptr(wsd), wsdb, 0, be.stream, ctypes.byref(e))
+        assert lib.last_gy_planes() == 0
+        be.sync()
+    finally:
+        lib.tune(23, 2000)
+
+
 def case_conv_transpose_fwd(be, N, Ci, Co, H, W, R, out_pad, act=O.ACT_RELU, seed=0):
     """ConvTranspose2d(Ci->Co, k=R, s=2, p=1, op) forward through the data-gradient entry point."""
     rng = np.random.default_rng(seed)

@@ -361,9 +361,17 @@ def test_conv_split16_reflect_data_gradient(be, variant):
         be.lib.tune(21, 4)
 
 
+def test_conv_split16_gy_split_once_for_both_gradients(be):
+    """nemar_conv_extras.gy_planes_out / .src2_planes: the data-gradient call's split pass writes both operand layouts of gy (reflect
+    fold rows and zero padding; plane rows rounded up to 4: two zero rows below a 6-row image; 32-, 64- and 128-pixel rows)."""
+    K.case_conv_split16_dual_gy(be, 1, 128, 8, 32, 128, K.PAD_REFLECT)
+    K.case_conv_split16_dual_gy(be, 2, 128, 4, 64, 192, K.PAD_ZERO)
+    K.case_conv_split16_dual_gy(be, 1, 128, 6, 128, 128, K.PAD_REFLECT)
+
+
 def test_conv_split16_weight_gradient(be):
-    """Weight gradient of the wide 3x3 layers on the 16-bit matrix pipe (conv_split16_wgrad.hip): three pre-shifted gy copies and
-    padded x planes in tile order, nine taps per workgroup, pixel slabs summed in order; reflect and zero padding, one and several
+    """Weight gradient of the wide 3x3 layers on the 16-bit matrix pipe (conv_split16_wgrad.hip): one copy of the gy planes (the
+    shifted operands built in registers: v_permlane32_swap + v_alignbit) and padded x planes in tile order, nine taps per workgroup, pixel slabs summed in order; reflect and zero padding, one and several
     slabs per image, 2 and 3 chunks per row, rectangular channel counts."""
     K.case_conv_split16_wgrad(be, 1, 128, 8, 8, 128, K.PAD_REFLECT)
     K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 192, K.PAD_ZERO)
@@ -371,6 +379,12 @@ def test_conv_split16_weight_gradient(be):
     K.case_conv_split16_wgrad(be, 1, 128, 6, 16, 128, K.PAD_ZERO)                  # 6 rows -> 8 plane rows (two of zeros)
     K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 128, K.PAD_ZERO, R=4)             # 4x4: 16 taps, gy 7x15, four shifts
     K.case_conv_split16_wgrad(be, 1, 128, 5, 32, 192, K.PAD_ZERO, R=4)             # gy 4x31
+    be.lib.tune(34, 0)             # first generation: KS shifted copies of the gy planes in HBM
+    try:
+        K.case_conv_split16_wgrad(be, 1, 192, 4, 24, 128, K.PAD_REFLECT)
+        K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 128, K.PAD_ZERO, R=4)
+    finally:
+        be.lib.tune(34, 1)
 
 
 def test_absmax_and_hint(be):

@@ -12,7 +12,7 @@ for kv in sys.argv[2:]:
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 rows = []
-ROUTES = {0: "exact", 1: "narrow", 2: "split16", 3: "s16g"}
+ROUTES = {0: "exact", 1: "narrow", 2: "split16", 3: "s16g", 4: "k7"}
 arena = None
 for line in open(sys.argv[1]):
     if not line.startswith('{'):
@@ -46,7 +46,7 @@ for line in open(sys.argv[1]):
         pass
     f(0)
     d["route"] = ROUTES.get(lib.last_route(), "?")
-    t = timeit(lambda: f(1), 10, 2)
+    t = min(timeit(lambda: f(1), 10, 2) for _ in range(3))      # min of three: an allocator hiccup once showed up as a 3.9 ms 'layer'
     flop = 2.0 * N * K * OH * OW * C * R * R
     rows.append((t * d["count"], t, flop, d))
 rows.sort(key=lambda r: -r[0])

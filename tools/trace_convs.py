@@ -9,7 +9,7 @@ from nemar_amd.models import create_model
 
 calls = collections.Counter()
 L = ops.L
-_f, _d, _w = L.conv2d_fwd, L.conv2d_bwd_data, L.conv2d_bwd_weight
+_f, _d, _w = L.conv2d_fwd_ex, L.conv2d_bwd_data_ex, L.conv2d_bwd_weight_ex          # the entry points nemar_amd/ops.py calls
 
 
 def fwd(x0, C0, x1, C1, w, b, y, N, H, W, K, R, S, stride, pad, pm, *rest):
@@ -27,7 +27,7 @@ def wgrad(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pm,
     return _w(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pm, *rest)
 
 
-L.conv2d_fwd, L.conv2d_bwd_data, L.conv2d_bwd_weight = fwd, dgrad, wgrad
+L.conv2d_fwd_ex, L.conv2d_bwd_data_ex, L.conv2d_bwd_weight_ex = fwd, dgrad, wgrad
 opt = bench.build_opt(8, 256)
 model = create_model(opt); model.setup(opt)
 g = torch.Generator(device='cuda').manual_seed(0)
