@@ -45,7 +45,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BORDER_REFLECT = 1;
 constexpr int ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3;      // (tanh: not served here, see nemar_s16g_plan)
 constexpr int BWORDS = 3568;          // LDS words of the halo region: 4 (2 planes x 2 k groups) x HR x HCP <= BWORDS
-constexpr int NSMAX = 7;              // halo pixels per loader thread (128 threads per k group)
+constexpr int NS4LIM = 2;             // 4-pixel halo groups per loader thread (128 threads per k group): 16-byte source loads
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte load at a 4-byte-aligned address
 constexpr int TEXP = 14;              // scaled magnitudes stay below 2^15
 
 // v s = h + l (+ e): both halves of eight values as two 16-byte words.  v * s is exact (s a power of two), so fmaf(v, s, -h) is the
@@ -115,9 +116,10 @@ struct S16gParams {
     long long* tl;                           // NEMAR_TIMELINE builds: cycle stamps of one workgroup (tools/timeline_s16g.py)
     int dbg;                                 // ablation bits (nemar_tune key 2, tools/ only): 1 no tap loop, 2 no source loads, 4 no conversion
     int TW, RT, wshift, tiles_x, tiles_y, mblks, nchunks;
-    int HR, HC, HCP, HCH, hp16, dymin, dxmin;
+    int HR, HC, HCP, HCH, GPR, OFS, hp16, dymin, dxmin;     // GPR: 4-pixel groups per halo row; HCP = 4 GPR words per row; OFS: LDS column of
+                                                            // image column ox0 SX (-dxmin rounded up to 4 when taps reach left of it, else 0)
     int aw16;                                // LDS words of the weight region
-    FastDiv fd_hc;
+    FastDiv fd_gpr;
     long long cls_words;                     // packed words per class
     int ntaps[S16G_MAX_CLS], OH[S16G_MAX_CLS], OW[S16G_MAX_CLS], ooy[S16G_MAX_CLS], oox[S16G_MAX_CLS];
     int tapoff[S16G_MAX_TAPS];               // halo word offset of tap t of class c at [c * S16G_CLS_TAPS + t] (one class: all 64)
@@ -233,7 +235,7 @@ struct RegS16gPack {
 // MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride.
 // LDS (dynamic: exactly what the layer needs, so that narrow layers keep several workgroups per CU): [weights of one chunk,
 // p.aw16 words][halo planes, 4 p.hp16 words]
-template <int MT, int NT, int SX>
+template <int MT, int NT, int SX, int NS4MAX>          // NS4MAX: 4-pixel halo groups per loader thread (1: tiles of <= 128 groups)
 __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     constexpr int MB = 32 * MT, NPW = 32 * NT;
 #ifdef NEMAR_HOST_EMULATION
@@ -264,36 +266,51 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     const int C = p.C0 + p.C1;
     const size_t HWs = (size_t)p.Hs * p.Ws;
 
-    // ---- loader role: waves 0, 1 fill k group 0 (channels 0..7 of the chunk), waves 2, 3 k group 1; thread = halo pixel ----
+    // ---- loader role: waves 0, 1 fill k group 0 (channels 0..7 of the chunk), waves 2, 3 k group 1; thread = FOUR consecutive IMAGE
+    // columns 4a .. 4a + 3 of a halo row, fetched with one aligned 16-byte load per channel (round 4: the vector-memory pipe issues
+    // about one wave-wide load per 30 clocks and CU whatever its width — profiles/r4_load_width.txt — and 56 four-byte loads per thread
+    // and chunk sat at that cap).  Groups are aligned to the IMAGE (Ws % 4 == 0), so no load straddles a border: a group is inside or
+    // outside as a whole.  Padding positions of the halo are never loaded: under a zero border they keep the zeros the region is
+    // filled with once; under a reflect border the owners of the first / last group of a row also write their words to the <= 3
+    // mirrored positions beside them (rows are mirrored by address).  LDS column of image column ix = ix - ox0 SX + OFS.
     const int kgl = wid >> 1;
-    const int hpn = p.HR * p.HC;
-    const int ns = __builtin_amdgcn_readfirstlane((hpn + 127) >> 7);          // halo slots in use (of NSMAX)
-    int soff[NSMAX], lpos[NSMAX];      // soff: source offset inside a channel image (always a valid address), < 0 flags in svalid
-    bool svalid[NSMAX], sany[NSMAX];   // this lane's halo pixel is inside the image / some lane of the wave is not (wave-uniform)
+    const int ngr = p.HR * p.GPR;
+    const int ns = __builtin_amdgcn_readfirstlane((ngr + 127) >> 7);          // group slots in use (of NS4MAX)
+    int soff[NS4MAX], lpos[NS4MAX];    // soff: source offset of the group inside a channel image; lpos < 0: nothing to load (padding / no group)
+    int mirr[NS4MAX];                  // reflect border: bits 0..1 = columns mirrored to the left of group 0, bits 2..3 = to the right of the last group
+    bool smirr[NS4MAX];                // some lane of the wave has mirror columns to write (wave-uniform)
+    bool sdead[NS4MAX];                // some lane of the wave has no group in this slot (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < NSMAX; ++i) {
-        const int hp = (tid & 127) + 128 * i;
-        soff[i] = -1;
+    for (int i = 0; i < NS4MAX; ++i) {
+        const int gp = (tid & 127) + 128 * i;
+        soff[i] = 0;
         lpos[i] = -1;
-        if (hp < hpn) {
-            const int hr = (int)fd_div((unsigned)hp, p.fd_hc), hc = hp - hr * p.HC;
-            int iy = oy0 * SX + p.dymin + hr, ix = ox0 * SX + p.dxmin + hc;
-            bool ok = true;
-            if (p.border == BORDER_REFLECT) {
-                iy = mirror_clamp(iy, p.Hs);
-                ix = mirror_clamp(ix, p.Ws);
-            } else {
-                ok = (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+        mirr[i] = 0;
+        if (gp < ngr) {
+            const int hr = (int)fd_div((unsigned)gp, p.fd_gpr), g = gp - hr * p.GPR;
+            int iy = oy0 * SX + p.dymin + hr;
+            const int ixg = ox0 * SX - p.OFS + 4 * g;
+            bool ok = ixg >= 0 && ixg < p.Ws;
+            if (p.border == BORDER_REFLECT) iy = mirror_clamp(iy, p.Hs);
+            else ok = ok && (unsigned)iy < (unsigned)p.Hs;
+            if (ok) {
+                soff[i] = iy * p.Ws + ixg;
+                lpos[i] = kgl * p.hp16 + hr * p.HCP + (SX == 2 ? 2 * g : 4 * g);
+                if (p.border == BORDER_REFLECT) {
+                    // halo columns left of the image: -1 .. ox0 SX + dxmin (tiles in the first column); right: Ws .. last halo column
+                    const int nl = ixg == 0 ? min(3, -(ox0 * SX + p.dxmin)) : 0;
+                    const int nr = ixg == p.Ws - 4 ? min(3, ox0 * SX - p.OFS + 4 * p.GPR - p.Ws) : 0;
+                    mirr[i] = max(nl, 0) | (max(nr, 0) << 2);
+                }
             }
-            soff[i] = ok ? iy * p.Ws + ix : -1;
-            lpos[i] = kgl * p.hp16 + hr * p.HCP + (SX == 2 ? (hc & 1) * p.HCH + (hc >> 1) : hc);
         }
-        svalid[i] = soff[i] >= 0;
-        sany[i] = __any(lpos[i] >= 0 && !svalid[i]) != 0;
-        soff[i] = svalid[i] ? soff[i] : 0;
+        smirr[i] = __any(mirr[i] != 0) != 0;
+        sdead[i] = __any(lpos[i] < 0) != 0;
     }
-    float v[NSMAX][8];
-    // source values of chunk `ch_`: 8 channels (wave-uniform base pointers) x this thread's halo pixels
+    // zero fill of the halo planes (padding positions are never written afterwards; the barrier of the first chunk orders it)
+    for (int w = tid; w < 4 * p.hp16; w += 256) Bs[w] = u32x4{0u, 0u, 0u, 0u};
+    f32x4u v[NS4MAX][8];
+    // source values of chunk `ch_`: 8 channels (wave-uniform base pointers) x this thread's groups
 #define S16G_LOAD(ch_)                                                                                                  \
     {                                                                                                                   \
         const float* cb_[8];                                                                                            \
@@ -303,22 +320,24 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
                                         : p.src1 + ((size_t)n * p.C1 + (c_ - p.C0)) * HWs;                              \
             cb_[j] = c_ < C ? b_ : p.src0;      /* beyond the last channel: any valid address, zeroed below */          \
         }                                                                                                               \
-        /* slots beyond the tile's halo (ns of NSMAX: wave-uniform) issue nothing — a 256-pixel stride-1 tile uses 4 of 7 */ \
-        _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) {                                                             \
+        /* slots beyond the tile's halo (ns of NS4MAX: wave-uniform) issue nothing */                                   \
+        _Pragma("unroll") for (int i = 0; i < NS4MAX; ++i) {                                                            \
             if (i < ns) {                                                                                               \
-                if (p.dbg & 2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = 1.f; }                         \
-                else { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = cb_[j][soff[i]]; }  /* unconditional per lane */ \
+                if (p.dbg & 2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = f32x4u{1.f, 1.f, 1.f, 1.f}; }  \
+                else { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = *reinterpret_cast<const f32x4u*>(cb_[j] + soff[i]); } /* unconditional per lane */ \
             }                                                                                                           \
         }                                                                                                               \
     }
-    // what the unconditional loads fetched for padding pixels / channels beyond C becomes zero (wave-uniform tests: interior tiles
-    // of layers with C % 16 == 0 skip all of it)
+    // lanes without a group loaded from offset 0 (their values take part in nothing but must not reach the maximum); channels
+    // beyond C become zero (wave-uniform test: layers with C % 16 == 0 skip it)
 #define S16G_MASK(ch_)                                                                                                  \
     {                                                                                                                   \
         const int jlim_ = C - (ch_) * 16 - kgl * 8;                                                                     \
-        _Pragma("unroll") for (int i = 0; i < NSMAX; ++i) {                                                             \
-            if (i < ns && (sany[i] || jlim_ < 8)) {                                                                                 \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) v[i][j] = (svalid[i] && j < jlim_) ? v[i][j] : 0.f;       \
+        _Pragma("unroll") for (int i = 0; i < NS4MAX; ++i) {                                                            \
+            if (i < ns && (sdead[i] || jlim_ < 8)) {                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
+                    if (lpos[i] < 0 || j >= jlim_) v[i][j] = f32x4u{0.f, 0.f, 0.f, 0.f};                                \
+                }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
     }
@@ -366,22 +385,26 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             // path that leaves non-finite values out of the maximum — they must not flush the finite ones)
             float mf = 0.f;
 #pragma unroll
-            for (int i = 0; i < NSMAX; ++i)
+            for (int i = 0; i < NS4MAX; ++i)
                 if (i < ns) {
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) mf = fmaxf(mf, fmaxf(__builtin_fabsf(v[i][j]), __builtin_fabsf(v[i][j + 1])));
+                    for (int j = 0; j < 8; ++j)
+                        mf = fmaxf(fmaxf(mf, fmaxf(__builtin_fabsf(v[i][j][0]), __builtin_fabsf(v[i][j][1]))),
+                                   fmaxf(__builtin_fabsf(v[i][j][2]), __builtin_fabsf(v[i][j][3])));
                 }
             unsigned m = __builtin_bit_cast(unsigned, mf);
             if (m >= 0x7f800000u) {
                 m = 0;
 #pragma unroll
-                for (int i = 0; i < NSMAX; ++i)
+                for (int i = 0; i < NS4MAX; ++i)
                     if (i < ns) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const unsigned u = __builtin_bit_cast(unsigned, v[i][j]) & 0x7fffffffu;
-                            m = max(m, u < 0x7f800000u ? u : 0u);
-                        }
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned u = __builtin_bit_cast(unsigned, (float)v[i][j][e]) & 0x7fffffffu;
+                                m = max(m, u < 0x7f800000u ? u : 0u);
+                            }
                     }
             }
             m = wave_max_to_lane63(m);
@@ -410,12 +433,36 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         {
             const float scale = pow2f(127 + TEXP + 127 - E);
 #pragma unroll
-            for (int i = 0; i < NSMAX; ++i) {
+            for (int i = 0; i < NS4MAX; ++i) {
                 if (lpos[i] < 0 || (p.dbg & 4)) continue;
-                u32x4 hi, lo;
-                split8(v[i], scale, hi, lo);
-                Bs[lpos[i]] = hi;
-                Bs[2 * p.hp16 + lpos[i]] = lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {              // pixel e of the group: its eight channels as one hi and one lo word
+                    float t8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t8[j] = v[i][j][e];
+                    u32x4 hi, lo;
+                    split8(t8, scale, hi, lo);
+                    const int pos = lpos[i] + (SX == 2 ? (e & 1) * p.HCH + (e >> 1) : e);      // stride 2: de-interleaved by column parity
+                    Bs[pos] = hi;
+                    Bs[2 * p.hp16 + pos] = lo;
+                    if (smirr[i]) {
+                        // reflect: column -c mirrors column c (group 0, element c -> LDS column OFS - c), column Ws - 1 + c mirrors
+                        // column Ws - 1 - c (last group, element 3 - c -> LDS column of the group + 3 + c)
+                        const int nl = mirr[i] & 3, nr = mirr[i] >> 2;
+                        if (e >= 1 && e <= nl) {
+                            const int col = -e;                                                 // relative to the group's first column
+                            const int q = lpos[i] + (SX == 2 ? (col & 1) * p.HCH + (col >> 1) : col);
+                            Bs[q] = hi;
+                            Bs[2 * p.hp16 + q] = lo;
+                        }
+                        if (e <= 2 && 3 - e <= nr) {
+                            const int col = 3 + (3 - e);
+                            const int q = lpos[i] + (SX == 2 ? (col & 1) * p.HCH + (col >> 1) : col);
+                            Bs[q] = hi;
+                            Bs[2 * p.hp16 + q] = lo;
+                        }
+                    }
+                }
             }
         }
         // the weight copies are the only vector-memory operations in flight here: wait for them, THEN issue the next chunk's source
@@ -581,6 +628,8 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
         if (q.OW[c] > OW) OW = q.OW[c];
     }
     if (OH < 1 || OW < 24 || OH >= 32768 || OW >= 32768) return pl;
+    if (q.Ws % 4 != 0 || q.Ws < 8) return pl;                                       // 16-byte source loads at image-aligned 4-column groups
+    if (q.border == BORDER_REFLECT && (dxmin < -3 || dxmax > 3)) return pl;         // (mirrored columns come from the first / last group)
     // channel tile: as wide as the layer, but the LDS must hold a chunk's weights for every tap (ATAPS x MB x 64 B) next to the halo
     pl.MT = q.M <= 32 ? 1 : (q.M <= 64 ? 2 : 4);
     if (pl.MT > g_s16g_maxmt) pl.MT = g_s16g_maxmt;
@@ -601,8 +650,11 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
             if (TW > 32 && TW / 2 >= OW) break;              // wider than the rows: pure waste
             const int RT = NP / TW;
             const int HR = (RT - 1) * sx + ey + 1, HC = (TW - 1) * sx + ex + 1;
-            const int HCH = (HC + 1) / 2, HCP = sx == 2 ? 2 * HCH : HC;
-            if (4 * HR * HCP > BWORDS || HR * HC > 128 * NSMAX) continue;
+            // rows are loaded as groups of 4 image columns starting OFS (a multiple of 4) columns left of the tile when taps reach there: the row pitch
+            // is a whole number of groups (stride 2: even | odd columns, half each)
+            const int OFS = dxmin < 0 ? (-dxmin + 3) / 4 * 4 : 0;
+            const int GPR = (OFS + (TW - 1) * sx + dxmax + 1 + 3) / 4, HCP = 4 * GPR, HCH = HCP / 2;
+            if (4 * HR * HCP > BWORDS || HR * GPR > 128 * NS4LIM) continue;
             if (maxtaps * 4 * MB + 4 * HR * HCP > 10200) continue;            // weights of a chunk + halo planes within the 160 KiB of LDS
             const int tx = (OW + TW - 1) / TW, ty = (OH + RT - 1) / RT;
             // cost: halo elements loaded + converted per launch (short rows coalesce badly: 16 elements of overhead per row),
@@ -686,7 +738,9 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     p.TW = pl.TW; p.RT = pl.RT; p.wshift = ilog2(pl.TW); p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.mblks = pl.mblks;
     p.nchunks = pl.nchunks;
     p.HR = pl.HR; p.HC = pl.HC; p.HCP = pl.HCP; p.HCH = pl.HCH; p.hp16 = pl.HR * pl.HCP; p.dymin = pl.dymin; p.dxmin = pl.dxmin;
-    p.fd_hc = make_fastdiv((unsigned)pl.HC);
+    p.GPR = pl.HCP / 4;
+    p.OFS = pl.dxmin < 0 ? (-pl.dxmin + 3) / 4 * 4 : 0;
+    p.fd_gpr = make_fastdiv((unsigned)p.GPR);
     p.cls_words = (long long)pl.pack_words_per_class;
     double flop = 0.0;
     for (int c = 0; c < S16G_MAX_CLS; ++c) {
@@ -701,7 +755,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     for (int i = 0; i < S16G_MAX_TAPS; ++i) p.tapoff[i] = 0;
     for (int c = 0; c < q.ncls; ++c)
         for (int t = 0; t < q.ntaps[c]; ++t) {
-            const int ddy = q.dy[c][t] - pl.dymin, ddx = q.dx[c][t] - pl.dxmin;
+            const int ddy = q.dy[c][t] - pl.dymin, ddx = q.dx[c][t] + p.OFS;      // LDS column = image column - ox0 SX + OFS
             p.tapoff[c * S16G_CLS_TAPS + t] = ddy * pl.HCP + (q.sstride == 2 ? (ddx & 1) * pl.HCH + (ddx >> 1) : ddx);
         }
     const dim3 g(pl.tiles_x * pl.tiles_y * q.N * pl.mblks * q.ncls), b(256);
@@ -721,20 +775,21 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     p.aw16 = maxtaps * 4 * 32 * pl.MT;
     const size_t lds = ((size_t)p.aw16 + 4 * (size_t)p.hp16) * 16;
 #ifdef NEMAR_HOST_EMULATION
-#define S16G_GO(MT_, NT_, SX_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_>), g, b, lds, st, p); }
+#define S16G_GO1(MT_, NT_, SX_, NS_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds, st, p); }
 #else
     // more than 64 KiB of dynamic LDS needs the attribute (set once per instantiation)
-#define S16G_GO(MT_, NT_, SX_)                                                                                          \
+#define S16G_GO1(MT_, NT_, SX_, NS_)                                                                                    \
     {                                                                                                                   \
         static bool attr_ = false;                                                                                      \
         if (!attr_) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_>),                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_, NS_>),                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);                     \
             attr_ = true;                                                                                               \
         }                                                                                                               \
-        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_>), g, b, lds, st, p);                                             \
+        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds, st, p);                                        \
     }
 #endif
+#define S16G_GO(MT_, NT_, SX_) { if (pl.HR * p.GPR <= 128) S16G_GO1(MT_, NT_, SX_, 1) else S16G_GO1(MT_, NT_, SX_, 2) }
 #define S16G_BY_TILE(MT_)                                           \
     if (sx == 1 && pl.NT == 2) S16G_GO(MT_, 2, 1)                   \
     else if (sx == 1) S16G_GO(MT_, 1, 1)                            \
@@ -745,6 +800,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     else { S16G_BY_TILE(1) }
 #undef S16G_BY_TILE
 #undef S16G_GO
+#undef S16G_GO1
     if (tm) {
         (void)hipEventRecord(g_tev[g_tev_used++][1], st);
         g_tev_flop += flop;

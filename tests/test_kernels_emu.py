@@ -417,9 +417,9 @@ S16G_FWD = [
     # N, C0, C1, H,  W,  K,  R, stride, pad, pad_mode
     (1, 16, 0, 8, 32, 32, 3, 1, 1, K.PAD_REFLECT),      # one 256-pixel tile, MT = 1
     (2, 24, 8, 6, 40, 64, 3, 1, 1, K.PAD_ZERO),         # two sources, ragged rows (40 = 32 + 8), MT = 2, 2 chunks
-    (1, 6, 0, 9, 66, 48, 4, 2, 1, K.PAD_ZERO),          # 4x4 stride 2 (D's first layer): 6 of 16 channels, de-interleaved columns
+    (1, 6, 0, 9, 68, 48, 4, 2, 1, K.PAD_ZERO),          # 4x4 stride 2 (D's first layer): 6 of 16 channels, de-interleaved columns
     (1, 32, 0, 8, 64, 128, 3, 2, 1, K.PAD_ZERO),        # 3x3 stride 2, MT = 4, odd halo width
-    (1, 20, 0, 5, 33, 40, 1, 1, 0, K.PAD_ZERO),         # 1x1, ragged everything
+    (1, 20, 0, 5, 36, 40, 1, 1, 0, K.PAD_ZERO),         # 1x1, ragged everything (the source width must be a multiple of 4: 16-byte loads)
     (1, 16, 16, 4, 64, 160, 3, 1, 1, K.PAD_ZERO),       # two channel blocks of 128 (second ragged), concat on a chunk boundary
 ]
 
@@ -451,8 +451,8 @@ S16G_DGRAD = [
     (1, 32, 0, 8, 32, 16, 3, 1, 1),
     (2, 16, 16, 4, 64, 24, 3, 1, 1),                    # two destinations
     (1, 64, 0, 8, 64, 32, 3, 2, 1),                     # stride 2: four parity classes of 1 / 2 / 2 / 4 taps (= ConvTranspose2d)
-    (1, 48, 0, 10, 66, 16, 4, 2, 1),                    # 4x4 stride 2: four classes of 4 taps
-    (1, 32, 0, 7, 32, 16, 4, 1, 1),                     # 4x4 stride 1 (full correlation of the 6 x 31 gradient)
+    (1, 48, 0, 10, 72, 16, 4, 2, 1),                    # 4x4 stride 2: four classes of 4 taps (gy 5 x 36)
+    (1, 32, 0, 7, 33, 16, 4, 1, 1),                     # 4x4 stride 1 (full correlation of the 6 x 32 gradient)
 ]
 
 
@@ -577,7 +577,7 @@ def test_conv_k7_data_gradient(be, case):
 @pytest.mark.parametrize("case", [
     (2, 32, 8, 24, 3, K.PAD_REFLECT, K.O.ACT_TANH),      # the RGB head: 32 -> 3, reflect border, tanh in the shift-sum pass
     (1, 16, 5, 40, 1, K.PAD_ZERO, K.O.ACT_NONE),         # one output channel, zero border
-    (1, 48, 6, 30, 4, K.PAD_REFLECT, K.O.ACT_RELU),      # four outputs: all 32 (k, dx) rows in use
+    (1, 48, 6, 28, 4, K.PAD_REFLECT, K.O.ACT_RELU),      # four outputs: all 32 (k, dx) rows in use
 ])
 def test_conv_k7_many_to_few_forward(be, case):
     """7x7 layers with <= 4 OUTPUT channels: vertical 7-tap convolution with (k, dx) pseudo-channels on the general 16-bit-pipe kernel +
@@ -588,7 +588,7 @@ def test_conv_k7_many_to_few_forward(be, case):
 
 
 @pytest.mark.parametrize("case", [
-    (2, 3, 9, 20, 32, K.PAD_REFLECT), (1, 2, 6, 26, 16, K.PAD_ZERO), (1, 4, 12, 18, 48, K.PAD_REFLECT),
+    (2, 3, 9, 20, 32, K.PAD_REFLECT), (1, 2, 6, 28, 16, K.PAD_ZERO), (1, 4, 12, 24, 48, K.PAD_REFLECT),
 ])
 def test_conv_k7_many_to_few_data_gradient(be, case):
     """data gradient of a 7x7 layer with <= 4 INPUT channels (the stem): the same two passes with flipped, transposed weights; reflect

@@ -547,7 +547,7 @@ def test_conv_k7_data_gradient(be, case):
 @pytest.mark.parametrize("case", [
     (2, 32, 8, 24, 3, K.PAD_REFLECT, K.O.ACT_TANH),      # the RGB head: 32 -> 3, reflect border, tanh in the shift-sum pass
     (1, 16, 5, 40, 1, K.PAD_ZERO, K.O.ACT_NONE),         # one output channel, zero border
-    (1, 48, 6, 30, 4, K.PAD_REFLECT, K.O.ACT_RELU),      # four outputs: all 32 (k, dx) rows in use
+    (1, 48, 6, 28, 4, K.PAD_REFLECT, K.O.ACT_RELU),      # four outputs: all 32 (k, dx) rows in use
     (2, 64, 128, 128, 3, K.PAD_REFLECT, K.O.ACT_TANH),
 ])
 def test_conv_k7_many_to_few_forward(be, case):
@@ -559,7 +559,7 @@ def test_conv_k7_many_to_few_forward(be, case):
 
 
 @pytest.mark.parametrize("case", [
-    (2, 3, 9, 20, 32, K.PAD_REFLECT), (1, 2, 6, 26, 16, K.PAD_ZERO), (1, 4, 12, 18, 48, K.PAD_REFLECT),
+    (2, 3, 9, 20, 32, K.PAD_REFLECT), (1, 2, 6, 28, 16, K.PAD_ZERO), (1, 4, 12, 24, 48, K.PAD_REFLECT),
     (2, 3, 96, 128, 64, K.PAD_REFLECT),
 ])
 def test_conv_k7_many_to_few_data_gradient(be, case):
