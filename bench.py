@@ -341,6 +341,32 @@ def main():
     elif a.graph == 'on':
         raise SystemExit('--graph on: single GPU only')
 
+    # --graph auto: a hipGraph replay runs the step's kernels as ONE chain (the ROCm graph executor does not overlap the branches a
+    # two-stream capture describes), eager launches put the weight-gradient branch on a side stream (ops._on_side) but pay ~900 kernel
+    # launches from Python.  Which wins depends on the configuration: time a few steps of each and keep the faster for the timed region.
+    launch_probe = None
+    if graph_on and a.graph == 'auto':
+        def probe(n=4):
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        t_graph = probe()
+        g_saved, model._graph = model._graph, None           # (eager launches with the step parameters still in device memory)
+        t_eager = probe()
+        launch_probe = {"graph_ms_per_step": t_graph, "eager_ms_per_step": t_eager}
+        if t_eager < 0.99 * t_graph:
+            graph_on = False
+            graph_note = 'eager launches were faster than the graph replay in the pre-run probe (%.2f vs %.2f ms/step)' % (t_eager, t_graph)
+            g_saved = None
+            ops.pin_workspaces(False)
+        else:
+            model._graph = g_saved
+
     multi = dist.is_distributed()        # world > 1 (or the one-rank RCCL smoke configuration, NEMAR_DIST_SINGLE=1)
 
     def barrier():
@@ -466,7 +492,8 @@ def main():
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world, "stn_cfg": stn_cfg,
                    "step": "NEMARModel.optimize_parameters(): fwd + D update + T/R update + 3x Adam"
                            + (" — the timed steps are replays of ONE captured hipGraph of the step" if graph_on else "")},
-        "launch": "hipGraph replay" if graph_on else ("eager" + (" (capture failed: %s)" % graph_note if graph_note else "")),
+        "launch": "hipGraph replay" if graph_on else ("eager, weight-gradient branch on a side stream" + (" (%s)" % graph_note if graph_note else "")),
+        "launch_probe": launch_probe,
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
         "rank_ms_per_step": rank_ms,                      # one entry per rank: the N > 1 run cannot degrade to one rank unnoticed
         "dist": {"backend": "nccl (RCCL)" if multi else None, "buckets_launched_last_step": buckets, "buckets": bucket_rows or None,

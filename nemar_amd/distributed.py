@@ -172,6 +172,8 @@ class GradSync:
             if b not in self._events:                     # one event per bucket for the life of the optimizer, re-recorded every step
                 self._events[b] = torch.cuda.Event()
             ev = self._events[b]
+            from . import ops
+            ops.order_current_after_both(buf.device)      # weight gradients are issued on a side stream (ops._on_side)
             ev.record()                                   # everything that wrote this bucket is ahead of this point
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)

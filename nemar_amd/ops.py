@@ -80,14 +80,109 @@ def _retire(buf):
         _retired.append(buf)
 
 
+_lane = [0]            # 0: the compute stream; 1: the side stream of the weight-gradient branch (its own workspace and arena)
+
+
 def _workspace(nbytes, device):
-    """Grow-only scratch buffer per device.  Kernels are stream-ordered, so one buffer serves consecutive ops."""
-    buf = _ws_cache.get(device)
+    """Grow-only scratch buffer per device and stream lane.  Kernels are stream-ordered, so one buffer serves consecutive ops."""
+    key = (device, _lane[0])
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         _retire(buf)
         buf = torch.empty(max(int(nbytes) // 4 + 64, 1 << 20), dtype=torch.float32, device=device)
-        _ws_cache[device] = buf
+        _ws_cache[key] = buf
     return buf
+
+
+# ---- the weight-gradient branch on a side stream ---------------------------------------------------------------------------------
+# Backward of a convolution = data gradient (feeds the rest of the chain) + weight gradient (feeds only the optimizer).  The second is
+# issued on a side HIP stream: its HBM-bound support passes, slab sums and bias reductions run beside the matrix-pipe-bound kernels of
+# the main chain (tools/overlap_probe.py: 500 -> 450 us per residual-block layer).  Rules that keep it race-free:
+#   * the side stream waits for everything issued so far (g, x and the gy planes exist) before a branch starts;
+#   * it has its own workspace / arena lane; the gy-planes buffers written by the main stream are a ring guarded by events;
+#   * every tensor the branch reads is kept alive until join_side() — the caching allocator would otherwise hand a block freed on the
+#     main stream to a later main-stream allocation while the side stream still reads it (also inside a graph capture);
+#   * join_side() (before an optimizer step / at the end of a phase) makes the main stream wait for the side stream.
+_side_on = [os.environ.get("NEMAR_SIDE_STREAM", "1") != "0"]
+_side_streams = {}
+_side_keep = []
+_side_busy = [False]
+_main_streams = {}     # device -> the compute stream the last branch forked from
+_side_cb = [False]     # join_side is queued as an end-of-backward callback of the running autograd pass
+
+
+def side_stream(on=None):
+    """Switch the side-stream weight-gradient branch on / off (returns the previous setting); joins first."""
+    prev = _side_on[0]
+    if on is not None:
+        join_side()
+        _side_on[0] = bool(on)
+    return prev
+
+
+def _side_stream_of(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _on_side:
+    """`with _on_side(device, keep...)`: the launches inside go to the side stream (lane 1) after everything issued so far"""
+
+    def __init__(self, device, *keep):
+        self.device, self.keep = device, keep
+
+    def __enter__(self):
+        if not _side_on[0]:
+            self.ctx = None
+            return self
+        side = _side_stream_of(self.device)
+        main = torch.cuda.current_stream(self.device)
+        _main_streams[self.device] = main
+        side.wait_stream(main)
+        _side_keep.extend(t for t in self.keep if t is not None)
+        _side_busy[0] = True
+        if not _side_cb[0]:
+            # the pass that issued a branch joins it when it ends: whoever reads .grad after backward() sees a single stream again
+            torch.autograd.Variable._execution_engine.queue_callback(join_side)
+            _side_cb[0] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        _lane[0] = 1
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            _lane[0] = 0
+            self.ctx.__exit__(*a)
+
+
+def order_current_after_both(device):
+    """Called on either lane: the current stream is ordered after everything issued so far on the compute stream AND on the side stream
+    (GradSync records its bucket-complete event right after: a bucket may hold gradients written from both)."""
+    if not _side_busy[0]:
+        return
+    side = _side_streams.get(device)
+    main = _main_streams.get(device)
+    if side is None or main is None:
+        return
+    cur = torch.cuda.current_stream(device)
+    other = main if cur == side else side
+    cur.wait_stream(other)
+
+
+def join_side():
+    """The compute stream waits for the side stream's branches; the tensors kept alive for them are released."""
+    if _side_busy[0]:
+        for dev, side in _side_streams.items():
+            torch.cuda.current_stream(dev).wait_stream(side)
+        _side_busy[0] = False
+        for ring in _garena.values():          # every consumer is behind the compute stream now: the ring's guards are moot (and an
+            for slot in ring:                  # event recorded outside a graph capture must not be waited for inside one)
+                slot[1] = None
+    _side_cb[0] = False
+    _side_keep.clear()
 
 
 _scratch_need = {}     # layer shape -> nemar_conv2d_scratch bytes (depends on the nemar_tune switches: ops.tune clears it)
@@ -104,33 +199,43 @@ def _conv_scratch(N, H, W, K, C, R, S, stride, pad, device):
         need = _scratch_need[key] = L.conv2d_scratch(N, H, W, K, C, R, S, stride, pad)
     if not need:
         return None
-    buf = _arena.get(device)
+    akey = (device, _lane[0])             # (the side stream's weight-gradient branch has its own arena)
+    buf = _arena.get(akey)
     if buf is None or buf.numel() * 4 < need:
         _retire(buf)
         buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
-        _arena[device] = buf
+        _arena[akey] = buf
     return buf
 
 
-_garena = {}           # device -> the buffer a layer's data-gradient call leaves the weight gradient's gy planes in
+_garena = {}           # device -> ring of [buffer, event of the side-stream consumer or None] for the gy planes
+_garena_next = {}
 _gplanes_need = {}
+GY_RING = int(os.environ.get("NEMAR_GY_RING", "4"))
 
 
 def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
-    """-> the buffer (tensor) in which the data-gradient call of this layer leaves the operand planes of gy its weight-gradient call
-    takes (nemar_conv_extras.gy_planes_out -> .src2_planes: gy is split once for both), or None.  Grow-only per device, stream-ordered."""
+    """-> (buffer, ring slot) in which the data-gradient call of this layer leaves the operand planes of gy its weight-gradient call
+    takes (nemar_conv_extras.gy_planes_out -> .src2_planes: gy is split once for both), or (None, None).  A ring of GY_RING buffers per
+    device: the weight gradient may run on the side stream while the compute stream writes the next layer's planes; a slot is handed out
+    again only after the compute stream has waited for the event its last consumer recorded."""
     key = (N, C, H, W, K, R, S, stride, pad, pad_mode)
     need = _gplanes_need.get(key)
     if need is None:
         need = _gplanes_need[key] = L.conv2d_gy_planes_bytes(N, C, H, W, K, R, S, stride, pad, pad_mode)
     if not need:
-        return None
-    buf = _garena.get(device)
-    if buf is None or buf.numel() * 4 < need:
-        _retire(buf)
-        buf = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
-        _garena[device] = buf
-    return buf
+        return None, None
+    ring = _garena.setdefault(device, [[None, None] for _ in range(GY_RING)])
+    k = _garena_next.get(device, 0)
+    _garena_next[device] = (k + 1) % GY_RING
+    slot = ring[k]
+    if slot[1] is not None:
+        torch.cuda.current_stream(device).wait_event(slot[1])
+        slot[1] = None
+    if slot[0] is None or slot[0].numel() * 4 < need:
+        _retire(slot[0])
+        slot[0] = torch.empty(int(need) // 4 + 64, dtype=torch.float32, device=device)
+    return slot[0], slot
 
 
 def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None):
@@ -424,7 +529,7 @@ class _Conv2d(Function):
     @staticmethod
     def _backward_body(ctx, x, x2, w, g, N, C0, C1, H, W, K, C, R, S, OH, OW, stride, pad, pad_mode, st, need_x, need_x2, need_w,
                        need_b, gmax):
-        gx = gx2 = gpl = None
+        gx = gx2 = gpl = gslot = None
         if need_x or need_x2:
             gx = torch.empty_like(x) if need_x else None
             gx2 = torch.empty_like(x2) if (need_x2 and x2 is not None) else None
@@ -448,7 +553,7 @@ class _Conv2d(Function):
             arena = _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
             if arena is not None and need_w and Nd == N and gmax is not None and x2 is None:
                 # wide layer whose weight gradient follows: the pass that splits gy for this call leaves its planes for that one too
-                gpl = _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, g.device)
+                gpl, gslot = _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, g.device)
             with _record(plan):
                 L.conv2d_bwd_data_ex(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
                                      stride, pad, pad_mode, _p(ws), wsb, hit, st,
@@ -459,15 +564,26 @@ class _Conv2d(Function):
                 gx2 = None
         want_b = need_b and ctx.bias is not None
         if need_w:
-            gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
-            wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
-            arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
-            L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
-                                   R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, st,
-                                   _extras(arena, ctx.xmax, gmax, src2_planes=gpl))
-            grad_ready(ctx.weight)
-            if want_b:
-                grad_ready(ctx.bias)
+            # the weight-gradient branch feeds only the optimizer: side stream (after everything issued so far)
+            # ... except the 7x7 layers: with their weight-gradient kernels (conv_k7.hip) on the side queue, a kernel of the compute
+            # stream that runs at the same moment (grid_sample's grid gradient, right behind the stem) was seen to lose 64-byte store
+            # sectors — 29 % of the steps of tools/diag_hooks.py, 0 of 300 without them; not understood, so they stay put.
+            # NEMAR_SIDE_MODE=all reproduces it.
+            _use = R != 7 or os.environ.get("NEMAR_SIDE_MODE", "") == "all"
+            with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl) if _use else contextlib.nullcontext()):
+                gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
+                wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
+                arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
+                L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
+                                       R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, _stream(),
+                                       _extras(arena, ctx.xmax, gmax, src2_planes=gpl))
+                if gslot is not None and _side_on[0]:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(g.device))
+                    gslot[1] = ev
+                grad_ready(ctx.weight)
+                if want_b:
+                    grad_ready(ctx.bias)
         elif want_b:
             _bias_grad(g, _grad_buffer(ctx.bias), N, K, OH * OW, st)
             grad_ready(ctx.bias)
@@ -1010,9 +1126,11 @@ class FlatAdam:
         self.offsets = offs
 
     def zero_grad(self, set_to_none=False):
+        join_side()                    # (a weight-gradient branch of an earlier pass must not land after the fill)
         self.flat_g.zero_()
 
     def step(self):
+        join_side()                    # every gradient contribution issued on the side stream is behind the compute stream from here
         self._epoch.n += 1
         self.step_count += 1
         g = self.param_groups[0]

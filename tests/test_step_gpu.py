@@ -188,3 +188,35 @@ def test_pack_plans_equal_lazy_packing(name):
     assert all(j > 0 for j in jobs[0]) and not any(jobs[1]), jobs
     for x, y in zip(*snaps):
         assert torch.equal(x, y), float((x - y).abs().max())
+
+
+def test_side_stream_weight_gradients_equal_single_stream():
+    """The weight-gradient branch of every convolution (but the 7x7 layers) is issued on a side HIP stream (ops._on_side): the gradients of
+    a full-width step must be the SAME BITS as with everything on one stream, run after run (a race would show as a run that differs —
+    the 7x7 layers on the side stream did, in 29 % of the runs: tools/diag_hooks.py)."""
+    import torch
+    import seeded
+    from nemar_amd import ops
+    from step_configs import FULL_CONFIGS
+    import test_step_full_gpu
+    cfg = FULL_CONFIGS['c2_full']
+    a, b = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
+
+    def grads():
+        m = test_step_full_gpu.build('c2_full')
+        for _ in range(2):
+            m.set_input({'A': torch.from_numpy(a), 'B': torch.from_numpy(b), 'A_paths': [''], 'B_paths': ['']})
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        return [o.flat_g.detach().cpu().clone() for o in m.optimizers] + [o.flat_p.detach().cpu().clone() for o in m.optimizers]
+
+    prev = ops.side_stream(False)
+    try:
+        ref = grads()
+        ops.side_stream(True)
+        for run in range(12):
+            got = grads()
+            for k, (x, y) in enumerate(zip(got, ref)):
+                assert torch.equal(x, y), ('run %d, buffer %d' % (run, k), int((x != y).sum()), float((x - y).abs().max()))
+    finally:
+        ops.side_stream(prev)
