@@ -383,6 +383,7 @@ def main():
     # per-launch durations of the roofline kernels: HIP events on the launch stream in a SEPARATE pass of two steps, after
     # the timed region (the event records would otherwise sit inside it)
     model._graph = None                  # the roofline pass needs eager launches (step parameters stay in device memory)
+    side_prev = ops.side_stream(False)   # ... on ONE stream: beside a side-stream kernel a launch shares the CUs and its duration says nothing about it
     timer.enabled = True
     from nemar_amd import _lib
     lib = _lib.load()
@@ -391,6 +392,7 @@ def main():
         step()
     torch.cuda.synchronize()
     timer.enabled = False
+    ops.side_stream(side_prev)
     import ctypes
     tk_ms_c, tk_fl_c, tk_n_c = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int(0)
     lib.kernel_timer_read(ctypes.byref(tk_ms_c), ctypes.byref(tk_fl_c), ctypes.byref(tk_n_c))

@@ -650,14 +650,16 @@ class _ConvTranspose2d(Function):
             with _record(plan):
                 L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
                              0.0, _p(ws), wsb, hit, st)
-        if ctx.needs_input_grad[1]:
-            wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
-            L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
-                                S, stride, pad, PAD_ZERO, _p(_workspace(wsb, g.device)), wsb, st)
-            grad_ready(ctx.weight)
-        if ctx.needs_input_grad[2] and ctx.bias is not None:
-            _bias_grad(g, _grad_buffer(ctx.bias), N, Co, Ho * Wo, st)
-            grad_ready(ctx.bias)
+        if ctx.needs_input_grad[1] or (ctx.needs_input_grad[2] and ctx.bias is not None):
+            with _on_side(g.device, g, x):                 # the weight-gradient branch: side stream (see _Conv2d)
+                if ctx.needs_input_grad[1]:
+                    wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
+                    L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
+                                        S, stride, pad, PAD_ZERO, _p(_workspace(wsb, g.device)), wsb, _stream())
+                    grad_ready(ctx.weight)
+                if ctx.needs_input_grad[2] and ctx.bias is not None:
+                    _bias_grad(g, _grad_buffer(ctx.bias), N, Co, Ho * Wo, _stream())
+                    grad_ready(ctx.bias)
         return gx, None, None, None, None, None, None, None
 
 
