@@ -20,6 +20,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                       peak assumes (profiles/r3_clock_trace.txt); a pure MFMA loop on random operands sustains 1730 TFLOP/s,
                       on all-zero operands 2530 (profiles/r4_mfma_peak_modes.txt): `frac_of_sustained_mfma` is priced on the former
   roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
+  launch / launch_probe  the timed steps are eager launches (weight-gradient branch on a side stream, nemar_amd/ops.py _on_side) or replays of one
+                      captured hipGraph, whichever a short pre-run probe measured faster (--graph on|off forces either)
   cpu_baseline        the CPU oracle (oracle/torch_ref.py, a proven-equal restatement of the reference's step) timed
                       on this box's host cores on a bounded sample (config-2 shape at batch 1)
 """

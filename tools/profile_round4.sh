@@ -33,6 +33,10 @@ python $R/tools/microbench.py > $O/microbench.jsonl 2>/dev/null
 cd $R
 timeout 600 python tools/trace_convs.py > $O/conv_trace.jsonl 2> $O/trace.err
 timeout 900 python tools/microbench_trace.py $O/conv_trace.jsonl > $O/conv_layers.txt 2> $O/layers.err
-timeout 300 python tools/overlap_timeline.py > $O/overlap_timeline.txt 2>&1
+timeout 300 python tools/overlap_timeline.py 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|c10d_logger\|return func" > $O/overlap_timeline.txt
+{ echo '# tools/timeline_s16g.py 64 128 256 3 2 16 (T.down1 forward, batch 16, NEMAR_TIMELINE build): s_memtime cycles per 16-channel chunk'; NEMAR_TL_LIB=$R/nemar_amd/lib/libnemar_hip_tl.so timeout 120 python tools/timeline_s16g.py 64 128 256 3 2 16 2>&1 | grep -v amdgpu.ids; echo '# tools/timeline_s16g.py 32 32 256 3 1 8 (R.res 32->32)'; NEMAR_TL_LIB=$R/nemar_amd/lib/libnemar_hip_tl.so timeout 120 python tools/timeline_s16g.py 32 32 256 3 1 8 2>&1 | grep -v amdgpu.ids; } > $O/s16g_timeline.txt 2>&1
+bash tools/gpu_pmc_s16g4.sh $1_sq 2>&1 | grep -v "^\[" > $O/pmc_s16g_sq.txt
+timeout 200 python tools/overlap_probe.py 2>&1 | grep -v amdgpu.ids > $O/overlap_probe.txt
+tools/probes/_build/load_width > $O/load_width_raw.txt 2>&1
 cat $O/bench.json
 rm -rf $O/stats/*/*.db $O/pmc_resblock16_* $O/pmc_stem_* $O/pmc_head_* $O/pmc_warp_*
