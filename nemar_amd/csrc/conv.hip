@@ -1099,6 +1099,7 @@ static thread_local size_t t_scratch_bytes = 0;
 static thread_local void* t_gy_planes_out = nullptr;  // bwd_data_ex: where the pass that splits gy also leaves the weight gradient's planes
 static thread_local size_t t_gy_planes_bytes = 0;
 static thread_local const void* t_src2_planes = nullptr;      // bwd_weight_ex: those planes
+static int g_split_act = 0;          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
 static int g_dual_gy = 1;            // key 35: the data-gradient call's split pass also writes the weight gradient's gy planes
 static thread_local int t_gy_planes_written = 0;      // did the last bwd_data_ex call on this thread fill gy_planes_out?
 #define g_scratch t_scratch
@@ -2116,13 +2117,21 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.N = N; p.P = N * OH * OW;
     p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope; p.pad = pad;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
-    if (FL.ksplit > 1 && act == ACT_NONE) {      // slab 0 carries the bias; an activation would have to follow the sum
+    // (a split with the activation applied by the sum pass — nemar_sum_partials_act — is wired but off: it changes the summation order of
+    // the registration net's decoder layers, and the reduced-width parity test then sits on a different LeakyReLU knife edge of D
+    // (tests/step_parity.py); 0.2 ms per step were not worth re-measuring every allowance.  nemar_tune(36, 1) switches it on.)
+    const bool split_act = g_split_act && (act == ACT_RELU || act == ACT_LRELU);
+    if (FL.ksplit > 1 && (act == ACT_NONE || split_act)) {      // slab 0 carries the bias; an activation follows the sum (ReLU / LeakyReLU)
         p.ksplit = FL.ksplit;
         p.part = (float*)workspace + FL.slab_off;
         p.part_stride = (long long)N * K * OH * OW;
+        p.act = ACT_NONE;
     }
     launch_igemm(p, st);
-    if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, y, p.part_stride, false, st);
+    if (p.ksplit > 1) {
+        if (split_act) nemar_sum_partials_act(p.part, p.part_stride, p.ksplit, y, p.part_stride, act == ACT_RELU ? 1 : 2, slope, st);
+        else nemar_sum_partials(p.part, p.part_stride, p.ksplit, y, p.part_stride, false, st);
+    }
     g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_fwd");
     return NEMAR_OK;
@@ -2309,10 +2318,11 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 nemar_narrow_fwd(gy, w2, nullptr, gx0, N, K, OH, OW, C, R, R - 1 - pad, BORDER_ZERO, ACT_NONE, 0.f, nullptr, 0, st);
             } else {
                 // split reductions (see dgrad_layout): each split stores its partial gradient to its own slab, summed in order
-                if (L.ksplit > 1 && !bias && act == ACT_NONE && mskip == 0 && gx1 == nullptr) {
+                if (L.ksplit > 1 && !bias && act == ACT_NONE && mskip == 0 && (gx1 == nullptr || (gx0 != nullptr && !ring))) {
                     p.ksplit = L.ksplit;
                     p.part = wsf + L.slab_off;
                     p.part_stride = (long long)N * C * H * W;
+                    if (gx1) { p.M0 = C; p.dst1 = nullptr; }      // two destinations: the slabs hold all C rows, the sum pass parts them
                 }
                 // 3x3 reflect layers that run on the wave-specialised 16-byte-load kernel fold the border INTO the main launch
                 // (reflect_aux_kernel); everything else adds the border ring with a second launch below
@@ -2326,7 +2336,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                     ring_done = true;
                 }
                 launch_igemm(p, st);
-                if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, gx0, p.part_stride, false, st);
+                if (p.ksplit > 1 && gx1) nemar_sum_partials_two(p.part, p.part_stride, p.ksplit, gx0, gx1, N, C0, C1, H * W, st);
+                else if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, gx0, p.part_stride, false, st);
                 p.rf = 0;
             }
             if (ring && !ring_done) {
@@ -2598,6 +2609,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 31) { nemar_norm_planes_debug(value); return NEMAR_OK; }
     if (key == 32) { g_split16_ring3 = value != 0; return NEMAR_OK; }
     if (key == 33) { g_k7 = value != 0; return NEMAR_OK; }
+    if (key == 36) { g_split_act = value != 0; return NEMAR_OK; }
     if (key == 35) { g_dual_gy = value != 0; return NEMAR_OK; }
     if (key == 34) { nemar_split16_wgrad_tune(value); return NEMAR_OK; }      // wide weight gradient: 1 one gy copy (default), 0 KS shifted copies
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }

@@ -38,6 +38,8 @@ size_t nemar_split16_wgrad_g_bytes(int N, int H, int W, int K, int KS);      // 
 void nemar_split16_dual_split(const float* gy, void* dplanes, void* gplanes, int N, int K, int H, int W, int mode, const unsigned* maxbits,
                               int mstride, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
+void nemar_sum_partials_two(const float* part, long long stride, int splits, float* d0, float* d1, int N, int C0, int C1, int HW, hipStream_t st);
+void nemar_sum_partials_act(const float* part, long long stride, int splits, float* dst, long long n, int act, float slope, hipStream_t st);
 
 // ---- max |t| of a source tensor (the fp16 form's power-of-two scale follows from it) ----
 // The scale is PER SAMPLE: out = `samples` words, ZERO on entry (the kernel takes an atomic max of the finite elements of sample i

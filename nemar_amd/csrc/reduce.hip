@@ -16,7 +16,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // large ones (256->256 3x3: 14 slabs of 590k floats), instead of one thread walking all slabs at memory latency.
 template <bool VEC>
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, long long stride, int splits,
-                                                           float* __restrict__ dst, long long n, int accumulate) {
+                                                           float* __restrict__ dst, long long n, int accumulate, int act,
+                                                           float slope) {
     __shared__ f32x4 red[16][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const long long cols = VEC ? (n >> 2) : n;            // columns of 4 floats (VEC) or 1 float
@@ -39,9 +40,14 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
             if (VEC) {
                 f32x4* d = reinterpret_cast<f32x4*>(dst + 4 * c);
                 if (accumulate) t += *d;
+                if (act) {                                     // 1 ReLU, 2 LeakyReLU (a split FORWARD convolution: the activation follows the sum)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : (act == 1 ? 0.f : t[e] * slope);
+                }
                 *d = t;
             } else {
                 if (accumulate) t[0] += dst[c];
+                if (act) t[0] = t[0] > 0.f ? t[0] : (act == 1 ? 0.f : t[0] * slope);
                 dst[c] = t[0];
             }
         }
@@ -49,10 +55,32 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     }
 }
 
+// the slabs hold [N][C0 + C1][HW]; channels < C0 go to d0 [N][C0][HW], the rest to d1 [N][C1][HW] (data gradient of a two-source layer);
+// slabs added in ascending order
+__global__ __launch_bounds__(256) void sum_partials_two_kernel(const float* __restrict__ part, long long stride, int splits, float* __restrict__ d0,
+                                                               float* __restrict__ d1, int C0, int C1, int HW, long long total) {
+    const int C = C0 + C1;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long n = idx / ((long long)C * HW);
+        const int r = (int)(idx - n * C * HW), c = r / HW, px = r - c * HW;
+        float t = 0.f;
+        for (int sidx = 0; sidx < splits; ++sidx) t += part[(long long)sidx * stride + idx];
+        if (c < C0) d0[((size_t)n * C0 + c) * HW + px] = t;
+        else d1[((size_t)n * C1 + (c - C0)) * HW + px] = t;
+    }
+}
+
 }  // namespace
 
-void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
-                        hipStream_t st) {
+void nemar_sum_partials_two(const float* part, long long stride, int splits, float* d0, float* d1, int N, int C0, int C1, int HW, hipStream_t st) {
+    const long long total = (long long)N * (C0 + C1) * HW;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_partials_two_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, d0, d1, C0, C1, HW, total);
+}
+
+static void sum_partials_launch(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, int act, float slope,
+                                hipStream_t st) {
     const bool vec = (n & 3) == 0 && (stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const long long cols = vec ? (n >> 2) : n;
     long long blocks = (cols + 15) / 16;
@@ -60,8 +88,17 @@ void nemar_sum_partials(const float* part, long long stride, int splits, float* 
     if (blocks < 1) blocks = 1;
     if (vec)
         hipLaunchKernelGGL((sum_partials_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, dst, n,
-                           accumulate ? 1 : 0);
+                           accumulate ? 1 : 0, act, slope);
     else
         hipLaunchKernelGGL((sum_partials_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, dst, n,
-                           accumulate ? 1 : 0);
+                           accumulate ? 1 : 0, act, slope);
+}
+
+void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st) {
+    sum_partials_launch(part, stride, splits, dst, n, accumulate, 0, 0.f, st);
+}
+
+// dst = act(sum of the slabs): the second stage of a reduction-split FORWARD convolution (slab 0 carries the bias); act 1 ReLU, 2 LeakyReLU
+void nemar_sum_partials_act(const float* part, long long stride, int splits, float* dst, long long n, int act, float slope, hipStream_t st) {
+    sum_partials_launch(part, stride, splits, dst, n, false, act, slope, st);
 }

@@ -241,11 +241,18 @@ def test_conv_reflect_dgrad_border_folded_into_main_launch(be, mt):
 
 def test_conv_fwd_split_reduction(be):
     """Tiny, deep forward layers (the registration net's 2x2 .. 8x8 maps) split their reduction over grid.z: per-split slabs
-    behind the packed weights, summed in split order (bias in slab 0); layers with a fused activation do not split."""
+    behind the packed weights, summed in split order (bias in slab 0); with nemar_tune(36, 1) a fused ReLU / LeakyReLU is applied by the sum pass."""
     K.case_conv_fwd(be, 1, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE)    # STN bottleneck layer, 72 stages
     K.case_conv_fwd(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE, bias=False)
-    K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)        # decoder conv with activation
+    K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)        # decoder conv with activation: not split by default
+    be.lib.tune(36, 1)                                                                       # ... split + activation in the sum pass
+    try:
+        K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)
+        K.case_conv_fwd(be, 1, 64, 0, 8, 8, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_RELU)
+    finally:
+        be.lib.tune(36, 0)
     K.case_conv_bwd_data(be, 2, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT)                  # main pass split + ring split
+    K.case_conv_bwd_data(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO)                      # two destinations: the sum pass parts the rows
 
 
 def test_conv_bwd_data_split_reduction(be):
