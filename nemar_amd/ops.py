@@ -570,6 +570,10 @@ class _Conv2d(Function):
             # sectors — 29 % of the steps of tools/diag_hooks.py, 0 of 300 without them; not understood, so they stay put.
             # NEMAR_SIDE_MODE=all reproduces it.
             _use = R != 7 or os.environ.get("NEMAR_SIDE_MODE", "") == "all"
+            # a layer without a data gradient (the first layer of a net: nothing left for the compute stream to do) keeps its weight
+            # gradient there — it is the last one of the pass, and the compute stream would only wait for it at the join
+            if not (need_x or need_x2):
+                _use = False
             with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl) if _use else contextlib.nullcontext()):
                 gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
                 wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
