@@ -20,7 +20,15 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-ffp-contract=off",        # keep a*b+c un-fused unless the source says fmaf (parity with the oracle)
     "-Wall", "-Wno-unused-function",
+    # No packed-FP32 VOP3P instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in any kernel of the library.  On the MI355X a
+    # v_pk_*_f32 whose op_sel swaps the halves of src1 (what the SLP vectoriser makes of two crossed scalar chains) returns wrong
+    # results in lanes 48..63 while waves of ANOTHER kernel on the same SIMD — a second HIP stream — issue 16-bit MFMAs next to VALU
+    # work: the round-4 "lost store" anomaly of the side-stream weight gradients (tools/probes/pk_f32_corun.hip is the
+    # stand-alone repro).  The feature switch is per compilation, so it also covers what a later compiler version would vectorise.
+    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]
+# (the host half of a hipcc compilation sees the same -target-feature and says so on stderr: not a diagnostic, filtered below)
+_HOST_NOISE = "is not a recognized feature for this target (ignoring feature)"
 
 
 # fp32 atomicAdd -> global_atomic_add_f32 instead of a CAS loop: only the sources that HAVE floating-point atomics (the non-default
@@ -56,8 +64,9 @@ def _compile(src, force):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        err = "".join(ln for ln in r.stderr.splitlines(True) if _HOST_NOISE not in ln)
+        if err.strip():
+            sys.stderr.write(err)
     return obj
 
 

@@ -925,6 +925,9 @@ def dropout(x, p=0.5, training=True):
 
 
 # ------------------------------------------------------------------------------------------------------
+_ggs_alloc = torch.empty_like      # (a seam for tools/diag_lost_stores.py: where the grid gradient's buffer comes from)
+
+
 class _Warp(Function):
     """grid_sample(img, grid(grid_src)) for every image in `imgs` with ONE shared grid source; the gradient w.r.t.
     the grid source is accumulated across the images inside the kernels."""
@@ -952,7 +955,7 @@ class _Warp(Function):
         mode, Ho, Wo = ctx.cfg
         st = _stream()
         need_gs = ctx.needs_input_grad[0]
-        ggs = torch.empty_like(gs)
+        ggs = _ggs_alloc(gs)
         first = True
         gimgs = []
         for k, (img, go) in enumerate(zip(imgs, gouts)):

@@ -1,0 +1,103 @@
+"""Variant builds of the C-ABI library for the lost-store investigation: a patched copy of ONE kernel source is
+compiled and linked with the product's other objects into tools/probes/_build/libnemar_hip_<variant>.so (git-ignored; travels to
+the GPU box).  tools/diag_lost_stores.py loads a variant through DIAG_LIB.  Diagnostic tooling only.
+
+    python tools/diag_variants.py            # builds every variant
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nemar_amd.csrc import build as B  # noqa: E402
+
+OUT = os.path.join(ROOT, "tools", "probes", "_build")
+
+STORE = "if (accum_ggrid) { q[0] += ggx; q[oplane] += ggy; } else { q[0] = ggx; q[oplane] = ggy; }"
+
+
+def _victim(repl):
+    def patch(src):
+        assert src.count(STORE) == 1
+        return src.replace(STORE, repl)
+    return patch
+
+
+def _k7env(src):
+    a = "    hipLaunchKernelGGL(k7_sample_max_kernel, dim3(SMAX_CHUNKS, N), dim3(256), 0, st, p.small.p, (long long)p.small.C * H * W, smax);"
+    assert src.count(a) == 1
+    src = src.replace(a, "    if (!getenv(\"K7_SKIP_SMAX\"))\n" + a)
+    b = "    if (!g.aligned) K7_WGC(false, false)\n    else if (edge) K7_WGC(true, true)\n    else K7_WGC(true, false)\n"
+    assert src.count(b) == 1
+    src = src.replace(b, "    if (!getenv(\"K7_SKIP_MAIN\")) {\n" + b + "    }\n")
+    c = "    nemar_sum_partials(part, stride, slabs, gw, J, true, st);\n    if (p.bias_off >= 0) nemar_sum_partials(part + J, stride, slabs, gb, K, true, st);\n"
+    assert src.count(c) == 1
+    src = src.replace(c, "    if (!getenv(\"K7_SKIP_SUMS\")) {\n" + c + "    }\n")
+    return "#include <cstdlib>\n" + src
+
+
+def _k7shfl(src):
+    a = "#ifdef NEMAR_HOST_EMULATION\n#pragma unroll\n    for (int o = 32; o > 0; o >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, o, 64));\n    return x;\n#else"
+    assert src.count(a) == 1
+    return src.replace(a, "#if 1\n#pragma unroll\n    for (int o = 32; o > 0; o >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, o, 64));\n    return x;\n#else")
+
+
+def _k7lb1(src):
+    a = "__global__ __launch_bounds__(256, 2) void k7_wgrad_kernel(K7WgParams p) {"
+    assert src.count(a) == 1
+    return src.replace(a, "__global__ __launch_bounds__(256) void k7_wgrad_kernel(K7WgParams p) {")
+
+
+def _k7nomfma(src):
+    import re
+    a = src.index("void k7_wgrad_kernel(K7WgParams p) {")
+    b = src.index("constexpr int WG_KW = 4;")
+    body = re.sub(r"acc\[i\] = __builtin_amdgcn_mfma_f32_32x32x16_f16\(([^;]*), acc\[i\], 0, 0, 0\);",
+                  r"acc[i][0] += __builtin_bit_cast(float, (\1)[0]);", src[a:b])
+    body = body.replace("(__builtin_bit_cast(f16x8, al[s]), __builtin_bit_cast(f16x8, bh))[0]", "al[s][0] ^ bh[0]")
+    return src[:a] + body + src[b:]
+
+
+VARIANTS = {
+    # the victim (grid_sample's grid-gradient kernel, warp.hip): what about ITS stores matters?
+    "fence": ("warp.hip", _victim("if (accum_ggrid) { q[0] += ggx; q[oplane] += ggy; } else { q[0] = ggx; q[oplane] = ggy; "
+                                  "asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); }")),
+    "swap": ("warp.hip", _victim("if (accum_ggrid) { q[0] += ggx; q[oplane] += ggy; } else { q[oplane] = ggy; q[0] = ggx; }")),
+    "nt": ("warp.hip", _victim("if (accum_ggrid) { q[0] += ggx; q[oplane] += ggy; } else { __builtin_nontemporal_store(ggx, q); "
+                               "__builtin_nontemporal_store(ggy, q + oplane); }")),
+    # the trigger (the stem's weight-gradient call on the side queue, conv_k7.hip): which of its launches?  K7_SKIP_SMAX / _MAIN / _SUMS
+    "k7env": ("conv_k7.hip", _k7env),
+    # ... and what about the kernel: the DPP wave maximum (row_bcast) replaced by shuffles; one workgroup per CU instead of two
+    "k7shfl": ("conv_k7.hip", _k7shfl),
+    "k7lb1": ("conv_k7.hip", _k7lb1),
+}
+
+
+def build(name):
+    fname, patch = VARIANTS[name]
+    os.makedirs(OUT, exist_ok=True)
+    B.build(verbose=False)                                      # the product objects are current
+    vdir = os.path.join(OUT, "src_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    for h in os.listdir(B.HERE):                                # headers next to the patched source
+        if h.endswith(".h"):
+            with open(os.path.join(B.HERE, h)) as f, open(os.path.join(vdir, h), "w") as o:
+                o.write(f.read())
+    with open(os.path.join(B.HERE, fname)) as f:
+        text = patch(f.read())
+    src = os.path.join(vdir, fname)
+    with open(src, "w") as o:
+        o.write(text)
+    obj = os.path.join(vdir, fname.replace(".hip", ".o"))
+    extra = ["-munsafe-fp-atomics"] if fname in B.UNSAFE_FP_ATOMICS else []
+    subprocess.run([B._hipcc(), *B.HIPCC_FLAGS, *extra, "-c", src, "-o", obj], check=True)
+    objs = [obj if s == fname else os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.sources()]
+    lib = os.path.join(OUT, "libnemar_hip_%s.so" % name)
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    return lib
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or list(VARIANTS)):
+        print(build(n))
