@@ -100,6 +100,15 @@ __device__ __forceinline__ void glds_b32(const float* g, float* lds) {
 }
 __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // s_waitcnt vmcnt(0)
 
+// a value every lane of the wave holds identically -> a scalar register (frees the vector register; the emulator has no scalar file)
+__device__ __forceinline__ float uniform_f(float v) {
+#ifdef NEMAR_HOST_EMULATION
+    return v;
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+#endif
+}
+
 // 64-lane wavefront reductions (gfx950 wave = 64; never 32)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

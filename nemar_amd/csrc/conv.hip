@@ -2211,12 +2211,12 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             g_scratch && g_scratch_bytes >= nemar_split16_scratch_total(N, H, W, C, K, H, W)) {
             if (!prepacked) nemar_split16_pack(w, workspace, K, C, R, 1, g_split16_variant, st);
             void* dual = nullptr;      // the weight gradient of the same layer follows and takes its gy planes from this call's split pass
-            if (R == 3 && t_gy_planes_out && t_gy_planes_bytes >= nemar_split16_wgrad_g_bytes(N, H, W, K, R) &&
+            if (g_dual_gy && R == 3 && t_gy_planes_out && t_gy_planes_bytes >= nemar_split16_wgrad_g_bytes(N, H, W, K, R) &&
                 nemar_split16_wgrad_g_bytes(N, H, W, K, R) > 0 && nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad))
                 dual = t_gy_planes_out;
-            t_gy_planes_written = dual ? 1 : 0;
-            nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch, g_xcd_map,
-                               g_split16_variant, g_tl, dual, st);
+            // (whether the planes were written is the split pass's own decision: variant, producer planes, g_dual_gy — ask it)
+            t_gy_planes_written = nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch,
+                                                     g_xcd_map, g_split16_variant, g_tl, dual, st) ? 1 : 0;
             g_last_route = 2;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (split-16)");
             return NEMAR_OK;

@@ -174,14 +174,14 @@ __global__ __launch_bounds__(256, 2) void k7_wgrad_kernel(K7WgParams p) {
     }
     // ---- Small loader: slot = (row of the batch, channel, column of the strip's window) ----
     int s_rci[NSS];                                          // row << 16 | channel << 8 | column, -1: no element
-    const float* s_ptr[NSS];
+    unsigned s_off[NSS];                                     // element offset of (sample, channel, column) in the Small tensor (< 2^30: eligibility)
 #pragma unroll
     for (int j = 0; j < NSS; ++j) {
         const int idx = tid + 256 * j, rr = idx / (CS * NSC), rem = idx - rr * (CS * NSC), c = rem / NSC, i = rem - c * NSC;
         const bool on = idx < BATCH * CS * NSC;
         const int col = on ? view_index(xs - XL + i, p.small.pad, p.small.W, p.small.mode) : -1;
         s_rci[j] = (on && col >= 0) ? ((rr << 16) | (c << 8) | i) : -1;
-        s_ptr[j] = p.small.p + ((size_t)n * CS + (on ? c : 0)) * p.small.H * p.small.W + (col >= 0 ? col : 0);
+        s_off[j] = (unsigned)(n * CS + (on ? c : 0)) * (unsigned)(p.small.H * p.small.W) + (unsigned)(col >= 0 ? col : 0);
     }
     float sS = 0.f;
     float sv[NSS];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k7_wgrad_kernel(K7WgParams p) {
         for (int j = 0; j < NSS; ++j) {
             const int rr = s_rci[j] < 0 ? 0 : (s_rci[j] >> 16);
             const int ry = view_index(R0 + rr, p.small.pad, p.small.H, p.small.mode);
-            sv[j] = s_ptr[j][(size_t)(ry < 0 ? 0 : ry) * p.small.W];
+            sv[j] = p.small.p[s_off[j] + (unsigned)((ry < 0 ? 0 : ry) * p.small.W)];
         }
     };
     _Float16* const sm16 = (_Float16*)&Sm[0][0][0][0];
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k7_wgrad_kernel(K7WgParams p) {
     for (int i = 0; i < PF; ++i) big_load(bq[i], y0 + i);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();                            // the zero fill is complete, smax_s is written
-    sS = pow2f(127 + TEXP + 127 - max_exponent(smax_s));
+    sS = uniform_f(pow2f(127 + TEXP + 127 - max_exponent(smax_s)));
     small_load(y0 - 2);                                      // rows y0 - 2 .. y0 + 1: the first two are overwritten right below
     small_store(y0 - 2);
     small_load(y0 + 2);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void k7_wgrad_kernel(K7WgParams p) {
             float* const bv = bq[ri];
             const int Y = y0 + r0 + ri;
             big_mask(bv, r0 + ri < rows ? Y : p.Hv);
-            if (p.bias_off >= 0) {
+            if (!EDGE && p.bias_off >= 0) {          // (the bias sums belong to the stem: Big = gy without a border, never an EDGE launch)
                 float t = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) t += bv[e];
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k7_wgrad_kernel(K7WgParams p) {
     // ---- epilogue: the two power-of-two scales out (exact), this workgroup's slab ----
     const float u1 = pow2f(E - TEXP), u2 = pow2f(max_exponent(smax_s) - TEXP);
     float* const slab = p.part + (size_t)((n * p.rblocks + rb) * p.strips + strip) * p.slab_stride;
-    if (p.bias_off >= 0 && q == 0) {                         // (the q == 1 wave loaded the same rows)
+    if (!EDGE && p.bias_off >= 0 && q == 0) {                // (the q == 1 wave loaded the same rows)
         bsum += __shfl_xor(bsum, 32, 64);
         if (!lhi && mc < p.big.C) slab[p.bias_off + mc] = bsum;
     }
@@ -521,15 +521,11 @@ __global__ __launch_bounds__(256, 2) void k7_fm_kernel(K7FmParams p) {
             Bs[rest / (GW * NRB)][(rest / NRB) % GW][rest % NRB][col] = zero;
         }
     }
-    int s_crx[NSL];                                          // loader slot = element (c, halo row r, halo column xi): c << 16 | r << 8 | xi
-#pragma unroll
-    for (int i = 0; i < NSL; ++i) {
-        const int idx = tid + 256 * i, c = idx / (NR * HCP), rem = idx - c * (NR * HCP), r = rem / HCP;
-        s_crx[i] = (c << 16) | (r << 8) | (rem - r * HCP);
-    }
-#define K7_SC(i_) (s_crx[i_] >> 16)
-#define K7_SR(i_) ((s_crx[i_] >> 8) & 0xff)
-#define K7_SX(i_) (s_crx[i_] & 0xff)
+    // loader slot i of this thread = element (c, halo row r, halo column xi) of the halo; recomputed where needed (constant divisors: a
+    // few multiplies) instead of held in NSL registers — with the 112 weight registers the kernel sits at the 256-register limit
+#define K7_SC(i_) ((tid + 256 * (i_)) / (NR * HCP))
+#define K7_SR(i_) (((tid + 256 * (i_)) % (NR * HCP)) / HCP)
+#define K7_SX(i_) ((tid + 256 * (i_)) % HCP)
     // the halo of a tile, one element per slot — UNCONDITIONAL loads from clamped addresses (a conditional load, or a select right
     // behind a load, makes hipcc wait for every load separately), zeros selected when the values are consumed.  Issued one tile AHEAD.
     float v[NSL];

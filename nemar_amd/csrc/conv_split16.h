@@ -19,7 +19,8 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int 
 // -> dst [N, M, OH, OW] fp32 (+ bias[M] when non-null): outputs at rows >= OH / columns >= OW of the domain are not stored.
 // 3x3: Hs = OH = H, Ws_src = OW = W, src_pad = 1.  4x4 / pad 1 forward: Hs = H, OH = H - 1, src_pad = 1; its data gradient (a full
 // correlation of gy [H-1, W-1]): Hs = H - 1, OH = H, src_pad = 2.  `scratch` >= nemar_split16_scratch_bytes
-void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
+// -> true when dual_g_out was filled (the data gradient's split pass also wrote the weight gradient's gy planes)
+bool nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
                          int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
                          long long* tl, void* dual_g_out, hipStream_t st);
 

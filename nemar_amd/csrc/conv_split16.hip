@@ -820,9 +820,10 @@ int g_split16_ring3 = 0;         // nemar_tune(32, 1): 3-slot weight ring (76.8 
                                  // (287.6 vs 292.3 us per call, bench 37.5 vs 37.2-37.5 ms) — the kernel needs 332 VGPRs (two fragment sets), so a
                                  // SIMD still holds ONE wave and the second workgroup never becomes resident; kept for the experiment only
 
-void nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
+bool nemar_split16_conv(const float* src, const void* packed, const float* bias, float* dst, int N, int H, int W, int M, int Cred,
                          int KS, int src_pad, int Hs, int Ws_src, int OH, int OW, int mode, void* scratch, int xcd_map, int variant,
                          long long* tl, void* dual_g_out, hipStream_t st) {
+    bool dual_written = false;
     const long long total = (long long)N * (Cred / 8) * (H + 4) * (W + 4);
     unsigned* const xmw = scratch_max_word(scratch, N, Cred, H, W);
     const unsigned* xmax = xmw;
@@ -838,8 +839,10 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
         if (!ready && dual_g_out && KS == 3 && src_pad == 1 && Hs == H && Ws_src == W && Cred % 64 == 0 &&
             (mode == SPLIT16_DGRAD_REFLECT || mode == SPLIT16_ZERO))
             // data gradient of a 3x3 layer whose weight gradient follows: both operand layouts of gy from one read (conv_split16_wgrad.hip)
+        {
             nemar_split16_dual_split(src, scratch, dual_g_out, N, Cred, H, W, mode, xmax, xstride, st);
-        else if (!ready)
+            dual_written = true;
+        } else if (!ready)
             hipLaunchKernelGGL((split_planes_kernel<2>), dim3(nemar_cdiv(total, 256)), dim3(256), 0, st, src, (u32x4*)scratch, N, Cred, H, W,
                                mode, total, xmax, xstride, src_pad, Hs, Ws_src);
     } else {
@@ -911,7 +914,7 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
             else if (nbw == 2) S16_GO(2, 2, 3, 4)
             else S16_GO(3, 2, 3, 4))
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
-        return;
+        return dual_written;
     }
     if (variant == 3) {
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
@@ -922,8 +925,9 @@ void nemar_split16_conv(const float* src, const void* packed, const float* bias,
         } else if (nbw <= 2) S16_GO(2, 3, 3, 4)
         else S16_GO(3, 3, 3, 4)
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
-        return;
+        return dual_written;
     }
 #undef S16_GO
     (void)region;
+    return dual_written;
 }

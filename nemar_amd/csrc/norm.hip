@@ -117,6 +117,132 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __re
     if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
 }
 
+// 16-byte form of the register-cached kernels (HW % 4 == 0, 16-byte aligned planes): a thread holds PER4 float4 — a quarter of the load /
+// store instructions and address registers of the scalar form (whose <1024, 64> instance spilled 32 registers), unconditional loads
+// from clamped addresses with the tail masked afterwards (a conditional load makes hipcc wait for every load on the spot).
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+
+// FULL: HW == 4 THREADS PER4 exactly (no clamped addresses, no tail masks: one address register for the whole plane)
+template <int THREADS, int PER4, bool FULL>
+__global__ __launch_bounds__(THREADS) void instnorm_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ residual,
+                                                                float* __restrict__ y, float* __restrict__ stats, int HW, float eps, int act,
+                                                                float slope, unsigned* maxw, int pps) {
+    __shared__ float red[16];
+    unsigned omax = 0;
+    const size_t base = (size_t)blockIdx.x * HW;
+    const f32x4n* xp = reinterpret_cast<const f32x4n*>(x + base);
+    f32x4n* yp = reinterpret_cast<f32x4n*>(y + base);
+    const f32x4n* rp = residual ? reinterpret_cast<const f32x4n*>(residual + base) : nullptr;
+    const int n4 = HW >> 2;
+    const float inv = 1.f / (float)HW;
+    f32x4n v[PER4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const int j = threadIdx.x + k * THREADS;
+        v[k] = xp[(FULL || j < n4) ? j : n4 - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        if (!FULL && threadIdx.x + k * THREADS >= n4) v[k] = f32x4n{0.f, 0.f, 0.f, 0.f};
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    const float mean = uniform_f(block_sum(s, red) * inv);        // (wave-uniform values live in scalar registers)
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        if (FULL || threadIdx.x + k * THREADS < n4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = uniform_f(1.f / sqrtf(block_sum(q, red) * inv + eps));
+    // (the residual is fetched in groups of four float4 per thread: all PER4 at once would double the register footprint)
+    constexpr int RG = PER4 >= 16 ? 1 : (PER4 < 4 ? PER4 : 4);
+#pragma unroll
+    for (int k0 = 0; k0 < PER4; k0 += RG) {
+        f32x4n r[RG];
+        if (rp) {
+#pragma unroll
+            for (int k = 0; k < RG; ++k) {
+                const int j = threadIdx.x + (k0 + k) * THREADS;
+                r[k] = rp[(FULL || j < n4) ? j : n4 - 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RG; ++k) {
+            const int j = threadIdx.x + (k0 + k) * THREADS;
+            f32x4n o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = act_f((v[k0 + k][e] - mean) * rstd, act, slope);
+                if (rp) o[e] += r[k][e];
+            }
+            if (FULL || j < n4) {
+                yp[j] = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) omax = max(omax, finite_mag(o[e]));
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        stats[2 * (size_t)blockIdx.x] = mean;
+        stats[2 * (size_t)blockIdx.x + 1] = rstd;
+    }
+    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+}
+
+template <int THREADS, int PER4>
+__global__ __launch_bounds__(THREADS) void instnorm_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                const float* __restrict__ gy, float* __restrict__ gx, int HW, int act,
+                                                                float slope, unsigned* maxw, int pps) {
+    __shared__ float red[16];
+    unsigned omax = 0;
+    const size_t base = (size_t)blockIdx.x * HW;
+    const f32x4n* xp = reinterpret_cast<const f32x4n*>(x + base);
+    const f32x4n* gp = reinterpret_cast<const f32x4n*>(gy + base);
+    f32x4n* op = reinterpret_cast<f32x4n*>(gx + base);
+    const float mean = stats[2 * (size_t)blockIdx.x], rstd = stats[2 * (size_t)blockIdx.x + 1];
+    const int n4 = HW >> 2;
+    const float inv = 1.f / (float)HW;
+    f32x4n xh[PER4], g[PER4];
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const int j = threadIdx.x + k * THREADS, jc = j < n4 ? j : n4 - 1;
+        xh[k] = xp[jc];
+        g[k] = gp[jc];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const bool on = threadIdx.x + k * THREADS < n4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = on ? (xh[k][e] - mean) * rstd : 0.f;
+            const float t = on ? g[k][e] * act_df(h, act, slope) : 0.f;
+            xh[k][e] = h;
+            g[k][e] = t;
+            s1 += t;
+            s2 += t * h;
+        }
+    }
+    const float m1 = uniform_f(block_sum(s1, red) * inv);
+    const float m2 = uniform_f(block_sum(s2, red) * inv);
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const int j = threadIdx.x + k * THREADS;
+        f32x4n o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[k][e] - m1 - xh[k][e] * m2);
+        if (j < n4) {
+            op[j] = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) omax = max(omax, finite_mag(o[e]));
+        }
+    }
+    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+}
+
 template <int THREADS, int PER>
 __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ stats,
@@ -205,14 +331,22 @@ static int instnorm_fwd_impl(const float* x, const float* residual, float* y, fl
     NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_fwd: unsupported act %d", act);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(planes);
-    if (HW <= 64 * 8)
+    const bool vec = HW % 4 == 0 && HW >= 1024 && HW <= 1024 * 64 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+    if (vec && HW <= 256 * 16)
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<256, 4, false>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    else if (vec && HW <= 1024 * 16)
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 4, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    else if (vec && HW <= 1024 * 32)
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 8, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    else if (vec && HW == 1024 * 64)
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 16, true>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    else if (HW <= 64 * 8)
         hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 256 * 16)
         hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 1024 * 16)
         hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
-    else if (HW <= 1024 * 64)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 64>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else
         hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     if (maxw) max_words_finalize(maxw, planes / pps, pps, st);
@@ -243,7 +377,15 @@ static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy
     NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_bwd: unsupported act %d", act);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(planes);
-    if (HW <= 64 * 8)
+    const bool vec = HW % 4 == 0 && HW >= 1024 && HW <= 1024 * 32 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0;
+    if (vec && HW <= 256 * 16)
+        hipLaunchKernelGGL((instnorm_bwd4_kernel<256, 4>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+    else if (vec && HW <= 1024 * 16)
+        hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 4>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+    else if (vec)
+        hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 8>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+    else if (HW <= 64 * 8)
         hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (HW <= 256 * 16)
         hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);

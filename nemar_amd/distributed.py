@@ -161,6 +161,11 @@ class GradSync:
         lo, hi = self.buckets[b]
         buf = self.opt.flat_g[lo:hi]
         self.launched.append(b)
+        if buf.is_cuda:
+            # a bucket may hold gradients written from BOTH lanes of the backward pass (the weight-gradient branch runs on a side
+            # stream, ops._on_side): whatever moves the bucket — RCCL on its own stream or the staged test path — starts behind both
+            from . import ops
+            ops.order_current_after_both(buf.device)
         if buf.is_cuda and td.get_backend() != 'nccl':
             # test configuration only (two gloo ranks sharing one GPU): staged through the host, synchronously
             host = buf.detach().cpu()

@@ -46,6 +46,7 @@ def _c(t):
     return t.contiguous()
 
 
+import collections
 import contextlib
 
 _timer = None
@@ -100,12 +101,20 @@ def _workspace(nbytes, device):
 # the main chain (tools/overlap_probe.py: 500 -> 450 us per residual-block layer).  Rules that keep it race-free:
 #   * the side stream waits for everything issued so far (g, x and the gy planes exist) before a branch starts;
 #   * it has its own workspace / arena lane; the gy-planes buffers written by the main stream are a ring guarded by events;
-#   * every tensor the branch reads is kept alive until join_side() — the caching allocator would otherwise hand a block freed on the
-#     main stream to a later main-stream allocation while the side stream still reads it (also inside a graph capture);
+#   * every tensor a branch reads is kept alive until the side stream has FINISHED that branch — the caching allocator would otherwise
+#     hand a block freed on the main stream to a later main-stream allocation while the side stream still reads it.  Each branch ends
+#     with an event; the next fork drops the tensors of every branch whose event has completed (a host-side query, no wait), so the
+#     activations / gradients of the pass are released layer by layer as without the side stream (at most the side stream's backlog is
+#     held; bench.py reports the peak).  Inside a graph capture nothing can be queried: there the tensors stay until join_side();
+#   * a weight's gradient accumulations stay on ONE lane within a pass (read-modify-write of the same buffer from two unordered
+#     streams otherwise): a weight that was accumulated on the side stream and is then applied by a layer without a data gradient
+#     (which would take the compute lane) makes the compute stream wait for the side stream first;
 #   * join_side() (before an optimizer step / at the end of a phase) makes the main stream wait for the side stream.
 _side_on = [os.environ.get("NEMAR_SIDE_STREAM", "1") != "0"]
+_SIDE_K7 = os.environ.get("NEMAR_SIDE_K7", "1") != "0"
 _side_streams = {}
-_side_keep = []
+_side_keep = collections.deque()     # (event recorded on the side stream behind a branch | None inside a capture, the tensors it reads)
+_side_touched = set()                # id() of the gradient buffers the side lane has accumulated into since the last join
 _side_busy = [False]
 _main_streams = {}     # device -> the compute stream the last branch forked from
 _side_cb = [False]     # join_side is queued as an end-of-backward callback of the running autograd pass
@@ -141,7 +150,10 @@ class _on_side:
         main = torch.cuda.current_stream(self.device)
         _main_streams[self.device] = main
         side.wait_stream(main)
-        _side_keep.extend(t for t in self.keep if t is not None)
+        if not torch.cuda.is_current_stream_capturing():
+            while _side_keep and _side_keep[0][0] is not None and _side_keep[0][0].query():
+                _side_keep.popleft()                               # that branch has run: its tensors may go back to the allocator
+        self.kept = [t for t in self.keep if t is not None]
         _side_busy[0] = True
         if not _side_cb[0]:
             # the pass that issued a branch joins it when it ends: whoever reads .grad after backward() sees a single stream again
@@ -154,8 +166,23 @@ class _on_side:
 
     def __exit__(self, *a):
         if self.ctx is not None:
+            ev = None
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+            _side_keep.append((ev, self.kept))
             _lane[0] = 0
             self.ctx.__exit__(*a)
+
+
+def _main_lane_grad(buf, device):
+    """A weight-gradient accumulation about to be issued on the COMPUTE lane into `buf`: if the side lane has accumulated into the same
+    buffer since the last join (a weight applied twice in one pass, once with and once without a data gradient), order the compute
+    stream behind the side stream first."""
+    if _side_busy[0] and id(buf) in _side_touched:
+        side = _side_streams.get(device)
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
 
 
 def order_current_after_both(device):
@@ -183,6 +210,7 @@ def join_side():
                 slot[1] = None
     _side_cb[0] = False
     _side_keep.clear()
+    _side_touched.clear()
 
 
 _scratch_need = {}     # layer shape -> nemar_conv2d_scratch bytes (depends on the nemar_tune switches: ops.tune clears it)
@@ -376,6 +404,7 @@ def tune(key, value):
     """nemar_tune through the packed-weight cache: several switches (tile family, split-16 route) change the packed image."""
     L.tune(key, value)
     _scratch_need.clear()
+    _gplanes_need.clear()            # (the gy-planes hand-over depends on the route switches too)
     invalidate_packed_weights()
 
 
@@ -564,21 +593,26 @@ class _Conv2d(Function):
                 gx2 = None
         want_b = need_b and ctx.bias is not None
         if need_w:
-            # the weight-gradient branch feeds only the optimizer: side stream (after everything issued so far)
-            # ... except the 7x7 layers: with their weight-gradient kernels (conv_k7.hip) on the side queue, a kernel of the compute
-            # stream that runs at the same moment (grid_sample's grid gradient, right behind the stem) was seen to lose 64-byte store
-            # sectors — 29 % of the steps of tools/diag_hooks.py, 0 of 300 without them; not understood, so they stay put.
-            # NEMAR_SIDE_MODE=all reproduces it.
-            _use = R != 7 or os.environ.get("NEMAR_SIDE_MODE", "") == "all"
+            # the weight-gradient branch feeds only the optimizer: side stream (after everything issued so far).  Every layer, the 7x7
+            # stem / head included: what round 4 saw go wrong with those two on the side queue (grid_sample's grid gradient, on the
+            # compute stream at that moment, came out wrong in lanes 48..63) was a packed-FP32 instruction form of THAT kernel
+            # miscomputing next to another kernel's MFMAs — the library is built without such instructions now.
+            # NEMAR_SIDE_K7=0 keeps the 7x7 layers on the compute stream (A/B of the schedule only).
+            _use = R != 7 or _SIDE_K7
             # a layer without a data gradient (the first layer of a net: nothing left for the compute stream to do) keeps its weight
             # gradient there — it is the last one of the pass, and the compute stream would only wait for it at the join
             if not (need_x or need_x2):
                 _use = False
+            gwbuf = _grad_buffer(ctx.weight)
+            if _use and _side_on[0]:
+                _side_touched.add(id(gwbuf))
+            else:
+                _main_lane_grad(gwbuf, g.device)
             with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl) if _use else contextlib.nullcontext()):
                 gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
                 wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
                 arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
-                L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(_grad_buffer(ctx.weight)), _p(gb), N, H, W, K, OH, OW,
+                L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(gwbuf), _p(gb), N, H, W, K, OH, OW,
                                        R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, _stream(),
                                        _extras(arena, ctx.xmax, gmax, src2_planes=gpl))
                 if gslot is not None and _side_on[0]:
@@ -655,6 +689,8 @@ class _ConvTranspose2d(Function):
                 L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
                              0.0, _p(ws), wsb, hit, st)
         if ctx.needs_input_grad[1] or (ctx.needs_input_grad[2] and ctx.bias is not None):
+            if _side_on[0] and ctx.needs_input_grad[1]:
+                _side_touched.add(id(_grad_buffer(ctx.weight)))
             with _on_side(g.device, g, x):                 # the weight-gradient branch: side stream (see _Conv2d)
                 if ctx.needs_input_grad[1]:
                     wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)

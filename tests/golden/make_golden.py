@@ -89,9 +89,19 @@ def run_full_config(name, cfg):
         getattr(ref_unet, key)['deep'] = val
     A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
     out = {}
-    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+    # cfg['perturbed'] = n: n further fp32 runs of the reference on inputs moved by 4 ulps up / down — what a different summation order
+    # does to the first layer's output.  The gradient through the discriminator's LeakyReLU masks (and with it everything of the
+    # affine registration net, whose whole gradient is one 6-vector) moves by PERCENTS under such a change: one fp32-vs-fp64 gap
+    # is a single draw of a heavy-tailed quantity, the test takes the largest of the n + 1 (tests/test_step_full_gpu.py compare()).
+    runs = [('f32', torch.float32, 0), ('f64', torch.float64, 0)] + [('f32p%d' % (i + 1), torch.float32, (-1) ** i * 4) for i in range(cfg.get('perturbed', 0))]
+    A0, B0 = A, B
+    for tag, dt, ulps in runs:
         if tag == 'f64' and not cfg.get('f64', True):
             continue          # 1024x1024 in fp64 does not fit this container's memory/time: see tests/test_step_gpu.py
+        A, B = A0, B0
+        for _ in range(abs(ulps)):
+            A = np.nextafter(A, np.float32(np.inf if ulps > 0 else -np.inf))
+            B = np.nextafter(B, np.float32(np.inf if ulps > 0 else -np.inf))
         t0 = time.time()
         torch.set_default_dtype(dt)
         try:
@@ -109,6 +119,8 @@ def run_full_config(name, cfg):
         finally:
             torch.set_default_dtype(torch.float32)
         for k, v in rec.items():
+            if ulps and not k.startswith(('grad', 'psum', 'pabs')):
+                continue      # (the perturbed runs calibrate the gradient / post-Adam rows only)
             out['%s/%s' % (tag, k)] = np.asarray(v, dtype=np.float64)
         print(name, tag, '%.1fs' % (time.time() - t0), {k: round(v, 6) for k, v in rec.items() if k.startswith('loss/')},
               flush=True)

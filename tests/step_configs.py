@@ -25,7 +25,7 @@ STEP_CONFIGS = {
 FULL_CONFIGS = {
     # C1: BASELINE config 1 at full width — affine STN, resnet_6blocks, 128x128, batch 1 (the reference's own CPU-runnable case)
     'c1_full': dict(stn_type='affine', netG='resnet_6blocks', ngf=64, ndf=64, size=128, batch=1, seed=37,
-                    lambda_smooth=0.5, steps=1, overrides_R={'net.local.2.weight': 0.02, 'net.local.2.bias': 0.05}),
+                    lambda_smooth=0.5, steps=1, perturbed=2, overrides_R={'net.local.2.weight': 0.02, 'net.local.2.bias': 0.05}),
     # C2: unet cfg 'A', 256x256 (the bench workload, at batch 1)
     'c2_full': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, size=256, batch=1, seed=41,
                     lambda_smooth=10.0, steps=1, overrides_R={'offset_map.output.conv2d.weight': 0.02}),
@@ -46,7 +46,7 @@ FULL_CONFIGS = {
     # The reference's DEFAULT geometry and nets (options/base_options.py:34,47-48: --img_height 288 --img_width 384, resnet_9blocks;
     # models/stn/__init__.py:12: --stn_type affine) — non-square, not a power of two: 72x96 residual-block maps, 36x48 / 35x47 D maps
     'default_full': dict(stn_type='affine', netG='resnet_9blocks', ngf=64, ndf=64, height=288, width=384, size=None, batch=1,
-                         seed=61, lambda_smooth=0.5, steps=1,
+                         seed=61, lambda_smooth=0.5, steps=1, perturbed=2,
                          overrides_R={'net.local.2.weight': 0.02, 'net.local.2.bias': 0.05}),
     # a non-square dense-field case: unet cfg 'A' at 256x384 (2x3 bottleneck), batch 1
     'c2_256x384': dict(stn_type='unet', netG='resnet_9blocks', ngf=64, ndf=64, height=256, width=384, size=None, batch=1,

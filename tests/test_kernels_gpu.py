@@ -308,7 +308,7 @@ def test_conv_hot_shapes(be, C0, C1, Kc, R, stride, pad, pm, HW):
     K.case_conv_bwd_weight(be, 2, C0, C1, HW, HW, Kc, R, stride, pad, pm)
 
 
-@pytest.mark.parametrize("H,W", [(2, 2), (4, 4), (9, 7), (31, 31), (64, 64), (128, 128), (256, 256), (300, 300)])
+@pytest.mark.parametrize("H,W", [(2, 2), (4, 4), (9, 7), (31, 31), (64, 64), (72, 96), (128, 128), (144, 192), (256, 256), (300, 300)])
 @pytest.mark.parametrize("act", [K.O.ACT_NONE, K.O.ACT_RELU, K.O.ACT_LRELU])
 def test_instnorm(be, H, W, act):
     K.case_instnorm(be, 2, 3, H, W, act, residual=(act == K.O.ACT_NONE))

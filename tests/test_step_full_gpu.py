@@ -69,11 +69,21 @@ def _rel_gaps_by_class(g):
     return {c: float(np.quantile(v, 0.9)) for c, v in out.items()}
 
 
+def _f32_tags(g):
+    """'f32' and, where the fixture holds them, the fp32 runs of the reference on inputs moved by +-4 ulps ('f32p1', 'f32p2': make_golden.py)"""
+    return ['f32'] + sorted({k.split('/')[0] for k in g.files if k.startswith('f32p')})
+
+
+def _gap(g, q):
+    """largest |fp32 run - fp64 run| of quantity q over the reference's fp32 runs"""
+    want = g['f64/' + q]
+    return max(float(np.abs(g['%s/%s' % (t, q)] - want).max()) for t in _f32_tags(g) if '%s/%s' % (t, q) in g.files)
+
+
 def _net_grad_gap(g, net):
-    """90th percentile over the weight tensors of one network of |gradnorm_f32 - gradnorm_f64| / gradnorm_f64"""
+    """90th percentile over the weight tensors of one network of |gradnorm_f32 - gradnorm_f64| / gradnorm_f64 (largest over the fp32 runs)"""
     pre = 'f64/gradnorm/%s/' % net
-    rel = [abs(float(g['f32/' + k[4:]]) - float(g[k])) / max(float(g[k]), 1e-30)
-           for k in g.files if k.startswith(pre) and k.endswith('weight')]
+    rel = [_gap(g, k[4:]) / max(float(g[k]), 1e-30) for k in g.files if k.startswith(pre) and k.endswith('weight')]
     return float(np.quantile(rel, 0.9)) if rel else 0.0
 
 
@@ -130,7 +140,7 @@ def compare(name, rec, report=None):
         else:
             scale = float(np.abs(want).max())
         if have64:
-            gap = float(np.abs(g['f32/' + q] - want).max())
+            gap = _gap(g, q)
             if cls.startswith('grad'):
                 gap = max(gap, _net_grad_gap(g, tail.split('/')[0]) * scale)
         else:
@@ -148,7 +158,7 @@ def compare(name, rec, report=None):
     return rows
 
 
-ROUTE_NAMES = {0: 'exact', 1: 'narrow', 2: 'split16', 3: 's16g'}
+ROUTE_NAMES = {0: 'exact', 1: 'narrow', 2: 'split16', 3: 's16g', 4: 'k7'}
 
 
 class _RouteLog:
@@ -161,12 +171,14 @@ class _RouteLog:
 
     def __enter__(self):
         L = self.L
+        # (the product path calls the _ex entry points — side inputs per call; ConvTranspose2d the plain ones: same argument positions)
         for nm, dims in (('conv2d_fwd', (7, 8, 9, 10, 11, 13, 14)), ('conv2d_bwd_data', (9, 10, 11, 12, 15, 17, 18)),
-                         ('conv2d_bwd_weight', (7, 8, 9, 10, 13, 15, 16))):
+                         ('conv2d_bwd_weight', (7, 8, 9, 10, 13, 15, 16)), ('conv2d_fwd_ex', (7, 8, 9, 10, 11, 13, 14)),
+                         ('conv2d_bwd_data_ex', (9, 10, 11, 12, 15, 17, 18)), ('conv2d_bwd_weight_ex', (7, 8, 9, 10, 13, 15, 16))):
             f = getattr(L, nm)
             self.saved[nm] = f
 
-            def wrapped(*a, _f=f, _nm=nm, _dims=dims):
+            def wrapped(*a, _f=f, _nm=nm[:-3] if nm.endswith('_ex') else nm, _dims=dims):
                 r = _f(*a)
                 key = (_nm,) + tuple(a[i] for i in _dims) + (ROUTE_NAMES.get(L.last_route(), '?'),)
                 self.rows[key] = self.rows.get(key, 0) + 1
@@ -177,6 +189,11 @@ class _RouteLog:
     def __exit__(self, *exc):
         for nm, f in self.saved.items():
             setattr(self.L, nm, f)
+
+    def routes_of(self, op, **want):
+        """the set of routes taken by the calls of `op` whose (N, H, W, K, R, stride, pad) match the given fields"""
+        names = ('N', 'H', 'W', 'K', 'R', 'stride', 'pad')
+        return {k[8] for k in self.rows if k[0] == op and all(k[1 + names.index(f)] == v for f, v in want.items())}
 
     def write(self, name, report):
         if not report:
@@ -271,3 +288,43 @@ def test_registration_submodel_of_config5_vs_fp64():
                 f.write('%-86s err=%.3e tol=%.1e %s\n' % (r[0], r[1], r[2], 'ok' if r[3] else 'FAIL'))
     bad = [r for r in rows if not r[3]]
     assert len(rows) > 150 and not bad, (len(rows), len(bad), bad[:8])
+
+
+SIDE_STEPS = 50
+
+
+@pytest.mark.parametrize("name", list(FULL_CONFIGS))
+def test_side_stream_equals_single_stream_on_every_config(name):
+    """The weight-gradient branch of EVERY convolution runs on a side HIP stream (ops._on_side).  Same bits as the single-stream order, on
+    every full-width configuration (different kernel mixes and timings: 128^2 ... 1024^2, affine / unet / deep STN, multi-resolution D,
+    non-square maps), over SIDE_STEPS consecutive steps each, dropout on: parameters, both Adam moments and the loss trajectory.
+    Round 4 saw one kernel pair go wrong here (the 7x7 stem's weight gradient next to grid_sample's grid gradient); the cause was
+    a packed-FP32 instruction form that miscomputes next to another kernel's MFMAs — the library has none any more
+    (tests/test_abi.py checks the ISA), and this test is the end-to-end guard."""
+    from nemar_amd import ops
+    cfg = FULL_CONFIGS[name]
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
+    data = {'A': torch.from_numpy(A), 'B': torch.from_numpy(B), 'A_paths': [''], 'B_paths': ['']}
+
+    def run(side):
+        ops.side_stream(side)
+        m = build(name)
+        ops.manual_seed(1234)            # (the model seeded the dropout generator from torch's seed: the same stream of masks in both runs)
+        losses = []
+        for _ in range(SIDE_STEPS):
+            m.set_input(data)
+            m.optimize_parameters()
+            losses.append(tuple(sorted(m.get_current_losses().items())))
+        torch.cuda.synchronize()
+        return losses, [t.detach().cpu().clone() for o in m.optimizers for t in (o.flat_p, o.m, o.v)]
+
+    prev = ops.side_stream(None)
+    try:
+        want_l, want = run(False)
+        got_l, got = run(True)
+    finally:
+        ops.side_stream(prev)
+    first = next((i for i, (x, y) in enumerate(zip(got_l, want_l)) if x != y), None)
+    assert first is None, ('losses differ from step %d on' % first, got_l[first], want_l[first])
+    for k, (x, y) in enumerate(zip(got, want)):
+        assert torch.equal(x, y), ('buffer %d' % k, int((x != y).sum()), float((x - y).abs().max()))

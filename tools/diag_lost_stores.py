@@ -1,7 +1,7 @@
 """The lost-store anomaly of the side-stream weight-gradient branch: statistics under one experimental condition.
 
 Runs DIAG_RUNS fresh one-step runs of a full-width config with the 7x7 layers' weight gradients on the side queue
-(NEMAR_SIDE_MODE=all) and compares the gradient w.r.t. the deformation field that the FIRST warp's backward returns (the victim:
+(the default since round 5; NEMAR_SIDE_K7=0 takes them off) and compares the gradient w.r.t. the deformation field that the FIRST warp's backward returns (the victim:
 grid_sample_bwd_kernel<UNET, false>, warp.hip) with the first run's, element by element.  Prints one summary line.
 
 Conditions (environment):
@@ -17,7 +17,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 sys.path.insert(0, ROOT)
-os.environ.setdefault('NEMAR_SIDE_MODE', 'all')
 os.environ.setdefault('NEMAR_SIDE_STREAM', '1')
 import torch  # noqa: E402
 from nemar_amd import _lib  # noqa: E402

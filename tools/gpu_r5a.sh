@@ -16,5 +16,5 @@ run DIAG_LIB=$V/libnemar_hip_k7env.so K7_SKIP_SMAX=1 K7_SKIP_MAIN=1 K7_SKIP_SUMS
 run HIP_FORCE_DEV_KERNARG=0
 run GPU_MAX_HW_QUEUES=8
 run HSA_ENABLE_SDMA=0
-run NEMAR_SIDE_MODE=off
+run NEMAR_SIDE_K7=0
 } 2>&1 | tee $O/lost_stores.txt
