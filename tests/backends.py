@@ -4,7 +4,7 @@
 import ctypes
 import numpy as np
 
-from tools.side_inputs import SideInputs
+from side_inputs import SideInputs
 
 
 class EmuBackend:

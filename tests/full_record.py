@@ -90,3 +90,30 @@ def registration_record(netR, l1, A, B, seed, lambda_recon=100.0, lambda_smooth=
             out['gradproj/R/' + k] = proj(p.grad, seed, 1000 + j)
             out['gradmax/R/' + k] = p.grad.double().abs().max().item()
     return out
+
+
+def traj_record(m, A, B, seed, steps):
+    """`steps` CONSECUTIVE optimize_parameters() of `m` on the same numpy batch (free running: every step starts from the weights and Adam
+    moments the previous one left).  Per step: the 8 losses, the regularisation term, statistics + a seeded projection of the
+    deformation field the step's forward pass used and of the translated image; after the last step the per-network parameter sums."""
+    out = {}
+    p0 = next(m.netT.parameters())
+    a, b = torch.from_numpy(A).to(p0.device, p0.dtype), torch.from_numpy(B).to(p0.device, p0.dtype)
+    for s in range(steps):
+        pre = 's%02d/' % s
+        with torch.no_grad():
+            off = m.netR.offset_map(a, b)
+        out[pre + 'offsets/mean'], out[pre + 'offsets/absmean'] = off.double().mean().item(), off.double().abs().mean().item()
+        out[pre + 'offsets/proj'] = proj(off, seed, 900)
+        m.set_input({'A': a, 'B': b, 'A_paths': ['a'], 'B_paths': ['b']})
+        m.optimize_parameters()
+        for k, v in m.get_current_losses().items():
+            out[pre + 'loss/' + k] = float(v)
+        out[pre + 'reg'] = float(m.stn_reg_term)
+        t = m.fake_B.detach()
+        out[pre + 'absmean/fake_B'] = t.double().abs().mean().item()
+        out[pre + 'proj/fake_B'] = proj(t, seed, 901)
+    for nm, net in (('T', m.netT), ('R', m.netR), ('D', m.netD)):
+        out['final/psum/' + nm] = sum(p.detach().double().sum().item() for p in net.parameters())
+        out['final/pabs/' + nm] = sum(p.detach().double().abs().sum().item() for p in net.parameters())
+    return out

@@ -128,6 +128,48 @@ def run_full_config(name, cfg):
     np.savez_compressed(os.path.join(HERE, 'step_%s.npz' % name), **out)
 
 
+TRAJ_STEPS = 10
+
+
+def run_trajectory(name='c2_full'):
+    """TRAJ_STEPS consecutive steps of the reference (fp32 and fp64) at a full-width configuration: step_c2_traj10.npz.  The one-step
+    fixtures start from seeded uniform weights; this one pins what the build does with Adam-moved weights, step after step
+    (tests/full_record.traj_record; tests/test_step_full_gpu.py::test_ten_step_trajectory_vs_reference)."""
+    import time
+    from models.nemar_model import NEMARModel
+    from full_record import traj_record
+    cfg = FULL_CONFIGS[name]
+    A, B = seeded.seeded_images(cfg['batch'], 3, *hw(cfg), cfg['seed'])
+    out = {}
+    # 'f32p1' / 'f32p2': fp32 runs on inputs moved by +-4 ulps.  A free-running GAN trajectory is chaotic (Adam's first steps move every
+    # weight by +-lr: the sign of a gradient element at rounding distance of zero decides); how fast two CORRECT fp32 runs drift apart
+    # is what these measure, and the test bounds the build's drift by the largest of the three.
+    A0, B0 = A, B
+    for tag, dt, ulps in (('f32', torch.float32, 0), ('f64', torch.float64, 0), ('f32p1', torch.float32, 4), ('f32p2', torch.float32, -4)):
+        A, B = A0, B0
+        for _ in range(abs(ulps)):
+            A = np.nextafter(A, np.float32(np.inf if ulps > 0 else -np.inf))
+            B = np.nextafter(B, np.float32(np.inf if ulps > 0 else -np.inf))
+        t0 = time.time()
+        torch.set_default_dtype(dt)
+        try:
+            opt = make_opt(cfg)
+            torch.manual_seed(0)
+            m = NEMARModel(opt)
+            m.setup(opt)
+            load_seeded(m.netT, cfg['seed'] + 1, cfg.get('overrides_T'))
+            load_seeded(m.netR, cfg['seed'] + 2, cfg.get('overrides_R'))
+            load_seeded(m.netD, cfg['seed'] + 3, cfg.get('overrides_D'))
+            rec = traj_record(m, A, B, cfg['seed'], TRAJ_STEPS)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        for k, v in rec.items():
+            out['%s/%s' % (tag, k)] = np.asarray(v, dtype=np.float64)
+        print(name, 'trajectory', tag, '%.1fs' % (time.time() - t0), [round(rec['s%02d/loss/L1_TR' % s], 5) for s in range(TRAJ_STEPS)], flush=True)
+        del m
+    np.savez_compressed(os.path.join(HERE, 'step_c2_traj%d.npz' % TRAJ_STEPS), **out)
+
+
 def run_registration_submodel(name='c5_full'):
     """fp32 AND fp64 runs of the reference's UnetSTN sub-model (tests/full_record.registration_record) at a full configuration's
     geometry — for BASELINE config 5 (1024x1024, 'deep' cfg) the fp64 truth the full step cannot have in this container."""
@@ -258,6 +300,8 @@ if __name__ == '__main__':
         run_unet_generator()
     if a.only in (None, 'regsub', 'full'):
         run_registration_submodel('c5_full')
+    if a.only in (None, 'traj', 'full'):
+        run_trajectory('c2_full')
     for name, cfg in STEP_CONFIGS.items():
         if a.only in (None, name):
             run_step_config(name, cfg)

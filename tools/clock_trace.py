@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from nemar_amd import _lib
-from tools.side_inputs import SideInputs
+from tests.side_inputs import SideInputs
 lib = SideInputs(_lib.load()); dev = torch.device('cuda:0')
 probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'probes', '_build', 'libclock_probe.so'))
 probe.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -3,7 +3,7 @@ import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib
-from tools.side_inputs import SideInputs
+from tests.side_inputs import SideInputs
 from tools.microbench import timeit
 
 lib = SideInputs(_lib.load()); dev = torch.device('cuda:0')

@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib
-from tools.side_inputs import SideInputs
+from tests.side_inputs import SideInputs
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 lib = SideInputs(_lib.load()); dev = torch.device('cuda:0')

@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib
-from tools.side_inputs import SideInputs
+from tests.side_inputs import SideInputs
 lib = SideInputs(_lib.load(os.environ.get('NEMAR_TL_LIB'))); dev = torch.device('cuda:0')
 VARIANT = int(os.environ.get('SPLIT16_VARIANT', '4'))
 lib.tune(21, VARIANT)
