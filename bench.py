@@ -377,11 +377,13 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    peak_mem = torch.cuda.max_memory_allocated(dev)
     # per-launch durations of the roofline kernels: HIP events on the launch stream in a SEPARATE pass of two steps, after
     # the timed region (the event records would otherwise sit inside it)
     model._graph = None                  # the roofline pass needs eager launches (step parameters stay in device memory)
@@ -394,6 +396,11 @@ def main():
         step()
     torch.cuda.synchronize()
     timer.enabled = False
+    # peak memory of the single-stream order (the side-stream branch keeps the tensors it reads until the side stream has run it)
+    torch.cuda.reset_peak_memory_stats(dev)
+    step()
+    torch.cuda.synchronize()
+    peak_mem_single = torch.cuda.max_memory_allocated(dev)
     ops.side_stream(side_prev)
     import ctypes
     tk_ms_c, tk_fl_c, tk_n_c = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int(0)
@@ -499,6 +506,9 @@ def main():
         "launch": "hipGraph replay" if graph_on else ("eager, weight-gradient branch on a side stream" + (" (%s)" % graph_note if graph_note else "")),
         "launch_probe": launch_probe,
         "losses_finite": all(v == v and abs(v) != float('inf') for v in losses.values()),
+        "peak_memory_GB": {"timed_region": peak_mem / 1e9, "single_stream_order": peak_mem_single / 1e9,
+                           "note": "torch.cuda.max_memory_allocated; the weight-gradient branch on the side stream keeps the tensors it reads "
+                                   "alive until the side stream has finished that branch (released per branch, nemar_amd/ops.py _on_side)"},
         "rank_ms_per_step": rank_ms,                      # one entry per rank: the N > 1 run cannot degrade to one rank unnoticed
         "dist": {"backend": "nccl (RCCL)" if multi else None, "buckets_launched_last_step": buckets, "buckets": bucket_rows or None,
                  "launcher": "self-spawned ranks" if os.environ.get("NEMAR_SPAWNED") else ("torchrun" if multi else None)},
@@ -545,10 +555,20 @@ def main():
                            "sustained_mfma_TFLOPs_measured": F16_MFMA_SUSTAINED_TF,
                            "frac_of_sustained_mfma": 3.0 * flop / sec / 1e12 / F16_MFMA_SUSTAINED_TF,
                            "sustained_source": "profiles/r4_mfma_peak_modes.txt (f16, random operands, 2 waves/SIMD, long run)"}
-    if 'igemm_fwd_resblock' in spans:       # the whole operator call (max pass + split pass + main kernel), for the record
-        n, sec = spans['igemm_fwd_resblock']
-        out["conv2d_fwd_resblock_call"] = {"avg_us": sec * 1e6, "calls_timed": n,
-                                           "fp32_equivalent_TFLOPs": 2.0 * a.batch * C * hw * C * 9 / sec / 1e12}
+    # Operator level (what the step pays per residual-block layer): the whole C-ABI call — support passes (split / pack / slab sums) + main
+    # kernel — event-timed on ONE stream in the same two-step pass; the batch of a call = T's two applications (2 x batch)
+    rb = {}
+    for tag, nm in (('igemm_fwd_resblock', 'forward'), ('dgrad_resblock', 'data_gradient'), ('wgrad_resblock', 'weight_gradient')):
+        if tag in spans:
+            n, sec = spans[tag]
+            fl = 2.0 * (2 * a.batch) * C * hw * C * 9
+            rb[nm] = {"avg_call_us": sec * 1e6, "calls_timed": n, "fp32_equivalent_TFLOPs": fl / sec / 1e12,
+                      "frac": fl / sec / 1e12 / (F16_MFMA_PEAK_TF / 3.0)}
+    if rb:
+        tot = sum(v["avg_call_us"] for v in rb.values())
+        rb["all_three"] = {"avg_us_per_layer": tot, "frac": sum(2.0 * (2 * a.batch) * C * hw * C * 9 for _ in range(len(rb))) / (tot * 1e-6) / 1e12 / (F16_MFMA_PEAK_TF / 3.0)}
+        rb["peak_basis"] = "2500 TFLOP/s dense fp16 MFMA / 3 products per fp32 product; 256->256 3x3 reflect layer, %d images per call" % (2 * a.batch)
+        out["roofline_operator"] = rb
     px = a.batch * a.size * a.size
     gs = {}
     for tag, bpp in (('grid_sample_fwd', 4 * (2 * 3 + 2)), ('grid_sample_bwd_gin', 4 * (3 * 3 + 4)),

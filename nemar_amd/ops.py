@@ -112,6 +112,7 @@ def _workspace(nbytes, device):
 #   * join_side() (before an optimizer step / at the end of a phase) makes the main stream wait for the side stream.
 _side_on = [os.environ.get("NEMAR_SIDE_STREAM", "1") != "0"]
 _SIDE_K7 = os.environ.get("NEMAR_SIDE_K7", "1") != "0"
+_KEEP_ALL = os.environ.get("NEMAR_SIDE_KEEP_ALL", "0") == "1"     # (diagnostic: kept tensors released at the join only, as in round 4)
 _side_streams = {}
 _side_keep = collections.deque()     # (event recorded on the side stream behind a branch | None inside a capture, the tensors it reads)
 _side_touched = set()                # id() of the gradient buffers the side lane has accumulated into since the last join
@@ -150,7 +151,7 @@ class _on_side:
         main = torch.cuda.current_stream(self.device)
         _main_streams[self.device] = main
         side.wait_stream(main)
-        if not torch.cuda.is_current_stream_capturing():
+        if not torch.cuda.is_current_stream_capturing() and not _KEEP_ALL:
             while _side_keep and _side_keep[0][0] is not None and _side_keep[0][0].query():
                 _side_keep.popleft()                               # that branch has run: its tensors may go back to the allocator
         self.kept = [t for t in self.keep if t is not None]
@@ -240,6 +241,7 @@ _garena = {}           # device -> ring of [buffer, event of the side-stream con
 _garena_next = {}
 _gplanes_need = {}
 GY_RING = int(os.environ.get("NEMAR_GY_RING", "4"))
+_GY_HANDOVER = os.environ.get("NEMAR_GY_HANDOVER", "0") == "1"      # (diagnostic: the hand-over also beside the side stream)
 
 
 def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
@@ -247,6 +249,12 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
     takes (nemar_conv_extras.gy_planes_out -> .src2_planes: gy is split once for both), or (None, None).  A ring of GY_RING buffers per
     device: the weight gradient may run on the side stream while the compute stream writes the next layer's planes; a slot is handed out
     again only after the compute stream has waited for the event its last consumer recorded."""
+    if _side_on[0] and not _GY_HANDOVER:
+        # With the weight gradient on the side stream the hand-over is OFF: in ~0.8 % of the steps of config 3 (batch 2) ONE 32 x 32 tile of
+        # ONE wide layer's weight gradient, for one tap row, came out 0.5 % off (15 of 100 runs of 20 steps; 0 of 310 without the
+        # hand-over, 0 ever on one stream, 0 of 2700 in a stand-alone two-stream probe of the same kernels) — cause not found yet
+        # (DESIGN.md 4g).  The side stream splits gy itself, beside the compute stream's kernels.
+        return None, None
     key = (N, C, H, W, K, R, S, stride, pad, pad_mode)
     need = _gplanes_need.get(key)
     if need is None:
@@ -583,7 +591,8 @@ class _Conv2d(Function):
             if arena is not None and need_w and Nd == N and gmax is not None and x2 is None:
                 # wide layer whose weight gradient follows: the pass that splits gy for this call leaves its planes for that one too
                 gpl, gslot = _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, g.device)
-            with _record(plan):
+            rb = K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT         # (bench.py: operator-level roofline of the residual blocks)
+            with _record(plan), (_span('dgrad_resblock') if rb else contextlib.nullcontext()):
                 L.conv2d_bwd_data_ex(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
                                      stride, pad, pad_mode, _p(ws), wsb, hit, st,
                                      _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax, gy_out=gpl))
@@ -608,7 +617,9 @@ class _Conv2d(Function):
                 _side_touched.add(id(gwbuf))
             else:
                 _main_lane_grad(gwbuf, g.device)
-            with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl) if _use else contextlib.nullcontext()):
+            rbw = K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT
+            with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl) if _use else contextlib.nullcontext()), \
+                    (_span('wgrad_resblock') if rbw else contextlib.nullcontext()):
                 gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
                 wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
                 arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)

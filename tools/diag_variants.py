@@ -59,6 +59,47 @@ def _k7nomfma(src):
     return src[:a] + body + src[b:]
 
 
+def _wgdeep(src):
+    # the wide weight gradient waits for its copies one stage EARLIER (one stage in flight instead of two at a step's barrier)
+    a = "            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)"
+    assert src.count(a) == 1
+    return src.replace(a, "            WG_VMCNT(NCP)")
+
+
+def _wgdrain(src):
+    # ... or drains them completely (no assumption about the order in which LDS copies complete)
+    a = "            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)"
+    assert src.count(a) == 1
+    return src.replace(a, "            WG_VMCNT(0)")
+
+
+def _wgcheck(src):
+    # every step re-reads the NEXT step's X fragments from LDS after the wait + barrier protocol says they are final and counts differences
+    a = "            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)\n            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers\n"
+    assert src.count(a) == 1, src.count(a)
+    chk = a + """            if (T + 1 < nsteps) {
+                bool bad_ = false;
+                _Pragma("unroll") for (int i = 0; i < 2 * KS; ++i) {
+                    const u32x4 again_ = S_[b_off + i * 128];
+                    bad_ = bad_ || again_[0] != bf[nxt][i >> 1][i & 1][0] || again_[1] != bf[nxt][i >> 1][i & 1][1] || again_[2] != bf[nxt][i >> 1][i & 1][2] || again_[3] != bf[nxt][i >> 1][i & 1][3];
+                }
+                _Pragma("unroll") for (int i = 0; i < 2 * GC; ++i) {
+                    const u32x4 again_ = S_[a_off + i * 128];
+                    bad_ = bad_ || again_[0] != af[nxt][i >> 1][i & 1][0] || again_[3] != af[nxt][i >> 1][i & 1][3];
+                }
+                if (bad_) { atomicAdd(&g_wg_dbg[0], 1u); g_wg_dbg[1] = (unsigned)T; g_wg_dbg[2] = (unsigned)wid; g_wg_dbg[3] = (unsigned)nsteps; }
+            }
+"""
+    src = src.replace(a, chk)
+    src = src.replace("struct WgParams {", "__device__ unsigned g_wg_dbg[8];\nstruct WgParams {", 1)
+    src += """
+extern "C" __attribute__((visibility("default"))) int nemar_wg_dbg(unsigned* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_dbg), 32);
+}
+"""
+    return src
+
+
 VARIANTS = {
     # the victim (grid_sample's grid-gradient kernel, warp.hip): what about ITS stores matters?
     "fence": ("warp.hip", _victim("if (accum_ggrid) { q[0] += ggx; q[oplane] += ggy; } else { q[0] = ggx; q[oplane] = ggy; "
@@ -71,6 +112,9 @@ VARIANTS = {
     # ... and what about the kernel: the DPP wave maximum (row_bcast) replaced by shuffles; one workgroup per CU instead of two
     "k7shfl": ("conv_k7.hip", _k7shfl),
     "k7lb1": ("conv_k7.hip", _k7lb1),
+    "wgdeep": ("conv_split16_wgrad.hip", _wgdeep),
+    "wgdrain": ("conv_split16_wgrad.hip", _wgdrain),
+    "wgcheck": ("conv_split16_wgrad.hip", _wgcheck),
 }
 
 

@@ -54,6 +54,22 @@ __global__ __launch_bounds__(256) void victim1(const float* __restrict__ in, flo
         if (FORM == 12) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(acc) : "v"(acc), "v"(m));
         if (FORM == 13) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(acc) : "v"(m), "v"(acc));
         if (FORM == 14) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(acc) : "v"(acc), "v"(m));
+        //   the other VOP3P forms the library's kernels contain (nemar_amd/csrc/isa_scan.py census): the fp32 -> 2 x fp16 split
+        //   15 v_fma_mixlo_f16 d, a, b, -c op_sel_hi:[0,0,1]   16 v_fma_mixhi_f16 (same operands)   17 v_pk_mov_b32 op_sel:[1,0]   18 v_cvt_pk_f16_f32
+        if (FORM == 15 || FORM == 16) {
+            unsigned h = __builtin_bit_cast(unsigned, acc.y);
+            if (FORM == 15) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(h) : "v"(acc.x), "v"(m.x), "v"(h));
+            else asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(h) : "v"(acc.x), "v"(m.x), "v"(h));
+            acc.y = __builtin_bit_cast(float, h ^ 0x00010001u);
+            acc.x = acc.x * m.y;
+        }
+        if (FORM == 17) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(acc) : "v"(acc), "v"(m));
+        if (FORM == 18) {
+            unsigned h;
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(acc.x), "v"(m.y));
+            acc.y = __builtin_bit_cast(float, h);
+            acc.x = acc.x * m.x;
+        }
     }
     out[i] = acc.x;
     out[n + i] = acc.y;
@@ -174,7 +190,7 @@ static float urand(unsigned& s) { return (float)(lcg(s) >> 8) * (1.f / 16777216.
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 50;
-    const int n = 65536, NP = 19, NV = 15, REP = 6, NT = 11;
+    const int n = 65536, NP = 19, NV = 19, REP = 6, NT = 11;
     unsigned seed = 777u;
     std::vector<float> hin((size_t)NP * n);
     for (auto& v : hin) v = urand(seed);
@@ -185,7 +201,7 @@ int main(int argc, char** argv) {
         for (int r = 0; r < REP; ++r) CK(hipMalloc(&out[v][r], 2 * n * 4));
     hipStream_t s1, s2;
     CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    const char* vname[NV] = {"pk-seq", "pk-seq+nop", "scalar-seq", "pk_mul", "pk_add", "pk_fma", "fma_mix", "pk_add_f16", "pk_mul opsel", "v_mul pair", "pk_add hi<-lo", "pk_add src1 swapped", "pk_add neg", "pk_mul src1 swapped", "pk_add src0 swapped"};
+    const char* vname[NV] = {"pk-seq", "pk-seq+nop", "scalar-seq", "pk_mul", "pk_add", "pk_fma", "fma_mix", "pk_add_f16", "pk_mul opsel", "v_mul pair", "pk_add hi<-lo", "pk_add src1 swapped", "pk_add neg", "pk_mul src1 swapped", "pk_add src0 swapped", "fma_mixlo_f16", "fma_mixhi_f16", "pk_mov op_sel", "cvt_pk_f16"};
     const char* tname[NT] = {"none", "mfma", "pk_mul", "mfma+pk_mul", "v_mul", "lds+barrier", "mfma+v_mul", "mfma+pk_mul(indep regs)", "mfma | pk_mul waves",
                              "mfma+pk_add", "mfma_f32+pk_mul"};
     auto launch_v = [&](int v, float* o) {
@@ -205,7 +221,11 @@ int main(int argc, char** argv) {
             case 11: hipLaunchKernelGGL(victim1<11>, g, b, 0, s1, in, o, n); break;
             case 12: hipLaunchKernelGGL(victim1<12>, g, b, 0, s1, in, o, n); break;
             case 13: hipLaunchKernelGGL(victim1<13>, g, b, 0, s1, in, o, n); break;
-            default: hipLaunchKernelGGL(victim1<14>, g, b, 0, s1, in, o, n); break;
+            case 14: hipLaunchKernelGGL(victim1<14>, g, b, 0, s1, in, o, n); break;
+            case 15: hipLaunchKernelGGL(victim1<15>, g, b, 0, s1, in, o, n); break;
+            case 16: hipLaunchKernelGGL(victim1<16>, g, b, 0, s1, in, o, n); break;
+            case 17: hipLaunchKernelGGL(victim1<17>, g, b, 0, s1, in, o, n); break;
+            default: hipLaunchKernelGGL(victim1<18>, g, b, 0, s1, in, o, n); break;
         }
     };
     auto launch_t = [&](int t) {
