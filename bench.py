@@ -16,7 +16,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                       launch duration, measured with HIP events on the launch stream inside the library (nemar_kernel_timer) in
                       two extra steps right after the timed region; peak = 2500 TF dense fp16 MFMA / 3 products;
                       traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same batch-16 launch from separate rocprofv3 --pmc passes
-                      (profiles/r4_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
+                      (profiles/r5_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
                       peak assumes (profiles/r3_clock_trace.txt); a pure MFMA loop on random operands sustains 1730 TFLOP/s,
                       on all-zero operands 2530 (profiles/r4_mfma_peak_modes.txt): `frac_of_sustained_mfma` is priced on the former
   roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
@@ -43,7 +43,7 @@ F16_MFMA_SUSTAINED_TF = 1730.0   # measured on the MI355X of this pool: back-to-
                                  # RANDOM operands, 2 waves / SIMD: the clock settles at ~1.75 GHz.  The same loop on all-zero / all-one
                                  # operands holds 2.37-2.43 GHz = 2450-2530 TFLOP/s — the guide's peak is a trivial-operand figure, the
                                  # power limit depends on the data (tools/probes/mfma_peak_modes.hip, profiles/r4_mfma_peak_modes.txt)
-PMC_FILE = "profiles/r4_pmc_traffic.json"
+PMC_FILE = "profiles/r5_pmc_traffic.json"
 
 
 def build_opt(batch, size, extra=()):

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-5 evidence run (on the GPU box, via gpurun): the default bench line (with its extras), rocprofv3 kernel stats of the same command
+# on two streams and on one, the traffic / SQ PMC passes of the dominant kernel (separate passes, no trace domains next to --pmc), the
+# per-layer convolution table, the grid_sample micro-benchmark.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$1
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 6 --warmup 2 --graph off --no-cpu-baseline --no-extras > $O/bench_line_two_streams.json 2>/dev/null
+python $R/tools/prof_summary.py $O/stats $O/kernel_stats.csv > /dev/null 2>&1
+rm -rf $O/stats
+NEMAR_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/stats1 -- python $R/bench.py --steps 6 --warmup 2 --graph off --no-cpu-baseline --no-extras > $O/bench_line_single_stream.json 2>/dev/null
+python $R/tools/prof_summary.py $O/stats1 $O/kernel_stats_single_stream.csv > /dev/null 2>&1
+rm -rf $O/stats1
+G1="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
+pmc() {  # tag shape which
+  for c in "$G1" FETCH_SIZE WRITE_SIZE; do
+    t=${c%% *}
+    NEMAR_PMC_SHAPE=$2 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$1_$3_$t -- python $R/tools/pmc_conv.py $3 4 > /dev/null 2>&1
+    echo "=== $1 $3 ($2) $t"; python $R/tools/pmc_summary.py $O/pmc_$1_$3_$t
+  done
+}
+{
+pmc resblock16 16,256,256,64,3,1,1,1 fwd
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_warp_$c -- python $R/tools/microbench.py --iters 3 > /dev/null 2>&1
+  echo "=== warp $c"; python $R/tools/pmc_summary.py $O/pmc_warp_$c grid_sample; python $R/tools/pmc_summary.py $O/pmc_warp_$c far_
+  echo "=== instnorm $c"; python $R/tools/pmc_summary.py $O/pmc_warp_$c instnorm
+done
+} > $O/pmc_summary.txt 2>&1
+python $R/tools/microbench.py > $O/microbench.jsonl 2>/dev/null
+cd $R
+timeout 600 python tools/trace_convs.py > $O/conv_trace.jsonl 2> $O/trace.err
+timeout 900 python tools/microbench_trace.py $O/conv_trace.jsonl > $O/conv_layers.txt 2> $O/layers.err
+python - <<PY
+import csv, json
+for tag in ('kernel_stats', 'kernel_stats_single_stream'):
+    rows = list(csv.DictReader(open('$O/%s.csv' % tag)))
+    tot = sum(float(r['total_us']) for r in rows); calls = sum(int(r['calls']) for r in rows)
+    print('%s: kernels %.1f ms over 11 steps (8 + the 3 steps of the roofline / memory pass) = %.2f ms/step, %d launches = %d per step' % (tag, tot / 1e3, tot / 1.1e4, calls, calls // 11))
+    for r in rows[:12]:
+        print('   %6.2f%% x%-5s avg %8.1f us  %s' % (float(r['pct']), r['calls'], float(r['avg_us']), r['name'][:100]))
+PY
+cat $O/bench.json
+rm -rf $O/pmc_resblock16_* $O/pmc_warp_*
