@@ -26,6 +26,10 @@ typedef int (*wgrad_fn)(const float*, int, const float*, int, const float*, floa
 typedef int (*fwd_fn)(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int,
                       float, void*, size_t, int, void*, const Extras*);
 typedef int (*amax_fn)(const float*, int, long long, void*, void*);
+typedef size_t (*dws_fn)(int, int, int, int, int, int, int, int, int, int);
+typedef size_t (*gpb_fn)(int, int, int, int, int, int, int, int, int, int);
+typedef int (*dgrad_fn)(const float*, const float*, const float*, int, float, float*, int, float*, int, int, int, int, int, int, int, int, int, int, int,
+                        int, void*, size_t, int, void*, const Extras*);
 typedef int (*route_fn)(void);
 
 static unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
@@ -44,7 +48,10 @@ int main(int argc, char** argv) {
     fwd_fn fwd = (fwd_fn)dlsym(h, "nemar_conv2d_fwd_ex");
     amax_fn amax = (amax_fn)dlsym(h, "nemar_absmax_samples");
     route_fn route = (route_fn)dlsym(h, "nemar_last_route");
-    if (!wws || !fws || !scr || !wgrad || !fwd || !amax || !route) { printf("missing symbol\n"); return 2; }
+    dws_fn dws = (dws_fn)dlsym(h, "nemar_conv2d_bwd_data_workspace");
+    gpb_fn gpb = (gpb_fn)dlsym(h, "nemar_conv2d_gy_planes_bytes");
+    dgrad_fn dgrad = (dgrad_fn)dlsym(h, "nemar_conv2d_bwd_data_ex");
+    if (!wws || !fws || !scr || !wgrad || !fwd || !amax || !route || !dws || !gpb || !dgrad) { printf("missing symbol\n"); return 2; }
     const int W = H, C = 256, K = 256;
     const size_t px = (size_t)H * W, nx = (size_t)N * C * px, nw = (size_t)K * C * 9;
     unsigned seed = 4242u;
@@ -75,7 +82,22 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&ws, wsb + 256)); CK(hipMalloc(&wst, fsb + 256));
     std::vector<float*> gw(nvict);
     for (auto& p : gw) CK(hipMalloc(&p, nw * 4));
-    Extras ev = {arena, sb, wx, N, wg, N, nullptr, nullptr, 0, nullptr};
+    // triggers 3 / 4: the step's own partner — the data-gradient call of the same layer shape on the other stream (its gy split writes the planes
+    // it hands to the weight gradient: 3; plain split: 4); victims then take their gy planes from such a call (hand-over), as in the step
+    const size_t dwb = dws(N, C, H, W, K, 3, 3, 1, 1, 1), gbytes = gpb(N, C, H, W, K, 3, 3, 1, 1, 1);
+    void *dwsb, *gplanes, *gplanes_t, *arena_d;
+    float* gx;
+    CK(hipMalloc(&dwsb, dwb + 256)); CK(hipMalloc(&gplanes, gbytes + 256)); CK(hipMalloc(&gplanes_t, gbytes + 256)); CK(hipMalloc(&arena_d, sb + 256));
+    CK(hipMalloc(&gx, nx * 4));
+    Extras ed = {arena_d, sb, wg, N, nullptr, 0, nullptr, gplanes, gbytes, nullptr};
+    const bool handover = trigger >= 3 && gbytes > 0;
+    if (handover) {
+        if (dgrad(g, w, nullptr, 0, 0.f, gx, C, nullptr, 0, N, H, W, K, H, W, 3, 3, 1, 1, 1, dwsb, dwb, 0, s_side, &ed)) { printf("bwd_data failed\n"); return 2; }
+        CK(hipDeviceSynchronize());
+        printf("data-gradient route %d, gy planes %zu bytes handed to the victims\n", route(), gbytes);
+    }
+    Extras edt = {arena_d, sb, wg, N, nullptr, 0, nullptr, trigger == 3 ? gplanes_t : nullptr, trigger == 3 ? gbytes : 0, nullptr};
+    Extras ev = {arena, sb, wx, N, wg, N, nullptr, nullptr, 0, handover ? gplanes : nullptr};
     Extras et = {arena_t, sbt, wxt, Nt, nullptr, 0, nullptr, nullptr, 0, nullptr};
     auto victim = [&](float* out) {
         CK(hipMemsetAsync(out, 0, nw * 4, s_side));
@@ -95,6 +117,8 @@ int main(int argc, char** argv) {
             for (int r = 0; r < 3; ++r) fwd(xt, C, nullptr, 0, w, nullptr, yt, Nt, H, W, K, 3, 3, 1, 1, 1, 0, 0.f, wst, fsb, 1, s_main, &et);
         if (trigger == 2)
             for (int r = 0; r < 12; ++r) CK(hipMemcpyAsync(yt, xt, (size_t)Nt * C * px * 4, hipMemcpyDeviceToDevice, s_main));
+        if (trigger >= 3)
+            for (int r = 0; r < 2 * nvict; ++r) dgrad(g, w, nullptr, 0, 0.f, gx, C, nullptr, 0, N, H, W, K, H, W, 3, 3, 1, 1, 1, dwsb, dwb, 1, s_main, &edt);
         for (int v = 0; v < nvict; ++v) victim(gw[v]);
         CK(hipDeviceSynchronize());
         for (int v = 0; v < nvict; ++v) {
