@@ -238,8 +238,46 @@ def grid_sample_hbm_stress(dev):
     return out
 
 
+def exact_route_ab(dev, batch, size, extra):
+    """(measurement library) the training step with every 16-bit-pipe kernel off — all convolutions on the exact-fp32 MFMA / VALU kernels —
+    beside the default routes: same model and batch, 5 eager steps each."""
+    from nemar_amd import ops
+    model, data = _make(batch, size, extra, dev)
+    for _ in range(3):
+        model.set_input(data)
+        model.optimize_parameters()
+    ms_default = _time_steps(model, data, 5)
+    for k in (20, 24):
+        ops.tune(k, 0)
+    for _ in range(2):
+        model.set_input(data)
+        model.optimize_parameters()
+    ms_exact = _time_steps(model, data, 5)
+    return {"ms_per_step_eager": ms_exact, "images_per_sec": batch / ms_exact * 1e3, "default_route_ms_per_step_eager": ms_default,
+            "speedup_from_fp16x3_routes": ms_exact / ms_default,
+            "how": "child process on libnemar_hip_ab.so (the product library has no switch): same model and batch, nemar_tune 20=0 and 24=0 "
+                   "(no fp16 x 3 kernel anywhere), 5 eager steps each"}
+
+
+def ab_child(kind, a):
+    """The side measurements that need a route switch run in a child process bound to the measurement build of the library
+    (NEMAR_AB_LIBRARY=1, nemar_amd/_lib.py): this process — the timed one — is on the product library, which has none."""
+    import subprocess
+    env = dict(os.environ, NEMAR_AB_LIBRARY="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--ab-child", kind, "--batch", str(a.batch), "--size", str(a.size)]
+    for o in a.opt:
+        cmd.append("--opt=" + o)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("child %s failed (%d): %s" % (kind, r.returncode, (r.stderr or r.stdout)[-400:]))
+    return json.loads(lines[-1])
+
+
 def route_agreement(dev):
-    """How far the fp16 x 3 routes move the step's GRADIENTS: one full-width config-2-shaped step (batch 1, no dropout, same seeded weights
+    """(measurement library) How far the fp16 x 3 routes move the step's GRADIENTS: one full-width config-2-shaped step (batch 1, no dropout, same seeded weights
     and inputs) on the default routes and with every 16-bit-pipe kernel off (nemar_tune 20=0, 24=0: exact-fp32 MFMA / VALU), compared
     per network as 1 - cos of the whole flat gradient and as relative L2 distance."""
     import gc
@@ -283,7 +321,16 @@ def main():
                          'either way (event records cannot sit inside a graph)')
     ap.add_argument('--opt', action='append', default=[], metavar='FLAG',
                     help='extra reference-style option for other BASELINE configs, e.g. --opt=--multi_resolution --opt=2')
+    ap.add_argument('--ab-child', choices=('exact_route', 'route_agreement'), default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.ab_child:
+        # side measurement on the measurement library (ab_child): one JSON line, nothing else
+        torch.cuda.set_device(0)
+        from nemar_amd import _lib
+        assert _lib.load().has_switches, _lib.load().path
+        dev0 = torch.device('cuda', 0)
+        print(json.dumps(exact_route_ab(dev0, a.batch, a.size, a.opt) if a.ab_child == 'exact_route' else route_agreement(dev0)))
+        return
 
     from nemar_amd import launch
     if a.gpus > 1 and not launch.under_launcher():
@@ -447,23 +494,6 @@ def main():
     extras = {}
     if world == 1 and not multi and not a.no_extras:
         # side measurements of the default single-GPU run — after the timed region, never inside it
-        try:
-            ms_default = _time_steps(model, data, 5)
-            for k in (20, 24):
-                ops.tune(k, 0)                     # every 16-bit-pipe kernel off: all convolutions on the exact-fp32 MFMA / VALU kernels
-            try:
-                for _ in range(2):
-                    step()
-                ms_exact = _time_steps(model, data, 5)
-            finally:
-                for k in (20, 24):
-                    ops.tune(k, 1)
-            extras["exact_route"] = {"ms_per_step_eager": ms_exact, "images_per_sec": a.batch / ms_exact * 1e3,
-                                     "default_route_ms_per_step_eager": ms_default,
-                                     "speedup_from_fp16x3_routes": ms_exact / ms_default,
-                                     "how": "same model and batch, nemar_tune 20=0 and 24=0 (no fp16 x 3 kernel anywhere), 5 eager steps each"}
-        except Exception as e:  # noqa: BLE001
-            extras["exact_route"] = {"error": '%s: %s' % (type(e).__name__, e)}
         import gc
         ops.pin_workspaces(False)
         ops.step_params(False)
@@ -471,11 +501,12 @@ def main():
         model = None
         gc.collect()
         torch.cuda.empty_cache()
-        if a.size == 256 and not a.opt:
+        for kind in ("exact_route",) + (("route_agreement",) if a.size == 256 and not a.opt else ()):
             try:
-                extras["route_agreement"] = route_agreement(dev)
+                extras[kind] = ab_child(kind, a)
             except Exception as e:  # noqa: BLE001
-                extras["route_agreement"] = {"error": '%s: %s' % (type(e).__name__, e)}
+                extras[kind] = {"error": '%s: %s' % (type(e).__name__, e)}
+        if a.size == 256 and not a.opt:
             extras["other_configs"] = other_configs(dev)
             try:
                 extras["roofline_grid_sample_1024"] = grid_sample_hbm_stress(dev)

@@ -10,7 +10,8 @@
  *   - every launch goes on `stream` (a hipStream_t passed as void*; NULL = the null stream), so the caller's
  *     stream ordering (torch's current stream under autograd) holds.  Re-entrant per stream: every input of an operator —
  *     including the side inputs of the wide-layer route (scratch arena, max words, planes: nemar_conv_extras) — travels with
- *     the call.  The only process-global state are the nemar_tune* measurement switches and the recorded weight-pack plans.
+ *     the call.  The only process-global state are the recorded weight-pack plans
+ *     (the measurement switches of earlier versions live in a separate build of the library: nemar_hip_ab.h).
  *   - return value: 0 on success, negative on error (NEMAR_EINVAL bad shape/pointer/unsupported,
  *     NEMAR_ELAUNCH HIP launch error, NEMAR_EWORKSPACE workspace too small); nemar_last_error() returns the
  *     message of the calling thread's last failure.  Python glue raises on non-zero.
@@ -31,7 +32,7 @@ extern "C" {
 #define NEMAR_EWORKSPACE (-3)
 
 /* library */
-int nemar_version(void);              /* major*10000 + minor*100 + patch; 400 = this header (0.3.x had nemar_set_scratch / *_hint) */
+int nemar_version(void);              /* major*10000 + minor*100 + patch; 500 = this header (0.4.x exported nemar_tune*) */
 const char* nemar_last_error(void);   /* thread-local message of the last failing call */
 
 /* ---- K9/K10/K11: sampling-grid generation fused into bilinear grid_sample ------------------------------
@@ -62,9 +63,6 @@ size_t nemar_grid_sample_bwd_zeroed_bytes(int N, int C, int H, int W);
 int nemar_grid_sample_bwd(const float* in, const float* grid_src, int grid_mode, const float* gout,
                           float* gin, int accum_gin, float* ggrid, int accum_ggrid,
                           int N, int C, int H, int W, int Ho, int Wo, void* workspace, size_t ws_bytes, void* stream);
-/* grad_input variant for A/B measurements: 0 (default) = gather + fixed point (needs the workspace), 1 = fp32 atomics through an
- * LDS tile per 16x64 output tile, 2 = global fp32 atomics (warp.hip has the numbers). */
-int nemar_grid_sample_tune(int variant);
 
 /* ---- K12: deformation smoothness / bilateral regulariser -------------------------------------------------
  * smoothness_loss(deformation, img, alpha)   reference models/stn/stn_losses.py:4-30,
@@ -118,8 +116,7 @@ int nemar_conv2d_bwd_data(const float* gy, const float* w, const float* bias, in
  * The pixel reduction is split across workgroups; every split stores its partial result to its own slab of `workspace`
  * and a second launch adds the slabs in split order.  Split data gradients (few-tile deep layers) do the same, so the
  * whole backward pass of the conv family is BITWISE REPRODUCIBLE run to run, like the forward pass (and like the
- * reference's CPU path).  nemar_tune(14, 0) restores the round-1 fp32-atomic accumulation for A/B timing
- * (then workspace may be NULL). */
+ * reference's CPU path). */
 size_t nemar_conv2d_bwd_weight_workspace(int N, int C, int H, int W, int K, int OH, int OW, int R, int S, int stride,
                                          int pad);
 int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb,
@@ -182,41 +179,13 @@ int nemar_pack_plan_dirty(int plan);
 int nemar_pack_plan_commit(int plan, void* device_buffer, size_t bytes, void* stream);
 int nemar_pack_plan_run(int plan, void* stream);
 int nemar_pack_plan_reset(int plan);
-/* Tuning switches for A/B measurements (tools/, tests/): not part of the operator contract, defaults = measured best.
- *   0  conv tile family for 128x128-capable shapes: 0 wave-specialised (default), 5 same without 16-byte B loads,
- *      6 one barrier per 32 reduction rows, 7 four loader waves, 4 first-generation wave-specialised, 1/2/3 generic
- *   1  extra dynamic LDS per workgroup (occupancy experiments)      2  ablation / experiment bit mask
- *   3  narrow (<= 4 channel) VALU kernels on/off                     4  weight gradient: 0 default, 1 first generation,
- *                                                                       2 wave-specialised without 16-byte source loads
- *   5  weight-gradient workgroup target (default 512)                6  grid-size threshold of the tile choice (384)
- *   7  force the wave-specialised channel tile (1, 2, 4 x 32)        8  3x3 reflect data gradient: border folded into the
- *                                                                       main launch (1, default) / separate ring launch (0)
- *   10 4-deep LDS ring for every 64x64 launch
- *   11 four loader waves for gathered B tiles (on)                   12 reduction splits in data gradients (on)
- *   14 fixed-order split reductions (1, default) / fp32 atomics in the weight + bias gradients (0)
- *   15 XCD-aware workgroup -> tile mapping of the wave-specialised kernels (1, default)
- *   16..19 loader / tile / ring-depth / narrow-kernel variants
- *   20 3x3 stride-1 layers with >= 128 output channels on the bf16 matrix pipe with three-way split operands (1, default;
- *      needs the scratch arena below; 0 = exact-fp32 MFMA kernels).  Packed weight images are per setting.
- *   21 operand split of those kernels: 4 fp16 x 3 (default), 3 bf16 x 6
- *   23 smallest layer (million multiply-adds, default 2000) that takes the split-16 route
- *   24 every other convolution with >= 5 output channels on the 16-bit matrix pipe with the operand split INSIDE the kernel
- *      (csrc/conv_s16g*.hip; 1, default; 0 = exact-fp32 MFMA kernels)      25 its work threshold (million multiply-adds, 30)
- *   26 the wide layers' weight gradient on the in-kernel-split kernel instead of wgrad_split16 (0, default: measured slower)
- *   27 widest channel tile of s16g_kernel (1, 2 = default, 4 x 32)                28 prefer pixel tiles that leave LDS for two workgroups
- *   29 weight gradients of the key-24 layers on s16g_wgrad_kernel (1)     30 stride-1 reflect 3x3 data gradients of those layers on
- *                                                                            the padded domain + reflect_fold_kernel (1)
- *   31 ablation bits of instnorm_planes_kernel (measurement only)
- *   32 3-slot weight ring of the wide-layer kernel for the unfolded 3x3 launches (0, default: no gain) */
-int nemar_tune(int key, int value);
 /* Which kernel family served the calling thread's last nemar_conv2d_* call: 0 exact-fp32 implicit GEMM, 1 narrow (<= 4 channel)
  * VALU kernels, 2 split-16 kernels of the wide residual-block layers, 3 general 16-bit-pipe kernels (tests / tools). */
 int nemar_last_route(void);
-/* Counter bumped by every nemar_tune call.  The route a shape takes — and with it the FORMAT of the packed
- * weight image a `prepacked` call finds in its workspace — is a function of (shape, these settings): a caller that caches packed
- * workspaces keys them with this value. */
+/* The route a shape takes — and with it the FORMAT of the packed weight image a `prepacked` call finds in its workspace — is a
+ * function of the shape and of the library's measurement switches.  This library has none: always 0.  In the measurement build
+ * (nemar_hip_ab.h) it is a counter bumped by every nemar_tune call, and a caller that caches packed workspaces keys them with it. */
 int nemar_config_epoch(void);
-int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/), NULL = off */
 /* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data / nemar_conv2d_bwd_weight.  The wide stride-1 / pad-1
  * layers (the 3x3 ResnetBlock convolutions, reference models/networks.py:418-439, and the discriminator's 256->512 4x4 layer,
  * :576-597; >= 128 channels, >= 2 G multiply-adds) run on the 16-bit matrix pipe at fp32 accuracy: each fp32 operand is split into

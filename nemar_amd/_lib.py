@@ -3,6 +3,10 @@
 There is NO fallback: if the gfx950 library is missing or fails to load, importing the operator layer
 raises.  `load(path)` with an explicit path exists only so the CPU test tier can bind the same signatures to
 the host-emulated build of the same kernel sources (tests/emu) — the product never passes a path.
+
+The product library has no measurement switch (nemar_tune*): those entry points (include/nemar_hip_ab.h) exist only in
+nemar_amd/lib/libnemar_hip_ab.so, the -DNEMAR_AB build of the same sources, which tools/ and the A/B tests select with
+NEMAR_AB_LIBRARY=1 (or NEMAR_TUNE=...) in the environment before the first load.
 """
 import ctypes as C
 import os
@@ -13,7 +17,9 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_PATH = os.path.join(_HERE, "lib", "libnemar_hip.so")
+PRODUCT_PATH = os.path.join(_HERE, "lib", "libnemar_hip.so")
+AB_PATH = os.path.join(_HERE, "lib", "libnemar_hip_ab.so")
+DEFAULT_PATH = AB_PATH if (os.environ.get("NEMAR_AB_LIBRARY") == "1" or os.environ.get("NEMAR_TUNE")) else PRODUCT_PATH
 
 _f = C.POINTER(C.c_float)
 _vp = C.c_void_p
@@ -52,12 +58,9 @@ SIGNATURES = {
     "nemar_kernel_timer_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "nemar_bias_grad_workspace": (_sz, [_i, _i, _i]),
     "nemar_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "nemar_tune": (_i, [_i, _i]),
     "nemar_last_route": (_i, []),
     "nemar_last_gy_planes": (_i, []),
     "nemar_config_epoch": (_i, []),
-    "nemar_grid_sample_tune": (_i, [_i]),
-    "nemar_tune_ptr": (_i, [_vp]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
@@ -94,6 +97,14 @@ SIGNATURES = {
 }
 
 
+# include/nemar_hip_ab.h: what the measurement build exports on top
+AB_SIGNATURES = {
+    "nemar_tune": (_i, [_i, _i]),
+    "nemar_grid_sample_tune": (_i, [_i]),
+    "nemar_tune_ptr": (_i, [_vp]),
+}
+
+
 class NemarHipError(RuntimeError):
     pass
 
@@ -124,6 +135,13 @@ class Library:
             fn.restype = res
             fn.argtypes = args
             self._fns[name] = fn
+        self.has_switches = all(hasattr(self._dll, name) for name in AB_SIGNATURES)
+        if self.has_switches:
+            for name, (res, args) in AB_SIGNATURES.items():
+                fn = getattr(self._dll, name)
+                fn.restype = res
+                fn.argtypes = args
+                self._fns[name] = fn
 
     def raw(self, name):
         return self._fns[name]
@@ -135,9 +153,12 @@ class Library:
         fns = self.__dict__.get("_fns", {})
         full = name if name.startswith("nemar_") else "nemar_" + name
         if full not in fns:
+            if full in AB_SIGNATURES:
+                raise NemarHipError("%s has no %s: the measurement switches exist only in the -DNEMAR_AB build "
+                                    "(libnemar_hip_ab.so; set NEMAR_AB_LIBRARY=1 before nemar_amd is imported)" % (self.__dict__.get("path"), full))
             raise AttributeError(name)
         fn = fns[full]
-        if SIGNATURES[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty"):
+        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

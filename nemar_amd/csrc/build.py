@@ -1,11 +1,18 @@
-"""Build the gfx950 C-ABI library (nemar_amd/lib/libnemar_hip.so) with hipcc.
+"""Build the gfx950 C-ABI library with hipcc — twice, from the same sources:
 
-In-tree build (the .so travels to the GPU box with the repo snapshot).  hipcc cross-compiles for
+  nemar_amd/lib/libnemar_hip.so      the product (include/nemar_hip.h): measurement switches are compile-time constants, the kernels
+                                     only a non-default switch reaches are not compiled, no nemar_tune* entry point exists;
+  nemar_amd/lib/libnemar_hip_ab.so   the measurement build (-DNEMAR_AB, include/nemar_hip_ab.h adds nemar_tune / nemar_tune_ptr /
+                                     nemar_grid_sample_tune) for tools/ and the A/B tests.  Sources that do not mention the macro
+                                     share their object file with the product.
+
+In-tree build (the .so files travel to the GPU box with the repo snapshot).  hipcc cross-compiles for
 gfx950 without a GPU.  Usage:  python -m nemar_amd.csrc.build [--force] [--jobs N]
 """
 import argparse
 import concurrent.futures as cf
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -15,6 +22,7 @@ PKG = os.path.dirname(HERE)
 LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(LIB_DIR, "libnemar_hip.so")
+LIB_PATH_AB = os.path.join(LIB_DIR, "libnemar_hip_ab.so")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
@@ -55,11 +63,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+_AB_WORDS = re.compile(r"\bNEMAR_(AB|SWITCH|AB_ONLY)\b")
+
+
+def ab_sensitive(src):
+    """Does -DNEMAR_AB change this translation unit?  (the source or a local header it includes — other than common.h, which only
+    DEFINES the macros — uses them)"""
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(os.path.join(HERE, f)):
+            continue
+        seen.add(f)
+        text = open(os.path.join(HERE, f)).read()
+        if f != "common.h" and _AB_WORDS.search(text):
+            return True
+        todo += re.findall(r'#include\s+"([^"]+)"', text)
+    return False
+
+
+def _compile(src, force, ab=False):
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", "_ab.o" if ab else ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
     if force or _stale(obj, deps):
         extra = ["-munsafe-fp-atomics"] if src in UNSAFE_FP_ATOMICS else []
+        if ab:
+            extra.append("-DNEMAR_AB")
         cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -74,16 +103,19 @@ def build(force=False, jobs=None, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = sources()
-    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    units = [(s, False) for s in srcs] + [(s, True) for s in srcs if ab_sensitive(s)]
+    jobs = jobs or min(len(units), os.cpu_count() or 4)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or _stale(LIB_PATH, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        objs = dict(zip(units, ex.map(lambda u: _compile(u[0], force, u[1]), units)))
+    for lib, ab in ((LIB_PATH, False), (LIB_PATH_AB, True)):
+        mine = [objs.get((s, ab), objs[(s, False)]) for s in srcs]
+        if force or _stale(lib, mine):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *mine, "-o", lib]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
-        print("built %s (%d sources)" % (LIB_PATH, len(srcs)))
+        print("built %s and %s (%d sources, %d of them also with -DNEMAR_AB)" % (LIB_PATH, LIB_PATH_AB, len(srcs), len(units) - len(srcs)))
     return LIB_PATH
 
 

@@ -15,6 +15,20 @@
 
 #define NEMAR_API extern "C" __attribute__((visibility("default")))
 
+// Measurement switches.  The library is built twice from the same sources (build.py):
+//   * libnemar_hip.so      (product): every switch is a compile-time constant at its default; kernels and launch branches that only
+//                          a non-default value reaches are not compiled; nemar_tune / nemar_tune_ptr / nemar_grid_sample_tune do
+//                          not exist (include/nemar_hip.h has no such entry point);
+//   * libnemar_hip_ab.so   (-DNEMAR_AB; include/nemar_hip_ab.h): the switches are variables behind nemar_tune, for tools/ and the
+//                          A/B tests that drive small shapes through a chosen route.
+#ifdef NEMAR_AB
+#define NEMAR_SWITCH(type, name, def) type name = def
+#define NEMAR_AB_ONLY(...) __VA_ARGS__
+#else
+#define NEMAR_SWITCH(type, name, def) __attribute__((unused)) constexpr type name = def
+#define NEMAR_AB_ONLY(...)
+#endif
+
 // include/nemar_hip.h's nemar_conv_extras (the per-call side inputs of nemar_conv2d_*_ex), field for field
 struct nemar_conv_extras {
     void* scratch;

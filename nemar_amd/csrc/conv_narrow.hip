@@ -382,7 +382,7 @@ bool nemar_narrow_eligible(int K, int C1, int R, int S, int stride, int N, int O
 
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st);
-int g_narrow_fwd4 = 1;      // nemar_tune(19): register-tiled narrow forward for wide images (1, default) / one pixel per lane (0)
+NEMAR_SWITCH(int, g_narrow_fwd4, 1);      // nemar_tune(19): register-tiled narrow forward for wide images (1, default) / one pixel per lane (0)
 
 // channel ranges of the forward split mode: few output tiles and many channels (no activation) — so the launch fills the chip
 static int narrow_fwd_csplit(int N, int C, int OH, int OW, int act) {

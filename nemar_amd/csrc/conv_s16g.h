@@ -54,7 +54,9 @@ void nemar_s16g_wgrad(const float* x0, int C0, const float* x1, int C1, const fl
                       int K, int OH, int OW, int KS, int stride, int pad_mode, float* part, int dbg, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
 
+#ifdef NEMAR_AB
 void nemar_s16g_tune(int key, int value);      // tile-plan switches for A/B runs (nemar_tune keys 27, 28)
+#endif
 
 // measurement hook shared with conv_split16.hip (bench.py's roofline entry)
 void nemar_s16g_timer(int on);

@@ -599,13 +599,15 @@ int nemar_s16g_timer_read(double* total_ms, double* total_flop) {
     return n;
 }
 
-static int g_s16g_maxmt = 2;      // widest channel tile (x 32): nemar_s16g_tune(0, v).  64 channels: the step is 1.3 % faster than with 128-channel
+static NEMAR_SWITCH(int, g_s16g_maxmt, 2);      // widest channel tile (x 32): nemar_s16g_tune(0, v).  64 channels: the step is 1.3 % faster than with 128-channel
                                    // tiles (36.4-36.7 vs 37.0-37.2 ms, A/B on one box) — their fragment sets leave no room for latency hiding
-static int g_s16g_lds_pref = 0;   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
+static NEMAR_SWITCH(int, g_s16g_lds_pref, 0);   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
+#ifdef NEMAR_AB
 void nemar_s16g_tune(int key, int value) {
     if (key == 0) g_s16g_maxmt = value == 1 || value == 4 ? value : 2;
     if (key == 1) g_s16g_lds_pref = value;
 }
+#endif
 
 S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     S16gPlan pl;
@@ -795,8 +797,10 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     else if (sx == 1) S16G_GO(MT_, 1, 1)                            \
     else S16G_GO(MT_, 1, 2)
     const int sx = q.sstride;
-    if (pl.MT == 4) { S16G_BY_TILE(4) }
-    else if (pl.MT == 2) { S16G_BY_TILE(2) }
+#ifdef NEMAR_AB
+    if (pl.MT == 4) { S16G_BY_TILE(4) } else       // (128-channel tiles: nemar_tune(27, 4) only — the plan caps MT at g_s16g_maxmt)
+#endif
+    if (pl.MT == 2) { S16G_BY_TILE(2) }
     else { S16G_BY_TILE(1) }
 #undef S16G_BY_TILE
 #undef S16G_GO

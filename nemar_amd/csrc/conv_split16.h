@@ -29,7 +29,9 @@ bool nemar_split16_wgrad_eligible(int N, int C, int H, int W, int K, int R, int 
 size_t nemar_split16_wgrad_scratch_bytes(int N, int C, int H, int W, int K, int KS);     // split gy (KS shifts) and padded x planes
 int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS);               // slabs of K C KS KS floats the caller provides
 // gw [K][C][KS][KS] += dW from x [N,C,H,W] and gy [N,K,H+3-KS,W+3-KS]; slabs summed in order (bitwise reproducible)
+#ifdef NEMAR_AB
 void nemar_split16_wgrad_tune(int one_copy);          // nemar_tune(34): 1 (default) one gy copy + in-register shifts, 0 KS copies
+#endif
 // g_planes != NULL: the G_0 planes of gy already exist (nemar_split16_dual_split wrote them, scaled by the max words hinted for gy)
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
                          void* scratch, float* part, int xcd_map, const void* g_planes, hipStream_t st);

@@ -816,7 +816,7 @@ void nemar_split16_pack(const float* w, void* packed, int K, int C, int KS, int 
                        (const unsigned*)nullptr, NT);
 }
 
-int g_split16_ring3 = 0;         // nemar_tune(32, 1): 3-slot weight ring (76.8 KB of LDS) for the unfolded 3x3 launches.  Measured: same time
+NEMAR_SWITCH(int, g_split16_ring3, 0);         // nemar_tune(32, 1): 3-slot weight ring (76.8 KB of LDS) for the unfolded 3x3 launches.  Measured: same time
                                  // (287.6 vs 292.3 us per call, bench 37.5 vs 37.2-37.5 ms) — the kernel needs 332 VGPRs (two fragment sets), so a
                                  // SIMD still holds ONE wave and the second workgroup never becomes resident; kept for the experiment only
 
@@ -901,21 +901,24 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), KS * KS - 3);
         // 3-slot weight ring where that lets two workgroups share a CU (<= 80 KiB each: 3x3 layers without the folded border rows)
-        const bool ring3 = g_split16_ring3 && KS == 3 && ((size_t)3 * 512 + (size_t)8 * (p.halo16 + p.aux16)) * 16 <= 80 * 1024 - 512;
+        NEMAR_AB_ONLY(const bool ring3 = g_split16_ring3 && KS == 3 && ((size_t)3 * 512 + (size_t)8 * (p.halo16 + p.aux16)) * 16 <= 80 * 1024 - 512;)
         S16_TIMED_LAUNCH(
             if (KS == 4) {
                 if (nbw <= 1) S16_GO(1, 2, 4, 4)
                 else S16_GO(2, 2, 4, 4)
-            } else if (ring3) {
+            }
+            NEMAR_AB_ONLY(else if (ring3) {
                 if (nbw <= 1) S16_GO(1, 2, 3, 3)
                 else if (nbw == 2) S16_GO(2, 2, 3, 3)
                 else S16_GO(3, 2, 3, 3)
-            } else if (nbw <= 1) S16_GO(1, 2, 3, 4)
+            })
+            else if (nbw <= 1) S16_GO(1, 2, 3, 4)
             else if (nbw == 2) S16_GO(2, 2, 3, 4)
             else S16_GO(3, 2, 3, 4))
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
         return dual_written;
     }
+#ifdef NEMAR_AB      // nemar_tune(21, 3): bf16 x 6 products
     if (variant == 3) {
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(6 * ipr, 4), KS * KS - 3);
@@ -927,6 +930,7 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
         return dual_written;
     }
+#endif
 #undef S16_GO
     (void)region;
     return dual_written;

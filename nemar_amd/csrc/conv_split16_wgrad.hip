@@ -441,8 +441,10 @@ int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS) {
 }
 
 // gw [K][C][KS][KS] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C KS KS floats.  x [N, C, H, W], gy [N, K, H + 3 - KS, W + 3 - KS]
-static int g_one_g = 1;        // nemar_tune(34): 1 = one copy of the gy planes, shifted operands built in registers; 0 = KS copies in HBM
+static NEMAR_SWITCH(int, g_one_g, 1);        // nemar_tune(34): 1 = one copy of the gy planes, shifted operands built in registers; 0 = KS copies in HBM
+#ifdef NEMAR_AB
 void nemar_split16_wgrad_tune(int v) { g_one_g = v ? 1 : 0; }
+#endif
 
 size_t nemar_split16_wgrad_g_bytes(int N, int H, int W, int K, int KS) {
     return g_one_g ? (size_t)2 * N * K * g_rows(H, KS) * ((W + 2 + 7) / 8) * 16 : 0;
@@ -479,12 +481,13 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     } else if (oneg)                                                                                                               \
         hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 1>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
                            gmax, gstride);                                                                                         \
+    NEMAR_AB_ONLY(                                                                                                                 \
     else if (KS == 3)                                                                                                              \
         hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 3>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
                            gmax, gstride);                                                                                         \
     else                                                                                                                           \
         hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 4>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
-                           gmax, gstride);                                                                                         \
+                           gmax, gstride);)                                                                                        \
     hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * Hx), dim3(256), 0, st, x, X, N, C, H, W, Hx, CPR, reflect, xtotal, \
                        xmax, xstride);
     if (W <= 64) { WG_SPLIT(64) } else if (W <= 128) { WG_SPLIT(128) } else { WG_SPLIT(256) }
@@ -501,8 +504,10 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
     if (KS == 3 && oneg) hipLaunchKernelGGL((wgrad_split16_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
-    else if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
     else if (oneg) hipLaunchKernelGGL((wgrad_split16_kernel<4, true>), dim3(grid), dim3(256), 0, st, p);
+#ifdef NEMAR_AB      // nemar_tune(34, 0): KS shifted copies of the gy planes in HBM
+    else if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_split16_kernel<4, false>), dim3(grid), dim3(256), 0, st, p);
+#endif
     nemar_sum_partials(part, (long long)K * C * KS * KS, splits, gw, (long long)K * C * KS * KS, true, st);
 }

@@ -2,8 +2,9 @@
 #include "common.h"
 #include <stdarg.h>
 
-#define NEMAR_HIP_VERSION 400  // major*10000 + minor*100 + patch  (0.4.0: round 4 — side inputs per call only (set_scratch / *_hint removed),
-                               // weight-pack plans, nemar_store_words, 7x7 layers on the 16-bit pipe (route 4))
+#define NEMAR_HIP_VERSION 500  // major*10000 + minor*100 + patch  (0.5.0: round 5 — no nemar_tune* in the product library: the measurement
+                               // switches are constants there and live in libnemar_hip_ab.so (-DNEMAR_AB, include/nemar_hip_ab.h);
+                               // 0.4.0: side inputs per call only, weight-pack plans, nemar_store_words, 7x7 layers on the 16-bit pipe)
 
 static thread_local char g_err[512] = "";
 

@@ -48,6 +48,29 @@ def _demangle(names):
     return list(names)
 
 
+def kernel_digests(lib_path):
+    """-> {mangled kernel symbol: sha1 of its instruction stream (mnemonics + operands, addresses and encodings stripped)}: two builds of
+    the same kernel source with the same flags give the same digest wherever the kernel sits in its code object."""
+    import hashlib
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for co in code_objects(lib_path, td):
+            dis = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", "--no-leading-addr", co], check=True,
+                                 capture_output=True, text=True).stdout
+            cur, h = None, None
+            for line in dis.splitlines():
+                m = re.match(r"^(?:[0-9a-f]+ )?<(\S+)>:", line)
+                if m:
+                    if cur:
+                        out[cur] = h.hexdigest()
+                    cur, h = m.group(1), hashlib.sha1()
+                elif cur and line.strip() and line.strip() != "...":      # ("...": alignment padding behind a kernel)
+                    h.update(line.split("//")[0].strip().encode() + b"\n")
+            if cur:
+                out[cur] = h.hexdigest()
+    return out
+
+
 def scan(lib_path):
     """-> {"kernels": [{name, scratch, spills, vgpr, agpr, lds}], "packed_f32": {mangled kernel symbol: count}}"""
     kernels, packed = [], {}

@@ -249,12 +249,14 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
     }
 }
 
-int g_norm_planes_dbg = 0;
+NEMAR_SWITCH(int, g_norm_planes_dbg, 0);
 }  // namespace
 
 extern const unsigned* g_dropout_base;          // pointwise.hip
 
+#ifdef NEMAR_AB
 void nemar_norm_planes_debug(int bits) { g_norm_planes_dbg = bits; }
+#endif
 
 // y (optional) = [residual +] dropout(act(InstanceNorm(x))), stats, AND the fp16 x 3 planes of y for a 3x3 / pad-1 reflect convolution
 // (conv_split16.hip layout, 2 * N * (C/8) * (H+4) * (W+4) 16-byte words), scaled by the a-priori bound written to scale_words[n].

@@ -763,10 +763,21 @@ __global__ __launch_bounds__(64) void affine_ggrid_fold_kernel(const float* __re
     ggrid[n * 6 + i] = accum ? ggrid[n * 6 + i] + t : t;
 }
 
+// nemar_grid_sample_tune (A/B build, common.h): 0 (default) = destination-tiled gather + fixed-point far path (needs the workspace; bitwise
+// reproducible), 1 = LDS-tile fp32-atomic variant, 2 = global fp32 atomics (the round-1 default), bits 1..2 of values >= 4:
+// ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
+// near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
+NEMAR_SWITCH(int, g_tiled_scatter, 0);
+NEMAR_SWITCH(int, g_gather_512, 1);       // 512-thread workgroups in the gather pass (default: 170 vs 249 us at 8x3x1024^2); nemar_grid_sample_tune(16): 256
+NEMAR_SWITCH(int, g_gather_follow, 1);    // gather windows follow the field (tile_offset_kernel); nemar_grid_sample_tune(32): centred on the tiles (round 2)
+NEMAR_SWITCH(int, g_fwd_vec1, 1);         // forward: one pixel per lane (default: every gather / store instruction of a wave covers whole cache lines;
+                            // 8x3x1024^2 identity 92 -> 71 us, smooth 3-px field 104 -> 74 us, profiles/r4_gs_fwd_vec.txt); nemar_grid_sample_tune(64):
+                            // the round-1 form, 4 pixels per lane with 16-byte stores
+NEMAR_SWITCH(int, g_gather_fused, 1);     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
+
 template <int MODE>
 int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int H, int W, int Ho, int Wo,
                hipStream_t st) {
-    extern int g_fwd_vec1;
     const bool vec4 = (Wo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (((uintptr_t)gsrc & 15) == 0) &&
                       (MODE != GRID_EXPLICIT) && !g_fwd_vec1;
     const long long items = (long long)Ho * (vec4 ? Wo / 4 : Wo);
@@ -774,24 +785,12 @@ int launch_fwd(const float* in, const float* gsrc, float* out, int N, int C, int
     const int cap = nemar_cdiv(256 * 8, N);
     if (gx > cap) gx = cap;
     dim3 grid(gx, N), block(256);
-    if (vec4)
+    NEMAR_AB_ONLY(if (vec4)
         hipLaunchKernelGGL((grid_sample_fwd_kernel<MODE, 4>), grid, block, 0, st, in, gsrc, out, C, H, W, Ho, Wo);
-    else
+    else)
         hipLaunchKernelGGL((grid_sample_fwd_kernel<MODE, 1>), grid, block, 0, st, in, gsrc, out, C, H, W, Ho, Wo);
     return 0;
 }
-
-// nemar_grid_sample_tune: 0 (default) = destination-tiled gather + fixed-point far path (needs the workspace; bitwise
-// reproducible), 1 = LDS-tile fp32-atomic variant, 2 = global fp32 atomics (the round-1 default), bits 1..2 of values >= 4:
-// ablations of the LDS-tile variant.  Round-1 measurements of the atomic variants (8x3x256^2, global vs LDS tile): zero /
-// near-identity field 26 vs 43 us, smooth 3-pixel field 64 vs 45 us, white 1-pixel field 139 vs 44 us.
-int g_tiled_scatter = 0;
-int g_gather_512 = 1;       // 512-thread workgroups in the gather pass (default: 170 vs 249 us at 8x3x1024^2); nemar_grid_sample_tune(16): 256
-int g_gather_follow = 1;    // gather windows follow the field (tile_offset_kernel); nemar_grid_sample_tune(32): centred on the tiles (round 2)
-int g_fwd_vec1 = 1;         // forward: one pixel per lane (default: every gather / store instruction of a wave covers whole cache lines;
-                            // 8x3x1024^2 identity 92 -> 71 us, smooth 3-px field 104 -> 74 us, profiles/r4_gs_fwd_vec.txt); nemar_grid_sample_tune(64):
-                            // the round-1 form, 4 pixels per lane with 16-byte stores
-int g_gather_fused = 1;     // grid gradient fused into the gather pass (default; measured 5-10 % faster); nemar_grid_sample_tune(8): two passes
 
 struct GatherLayout { size_t acc_off, dirty_off, zero_bytes, misc_off, wgc_off, list_off, gpart_off, toff_off, total; int tiles_x, tiles_y; };
 GatherLayout gather_layout(int N, int C, int H, int W) {
@@ -846,16 +845,18 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
             // (else: any_shift stays 0 = windows centred on the tiles, the round-2 scheme, for A/B)
         }
         if (g_gather_fused) {
-            if (g_gather_512)
-                hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true, 512>), tg, dim3(512), 0, st, in, gsrc, gout, gin,
-                                   accum_gin, ggrid, accum_ggrid, C, H, W, ws);
-            else
+            NEMAR_AB_ONLY(if (!g_gather_512)
                 hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true, 256>), tg, dim3(256), 0, st, in, gsrc, gout, gin,
+                                   accum_gin, ggrid, accum_ggrid, C, H, W, ws);
+            else)
+                hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, true, 512>), tg, dim3(512), 0, st, in, gsrc, gout, gin,
                                    accum_gin, ggrid, accum_ggrid, C, H, W, ws);
             if (MODE == GRID_AFFINE)
                 hipLaunchKernelGGL(affine_ggrid_fold_kernel, dim3(N), dim3(64), 0, st, (const float*)ws.gpart, ggrid,
                                    L.tiles_x * L.tiles_y, accum_ggrid);
-        } else {
+        }
+#ifdef NEMAR_AB
+        else {
             // A/B variant: two streaming passes — d loss / d grid (grid_sample_bwd_kernel without grad_input), then the gather
             // pass over gsrc + gout only.  Measured 5-10 % SLOWER than the fused pass (profiles/r2_microbench.jsonl).
             hipLaunchKernelGGL((grid_sample_bwd_kernel<MODE, false>), grid, block, 0, st, in, gsrc, gout, nullptr, ggrid,
@@ -865,6 +866,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
             hipLaunchKernelGGL((grid_sample_bwd_gather_kernel<MODE, false, 256>), tg, dim3(256), 0, st, in, gsrc, gout, gin,
                                accum_gin, ggrid, accum_ggrid, C, H, W, ws);
         }
+#endif
         hipLaunchKernelGGL((far_scatter_kernel<MODE>), tg, dim3(256), 0, st, gsrc, gout, C, H, W, ws);
         hipLaunchKernelGGL(far_fold_kernel, tg, dim3(256), 0, st, gin, C, H, W, ws);
         return 0;
@@ -872,12 +874,14 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
     // legacy scatter kernels: grad_input through fp32 atomics into the zero-filled (or accumulated) buffer
     if (gin && !accum_gin) (void)hipMemsetAsync(gin, 0, sizeof(float) * (size_t)N * C * H * W, st);
     if (MODE == GRID_AFFINE && !accum_ggrid && !gpart) (void)hipMemsetAsync(ggrid, 0, sizeof(float) * (size_t)N * 6, st);
+#ifdef NEMAR_AB
     if (gin && H == Ho && W == Wo && (g_tiled_scatter & 1) && N <= 65535) {
         if (MODE == GRID_AFFINE && !accum_ggrid && gpart) (void)hipMemsetAsync(ggrid, 0, sizeof(float) * (size_t)N * 6, st);
         hipLaunchKernelGGL((grid_sample_bwd_tiled_kernel<MODE>), dim3(nemar_cdiv(W, TL_W), nemar_cdiv(H, TL_H), N),
                            dim3(TL_THREADS), 0, st, in, gsrc, gout, gin, ggrid, accum_ggrid, C, H, W, g_tiled_scatter >> 2);
         return 0;
     }
+#endif
     if (gin)
         hipLaunchKernelGGL((grid_sample_bwd_kernel<MODE, true>), grid, block, 0, st, in, gsrc, gout, gin, ggrid,
                            accum_ggrid, C, H, W, Ho, Wo, gpart);
@@ -891,6 +895,7 @@ int launch_bwd(const float* in, const float* gsrc, const float* gout, float* gin
 
 }  // namespace
 
+#ifdef NEMAR_AB
 NEMAR_API int nemar_grid_sample_tune(int variant) {
     g_fwd_vec1 = (variant & 64) ? 0 : 1;
     g_gather_fused = (variant & 8) ? 0 : 1;
@@ -899,6 +904,7 @@ NEMAR_API int nemar_grid_sample_tune(int variant) {
     g_tiled_scatter = variant & ~56;
     return NEMAR_OK;
 }
+#endif
 
 NEMAR_API int nemar_grid_sample_fwd(const float* in, const float* grid_src, int grid_mode, float* out, int N, int C,
                                     int H, int W, int Ho, int Wo, void* stream) {

@@ -33,7 +33,8 @@ def build(force=False):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs += [os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-             "-I", os.path.join(HERE, "include"), "-Wno-unused-function", "-Wno-unknown-attributes"]
+             "-I", os.path.join(HERE, "include"), "-Wno-unused-function", "-Wno-unknown-attributes",
+             "-DNEMAR_AB"]          # the measurement build: the emulated kernel tests drive routes through nemar_tune
 
     def one(src):
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")

@@ -1,6 +1,7 @@
 """The C-ABI library builds for gfx950 without a GPU, loads, and exports exactly the entry points that
 include/nemar_hip.h declares — and the ctypes table in nemar_amd/_lib.py covers each of them with the right arity.
-No compute calls (there is no GPU in the CPU tier)."""
+The measurement build (libnemar_hip_ab.so, -DNEMAR_AB) exports those plus exactly what include/nemar_hip_ab.h adds; the product
+exports no nemar_tune*.  No compute calls (there is no GPU in the CPU tier)."""
 import ctypes
 import os
 import re
@@ -11,8 +12,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_decls():
-    src = open(os.path.join(ROOT, "include", "nemar_hip.h")).read()
+def header_decls(name="nemar_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
     for m in re.finditer(r"\b(?:int|size_t|const char\s*\*)\s*(nemar_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
@@ -28,18 +29,53 @@ def libpath():
     return build.build(verbose=False)
 
 
+@pytest.fixture(scope="module")
+def ab_libpath(libpath):
+    from nemar_amd.csrc import build
+    assert os.path.exists(build.LIB_PATH_AB)
+    return build.LIB_PATH_AB
+
+
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("nemar_")}
+
+
 def test_header_declares_something():
     d = header_decls()
     assert len(d) >= 25 and "nemar_grid_sample_fwd" in d and "nemar_conv2d_bwd_weight" in d
 
 
 def test_library_exports_every_declared_symbol(libpath):
-    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
-    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     declared = set(header_decls())
-    assert declared <= exported, sorted(declared - exported)
-    extra = {s for s in exported if s.startswith("nemar_")} - declared
-    assert not extra, "exported but undeclared: %s" % sorted(extra)
+    have = exported(libpath)
+    assert declared <= have, sorted(declared - have)
+    assert not have - declared, "exported but undeclared: %s" % sorted(have - declared)
+
+
+def test_product_library_has_no_measurement_switch(libpath):
+    """`nm -D` of the product shows no nemar_tune*, and nothing else a caller could re-route kernels with."""
+    assert not [s for s in exported(libpath) if "tune" in s or "debug" in s]
+    assert not [s for s in header_decls() if "tune" in s]
+
+
+def test_measurement_library_exports_the_switches_on_top(libpath, ab_libpath):
+    extra = set(header_decls("nemar_hip_ab.h"))
+    assert extra == {"nemar_tune", "nemar_tune_ptr", "nemar_grid_sample_tune"}
+    assert exported(ab_libpath) == exported(libpath) | extra
+
+
+def test_product_library_refuses_switch_calls(libpath):
+    from nemar_amd import _lib
+    lib = _lib.Library(libpath)
+    assert not lib.has_switches and lib.nemar_config_epoch() == 0
+    with pytest.raises(_lib.NemarHipError, match="NEMAR_AB"):
+        lib.tune(20, 0)
+    ab = _lib.Library(os.path.join(os.path.dirname(libpath), "libnemar_hip_ab.so"))
+    assert ab.has_switches
+    e0 = ab.nemar_config_epoch()
+    ab.tune(15, 1)                       # (a default value: host-side state only, no GPU needed)
+    assert ab.nemar_config_epoch() == e0 + 1
 
 
 def test_ctypes_table_matches_header(libpath):
@@ -48,8 +84,12 @@ def test_ctypes_table_matches_header(libpath):
     assert set(_lib.SIGNATURES) == set(decls), set(_lib.SIGNATURES) ^ set(decls)
     for name, (_, argtypes) in _lib.SIGNATURES.items():
         assert len(argtypes) == decls[name], (name, len(argtypes), decls[name])
+    ab = header_decls("nemar_hip_ab.h")
+    assert set(_lib.AB_SIGNATURES) == set(ab)
+    for name, (_, argtypes) in _lib.AB_SIGNATURES.items():
+        assert len(argtypes) == ab[name], name
     lib = _lib.load()                       # dlopen + symbol binding works without a GPU
-    assert lib.nemar_version() >= 100
+    assert lib.nemar_version() >= 500
     assert lib.last_error() == ""
 
 
@@ -67,6 +107,17 @@ def test_gpu_object_targets_gfx950(libpath):
         assert other not in data
 
 
+def test_product_kernels_are_the_measurement_builds_kernels(libpath, ab_libpath):
+    """The test session runs on libnemar_hip_ab.so (tests/conftest.py).  Every kernel of the product library is in it with the same
+    instruction stream, instruction for instruction: what the kernel tests establish there holds for the product's device code.  (The
+    host-side routing of the product — the same code with the switches as constants — is what tests/test_product_lib_gpu.py covers.)"""
+    from nemar_amd.csrc import isa_scan
+    p, a = isa_scan.kernel_digests(libpath), isa_scan.kernel_digests(ab_libpath)
+    assert len(p) > 100 and len(a) > len(p)
+    assert not [k for k in p if k not in a]
+    assert not [k for k in p if p[k] != a[k]]
+
+
 @pytest.fixture(scope="module")
 def isa(libpath):
     from nemar_amd.csrc import isa_scan
@@ -82,12 +133,11 @@ def test_no_kernel_contains_packed_fp32_instructions(isa):
     assert not isa["packed_f32"], sorted(isa["packed_f32"].items(), key=lambda kv: -kv[1])[:10]
 
 
-# kernels that may still spill.  Instantiated for A/B switches or shapes no BASELINE configuration launches: nemar_tune(27)'s 128-channel
-# tiles.  On the default path and OPEN (DESIGN.md 4g lists them with where the spill code sits): the head's folded data gradient
-# (20 registers, reloaded in the per-tile halo phase, not in the MFMA loop), the stride-2 in-kernel-split weight gradients (7 / 17), the
-# discriminator's 4x4 wide-layer weight gradient (1).  Round 4 had twelve such kernels, among them InstanceNorm at 256^2 (32 registers).
-SCRATCH_ALLOWED = ("s16g_kernel<4, 2,", "k7_fm_kernel<3, true>", "s16g_wgrad_kernel<3, 2, 64>", "s16g_wgrad_kernel<3, 2, 32>",
-                   "wgrad_split16_kernel<4, true>")
+# kernels of the PRODUCT library that may still spill — all four on the default path and OPEN (DESIGN.md 4g lists them with where the spill
+# code sits): the head's folded data gradient (20 registers, reloaded in the per-tile halo phase, not in the MFMA loop), the stride-2
+# in-kernel-split weight gradients (17 / 7), the discriminator's 4x4 wide-layer weight gradient (1).  Round 4 had twelve such kernels,
+# among them InstanceNorm at 256^2 (32 registers); the 128-channel s16g tiles (144 registers) are in the measurement build only.
+SCRATCH_ALLOWED = ("k7_fm_kernel<3, true>", "s16g_wgrad_kernel<3, 2, 64>", "s16g_wgrad_kernel<3, 2, 32>", "wgrad_split16_kernel<4, true>")
 
 
 def test_default_path_kernels_use_no_scratch(isa):

@@ -1,6 +1,7 @@
 """Diagnostic: the D step of a step-parity configuration on the fp32 oracle's fakes, once per nemar_tune setting, with the
 route every convolution launch took — where does a D gradient differ from the oracle, and is the run reproducible?"""
 import os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch

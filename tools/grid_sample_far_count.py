@@ -1,4 +1,5 @@
 import ctypes, sys, os
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, '/root/repo')
 import torch
 from nemar_amd import _lib

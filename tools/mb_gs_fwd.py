@@ -1,5 +1,6 @@
 """grid_sample forward: 1 pixel per lane (default) vs 4 pixels per lane (nemar_grid_sample_tune(64))"""
 import ctypes, os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib

@@ -1,5 +1,6 @@
 """instnorm_fwd_planes (norm_planes.hip) stand-alone at the residual blocks' shape: which of its parts cost what."""
 import sys, os
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 from nemar_amd import _lib

@@ -1,5 +1,6 @@
 """Time every traced conv call shape (tools/trace_convs.py output) and rank by time x count per step."""
 import ctypes, json, os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib

@@ -1,6 +1,7 @@
 """Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: pmc_conv.py [fwd|dgrad|wgrad] [iters] [key=value ...]
 The scratch arena is registered (NEMAR_ARENA=0: not), i.e. the resblock shape runs on the split-16 kernels as in the product."""
 import ctypes, os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib

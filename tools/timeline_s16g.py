@@ -2,6 +2,7 @@
 top -> [max + exchange barrier] -> [weights DMA issue + rescale + conversion] -> [DMA wait] -> [next loads issue + barrier] -> [tap loop].
 Needs tools/build_timeline_lib.py.  usage: timeline_s16g.py C K H R stride [N]"""
 import ctypes, os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib

@@ -1,6 +1,7 @@
 """Cycle stamps of workgroup 0 of the pipelined split-16 convolution (taps 40..47): loader waves (wait-for-landing | barrier |
 issue) and MFMA waves (MFMA blocks | lgkmcnt(0) | barrier).  Needs tools/build_timeline_lib.py.  usage: timeline_split16.py [k=v ...]"""
 import ctypes, os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib

@@ -2,6 +2,7 @@
 T resblock conv.  Needs a build with -DNEMAR_TIMELINE (the probe is compiled out by default: its s_memtime waits perturb the
 loop).  usage: timeline_ws2.py [key=value ...]"""
 import ctypes, os, sys
+os.environ.setdefault('NEMAR_AB_LIBRARY', '1')      # nemar_tune*: the measurement build of the library (nemar_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nemar_amd import _lib
