@@ -29,6 +29,24 @@
 #define NEMAR_AB_ONLY(...)
 #endif
 
+// Whole-CU LDS claim.  A workgroup whose operands are staged by LDS-DMA (global_load_lds) reads wrong fragments — rarely:
+// ~3e-4 per launch — while an LDS-ACTIVE workgroup of ANOTHER kernel shares its CU (a second HIP stream): measured on
+// wgrad_split16_kernel beside split_dual_kernel and beside a 1 KiB ds_read / ds_write test kernel (tools/diag_wgrad_beside.py), with any
+// wait / barrier protocol inside the kernel, __syncthreads() per step included; never alone on its CU.  Such kernels therefore launch
+// with as much dynamic LDS as it takes to fill the CU's 160 KiB, so that no other kernel's LDS-using workgroup can be placed beside
+// them (they run one workgroup per CU anyway: registers).  nemar_lds_bytes: the dynamic LDS size to launch `kernel` with — `need`
+// bytes, or what fills the CU beside the kernel's static LDS when `claim` — and, once per kernel, the attribute that allows it.
+size_t nemar_lds_bytes(const void* kernel, size_t need, bool claim);
+// which kernel families claim (bit mask): 1 wgrad_split16_kernel, 2 igemm_split16_kernel (both: one workgroup per CU by registers, the claim
+// costs them nothing), 4 s16g_kernel (two workgroups per CU where its LDS image allows: off by default).  The exact-fp32 kernels and
+// wgrad2_kernel also stage by LDS-DMA and run several workgroups per CU; they do not claim (DESIGN.md 4g says what that leaves open).
+#define NEMAR_LDS_CLAIM_DEFAULT 3
+#ifdef NEMAR_AB
+extern int g_lds_claim;      // nemar_tune(37, mask)
+#else
+constexpr int g_lds_claim = NEMAR_LDS_CLAIM_DEFAULT;
+#endif
+
 // include/nemar_hip.h's nemar_conv_extras (the per-call side inputs of nemar_conv2d_*_ex), field for field
 struct nemar_conv_extras {
     void* scratch;

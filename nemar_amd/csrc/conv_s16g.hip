@@ -779,16 +779,11 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
 #ifdef NEMAR_HOST_EMULATION
 #define S16G_GO1(MT_, NT_, SX_, NS_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds, st, p); }
 #else
-    // more than 64 KiB of dynamic LDS needs the attribute (set once per instantiation)
+    // more than 64 KiB of dynamic LDS needs the attribute (nemar_lds_bytes sets it once per instantiation; whole-CU claim: common.h)
 #define S16G_GO1(MT_, NT_, SX_, NS_)                                                                                    \
     {                                                                                                                   \
-        static bool attr_ = false;                                                                                      \
-        if (!attr_) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_, NS_>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);                     \
-            attr_ = true;                                                                                               \
-        }                                                                                                               \
-        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds, st, p);                                        \
+        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_, NS_>), lds, (g_lds_claim & 4) != 0);       \
+        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds_, st, p);                                       \
     }
 #endif
 #define S16G_GO(MT_, NT_, SX_) { if (pl.HR * p.GPR <= 128) S16G_GO1(MT_, NT_, SX_, 1) else S16G_GO1(MT_, NT_, SX_, 2) }

@@ -881,19 +881,15 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (p.mblks * p.ksplit) == 0) ? 1 : 0;
     const int region = p.halo_instr + p.aux_instr;
     const dim3 g(grid);
-    // dynamic LDS: [RING weight stages][two halo buffers]; above 64 KiB the attribute is needed (set once per instantiation)
+    // dynamic LDS: [RING weight stages][two halo buffers]; above 64 KiB the attribute is needed (nemar_lds_bytes sets it once per instantiation)
 #ifdef NEMAR_HOST_EMULATION
 #define S16_GO(NBW_, NPL_, KS_, RING_) { hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), g, dim3(256), 0, st, p); }
 #else
 #define S16_GO(NBW_, NPL_, KS_, RING_)                                                                                  \
     {                                                                                                                   \
-        static bool attr_ = false;                                                                                      \
-        if (!attr_) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_split16_kernel<NBW_, NPL_, KS_, RING_>),     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);                     \
-            attr_ = true;                                                                                               \
-        }                                                                                                               \
-        const size_t lds_ = ((size_t)(RING_) * 256 * (NPL_) + (size_t)2 * 2 * (NPL_) * (p.halo16 + p.aux16)) * 16;      \
+        const size_t need_ = ((size_t)(RING_) * 256 * (NPL_) + (size_t)2 * 2 * (NPL_) * (p.halo16 + p.aux16)) * 16;     \
+        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), need_,      \
+                                            (g_lds_claim & 2) != 0);                 /* (whole-CU claim: common.h) */   \
         hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), g, dim3(256), lds_, st, p);                  \
     }
 #endif

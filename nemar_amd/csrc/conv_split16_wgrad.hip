@@ -234,7 +234,11 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     constexpr int STAGE16 = NCOL * 64;                 // 4 GC G columns + 4 KS X columns: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
     constexpr int NMF = 3 * KS * KS, NSL = 2 * GC + 2 * KS + NCP;       // MFMAs and slots per step
     constexpr int NPV = KS / 2;                        // dwords of the previous chunk a shift by <= KS - 1 pixels reaches into
-    __shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];
+#ifdef NEMAR_HOST_EMULATION
+    __shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];      // (the emulator has no dynamic LDS)
+#else
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];             // wg_lds_bytes<KS, ONEG>(), or the whole CU's LDS (common.h)
+#endif
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int tiles = p.KBLK * p.CBLK;
     int t = blockIdx.x;
@@ -399,6 +403,15 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     }
 }
 
+template <int KS, bool ONEG>
+constexpr size_t wg_lds_bytes() { return (size_t)4 * (4 * (ONEG ? 1 : KS) + 4 * KS) * 64 * 16; }      // RING x STAGE16 words of 16 bytes
+
+template <int KS, bool ONEG>
+void wg_launch(int grid, const WgParams& p, hipStream_t st) {
+    const void* const k = reinterpret_cast<const void*>(&wgrad_split16_kernel<KS, ONEG>);
+    hipLaunchKernelGGL((wgrad_split16_kernel<KS, ONEG>), dim3(grid), dim3(256), nemar_lds_bytes(k, wg_lds_bytes<KS, ONEG>(), (g_lds_claim & 1) != 0), st, p);
+}
+
 int rows_per_split(int N, int H, int CPR, int tiles) {
     // ~256 workgroups: splits per image = ceil(256 / (tiles N)), rounded to a divisor of H whose row block is a whole number of
     // double steps (RB CPR % 4 == 0)
@@ -503,11 +516,11 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     p.gmax = gmax; p.xmax = xmax; p.gstride = gstride; p.xstride = xstride;
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
-    if (KS == 3 && oneg) hipLaunchKernelGGL((wgrad_split16_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
-    else if (oneg) hipLaunchKernelGGL((wgrad_split16_kernel<4, true>), dim3(grid), dim3(256), 0, st, p);
+    if (KS == 3 && oneg) wg_launch<3, true>(grid, p, st);
+    else if (oneg) wg_launch<4, true>(grid, p, st);
 #ifdef NEMAR_AB      // nemar_tune(34, 0): KS shifted copies of the gy planes in HBM
-    else if (KS == 3) hipLaunchKernelGGL((wgrad_split16_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wgrad_split16_kernel<4, false>), dim3(grid), dim3(256), 0, st, p);
+    else if (KS == 3) wg_launch<3, false>(grid, p, st);
+    else wg_launch<4, false>(grid, p, st);
 #endif
     nemar_sum_partials(part, (long long)K * C * KS * KS, splits, gw, (long long)K * C * KS * KS, true, st);
 }

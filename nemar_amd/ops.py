@@ -241,7 +241,7 @@ _garena = {}           # device -> ring of [buffer, event of the side-stream con
 _garena_next = {}
 _gplanes_need = {}
 GY_RING = int(os.environ.get("NEMAR_GY_RING", "4"))
-_GY_HANDOVER = os.environ.get("NEMAR_GY_HANDOVER", "0") == "1"      # (diagnostic: the hand-over also beside the side stream)
+_GY_HANDOVER = os.environ.get("NEMAR_GY_HANDOVER", "1") == "1"      # (NEMAR_GY_HANDOVER=0: A/B of the schedule — the side stream splits gy itself)
 
 
 def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
@@ -250,10 +250,11 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
     device: the weight gradient may run on the side stream while the compute stream writes the next layer's planes; a slot is handed out
     again only after the compute stream has waited for the event its last consumer recorded."""
     if _side_on[0] and not _GY_HANDOVER:
-        # With the weight gradient on the side stream the hand-over is OFF: in ~0.8 % of the steps of config 3 (batch 2) ONE 32 x 32 tile of
-        # ONE wide layer's weight gradient, for one tap row, came out 0.5 % off (15 of 100 runs of 20 steps; 0 of 310 without the
-        # hand-over, 0 ever on one stream, 0 of 2700 in a stand-alone two-stream probe of the same kernels) — cause not found yet
-        # (DESIGN.md 4g).  The side stream splits gy itself, beside the compute stream's kernels.
+        # (diagnostic) Round 5 shipped for a while WITHOUT the hand-over beside the side stream: with it, ~1 % of the steps of config 3 showed
+        # one 32 x 32 tile of one wide layer's weight gradient, for one tap row, off by 0.5 - 3 % of the tensor's maximum.  The cause was not
+        # the hand-over but WHEN it lets wgrad_split16_kernel start: next to the compute stream's split_dual_kernel.  A workgroup staged by
+        # LDS-DMA misreads fragments while an LDS-active workgroup of another kernel shares its CU; the split-16 kernels now claim the whole
+        # LDS of their CU (csrc/common.h nemar_lds_bytes, DESIGN.md 4g) and the hand-over is back on.
         return None, None
     key = (N, C, H, W, K, R, S, stride, pad, pad_mode)
     need = _gplanes_need.get(key)

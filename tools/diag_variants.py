@@ -73,6 +73,38 @@ def _wgdrain(src):
     return src.replace(a, "            WG_VMCNT(0)")
 
 
+def _wgprolog(src):
+    # every copy of the four prologue stages has landed before the first barrier
+    a = "    WG_VMCNT(2 * NCP)                                  // stages 0 and 1 have landed (2 and 3 may be in flight)"
+    assert src.count(a) == 1
+    return src.replace(a, "    WG_VMCNT(0)")
+
+
+def _wgsync(src):
+    # __syncthreads() (fence + full drain) instead of the counted wait + raw barrier at the end of a step
+    a = "            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)\n            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers\n            __builtin_amdgcn_s_barrier();              // stage T + 2 complete for all waves; slot of stage T + 1 is free\n"
+    assert src.count(a) == 1, src.count(a)
+    return src.replace(a, "            __syncthreads();\n")
+
+
+def _wgnoxcd(src):
+    a = "    if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);      // the tiles of one pixel slab stay on one XCD (same sources)"
+    assert src.count(a) == 1
+    return src.replace(a, "")
+
+
+def _wglds(nbytes):
+    # the kernel's workgroup claims `nbytes` of LDS (dynamic), so that no other kernel's LDS-using workgroup fits beside it on the CU
+    def patch(src):
+        a = "    __shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];\n    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;\n    const int tiles = p.KBLK * p.CBLK;"
+        assert src.count(a) == 1, src.count(a)
+        src = src.replace(a, a.replace("__shared__ __attribute__((aligned(16))) u32x4 smem[RING * STAGE16];", "extern __shared__ __attribute__((aligned(16))) u32x4 smem[];"))
+        b = "    if (KS == 3 && oneg) hipLaunchKernelGGL((wgrad_split16_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);"
+        assert src.count(b) == 1
+        return src.replace(b, "    if (KS == 3 && oneg) {\n        static bool attr_ = false;\n        if (!attr_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split16_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, %d); attr_ = true; }\n        hipLaunchKernelGGL((wgrad_split16_kernel<3, true>), dim3(grid), dim3(256), %d, st, p);\n    }" % (nbytes, nbytes))
+    return patch
+
+
 def _wgcheck(src):
     # every step re-reads the NEXT step's X fragments from LDS after the wait + barrier protocol says they are final and counts differences
     a = "            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)\n            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers\n"
@@ -115,6 +147,11 @@ VARIANTS = {
     "wgdeep": ("conv_split16_wgrad.hip", _wgdeep),
     "wgdrain": ("conv_split16_wgrad.hip", _wgdrain),
     "wgcheck": ("conv_split16_wgrad.hip", _wgcheck),
+    "wgprolog": ("conv_split16_wgrad.hip", _wgprolog),
+    "wglds64": ("conv_split16_wgrad.hip", _wglds(65536)),
+    "wglds148": ("conv_split16_wgrad.hip", _wglds(148 * 1024)),
+    "wgsync": ("conv_split16_wgrad.hip", _wgsync),
+    "wgnoxcd": ("conv_split16_wgrad.hip", _wgnoxcd),
 }
 
 
