@@ -1,7 +1,7 @@
 """`-m gpu`: the wide-layer weight gradient (nemar_conv2d_bwd_weight_ex on the fp16 x 3 route: split passes, wgrad_split16_kernel, slab sum)
 is bitwise repeatable on a side stream while the compute stream runs LDS-active kernels — the data-gradient call whose split pass also
-writes gy planes (split_dual_kernel: the co-runner that made ~0.3 % of such calls differ in one wave tile before the split-16 kernels
-claimed the whole LDS of their CU) and a plain data-gradient call.  tools/diag_wgrad_beside.py is the probe (every call is
+writes gy planes (split_dual_kernel: the co-runner that made ~0.3 % of such calls differ in one wave tile before wgrad_split16_kernel
+claimed the whole LDS of its CU) and a plain data-gradient call.  tools/diag_wgrad_beside.py is the probe (every call is
 compared on the device); it runs in a fresh process on the PRODUCT library."""
 import os
 import re

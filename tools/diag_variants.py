@@ -105,6 +105,34 @@ def _wglds(nbytes):
     return patch
 
 
+def _wgrot(src):
+    # WHICH wave copies what: wave 3 copies the G pieces, waves 0 .. 2 the X pieces (content and LDS position unchanged) — are the failing X
+    # fragments tied to the X pieces or to the waves that copy them?
+    a = "        const int i = NCP * wid + q;\n        if (i < 4 * GC) {"
+    assert src.count(a) == 1, src.count(a)
+    src = src.replace(a, "        const int i = (NCP * wid + q + NCP) % NCOL;\n        if (i < 4 * GC) {")
+    b = "        u32x4* const d_ = smem + ((stage_) & (RING - 1)) * STAGE16 + wid * (NCP * 64);"
+    assert src.count(b) == 1
+    src = src.replace(b, "        u32x4* const d_ = smem + ((stage_) & (RING - 1)) * STAGE16 + ((wid + 1) & 3) * (NCP * 64);")
+    c = "                u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + wid * (NCP * 64);"
+    assert src.count(c) == 1
+    return src.replace(c, "                u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + ((wid + 1) & 3) * (NCP * 64);")
+
+
+def _wgnoclaim(src):
+    a = "(g_lds_claim & 1) != 0"
+    assert src.count(a) == 1
+    return src.replace(a, "false")
+
+
+def _chain(*fs):
+    def patch(src):
+        for f in fs:
+            src = f(src)
+        return src
+    return patch
+
+
 def _wgcheck(src):
     # every step re-reads the NEXT step's X fragments from LDS after the wait + barrier protocol says they are final and counts differences
     a = "            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)\n            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers\n"
@@ -148,6 +176,8 @@ VARIANTS = {
     "wgdrain": ("conv_split16_wgrad.hip", _wgdrain),
     "wgcheck": ("conv_split16_wgrad.hip", _wgcheck),
     "wgprolog": ("conv_split16_wgrad.hip", _wgprolog),
+    "wgnoclaim": ("conv_split16_wgrad.hip", _wgnoclaim),
+    "wgrot": ("conv_split16_wgrad.hip", _chain(_wgnoclaim, _wgrot)),
     "wglds64": ("conv_split16_wgrad.hip", _wglds(65536)),
     "wglds148": ("conv_split16_wgrad.hip", _wglds(148 * 1024)),
     "wgsync": ("conv_split16_wgrad.hip", _wgsync),

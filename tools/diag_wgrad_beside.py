@@ -93,15 +93,45 @@ def victim(out, handover):
 
 
 NV = 8
-gws = [torch.empty_like(w) for _ in range(NV)]
-refs = {}
-for ho in (True, False):
+VICTIM = os.environ.get('DIAG_VICTIM', 'wide_wgrad')
+if VICTIM == 'wide_wgrad':
+    gws = [torch.empty_like(w) for _ in range(NV)]
+    refs = {}
+    for ho in (True, False):
+        with torch.cuda.stream(side):
+            victim(gws[0], ho)
+        torch.cuda.synchronize()
+        assert L.last_route() == 2
+        refs[ho] = gws[0].clone()
+    print('references: hand-over vs own split equal: %s' % torch.equal(refs[True], refs[False]))
+else:
+    # other LDS-DMA staged kernels as the victim: a forward call on the side stream (DIAG_VICTIM = wide_fwd: igemm_split16_kernel, the same
+    # layer; s16g_fwd: s16g_kernel, 64 -> 128 3x3 stride 2 at 256 x 256, the translation net's first down-sampling layer)
+    if VICTIM == 'wide_fwd':
+        vx, vw, vs, vp, vmode, vK = x, w, 1, 1, 1, K
+    else:
+        vx = torch.rand(N, 64, 256, 256, device=dev, generator=g0) * 2 - 1
+        vw = (torch.rand(128, 64, 3, 3, device=dev, generator=g0) * 2 - 1) * 0.05
+        vs, vp, vmode, vK = 2, 1, 0, 128
+    vN, vC, vH, vW = vx.shape
+    oh = (vH + 2 * vp - 3) // vs + 1
+    fwb = L.conv2d_fwd_workspace(vN, vH, vW, vK, vC, 3, 3, vs, vp)
+    fws_ = torch.empty(fwb // 4 + 64, device=dev)
+    vxmax = None
+    if VICTIM == 'wide_fwd':
+        vxmax = xmax
+
+    def victim(out, handover, hit=1):
+        e = extras(arena_s, vxmax) if VICTIM == 'wide_fwd' else None
+        L.conv2d_fwd_ex(p(vx), vC, None, 0, p(vw), None, p(out), vN, vH, vW, vK, 3, 3, vs, vp, vmode, 0, 0.0, p(fws_), fwb, hit,
+                        ctypes.c_void_p(side.cuda_stream), ctypes.byref(e) if e is not None else None)
+
+    gws = [torch.empty(vN, vK, oh, oh, device=dev) for _ in range(NV)]
     with torch.cuda.stream(side):
-        victim(gws[0], ho)
+        victim(gws[0], False, 0)
     torch.cuda.synchronize()
-    assert L.last_route() == 2
-    refs[ho] = gws[0].clone()
-print('references: hand-over vs own split equal: %s' % torch.equal(refs[True], refs[False]))
+    print('victim %s: route %d' % (VICTIM, L.last_route()))
+    refs = {True: gws[0].clone(), False: gws[0].clone()}
 
 a = torch.rand(N, C, H, W, device=dev)
 b = torch.rand(N, C, H, W, device=dev)
@@ -198,7 +228,7 @@ CO = dict(agg_alloc=agg(0), agg_lds=agg(1), agg_glob=agg(2), agg_lds1k=agg(3), d
 for name, co in CO.items():
     if only and name not in only:
         continue
-    for ho in ((False,) if os.environ.get('DIAG_OWN_ONLY') else (True, False)):
+    for ho in ((False,) if (os.environ.get('DIAG_OWN_ONLY') or VICTIM != 'wide_wgrad') else (True, False)):
         cnt = torch.zeros((), dtype=torch.int64, device=dev)
         snap = refs[ho].clone()                                        # the LAST differing result (one extra elementwise kernel per call)
         done = 0
@@ -218,7 +248,11 @@ for name, co in CO.items():
         torch.cuda.synchronize()
         print('co-runner %-10s victim %-9s: %d of %d calls differ  (%.1f s)' % (name, 'hand-over' if ho else 'own split', int(cnt), done, time.time() - t0),
               flush=True)
-        if int(cnt):
+        if int(cnt) and VICTIM != 'wide_wgrad':
+            d = snap != refs[ho]
+            print('      last event: %d elements differ, samples %s, channels %s' % (int(d.sum()), d.any(3).any(2).any(1).nonzero().flatten().tolist(),
+                                                                                   d.any(3).any(2).any(0).nonzero().flatten().tolist()[:40]), flush=True)
+        elif int(cnt):
             d = (snap != refs[ho]).view(K, C, 9)
             ks, cs = d.any(2).any(1).nonzero().flatten().tolist(), d.any(2).any(0).nonzero().flatten().tolist()
             rel = float((snap - refs[ho]).abs().max() / refs[ho].abs().max())
