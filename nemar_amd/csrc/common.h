@@ -29,19 +29,21 @@
 #define NEMAR_AB_ONLY(...)
 #endif
 
-// Whole-CU LDS claim.  wgrad_split16_kernel (operands staged by LDS-DMA, one workgroup per CU) reads wrong X fragments —
-// rarely: ~3e-3 of its launches on the worst box — while an LDS-ACTIVE workgroup of ANOTHER kernel shares its CU (a second HIP stream):
-// measured beside split_dual_kernel and beside a 1 KiB ds_read / ds_write test kernel (tools/diag_wgrad_beside.py, 60 000 launches per
-// cell), with any wait / barrier protocol inside the kernel, __syncthreads() per step included; never alone on its CU, never beside
-// workgroups without LDS traffic.  It therefore launches with as much dynamic LDS as it takes to fill the CU's 160 KiB, so that no other
-// kernel's LDS-using workgroup can be placed beside it (0 of 240 000 launches, 0 of 2 166 training steps).  The other LDS-DMA staged
-// kernels were measured the same way WITHOUT a claim — igemm_split16_kernel and s16g_kernel forward calls as the victim: 0 of 240 000 —
-// and do not claim (a claim costs what it keeps off the CU: 0.9 ms of a 30 ms step for this kernel, 0.15 ms more for igemm_split16,
-// and s16g_kernel's second workgroup per CU).
+// Whole-CU LDS claim.  wgrad_split16_kernel with its operands staged by LDS-DMA (one workgroup per CU) reads wrong X
+// fragments — rarely: ~3e-3 of its launches on the worst box — while an LDS-ACTIVE workgroup of ANOTHER kernel shares its CU (a second
+// HIP stream): measured beside split_dual_kernel and beside a 1 KiB ds_read / ds_write test kernel (tools/diag_wgrad_beside.py, 60 000
+// launches per cell), with any wait / barrier protocol inside the kernel, __syncthreads() per step included; never alone on its CU,
+// never beside workgroups without LDS traffic, and never when the same pieces travel global -> registers -> ds_write (0 of 240 000).
+// Two remedies: the 3x3 form of the kernel stages through registers (conv_split16_wgrad.hip, XREG: the default); a form that keeps
+// LDS-DMA (the 4x4 layer's, one launch per step) launches with as much dynamic LDS as it takes to fill the CU's 160 KiB, so that no
+// other kernel's LDS-using workgroup can be placed beside it (0 of 240 000 launches, 0 of 2 166 training steps).  The other LDS-DMA
+// staged kernels were measured the same way WITHOUT a claim — igemm_split16_kernel and s16g_kernel forward calls as the victim:
+// 0 of 240 000 — and do not claim (a claim costs what it keeps off the CU: 0.7 - 0.9 ms of a 30 ms step for the 3x3 weight gradient).
 // nemar_lds_bytes: the dynamic LDS size to launch `kernel` with — `need` bytes, or what fills the CU beside the kernel's static LDS when
 // `claim` — and, once per kernel, the attribute that allows more than 64 KiB.
 size_t nemar_lds_bytes(const void* kernel, size_t need, bool claim);
-// which kernel families claim (bit mask, nemar_tune(37) in the measurement build): 1 wgrad_split16_kernel, 2 igemm_split16_kernel, 4 s16g_kernel
+// which kernel families claim (bit mask, nemar_tune(37) in the measurement build): 1 wgrad_split16_kernel's LDS-DMA forms, 2 igemm_split16_kernel,
+// 4 s16g_kernel
 #define NEMAR_LDS_CLAIM_DEFAULT 1
 #ifdef NEMAR_AB
 extern int g_lds_claim;      // nemar_tune(37, mask)

@@ -27,6 +27,7 @@
 #ifdef NEMAR_AB
 extern int g_split16_ring3;                      // conv_split16.hip
 extern int g_narrow_fwd4;                        // conv_narrow.hip
+extern int g_wg_xreg;                            // conv_split16_wgrad.hip
 void nemar_norm_planes_debug(int bits);          // norm_planes.hip: ablation bits of the fused producer (measurement only)
 #endif
 
@@ -1421,6 +1422,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 33) { g_k7 = value != 0; return NEMAR_OK; }
     if (key == 36) { g_split_act = value != 0; return NEMAR_OK; }
     if (key == 37) { g_lds_claim = value; return NEMAR_OK; }      // kernel families whose workgroups claim the whole CU's LDS (common.h)
+    if (key == 38) { g_wg_xreg = value != 0; return NEMAR_OK; }   // wide 3x3 weight gradient: X pieces through registers
     if (key == 35) { g_dual_gy = value != 0; return NEMAR_OK; }
     if (key == 34) { nemar_split16_wgrad_tune(value); return NEMAR_OK; }      // wide weight gradient: 1 one gy copy (default), 0 KS shifted copies
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }

@@ -227,8 +227,13 @@ struct WgParams {
 };
 
 // 3x3 layers, or the discriminator's 4x4 / pad 1 layers (16 taps: 16 accumulators per wave).  ONEG: G_0 only comes from HBM.
-template <int KS, bool ONEG>
+// XREG: no LDS-DMA — every piece travels global -> registers -> ds_write_b128: loaded at step T for stage T + 4 into one of two register
+// sets, written to the ring at the start of step T + 2 (so a stage is complete at the same barrier as with LDS-DMA).  The same code in
+// every wave: no role branches for the compiler to guard with vmcnt(0).  (LDS-DMA written X pieces are what is misread
+// beside a foreign LDS-active workgroup; nemar_tune(38) selects the form, common.h has the LDS claim the DMA form needs.)
+template <int KS, bool ONEG, bool XREG = false>
 __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
+
     constexpr int GC = ONEG ? 1 : KS;                  // copies of G staged per chunk
     constexpr int RING = 4, NCOL = 4 * GC + 4 * KS, NCP = NCOL / 4;     // copies per wave per stage: NCOL columns over four waves
     constexpr int STAGE16 = NCOL * 64;                 // 4 GC G columns + 4 KS X columns: [(s | r) * 2 + plane][chunk 0 | 1][64 channels]
@@ -312,11 +317,28 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #define WG_A(set_, s_, pl_) ((ONEG && (s_) > 0) ? sh[set_][(ONEG ? (s_) : 0)][pl_] : af[set_][ONEG ? 0 : (s_)][pl_])
 
-    WG_COPIES(0)
-    WG_COPIES(1)
-    WG_COPIES(2)
-    WG_COPIES(3)
-    WG_VMCNT(2 * NCP)                                  // stages 0 and 1 have landed (2 and 3 may be in flight)
+    u32x4 xr[2][XREG ? NCP : 1];                       // XREG: stage T + 4 (set T & 1) on its way from global memory to the ring
+    if (XREG) {
+        // stages 0, 1 straight into the ring; stages 2, 3 wait in the two register sets for steps 0 and 1
+#pragma unroll
+        for (int stg = 0; stg < 2; ++stg) {
+            const int st_ = min(stg, nsteps - 1);
+            u32x4* const d_ = smem + stg * STAGE16 + wid * (NCP * 64);
+#pragma unroll
+            for (int q = 0; q < NCP; ++q) d_[q * 64 + lane] = csrc[q][(size_t)st_ * 128];
+        }
+#pragma unroll
+        for (int stg = 2; stg < 4; ++stg)
+#pragma unroll
+            for (int q = 0; q < (XREG ? NCP : 1); ++q) xr[stg & 1][q] = csrc[q][(size_t)min(stg, nsteps - 1) * 128];
+    } else {
+        WG_COPIES(0)
+        WG_COPIES(1)
+        WG_COPIES(2)
+        WG_COPIES(3)
+        WG_VMCNT(2 * NCP)                              // stages 0 and 1 have landed (2 and 3 may be in flight)
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // (XREG: the ds_writes of stages 0, 1)
     __builtin_amdgcn_s_barrier();
     WG_READ(0, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -343,6 +365,12 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
             }                                                                                                           \
             __builtin_amdgcn_sched_barrier(0);
 #define WG_SLOT(i_) WG_MFMAS((i_) * NMF / NSL, ((i_) + 1) * NMF / NSL)
+            if (XREG) {
+                // stage T + 2 (loaded at step T - 2 into set `cur`) into its ring slot, free since step T - 2
+                u32x4* const d2_ = smem + ((T + 2) & (RING - 1)) * STAGE16 + wid * (NCP * 64);
+#pragma unroll
+                for (int q = 0; q < (XREG ? NCP : 1); ++q) d2_[q * 64 + lane] = xr[cur][q];
+            }
             const u32x4* const S_ = smem + ((T + 1) & (RING - 1)) * STAGE16;
 #pragma unroll
             for (int i = 0; i < 2 * GC; ++i) {
@@ -370,14 +398,15 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
                 u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + wid * (NCP * 64);
 #pragma unroll
                 for (int q = 0; q < NCP; ++q) {
-                    glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
+                    if (XREG) xr[cur][XREG ? q : 0] = csrc[q][(size_t)st_ * 128];
+                    else glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
                     WG_SLOT(2 * GC + 2 * KS + q)
                 }
             }
 #undef WG_SLOT
 #undef WG_MFMAS
-            WG_VMCNT(2 * NCP)                          // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)
-            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers
+            if (!XREG) WG_VMCNT(2 * NCP)               // this wave's copies of stage T + 2 have landed (T + 3, T + 4 in flight)
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): every fragment of step T + 1 is in registers (XREG: and stage T + 2 is written)
             __builtin_amdgcn_s_barrier();              // stage T + 2 complete for all waves; slot of stage T + 1 is free
         }
     }
@@ -406,10 +435,11 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
 template <int KS, bool ONEG>
 constexpr size_t wg_lds_bytes() { return (size_t)4 * (4 * (ONEG ? 1 : KS) + 4 * KS) * 64 * 16; }      // RING x STAGE16 words of 16 bytes
 
-template <int KS, bool ONEG>
+template <int KS, bool ONEG, bool XREG = false>
 void wg_launch(int grid, const WgParams& p, hipStream_t st) {
-    const void* const k = reinterpret_cast<const void*>(&wgrad_split16_kernel<KS, ONEG>);
-    hipLaunchKernelGGL((wgrad_split16_kernel<KS, ONEG>), dim3(grid), dim3(256), nemar_lds_bytes(k, wg_lds_bytes<KS, ONEG>(), (g_lds_claim & 1) != 0), st, p);
+    const void* const k = reinterpret_cast<const void*>(&wgrad_split16_kernel<KS, ONEG, XREG>);
+    // (only a form that stages by LDS-DMA needs the whole-CU claim: common.h)
+    hipLaunchKernelGGL((wgrad_split16_kernel<KS, ONEG, XREG>), dim3(grid), dim3(256), nemar_lds_bytes(k, wg_lds_bytes<KS, ONEG>(), !XREG && (g_lds_claim & 1) != 0), st, p);
 }
 
 int rows_per_split(int N, int H, int CPR, int tiles) {
@@ -454,6 +484,8 @@ int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS) {
 }
 
 // gw [K][C][KS][KS] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C KS KS floats.  x [N, C, H, W], gy [N, K, H + 3 - KS, W + 3 - KS]
+NEMAR_SWITCH(int, g_wg_xreg, 1);      // nemar_tune(38): the 3x3 kernel stages through registers (1, default: 379 vs 368 us per batch-16 call, and no
+                                      // whole-CU LDS claim needed: 0.25 ms per step less than LDS-DMA + claim) / by LDS-DMA (0)
 static NEMAR_SWITCH(int, g_one_g, 1);        // nemar_tune(34): 1 = one copy of the gy planes, shifted operands built in registers; 0 = KS copies in HBM
 #ifdef NEMAR_AB
 void nemar_split16_wgrad_tune(int v) { g_one_g = v ? 1 : 0; }
@@ -516,7 +548,8 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     p.gmax = gmax; p.xmax = xmax; p.gstride = gstride; p.xstride = xstride;
     const int splits = N * p.spi, grid = splits * KBLK * CBLK;
     p.xcd = (xcd_map && grid % 8 == 0 && (grid / 8) % (KBLK * CBLK) == 0) ? 1 : 0;
-    if (KS == 3 && oneg) wg_launch<3, true>(grid, p, st);
+    NEMAR_AB_ONLY(if (KS == 3 && oneg && !g_wg_xreg) wg_launch<3, true, false>(grid, p, st); else)
+    if (KS == 3 && oneg) wg_launch<3, true, true>(grid, p, st);
     else if (oneg) wg_launch<4, true>(grid, p, st);
 #ifdef NEMAR_AB      // nemar_tune(34, 0): KS shifted copies of the gy planes in HBM
     else if (KS == 3) wg_launch<3, false>(grid, p, st);

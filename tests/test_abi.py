@@ -137,7 +137,7 @@ def test_no_kernel_contains_packed_fp32_instructions(isa):
 # code sits): the head's folded data gradient (20 registers, reloaded in the per-tile halo phase, not in the MFMA loop), the stride-2
 # in-kernel-split weight gradients (17 / 7), the discriminator's 4x4 wide-layer weight gradient (1).  Round 4 had twelve such kernels,
 # among them InstanceNorm at 256^2 (32 registers); the 128-channel s16g tiles (144 registers) are in the measurement build only.
-SCRATCH_ALLOWED = ("k7_fm_kernel<3, true>", "s16g_wgrad_kernel<3, 2, 64>", "s16g_wgrad_kernel<3, 2, 32>", "wgrad_split16_kernel<4, true>")
+SCRATCH_ALLOWED = ("k7_fm_kernel<3, true>", "s16g_wgrad_kernel<3, 2, 64>", "s16g_wgrad_kernel<3, 2, 32>", "wgrad_split16_kernel<4, true, false>")
 
 
 def test_default_path_kernels_use_no_scratch(isa):

@@ -399,6 +399,14 @@ def test_conv_split16_weight_gradient(be):
         K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 128, K.PAD_ZERO, R=4)
     finally:
         be.lib.tune(34, 1)
+    be.lib.tune(38, 0)             # the 3x3 kernel staged by LDS-DMA (the default stages through registers: DESIGN.md 4g)
+    try:
+        K.case_conv_split16_wgrad(be, 1, 128, 8, 8, 128, K.PAD_REFLECT)
+        K.case_conv_split16_wgrad(be, 2, 128, 8, 16, 192, K.PAD_ZERO)
+        K.case_conv_split16_wgrad(be, 1, 192, 4, 24, 128, K.PAD_REFLECT)
+        K.case_conv_split16_wgrad(be, 1, 128, 6, 16, 128, K.PAD_ZERO)
+    finally:
+        be.lib.tune(38, 1)
 
 
 def test_absmax_and_hint(be):

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from nemar_amd import _lib
-from tools.side_inputs import SideInputs
+from tests.side_inputs import SideInputs
 from tools.microbench import timeit
 
 SHAPES = [  # name, C0, C1, K, R, stride, pad, pad_mode, H
