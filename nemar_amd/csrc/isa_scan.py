@@ -19,6 +19,7 @@ import tempfile
 
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 PACKED_F32 = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+LDS_DMA = re.compile(r"\b(global|buffer)_load_lds_|\bbuffer_load_\w+ .*\blds\b")
 
 
 def _tool(name):
@@ -72,8 +73,9 @@ def kernel_digests(lib_path):
 
 
 def scan(lib_path):
-    """-> {"kernels": [{name, scratch, spills, vgpr, agpr, lds}], "packed_f32": {mangled kernel symbol: count}}"""
-    kernels, packed = [], {}
+    """-> {"kernels": [{name, scratch, spills, vgpr, agpr, lds}], "packed_f32": {mangled kernel symbol: count},
+    "lds_dma": {mangled kernel symbol: count of LDS-DMA (global_load_lds_*) instructions}}"""
+    kernels, packed, dma = [], {}, {}
     with tempfile.TemporaryDirectory() as td:
         for co in code_objects(lib_path, td):
             notes = subprocess.run([_tool("llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
@@ -90,9 +92,11 @@ def scan(lib_path):
                     cur = m.group(1)
                 elif PACKED_F32.search(line):
                     packed[cur] = packed.get(cur, 0) + 1
+                elif LDS_DMA.search(line):
+                    dma[cur] = dma.get(cur, 0) + 1
     for k, n in zip(kernels, _demangle([k["name"] for k in kernels])):
         k["pretty"] = n
-    return {"kernels": kernels, "packed_f32": packed}
+    return {"kernels": kernels, "packed_f32": packed, "lds_dma": dma}
 
 
 if __name__ == "__main__":
@@ -102,6 +106,9 @@ if __name__ == "__main__":
     print("%d kernels in %s" % (len(r["kernels"]), lib))
     print("packed-FP32 VOP3P instructions: %d in %d kernels" % (sum(r["packed_f32"].values()), len(r["packed_f32"])))
     for name, n in sorted(r["packed_f32"].items(), key=lambda kv: -kv[1])[:20]:
+        print("   %5d  %s" % (n, _demangle([name])[0][:140]))
+    print("kernels that stage by LDS-DMA: %d" % len(r["lds_dma"]))
+    for name, n in sorted(r["lds_dma"].items(), key=lambda kv: -kv[1]):
         print("   %5d  %s" % (n, _demangle([name])[0][:140]))
     sc = [k for k in r["kernels"] if k["scratch"]]
     print("kernels with scratch: %d" % len(sc))

@@ -133,6 +133,22 @@ def test_no_kernel_contains_packed_fp32_instructions(isa):
     assert not isa["packed_f32"], sorted(isa["packed_f32"].items(), key=lambda kv: -kv[1])[:10]
 
 
+def test_wide_weight_gradient_of_the_product_stages_without_lds_dma(isa):
+    """wgrad_split16_kernel misread LDS-DMA written fragments while an LDS-active workgroup of another kernel shared its CU
+    (~1 % of training steps with the weight gradients on a side stream).  The 3x3 form the product launches stages through registers:
+    no global_load_lds instruction in it; the kernels that do stage by LDS-DMA are a known list (each measured clean beside LDS-active
+    co-runners, or launched with the whole-CU LDS claim: csrc/common.h)."""
+    from nemar_amd.csrc import isa_scan
+    pretty = dict(zip(isa["lds_dma"], isa_scan._demangle(list(isa["lds_dma"]))))
+    assert len(pretty) >= 5                                            # (the census itself works)
+    assert not [p for p in pretty.values() if "wgrad_split16_kernel<3, true, true>" in p]
+    names = [k["pretty"] for k in isa["kernels"]]
+    assert any("wgrad_split16_kernel<3, true, true>" in n for n in names)
+    assert not any("wgrad_split16_kernel<3, true, false>" in n for n in names)      # the LDS-DMA form: measurement build only
+    families = ("igemm_split16_kernel", "igemm_kernel", "igemm_ws2_kernel", "s16g_kernel", "wgrad2_kernel", "wgrad_split16_kernel<4, true, false>")
+    assert not [p for p in pretty.values() if not any(f in p for f in families)], sorted(pretty.values())
+
+
 # kernels of the PRODUCT library that may still spill — all four on the default path and OPEN (DESIGN.md 4g lists them with where the spill
 # code sits): the head's folded data gradient (20 registers, reloaded in the per-tile halo phase, not in the MFMA loop), the stride-2
 # in-kernel-split weight gradients (17 / 7), the discriminator's 4x4 wide-layer weight gradient (1).  Round 4 had twelve such kernels,
