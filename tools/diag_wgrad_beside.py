@@ -104,6 +104,25 @@ if VICTIM == 'wide_wgrad':
         assert L.last_route() == 2
         refs[ho] = gws[0].clone()
     print('references: hand-over vs own split equal: %s' % torch.equal(refs[True], refs[False]))
+elif VICTIM == 'wgrad2':
+    # the exact-fp32 weight gradient (wgrad2_kernel, LDS-DMA staged, several workgroups per CU): the discriminator's 64 -> 128 4x4 stride-2 layer
+    vN = 8
+    vx = torch.rand(vN, 64, 128, 128, device=dev, generator=g0) * 2 - 1
+    vg = (torch.rand(vN, 128, 64, 64, device=dev, generator=g0) * 2 - 1) * 0.01
+    vwb = L.conv2d_bwd_weight_workspace(vN, 64, 128, 128, 128, 64, 64, 4, 4, 2, 1)
+    vws = torch.empty(vwb // 4 + 64, device=dev)
+
+    def victim(out, handover):
+        out.zero_()
+        L.conv2d_bwd_weight_ex(p(vx), 64, None, 0, p(vg), p(out), None, vN, 128, 128, 128, 64, 64, 4, 4, 2, 1, 0, p(vws), vwb,
+                               ctypes.c_void_p(side.cuda_stream), None)
+
+    gws = [torch.empty(128, 64, 4, 4, device=dev) for _ in range(NV)]
+    with torch.cuda.stream(side):
+        victim(gws[0], False)
+    torch.cuda.synchronize()
+    print('victim %s: route %d' % (VICTIM, L.last_route()))
+    refs = {True: gws[0].clone(), False: gws[0].clone()}
 else:
     # other LDS-DMA staged kernels as the victim: a forward call on the side stream (DIAG_VICTIM = wide_fwd: igemm_split16_kernel, the same
     # layer; s16g_fwd: s16g_kernel, 64 -> 128 3x3 stride 2 at 256 x 256, the translation net's first down-sampling layer)
@@ -250,8 +269,8 @@ for name, co in CO.items():
               flush=True)
         if int(cnt) and VICTIM != 'wide_wgrad':
             d = snap != refs[ho]
-            print('      last event: %d elements differ, samples %s, channels %s' % (int(d.sum()), d.any(3).any(2).any(1).nonzero().flatten().tolist(),
-                                                                                   d.any(3).any(2).any(0).nonzero().flatten().tolist()[:40]), flush=True)
+            print('      last event: %d elements differ, dim 0 %s, dim 1 %s' % (int(d.sum()), d.any(3).any(2).any(1).nonzero().flatten().tolist()[:40],
+                                                                              d.any(3).any(2).any(0).nonzero().flatten().tolist()[:40]), flush=True)
         elif int(cnt):
             d = (snap != refs[ho]).view(K, C, 9)
             ks, cs = d.any(2).any(1).nonzero().flatten().tolist(), d.any(2).any(0).nonzero().flatten().tolist()
