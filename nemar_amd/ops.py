@@ -250,11 +250,11 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
     device: the weight gradient may run on the side stream while the compute stream writes the next layer's planes; a slot is handed out
     again only after the compute stream has waited for the event its last consumer recorded."""
     if _side_on[0] and not _GY_HANDOVER:
-        # (diagnostic) Round 5 shipped for a while WITHOUT the hand-over beside the side stream: with it, ~1 % of the steps of config 3 showed
-        # one 32 x 32 tile of one wide layer's weight gradient, for one tap row, off by 0.5 - 3 % of the tensor's maximum.  The cause was not
-        # the hand-over but WHEN it lets wgrad_split16_kernel start: next to the compute stream's split_dual_kernel.  That workgroup, staged by
-        # LDS-DMA misreads fragments while an LDS-active workgroup of another kernel shares its CU; that kernel now claims the whole LDS
-        # of its CU (csrc/common.h nemar_lds_bytes, DESIGN.md 4g) and the hand-over is back on.
+        # (A/B of the schedule.)  The round-5 build ran for a while WITHOUT the hand-over beside the side stream: with it, ~1 % of the steps of
+        # config 3 showed one 32 x 32 tile of one wide layer's weight gradient, for one tap row, off by 0.5 - 3 % of the tensor's maximum.  The
+        # cause was not the hand-over but WHEN it lets wgrad_split16_kernel start — next to the compute stream's split_dual_kernel: that kernel,
+        # staged by LDS-DMA, misread fragments while an LDS-active workgroup of another kernel shared its CU.  It stages through registers now
+        # (csrc/conv_split16_wgrad.hip XREG, csrc/common.h, DESIGN.md 4g) and the hand-over is back on.
         return None, None
     key = (N, C, H, W, K, R, S, stride, pad, pad_mode)
     need = _gplanes_need.get(key)
