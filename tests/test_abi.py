@@ -78,6 +78,22 @@ def test_product_library_refuses_switch_calls(libpath):
     assert ab.nemar_config_epoch() == e0 + 1
 
 
+@pytest.mark.parametrize("env,want_lib,want_switches", [({}, "libnemar_hip.so", False), ({"NEMAR_AB_LIBRARY": "1"}, "libnemar_hip_ab.so", True),
+                                                        ({"NEMAR_TUNE": "15=1"}, "libnemar_hip_ab.so", True)])
+def test_which_library_a_process_binds(libpath, env, want_lib, want_switches):
+    """nemar_amd/_lib.py: the product library unless the environment asks for the measurement build before the first load (tools/, the
+    test session through tests/conftest.py, bench.py's child processes) — and NEMAR_TUNE is applied once at load there."""
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("NEMAR_AB_LIBRARY", "NEMAR_TUNE")}
+    e.update(env)
+    code = "import sys; sys.path.insert(0, %r); from nemar_amd import _lib; L = _lib.load(); print(L.path, L.has_switches, L.nemar_config_epoch())" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    path, switches, epoch = r.stdout.split()[-3:]
+    assert os.path.basename(path) == want_lib and switches == str(want_switches)
+    assert int(epoch) == (1 if "NEMAR_TUNE" in env else 0)
+
+
 def test_ctypes_table_matches_header(libpath):
     from nemar_amd import _lib
     decls = header_decls()
