@@ -233,7 +233,7 @@ struct WgParams {
 // beside a foreign LDS-active workgroup; nemar_tune(38) selects the form, common.h has the LDS claim the DMA form needs.)
 template <int KS, bool ONEG, bool XREG = false>
 __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
-    static_assert(!XREG || (KS == 3 && ONEG), "XREG: the lgkmcnt count in front of WG_SHIFT assumes W0 A0 W1 A1 W2 B0 W3 B1 .. B5");
+    static_assert(!XREG || (KS == 3 && ONEG), "XREG: instantiated and measured for the 3x3 one-copy form only");
 
     constexpr int GC = ONEG ? 1 : KS;                  // copies of G staged per chunk
     constexpr int RING = 4, NCOL = 4 * GC + 4 * KS, NCP = NCOL / 4;     // copies per wave per stage: NCOL columns over four waves
@@ -366,19 +366,14 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
             }                                                                                                           \
             __builtin_amdgcn_sched_barrier(0);
 #define WG_SLOT(i_) WG_MFMAS((i_) * NMF / NSL, ((i_) + 1) * NMF / NSL)
-            // XREG: stage T + 2 (loaded at step T - 2 into set `cur`) goes into its ring slot, free since step T - 2 — one ds_write per slot,
-            // in front of the slot's fragment read (LDS executes in order: the waits on the reads below still mean what they say)
-            u32x4* const d2_ = smem + ((T + 2) & (RING - 1)) * STAGE16 + wid * (NCP * 64);
             const u32x4* const S_ = smem + ((T + 1) & (RING - 1)) * STAGE16;
 #pragma unroll
             for (int i = 0; i < 2 * GC; ++i) {
-                if (XREG && i < NCP) d2_[i * 64 + lane] = xr[cur][XREG ? i : 0];
                 af[nxt][i >> 1][i & 1] = S_[a_off + i * 128];
                 WG_SLOT(i)
             }
 #pragma unroll
             for (int i = 0; i < 2 * KS; ++i) {
-                if (XREG && 2 * GC + i < NCP) d2_[(2 * GC + i) * 64 + lane] = xr[cur][XREG ? 2 * GC + i : 0];
                 bf[nxt][i >> 1][i & 1] = S_[b_off + i * 128];
                 WG_SLOT(2 * GC + i)
             }
@@ -396,10 +391,17 @@ __global__ __launch_bounds__(256) void wgrad_split16_kernel(WgParams p) {
             {
                 const int st_ = min(T + 4, nsteps - 1);
                 u32x4* const d_ = smem + (T & (RING - 1)) * STAGE16 + wid * (NCP * 64);
+                // XREG: in the slot that reloads a register of set `cur`, its old content — stage T + 2, loaded at step T - 2 — goes into its
+                // ring slot (free since step T - 2) first.  Late in the step: the wait for that load sits behind most of the step's MFMAs.
+                u32x4* const d2_ = smem + ((T + 2) & (RING - 1)) * STAGE16 + wid * (NCP * 64);
 #pragma unroll
                 for (int q = 0; q < NCP; ++q) {
-                    if (XREG) xr[cur][XREG ? q : 0] = csrc[q][(size_t)st_ * 128];
-                    else glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
+                    if (XREG) {
+                        d2_[q * 64 + lane] = xr[cur][XREG ? q : 0];
+                        xr[cur][XREG ? q : 0] = csrc[q][(size_t)st_ * 128];
+                    } else {
+                        glds16(csrc[q] + (size_t)st_ * 128, d_ + q * 64);
+                    }
                     WG_SLOT(2 * GC + 2 * KS + q)
                 }
             }
