@@ -228,7 +228,7 @@ struct WgParams {
 
 // 3x3 layers, or the discriminator's 4x4 / pad 1 layers (16 taps: 16 accumulators per wave).  ONEG: G_0 only comes from HBM.
 // XREG: no LDS-DMA — every piece travels global -> registers -> ds_write_b128: loaded at step T for stage T + 4 into one of two register
-// sets, written to the ring at the start of step T + 2 (so a stage is complete at the same barrier as with LDS-DMA).  The same code in
+// sets, written to the ring during step T + 2, in the slot that reloads the register (so a stage is complete at the same barrier as with LDS-DMA).  The same code in
 // every wave: no role branches for the compiler to guard with vmcnt(0).  (LDS-DMA written X pieces are what is misread
 // beside a foreign LDS-active workgroup; nemar_tune(38) selects the form, common.h has the LDS claim the DMA form needs.)
 template <int KS, bool ONEG, bool XREG = false>
@@ -486,7 +486,7 @@ int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS) {
 }
 
 // gw [K][C][KS][KS] += dW;  `part` holds nemar_split16_wgrad_splits slabs of K C KS KS floats.  x [N, C, H, W], gy [N, K, H + 3 - KS, W + 3 - KS]
-NEMAR_SWITCH(int, g_wg_xreg, 1);      // nemar_tune(38): the 3x3 kernel stages through registers (1, default: 379 vs 368 us per batch-16 call, and no
+NEMAR_SWITCH(int, g_wg_xreg, 1);      // nemar_tune(38): the 3x3 kernel stages through registers (1, default: 373 vs 364 us per batch-16 call, and no
                                       // whole-CU LDS claim needed: 0.25 ms per step less than LDS-DMA + claim) / by LDS-DMA (0)
 static NEMAR_SWITCH(int, g_one_g, 1);        // nemar_tune(34): 1 = one copy of the gy planes, shifted operands built in registers; 0 = KS copies in HBM
 #ifdef NEMAR_AB
