@@ -105,6 +105,36 @@ if VICTIM == 'wide_wgrad':
         assert L.last_route() == 2
         refs[ho] = gws[0].clone()
     print('references: hand-over vs own split equal: %s' % torch.equal(refs[True], refs[False]))
+elif VICTIM == 'wide_wgrad4':
+    # the discriminator's 256 -> 512 4x4 stride-1 layer: wgrad_split16_kernel<4, true>, the form that keeps LDS-DMA and claims its CU's whole LDS
+    vN = 8
+    vx = torch.rand(vN, 256, 32, 32, device=dev, generator=g0) * 2 - 1
+    vg = (torch.rand(vN, 512, 31, 31, device=dev, generator=g0) * 2 - 1) * 0.01
+
+    def vwords(t):
+        out = torch.zeros(vN, dtype=torch.int32, device=dev)
+        L.absmax_samples(p(t), vN, t[0].numel(), p(out), ctypes.c_void_p(main.cuda_stream))
+        return out
+
+    vxm, vgm = vwords(vx), vwords(vg)
+    vsb = L.conv2d_scratch(vN, 32, 32, 512, 256, 4, 4, 1, 1)
+    assert vsb, "not the wide route"
+    varena = torch.empty(vsb // 4 + 64, device=dev)
+    vwb = L.conv2d_bwd_weight_workspace(vN, 256, 32, 32, 512, 31, 31, 4, 4, 1, 1)
+    vws = torch.empty(vwb // 4 + 64, device=dev)
+
+    def victim(out, handover):
+        e = extras(varena, vxm, vgm)
+        out.zero_()
+        L.conv2d_bwd_weight_ex(p(vx), 256, None, 0, p(vg), p(out), None, vN, 32, 32, 512, 31, 31, 4, 4, 1, 1, 0, p(vws), vwb,
+                               ctypes.c_void_p(side.cuda_stream), ctypes.byref(e))
+
+    gws = [torch.empty(512, 256, 4, 4, device=dev) for _ in range(NV)]
+    with torch.cuda.stream(side):
+        victim(gws[0], False)
+    torch.cuda.synchronize()
+    print('victim %s: route %d' % (VICTIM, L.last_route()))
+    refs = {True: gws[0].clone(), False: gws[0].clone()}
 elif VICTIM == 'wgrad2':
     # the exact-fp32 weight gradient (wgrad2_kernel, LDS-DMA staged, several workgroups per CU): the discriminator's 64 -> 128 4x4 stride-2 layer
     vN = 8
