@@ -32,7 +32,7 @@ extern "C" {
 #define NEMAR_EWORKSPACE (-3)
 
 /* library */
-int nemar_version(void);              /* major*10000 + minor*100 + patch; 500 = this header (0.4.x exported nemar_tune*) */
+int nemar_version(void);              /* major*10000 + minor*100 + patch; 600 = this header (0.4.x exported nemar_tune*) */
 const char* nemar_last_error(void);   /* thread-local message of the last failing call */
 
 /* ---- K9/K10/K11: sampling-grid generation fused into bilinear grid_sample ------------------------------
@@ -128,13 +128,21 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   scratch / scratch_bytes     transient arena of the wide-layer fp16 x 3 route for THIS call (nemar_conv2d_scratch bytes)
  *   src_max_words / _count      per-sample max |source| words (source = x0 for fwd / bwd_weight, gy for bwd_data); count = N or 1
  *   src2_max_words / _count     bwd_weight only: the same for gy
- *   src_planes                  fwd only: the source's operand planes written by its producer (nemar_instnorm_fwd_planes), scaled by
- *                               src_max_words
+ *   src_planes                  the source's operand planes written by its producer, scaled by src_max_words (count = N).  fwd: the
+ *                               channel-blocked planes of x0 (nemar_instnorm_fwd_planes `planes`); bwd_data: the data-gradient planes of
+ *                               gy (nemar_instnorm_bwd_planes `dgrad_planes`, written for THIS layer's pad_mode); bwd_weight: the
+ *                               pixel-major X planes of x0 (nemar_instnorm_fwd_planes `wgrad_planes`).  With planes the fp32 tensor of
+ *                               that operand is not read: its pointer only has to be non-NULL and distinct
  *   gy_planes_out / _bytes      bwd_data only: a buffer of nemar_conv2d_gy_planes_bytes(...) bytes.  When given together with
  *                               src_max_words (count = N) on a layer of the wide route, the pass that splits gy for the data gradient
  *                               ALSO writes the operand planes the weight gradient of the same layer needs (gy is read once) ...
  *   src2_planes                 ... and bwd_weight takes them here (with the SAME words as src2_max_words) instead of splitting gy again.
- *                               The buffer must stay untouched between the two calls.
+ *                               The buffer must stay untouched between the two calls.  (nemar_instnorm_bwd_planes `wgrad_planes`
+ *                               are the same planes from the producer of gy.)
+ *   addend                      bwd_data only: a tensor of gx0's shape ADDED to the data gradient in the kernel's epilogue (the
+ *                               ResnetBlock skip gradient, reference models/networks.py:443-446: out = x + conv_block(x))
+ *   out_max_words               bwd_data only: a NEMAR_MAX_WORDS(N) buffer; the epilogue publishes the per-sample max |gx0| (words 0..N-1)
+ *                               Both only where nemar_conv2d_bwd_data_fusable(...) says 1 — elsewhere the call fails with NEMAR_EINVAL.
  * A packed-weight workspace (prepacked = 1) must be reused under the same route conditions it was written under (arena present or
  * not, nemar_config_epoch unchanged). */
 typedef struct nemar_conv_extras {
@@ -148,7 +156,13 @@ typedef struct nemar_conv_extras {
     void* gy_planes_out;
     size_t gy_planes_bytes;
     const void* src2_planes;
+    const float* addend;
+    void* out_max_words;
 } nemar_conv_extras;
+/* 1: the layer's bwd_data_ex honours addend / out_max_words and takes src_planes, and its bwd_weight_ex takes both operands as planes */
+int nemar_conv2d_bwd_data_fusable(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode);
+/* bytes of the pixel-major X planes nemar_instnorm_fwd_planes can write for the weight gradient of a KS x KS / pad-1 reflect layer (0: none) */
+size_t nemar_conv2d_x_planes_bytes(int N, int C, int H, int W, int KS);
 /* bytes of the gy planes a bwd_data call can leave behind for the bwd_weight call of the same layer (0: this layer does not take them) */
 size_t nemar_conv2d_gy_planes_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode);
 /* 1 when the last nemar_conv2d_bwd_data_ex call on this thread filled its gy_planes_out buffer (check before passing it on as src2_planes) */
@@ -252,11 +266,33 @@ int nemar_instnorm_bwd_max(const float* x, const float* stats, const float* gy, 
  *              <= 2^(k-36) x max (norm_planes.hip).
  *   residual_max_words[N]  required with a residual: its per-sample maxima (a producer's max words)
  *   max_words  NEMAR_MAX_WORDS(N) buffer or NULL: the ACTUAL per-sample maxima of the output (the next layer's residual bound)
+ *   wgrad_planes  NULL, or nemar_conv2d_x_planes_bytes(N, C, H, W, 3) bytes: ALSO the pixel-major X planes the WEIGHT gradient of that
+ *              convolution reads (same scale; pass as src_planes + src_max_words of its nemar_conv2d_bwd_weight_ex): the layer then
+ *              runs neither of its split passes over this tensor
  * Limits: C % 8 == 0, W % 4 == 0, H * W <= 4096, N <= 256. */
 int nemar_instnorm_fwd_planes(const float* x, const float* residual, const void* residual_max_words, float* y, float* stats,
                               int N, int C, int H, int W, float eps, int act, float slope, float dropout_p,
                               unsigned long long seed, unsigned offset, void* planes, void* scale_words, void* max_words,
-                              void* stream);
+                              void* wgrad_planes, void* stream);
+/* The backward of that producer for a 3x3 / pad-1 convolution of the wide route IN FRONT of it (reference: autograd through
+ * conv -> InstanceNorm -> ReLU -> [Dropout] of ResnetBlock, models/networks.py:418-446): gx = InstanceNorm backward of gy through
+ * [dropout ->] act -> InstanceNorm (nemar_instnorm_bwd's formula; the dropout mask of (p, seed, offset) regenerated), written as the
+ * OPERAND PLANES of the convolution's two gradient calls instead of (gx != NULL: besides) the fp32 tensor:
+ *   dgrad_planes   2 * N * (C/8) * (H+4) * (W+4) 16-byte words: gy planes of nemar_conv2d_bwd_data_ex (extras.src_planes) for a layer
+ *                  with this pad_mode (0 zero, 1 reflect: the folded border rows of the reflect data gradient)
+ *   wgrad_planes   nemar_conv2d_gy_planes_bytes(...) bytes: gy planes of nemar_conv2d_bwd_weight_ex (extras.src2_planes)
+ *   scale_words[N] out: the a-priori bound the planes are scaled by, rstd_max(sample) * (2 + sqrt(HW)) [/ (1-p)] * max|gy|(sample);
+ *                  pass as src_max_words / src2_max_words of the two calls
+ *   gy_max_words[N]  per-sample max |gy| (a producer's words, nemar_conv_extras.out_max_words, or nemar_absmax_samples)
+ *   bias_partials  NULL or [N, C]: the sum of gx over each plane (the convolution's bias gradient = their sum over the batch:
+ *                  nemar_bias_from_partials)
+ * Either planes pointer may be NULL.  Limits as nemar_instnorm_fwd_planes; wgrad_planes: C % 64 == 0, W % 8 == 0. */
+int nemar_instnorm_bwd_planes(const float* x, const float* stats, const float* gy, const void* gy_max_words, int N, int C,
+                              int H, int W, int act, float slope, float dropout_p, unsigned long long seed, unsigned offset,
+                              int pad_mode, float* gx, void* dgrad_planes, void* wgrad_planes, void* scale_words,
+                              float* bias_partials, void* stream);
+/* gb[C] += sum over the batch of bias_partials [N, C], in batch order (bitwise reproducible) */
+int nemar_bias_from_partials(const float* bias_partials, int N, int C, float* gb, void* stream);
 /* ---- K5/K6/K7: pointwise, pooling, resize, dropout -----------------------------------------------------------------
  * act_bwd: gx = gy * f'(.) expressed with the activation OUTPUT y (f fused into a conv epilogue):
  *     nn.LeakyReLU / nn.ReLU / nn.Tanh — reference models/networks.py:377,576 ; models/stn/layers.py:61-64. */

@@ -64,7 +64,11 @@ SIGNATURES = {
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
-    "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp]),
+    "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "nemar_instnorm_bwd_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _fl, _fl, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nemar_bias_from_partials": (_i, [_vp, _i, _i, _vp, _vp]),
+    "nemar_conv2d_bwd_data_fusable": (_i, [_i] * 10),
+    "nemar_conv2d_x_planes_bytes": (_sz, [_i] * 5),
     "nemar_set_dropout_base": (_i, [_vp]),
     "nemar_store_words": (_i, [_vp, _vp, _i, _vp]),
     "nemar_pack_plan_record": (_i, [_i]),
@@ -113,7 +117,8 @@ class ConvExtras(C.Structure):
     """include/nemar_hip.h nemar_conv_extras"""
     _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("src_max_words", C.c_void_p), ("src_max_count", C.c_int),
                 ("src2_max_words", C.c_void_p), ("src2_max_count", C.c_int), ("src_planes", C.c_void_p),
-                ("gy_planes_out", C.c_void_p), ("gy_planes_bytes", C.c_size_t), ("src2_planes", C.c_void_p)]
+                ("gy_planes_out", C.c_void_p), ("gy_planes_bytes", C.c_size_t), ("src2_planes", C.c_void_p),
+                ("addend", C.c_void_p), ("out_max_words", C.c_void_p)]
 
 
 class Library:
@@ -158,7 +163,7 @@ class Library:
                                     "(libnemar_hip_ab.so; set NEMAR_AB_LIBRARY=1 before nemar_amd is imported)" % (self.__dict__.get("path"), full))
             raise AttributeError(name)
         fn = fns[full]
-        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty"):
+        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty", "nemar_conv2d_bwd_data_fusable"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

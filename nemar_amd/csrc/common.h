@@ -63,6 +63,8 @@ struct nemar_conv_extras {
     void* gy_planes_out;
     size_t gy_planes_bytes;
     const void* src2_planes;
+    const float* addend;
+    void* out_max_words;
 };
 
 // thread-local so the message survives being raised on autograd's backward thread

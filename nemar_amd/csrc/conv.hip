@@ -26,6 +26,7 @@
 
 #ifdef NEMAR_AB
 extern int g_split16_ring3;                      // conv_split16.hip
+extern int g_split16_ksplit_cap;
 extern int g_narrow_fwd4;                        // conv_narrow.hip
 extern int g_wg_xreg;                            // conv_split16_wgrad.hip
 void nemar_norm_planes_debug(int bits);          // norm_planes.hip: ablation bits of the fused producer (measurement only)
@@ -78,6 +79,10 @@ static thread_local size_t t_scratch_bytes = 0;
 static thread_local void* t_gy_planes_out = nullptr;  // bwd_data_ex: where the pass that splits gy also leaves the weight gradient's planes
 static thread_local size_t t_gy_planes_bytes = 0;
 static thread_local const void* t_src2_planes = nullptr;      // bwd_weight_ex: those planes
+static thread_local const void* t_x_wplanes = nullptr;        // bwd_weight_ex: the X planes of x a forward producer wrote (extras.src_planes)
+static thread_local const float* t_addend = nullptr;          // bwd_data_ex: tensor added to gx0 in the epilogue (extras.addend)
+static thread_local void* t_out_max = nullptr;                // bwd_data_ex: per-sample max |gx0| words (extras.out_max_words)
+static thread_local int t_fused_epilogue = 0;                 // did the last bwd_data_ex call honour them?
 static NEMAR_SWITCH(int, g_split_act, 0);          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
 static NEMAR_SWITCH(int, g_dual_gy, 1);            // key 35: the data-gradient call's split pass also writes the weight gradient's gy planes
 static thread_local int t_gy_planes_written = 0;      // did the last bwd_data_ex call on this thread fill gy_planes_out?
@@ -1025,8 +1030,11 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 nemar_split16_wgrad_g_bytes(N, H, W, K, R) > 0 && nemar_split16_wgrad_eligible(N, C, H, W, K, R, S, stride, pad))
                 dual = t_gy_planes_out;
             // (whether the planes were written is the split pass's own decision: variant, producer planes, g_dual_gy — ask it)
+            nemar_split16_set_epilogue(t_addend, t_out_max);
             t_gy_planes_written = nemar_split16_conv(gy, workspace, nullptr, gx0, N, H, W, C, K, R, R - 1 - pad, OH, OW, H, W, mode, g_scratch,
                                                      g_xcd_map, g_split16_variant, g_tl, dual, st) ? 1 : 0;
+            t_fused_epilogue = nemar_split16_epilogue_done();
+            nemar_split16_set_epilogue(nullptr, nullptr);
             g_last_route = 2;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (split-16)");
             return NEMAR_OK;
@@ -1332,7 +1340,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         (R == 3 || pad_mode == BORDER_ZERO) && g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K, R)) {
         // wide 3x3 stride-1 layers: fp16 x 3 on the 16-bit matrix pipe (conv_split16_wgrad.hip); bias gradient as its own reduction
         nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map,
-                            R == 3 ? t_src2_planes : nullptr, st);
+                            R == 3 ? t_src2_planes : nullptr, (R == 3 && pad_mode == BORDER_REFLECT) ? t_x_wplanes : nullptr, st);
         if (gb) {
             const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
             float* pb = part + (size_t)nemar_split16_wgrad_splits(N, C0, H, W, K, R) * K * J;
@@ -1423,6 +1431,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 36) { g_split_act = value != 0; return NEMAR_OK; }
     if (key == 37) { g_lds_claim = value; return NEMAR_OK; }      // kernel families whose workgroups claim the whole CU's LDS (common.h)
     if (key == 38) { g_wg_xreg = value != 0; return NEMAR_OK; }   // wide 3x3 weight gradient: X pieces through registers
+    if (key == 39) { g_split16_ksplit_cap = value < 1 ? 1 : (value > 8 ? 8 : value); return NEMAR_OK; }      // most reduction runs per tile of the wide-layer kernel
     if (key == 35) { g_dual_gy = value != 0; return NEMAR_OK; }
     if (key == 34) { nemar_split16_wgrad_tune(value); return NEMAR_OK; }      // wide weight gradient: 1 one gy copy (default), 0 KS shifted copies
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
@@ -1450,21 +1459,24 @@ struct ExtrasScope {
     const void* t0 = nullptr;
     const void* t1 = nullptr;
     const void* tp = nullptr;
-    ExtrasScope(const nemar_conv_extras* ex, const void* src, const void* src2, int N, int C, int H, int W) {
+    // planes_kind: the SPLIT16_* content extras.src_planes holds for this call (-1: the call takes no channel-blocked planes)
+    ExtrasScope(const nemar_conv_extras* ex, const void* src, const void* src2, int N, int C, int H, int W, int planes_kind) {
         if (!ex) return;
         if (ex->scratch && ex->scratch_bytes) { t_scratch = ex->scratch; t_scratch_bytes = ex->scratch_bytes; }
         if (ex->src_max_words && ex->src_max_count > 0) { nemar_split16_set_hint(src, ex->src_max_words, ex->src_max_count); t0 = src; }
         if (src2 && ex->src2_max_words && ex->src2_max_count > 0) { nemar_split16_set_hint(src2, ex->src2_max_words, ex->src2_max_count); t1 = src2; }
-        if (ex->src_planes) { nemar_split16_set_planes_hint(src, ex->src_planes, N, C, H, W); tp = src; }
+        if (ex->src_planes && planes_kind >= 0) { nemar_split16_set_planes_hint(src, ex->src_planes, N, C, H, W, planes_kind); tp = src; }
         t_gy_planes_out = ex->gy_planes_out; t_gy_planes_bytes = ex->gy_planes_bytes;
         t_src2_planes = ex->src2_planes;
+        t_addend = ex->addend; t_out_max = ex->out_max_words;
     }
     ~ExtrasScope() {
         t_scratch = nullptr; t_scratch_bytes = 0;
         t_gy_planes_out = nullptr; t_gy_planes_bytes = 0; t_src2_planes = nullptr;
+        t_addend = nullptr; t_out_max = nullptr; t_x_wplanes = nullptr;
         if (t0) nemar_split16_set_hint(t0, nullptr, 0);
         if (t1) nemar_split16_set_hint(t1, nullptr, 0);
-        if (tp) nemar_split16_set_planes_hint(tp, nullptr, 0, 0, 0, 0);
+        if (tp) nemar_split16_set_planes_hint(tp, nullptr, 0, 0, 0, 0, 0);
     }
 };
 }  // namespace
@@ -1480,6 +1492,13 @@ NEMAR_API size_t nemar_conv2d_gy_planes_bytes(int N, int C, int H, int W, int K,
     return nemar_split16_wgrad_g_bytes(N, H, W, K, R);
 }
 
+// 1 when nemar_conv2d_bwd_data_ex of this layer honours nemar_conv_extras.addend / .out_max_words and takes gy as producer-written planes
+// (.src_planes), and its nemar_conv2d_bwd_weight_ex takes both operands as planes: the wide 3x3 route with an unsplit reduction
+NEMAR_API int nemar_conv2d_bwd_data_fusable(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
+    if (nemar_conv2d_gy_planes_bytes(N, C, H, W, K, R, S, stride, pad, pad_mode) == 0) return 0;
+    return nemar_split16_ksplit(N, H, W, C, K) == 1 ? 1 : 0;
+}
+
 // 1 when the last nemar_conv2d_bwd_data_ex call on this thread filled its gy_planes_out buffer (the route it took supports it): only then
 // may the buffer be handed to nemar_conv2d_bwd_weight_ex as src2_planes
 NEMAR_API int nemar_last_gy_planes(void) { return t_gy_planes_written; }
@@ -1488,8 +1507,8 @@ NEMAR_API int nemar_conv2d_fwd_ex(const float* x0, int C0, const float* x1, int 
                                   int H, int W, int K, int R, int S, int stride, int pad, int pad_mode, int act, float slope,
                                   void* workspace, size_t ws_bytes, int prepacked, void* stream, const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.src2_planes = nullptr; }
-    ExtrasScope scope(extras ? &e : nullptr, x0, nullptr, N, C0 + C1, H, W);
+    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.src2_planes = nullptr; e.addend = nullptr; e.out_max_words = nullptr; }
+    ExtrasScope scope(extras ? &e : nullptr, x0, nullptr, N, C0 + C1, H, W, SPLIT16_REFLECT);
     return nemar_conv2d_fwd(x0, C0, x1, C1, w, bias, y, N, H, W, K, R, S, stride, pad, pad_mode, act, slope, workspace, ws_bytes, prepacked, stream);
 }
 
@@ -1498,19 +1517,28 @@ NEMAR_API int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const fl
                                        int pad_mode, void* workspace, size_t ws_bytes, int prepacked, void* stream,
                                        const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.src_planes = nullptr; e.src2_planes = nullptr; }
-    ExtrasScope scope(extras ? &e : nullptr, gy, nullptr, N, K, OH, OW);
+    if (extras) { e = *extras; e.src2_planes = nullptr; }
+    // (extras.src_planes: the data-gradient planes of gy nemar_instnorm_bwd_planes wrote, in the content of THIS layer's padding)
+    ExtrasScope scope(extras ? &e : nullptr, gy, nullptr, N, K, OH, OW, pad_mode == BORDER_REFLECT ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO);
     t_gy_planes_written = 0;
-    return nemar_conv2d_bwd_data(gy, w, bias, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes,
-                                 prepacked, stream);
+    t_fused_epilogue = 0;
+    const int rc = nemar_conv2d_bwd_data(gy, w, bias, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace,
+                                         ws_bytes, prepacked, stream);
+    if (rc == NEMAR_OK && extras && (extras->addend || extras->out_max_words) && !t_fused_epilogue) {
+        nemar_set_error("conv2d_bwd_data_ex: this layer's route has no fused epilogue (addend / out_max_words): ask nemar_conv2d_bwd_data_fusable first");
+        return NEMAR_EINVAL;
+    }
+    return rc;
 }
 
 NEMAR_API int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x1, int C1, const float* gy, float* gw, float* gb, int N,
                                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
                                          void* workspace, size_t ws_bytes, void* stream, const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.src_planes = nullptr; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; }
-    ExtrasScope scope(extras ? &e : nullptr, x0, gy, N, C0 + C1, H, W);
+    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.addend = nullptr; e.out_max_words = nullptr; }
+    // (extras.src_planes: the weight gradient's X planes of x0 nemar_instnorm_fwd_planes wrote — pixel-major, not a channel-blocked hint)
+    ExtrasScope scope(extras ? &e : nullptr, x0, gy, N, C0 + C1, H, W, -1);
+    t_x_wplanes = extras ? extras->src_planes : nullptr;
     return nemar_conv2d_bwd_weight(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes, stream);
 }
 

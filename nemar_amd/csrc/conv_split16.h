@@ -33,8 +33,9 @@ int nemar_split16_wgrad_splits(int N, int C, int H, int W, int K, int KS);      
 void nemar_split16_wgrad_tune(int one_copy);          // nemar_tune(34): 1 (default) one gy copy + in-register shifts, 0 KS copies
 #endif
 // g_planes != NULL: the G_0 planes of gy already exist (nemar_split16_dual_split wrote them, scaled by the max words hinted for gy)
+// x_planes != NULL: the X planes of x already exist (nemar_instnorm_fwd_planes wrote them, scaled by the max words hinted for x)
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
-                         void* scratch, float* part, int xcd_map, const void* g_planes, hipStream_t st);
+                         void* scratch, float* part, int xcd_map, const void* g_planes, const void* x_planes, hipStream_t st);
 size_t nemar_split16_wgrad_g_bytes(int N, int H, int W, int K, int KS);      // bytes of the G_0 planes (two 16-bit planes)
 // one pass over gy [N, K, H, W] (3x3 / pad 1 layers): the data gradient's channel-blocked padded planes (mode SPLIT16_ZERO or
 // SPLIT16_DGRAD_REFLECT, bit-identical to split_planes_kernel's) into `dplanes` AND the weight gradient's G_0 planes into `gplanes`
@@ -50,7 +51,12 @@ void nemar_sum_partials_act(const float* part, long long stride, int splits, flo
 void nemar_split16_absmax(const float* x, int samples, long long per, void* out, hipStream_t st);
 void nemar_split16_set_hint(const void* tensor, const void* word, int count);  // word == NULL clears; count = words (N or 1)
 const unsigned* nemar_split16_hint(const void* tensor, int* count);
-void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W);
+void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W, int kind);      // kind: SPLIT16_* content
+// epilogue side inputs of the NEXT nemar_split16_conv call on this thread: addend [N, M, OH, OW] added to the result, max_words
+// (NEMAR_MAX_WORDS(N)) <- per-sample max |result|.  Honoured only when the tile's reduction is not split over workgroups:
+// nemar_split16_epilogue_done() says whether the last call did both.  set_epilogue(nullptr, nullptr) clears.
+void nemar_split16_set_epilogue(const float* addend, void* max_words);
+int nemar_split16_epilogue_done();
 const unsigned* nemar_split16_source_max(const float* src, int N, long long per, unsigned* own, int* stride, hipStream_t st);
 
 // ---- measurement hook: HIP events on the launch stream around the main kernel of every nemar_split16_conv call while enabled ----

@@ -40,6 +40,7 @@
 #include "common.h"
 #include "conv_split16.h"
 #include "pack_plan.h"
+#include "max_words.h"
 
 namespace {
 
@@ -271,6 +272,7 @@ struct Split16Params {
     const u32x4* planes;       // split source, see split_planes_kernel
     const u32x4* wp;           // packed weights
     const float* bias;         // [M] or null
+    int bias_al;               // bias is 16-byte aligned (float4 loads in the epilogue)
     float* dst;                // [N, M, H, W]
     int N, H, W, M, Cred;
     int Ws, HpWs;              // slots per plane row, 16-byte words per (plane, n, channel group) image
@@ -288,6 +290,8 @@ struct Split16Params {
     const unsigned* wmax;      // power-of-two scales follow from them)
     int xstride;
     long long* tl;             // NEMAR_TIMELINE builds: cycle stamps of workgroup 0 (tools/timeline_split16.py)
+    const float* addend;       // [N, M, OH, OW] added to the result in the epilogue (the ResnetBlock skip gradient), or null (ksplit == 1 only)
+    unsigned* maxw;            // NEMAR_MAX_WORDS(N) buffer: this workgroup's max |result| into its partial word, or null (ksplit == 1 only)
 };
 
 __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
@@ -326,7 +330,10 @@ __device__ __forceinline__ void glds16u(const u32x4* ubase, unsigned lane_bytes,
 // needs 76.8 KB of LDS and TWO workgroups share a CU (two waves per SIMD: while one sits at a barrier or waits for LDS the other issues
 // MFMAs).  LDS is dynamic: [RING weight stages][two halo buffers].  (RING = 3 needs NT % 3 == 0: the slot of a tap is then a
 // compile-time constant.)
-template <int NBW, int NPL, int KS = 3, int RING = 4>   // NBW = halo copy slots per wave per tap on taps 3..NT-1 of a chunk (they carry the next chunk's halo)
+// EPI = the fused epilogue of the ResnetBlock data gradient (p.addend, p.maxw): its own instantiation, so that the forward / plain
+// data-gradient kernel keeps the register allocation it was tuned with (with the 128 addend loads in one epilogue the allocator ran
+// out of architectural registers and moved loop-carried values to the accumulator file: 189 -> 218 us per launch)
+template <int NBW, int NPL, int KS = 3, int RING = 4, int EPI = 0>      // EPI: 0 plain, 1 + max words, 2 + addend + max words   // NBW = halo copy slots per wave per tap on taps 3..NT-1 of a chunk (they carry the next chunk's halo)
 __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
     constexpr int NT = KS * KS;                          // taps
     constexpr int ASTAGE16 = 256 * NPL, KB = (NT - 3) * NBW, NREG = 2 * NPL, NP = NPL == 3 ? 6 : 3, NMFMA = 8 * NP;
@@ -597,20 +604,76 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
     const size_t HW = (size_t)p.OH * p.OW;
     // fp16 form: take the two power-of-two operand scales out again (exact)
     const float unscale = NPL == 2 ? 1.f / (pow2_scale(p.xmax[n * p.xstride]) * pow2_scale(*p.wmax)) : 1.f;
+    if (!EPI) {
+        // element (mt, r) of a lane lies a wave-uniform (32 mt + (r & 3) + 8 (r >> 2)) HW floats behind the lane's first one: one 64-bit
+        // add per store; the 16 bias values of a group are four aligned 16-byte loads (round 6: the per-element form — a guarded scalar
+        // load and a 64-bit multiply per store — cost 15 us of a 200 us launch)
+        const bool with_bias = p.bias != nullptr && zsplit == 0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (KS != 3 && (y0 + row[nt] >= p.OH || col[nt] >= p.OW)) continue;      // the row / column beyond the valid output
+            float* const d0 = p.dst + (size_t)zsplit * p.slab_stride + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt] +
+                              (size_t)(mblk * 128 + 4 * lhi) * HW;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float bv[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (with_bias) {
+                        const float* const bp = p.bias + mblk * 128 + 4 * lhi + mt * 32 + 8 * q;
+                        b4 = p.bias_al ? *reinterpret_cast<const float4*>(bp) : make_float4(bp[0], bp[1], bp[2], bp[3]);
+                    }
+                    bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mt][nt][r];
+                    if (NPL == 2) v *= unscale;
+                    v += bv[r];
+                    d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
+    // ---- EPI: result [+ addend (the skip gradient)] -> dst, and the tile's max |result| into its partial word (max_words.h).  Eight groups
+    // of 16 elements, each [its addend loads][add, max, stores], fenced: at most 16 loads' worth of extra registers.  Element (mt, r) of a
+    // lane lies a wave-uniform (32 mt + (r & 3) + 8 (r >> 2)) HW floats behind the lane's first one.
+    unsigned omax = 0;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        if (KS != 3 && (y0 + row[nt] >= p.OH || col[nt] >= p.OW)) continue;      // the row / column beyond the valid output
-        float* const d0 = p.dst + (size_t)zsplit * p.slab_stride + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt];
+        const size_t o0 = (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt] + (size_t)(mblk * 128 + 4 * lhi) * HW;
+        float* const d0 = p.dst + o0;
+        const float* const a0 = p.addend + o0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+            float ad[16];
+            if (EPI == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ad[r] = a0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW];
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mblk * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float v = acc[mt][nt][r];
-                if (NPL == 2) v *= unscale;
-                if (p.bias && zsplit == 0) v += p.bias[m];
-                d0[(size_t)m * HW] = v;
+                float v = acc[mt][nt][r] * unscale;
+                if (EPI == 2) v += ad[r];
+                d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW] = v;
+                omax = max(omax, finite_bits(__builtin_bit_cast(unsigned, v)));
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (p.maxw) {
+        __shared__ unsigned mred[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+        if (lane == 0) mred[wid] = omax;
+        __syncthreads();
+        if (tid == 0) {
+            const int parts = p.tiles_per_img * p.mblks;
+            p.maxw[p.N + (size_t)n * parts + (ptile - n * p.tiles_per_img) * p.mblks + mblk] = max(max(mred[0], mred[1]), max(mred[2], mred[3]));
         }
     }
 }
@@ -639,10 +702,11 @@ bool nemar_split16_eligible(int N, int H, int W, int M, int Cred, int R, int S, 
 }
 
 // reduction runs per tile: enough workgroups for the 256 CUs when the layer has few tiles (each run >= 4 chunks)
+NEMAR_SWITCH(int, g_split16_ksplit_cap, 8);    // nemar_tune(39): most reduction runs per tile (1: never split — the tests' small shapes with the fused epilogue)
 int nemar_split16_ksplit(int N, int H, int W, int M, int Cred) {
     const int tiles = N * (H / (256 / W)) * (M / 128), nchunks = Cred / 16;
     int ks = 1;
-    while (tiles * ks * 2 <= 256 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 4 && ks < 8) ks *= 2;
+    while (tiles * ks * 2 <= 256 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 4 && ks < g_split16_ksplit_cap) ks *= 2;
     return ks;
 }
 
@@ -673,29 +737,38 @@ thread_local const void* g_hint_tensor[4] = {nullptr, nullptr, nullptr, nullptr}
 thread_local const unsigned* g_hint_word[4] = {nullptr, nullptr, nullptr, nullptr};
 thread_local int g_hint_count[4] = {0, 0, 0, 0};
 // nemar_planes_hint: the fp16 x 3 planes of a source already exist (a producer wrote them: norm_planes.hip) — reflect 3x3 layout only
-struct PlanesHint { const void* tensor; const void* planes; int N, C, H, W; };
-thread_local PlanesHint g_planes_hint[2] = {{nullptr, nullptr, 0, 0, 0, 0}, {nullptr, nullptr, 0, 0, 0, 0}};
+// kind = the SPLIT16_* content the planes hold (SPLIT16_REFLECT: a forward producer's; SPLIT16_ZERO / SPLIT16_DGRAD_REFLECT: the
+// data-gradient planes nemar_instnorm_bwd_planes writes)
+struct PlanesHint { const void* tensor; const void* planes; int N, C, H, W, kind; };
+thread_local PlanesHint g_planes_hint[2] = {{nullptr, nullptr, 0, 0, 0, 0, 0}, {nullptr, nullptr, 0, 0, 0, 0, 0}};
 }  // namespace
 
-void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W) {
+void nemar_split16_set_planes_hint(const void* tensor, const void* planes, int N, int C, int H, int W, int kind) {
     int slot = -1;
     for (int i = 0; i < 2; ++i)
         if (g_planes_hint[i].tensor == tensor) slot = i;
     if (!planes) {
-        if (slot >= 0) g_planes_hint[slot] = PlanesHint{nullptr, nullptr, 0, 0, 0, 0};
+        if (slot >= 0) g_planes_hint[slot] = PlanesHint{nullptr, nullptr, 0, 0, 0, 0, 0};
         return;
     }
     if (slot < 0) slot = g_planes_hint[0].tensor ? 1 : 0;
-    g_planes_hint[slot] = PlanesHint{tensor, planes, N, C, H, W};
+    g_planes_hint[slot] = PlanesHint{tensor, planes, N, C, H, W, kind};
 }
 
-static const void* planes_hint_for(const void* tensor, int N, int C, int H, int W) {
+static const void* planes_hint_for(const void* tensor, int N, int C, int H, int W, int kind) {
     for (int i = 0; i < 2; ++i) {
         const PlanesHint& h = g_planes_hint[i];
-        if (h.tensor == tensor && tensor && h.N == N && h.C == C && h.H == H && h.W == W) return h.planes;
+        if (h.tensor == tensor && tensor && h.N == N && h.C == C && h.H == H && h.W == W && h.kind == kind) return h.planes;
     }
     return nullptr;
 }
+
+// the epilogue side inputs of the next nemar_split16_conv call on this thread (conv.hip sets them from nemar_conv_extras, one call)
+thread_local const float* g_s16_addend = nullptr;
+thread_local unsigned* g_s16_maxw = nullptr;
+thread_local int g_s16_epilogue_done = 0;
+void nemar_split16_set_epilogue(const float* addend, void* max_words) { g_s16_addend = addend; g_s16_maxw = (unsigned*)max_words; g_s16_epilogue_done = 0; }
+int nemar_split16_epilogue_done() { return g_s16_epilogue_done; }
 
 const unsigned* nemar_split16_hint(const void* tensor, int* count) {
     for (int i = 0; i < 4; ++i)
@@ -829,9 +902,9 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     const unsigned* xmax = xmw;
     int xstride = 0;
     const void* ready = nullptr;          // planes a producer already wrote (with the max-word hint they were scaled by)
-    if (variant == 4 && mode == SPLIT16_REFLECT && src_pad == 1 && Hs == H && Ws_src == W) {
+    if (variant == 4 && KS == 3 && src_pad == 1 && Hs == H && Ws_src == W) {
         int count = 0;
-        ready = planes_hint_for(src, N, Cred, H, W);
+        ready = planes_hint_for(src, N, Cred, H, W, mode);
         if (ready && !(nemar_split16_hint(src, &count) && count == N)) ready = nullptr;
     }
     if (variant == 4) {
@@ -853,6 +926,7 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     p.planes = ready ? (const u32x4*)ready : (const u32x4*)scratch;
     p.wp = (const u32x4*)packed;
     p.bias = bias;
+    p.bias_al = (((uintptr_t)bias) & 15) == 0 ? 1 : 0;
     p.dst = dst;
     p.N = N; p.H = H; p.W = W; p.M = M; p.Cred = Cred;
     p.Ws = W + 4;
@@ -875,6 +949,11 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     const int tiles = N * p.tiles_per_img * p.mblks;
     p.ksplit = nemar_split16_ksplit(N, H, W, M, Cred);
     p.slab_stride = (long long)N * M * OH * OW;
+    // fused epilogue (skip-gradient add, per-sample max of the result): only where a tile's whole reduction runs in one workgroup
+    const bool fuse = p.ksplit == 1 && variant == 4 && KS == 3 && !bias && (g_s16_addend || g_s16_maxw);
+    p.addend = fuse ? g_s16_addend : nullptr;
+    p.maxw = fuse ? g_s16_maxw : nullptr;
+    g_s16_epilogue_done = fuse ? 1 : 0;
     float* const final_dst = dst;
     if (p.ksplit > 1) p.dst = (float*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W));       // slabs behind the planes
     const int grid = tiles * p.ksplit;
@@ -883,16 +962,17 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     const dim3 g(grid);
     // dynamic LDS: [RING weight stages][two halo buffers]; above 64 KiB the attribute is needed (nemar_lds_bytes sets it once per instantiation)
 #ifdef NEMAR_HOST_EMULATION
-#define S16_GO(NBW_, NPL_, KS_, RING_) { hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), g, dim3(256), 0, st, p); }
+#define S16_GO_(NBW_, NPL_, KS_, RING_, EPI_) { hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_, EPI_>), g, dim3(256), 0, st, p); }
 #else
-#define S16_GO(NBW_, NPL_, KS_, RING_)                                                                                  \
+#define S16_GO_(NBW_, NPL_, KS_, RING_, EPI_)                                                                           \
     {                                                                                                                   \
         const size_t need_ = ((size_t)(RING_) * 256 * (NPL_) + (size_t)2 * 2 * (NPL_) * (p.halo16 + p.aux16)) * 16;     \
-        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), need_,      \
+        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&igemm_split16_kernel<NBW_, NPL_, KS_, RING_, EPI_>), need_,      \
                                             (g_lds_claim & 2) != 0);                 /* (whole-CU claim: common.h) */   \
-        hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_>), g, dim3(256), lds_, st, p);                  \
+        hipLaunchKernelGGL((igemm_split16_kernel<NBW_, NPL_, KS_, RING_, EPI_>), g, dim3(256), lds_, st, p);            \
     }
 #endif
+#define S16_GO(NBW_, NPL_, KS_, RING_) S16_GO_(NBW_, NPL_, KS_, RING_, 0)
     if (variant == 4) {                 // fp16 x 3 (nemar_split16_eligible checked the LDS budget)
         const int ipr = nemar_cdiv(p.halo16, 64) + nemar_cdiv(p.aux16, 64);
         const int nbw = nemar_cdiv(nemar_cdiv(4 * ipr, 4), KS * KS - 3);
@@ -908,10 +988,17 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
                 else if (nbw == 2) S16_GO(2, 2, 3, 3)
                 else S16_GO(3, 2, 3, 3)
             })
+            else if (fuse && p.addend && nbw <= 1) S16_GO_(1, 2, 3, 4, 2)
+            else if (fuse && p.addend && nbw == 2) S16_GO_(2, 2, 3, 4, 2)
+            else if (fuse && p.addend) S16_GO_(3, 2, 3, 4, 2)
+            else if (fuse && nbw <= 1) S16_GO_(1, 2, 3, 4, 1)
+            else if (fuse && nbw == 2) S16_GO_(2, 2, 3, 4, 1)
+            else if (fuse) S16_GO_(3, 2, 3, 4, 1)
             else if (nbw <= 1) S16_GO(1, 2, 3, 4)
             else if (nbw == 2) S16_GO(2, 2, 3, 4)
             else S16_GO(3, 2, 3, 4))
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
+        if (p.maxw) max_words_finalize(p.maxw, N, p.tiles_per_img * p.mblks, st);
         return dual_written;
     }
 #ifdef NEMAR_AB      // nemar_tune(21, 3): bf16 x 6 products
@@ -928,6 +1015,7 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     }
 #endif
 #undef S16_GO
+#undef S16_GO_
     (void)region;
     return dual_written;
 }

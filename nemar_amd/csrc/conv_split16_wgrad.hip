@@ -511,14 +511,15 @@ void nemar_split16_dual_split(const float* gy, void* dplanes, void* gplanes, int
 }
 
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
-                         void* scratch, float* part, int xcd_map, const void* g_planes, hipStream_t st) {
+                         void* scratch, float* part, int xcd_map, const void* g_planes, const void* x_planes, hipStream_t st) {
     const int CPR = (W + 2 + 7) / 8, KBLK = K / 64, CBLK = C / 64;
     const int OHg = H + 3 - KS, OWg = W + 3 - KS, Hg = g_rows(H, KS), Hx = Hg + KS - 1;
     const long long gtotal = (long long)N * K * Hg * CPR, xtotal = (long long)N * C * Hx * CPR;      // words per plane block
     const bool oneg = g_one_g != 0;
     const bool have_g = oneg && g_planes != nullptr;
     const u32x4* const G = have_g ? (const u32x4*)g_planes : (const u32x4*)scratch;
-    u32x4* const X = (u32x4*)scratch + 2 * (oneg ? 1 : KS) * gtotal;
+    const bool have_x = x_planes != nullptr && KS == 3;       // a forward producer wrote the X planes (norm_planes.hip)
+    u32x4* const X = have_x ? (u32x4*)const_cast<void*>(x_planes) : (u32x4*)scratch + 2 * (oneg ? 1 : KS) * gtotal;
     unsigned* const mw = (unsigned*)((char*)scratch + nemar_split16_wgrad_scratch_bytes(N, C, H, W, K, KS) - 2048);    // 2 x 256 words
     int gstride = 0, xstride = 0;
     const unsigned* const gmax = nemar_split16_source_max(gy, N, (long long)K * OHg * OWg, mw, &gstride, st);
@@ -535,8 +536,9 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     else                                                                                                                           \
         hipLaunchKernelGGL((split_wgrad_g_kernel<TW_, 4>), dim3(N * KBLK * Hg), dim3(256), 0, st, gy, (u32x4*)scratch, N, K, OHg, OWg, Hg, CPR, gtotal, \
                            gmax, gstride);)                                                                                        \
-    hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * Hx), dim3(256), 0, st, x, X, N, C, H, W, Hx, CPR, reflect, xtotal, \
-                       xmax, xstride);
+    if (!have_x)                                                                                                                   \
+        hipLaunchKernelGGL((split_wgrad_x_kernel<TW_>), dim3(N * CBLK * Hx), dim3(256), 0, st, x, X, N, C, H, W, Hx, CPR, reflect, xtotal, \
+                           xmax, xstride);
     if (W <= 64) { WG_SPLIT(64) } else if (W <= 128) { WG_SPLIT(128) } else { WG_SPLIT(256) }
 #undef WG_SPLIT
     WgParams p;

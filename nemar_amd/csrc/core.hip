@@ -14,22 +14,34 @@ size_t nemar_lds_bytes(const void* kernel, size_t need, bool claim) {
     return need;                                       // (the emulator's kernels hold their LDS image as static arrays)
 #else
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> fill_of;      // kernel -> dynamic bytes that fill the CU beside its static LDS
+    // (device, kernel) -> dynamic bytes that fill the CU beside the kernel's static LDS (the attribute is per device)
+    static std::unordered_map<unsigned long long, size_t> fill_of;
     size_t fill;
     {
         std::lock_guard<std::mutex> lock(mu);
-        auto it = fill_of.find(kernel);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long key = (unsigned long long)(uintptr_t)kernel ^ ((unsigned long long)(dev + 1) << 56);
+        auto it = fill_of.find(key);
         if (it == fill_of.end()) {
             hipFuncAttributes fa;
             size_t stat = 0;
             if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) stat = fa.sharedSizeBytes;
-            int dev = 0, cu = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || cu <= 0) cu = 160 * 1024;
+            int cu = 0;
+            // gfx950 has 160 KiB of LDS per CU; a runtime that reports less (64 KiB: the per-workgroup default of older ROCm) must not
+            // put the attribute below what the kernels ask for
+            if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || cu < 160 * 1024) cu = 160 * 1024;
             fill = (size_t)cu > stat ? (size_t)cu - stat : 0;
-            (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill);
+            if (fill < need) fill = need;
+            const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill);
+            if (e != hipSuccess) nemar_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu): %s", fill, hipGetErrorString(e));
             (void)hipGetLastError();
-            it = fill_of.emplace(kernel, fill).first;
+            it = fill_of.emplace(key, fill).first;
+        } else if (it->second < need) {
+            const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (e != hipSuccess) nemar_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu): %s", need, hipGetErrorString(e));
+            (void)hipGetLastError();
+            it->second = need;
         }
         fill = it->second;
     }
@@ -37,7 +49,8 @@ size_t nemar_lds_bytes(const void* kernel, size_t need, bool claim) {
 #endif
 }
 
-#define NEMAR_HIP_VERSION 500  // major*10000 + minor*100 + patch  (0.5.0: round 5 — no nemar_tune* in the product library: the measurement
+#define NEMAR_HIP_VERSION 600  // major*10000 + minor*100 + patch  (0.6.0: round 6 — producer-written operand planes for all three calls of the
+                               // wide layers, fused skip-gradient add / max words in the data gradient's epilogue; 0.5.0: round 5 — no nemar_tune* in the product library: the measurement
                                // switches are constants there and live in libnemar_hip_ab.so (-DNEMAR_AB, include/nemar_hip_ab.h);
                                // 0.4.0: side inputs per call only, weight-pack plans, nemar_store_words, 7x7 layers on the 16-bit pipe)
 

@@ -18,6 +18,7 @@
 // words, the plane is read once (float4 per channel), statistics are the exact two-pass form of norm.hip from registers.
 #include "common.h"
 #include "max_words.h"
+#include "conv_split16.h"
 
 namespace {
 
@@ -82,7 +83,15 @@ struct NormPlanesParams {
     unsigned seed_lo, seed_hi, offset;
     const unsigned* obase;     // nemar_set_dropout_base word (added to offset) or null
     int dbg;                   // measurement only (nemar_tune(31, bits)): 1 no plane stores, 2 no LDS transpose, 4 no statistics, 8 no fp32 stores
+    u32x4* xw;                 // the weight gradient's pixel-major X planes of y (conv_split16_wgrad.hip layout, reflect border) or null
+    long long xplane16;        // 16-byte words per X plane
+    int CPR, Hx;               // 8-pixel chunks per padded row, plane rows (>= H + 2; rows beyond the padded image are zero)
 };
+
+// the X planes' staging tile: [8 channels][H rows][CPR * 8 padded pixels] 16-bit values (+ 8 per channel: the 16-byte reads of the 8
+// channels of one chunk fall into different LDS banks); one plane (hi, then lo) at a time, in the memory of the transpose buffer
+constexpr int XT_MAX = 64 * 72;                    // H * CPR * 8 of the largest plane served (64 x 64)
+constexpr int NP_LDS_BYTES = 8 * (XT_MAX + 8) * 2 > 16 * 256 * 16 ? 8 * (XT_MAX + 8) * 2 : 16 * 256 * 16;
 
 // sums of eight per-thread values over the workgroup -> tot[0..7] (all threads)
 __device__ __forceinline__ void block_sum8(float* s, float* red, float* tot) {
@@ -108,7 +117,8 @@ __device__ __forceinline__ void block_sum8(float* s, float* red, float* tot) {
 __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams p) {
     __shared__ float red[136];
     __shared__ unsigned mred[16];
-    __shared__ u32x4 xpose[16][256];                       // per wave: 256 plane words in flight between the two orders
+    __shared__ __attribute__((aligned(16))) unsigned char np_lds[NP_LDS_BYTES];
+    u32x4 (*const xpose)[256] = reinterpret_cast<u32x4 (*)[256]>(np_lds);      // per wave: 256 plane words in flight between the two orders
     const int CG = p.C >> 3;
     const int n = blockIdx.x / CG, cg = blockIdx.x - n * CG;
     const int HW = p.H * p.W, W = p.W, H = p.H;
@@ -236,6 +246,49 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
             }
         }
     }
+    // ---- the weight gradient's X planes (conv_split16_wgrad.hip: word ((pl N + n) CBLK + cblk) FX + yp CPR + q) 64 + cc = padded pixels
+    // 8 q .. 8 q + 7 of channel cc in padded row yp, mirrored border materialised, zero beyond column W + 1 / row H + 1).  A word runs
+    // along the row of ONE channel: the 16-bit halves go through an LDS tile [channel][row][padded pixel] and come back as 16-byte reads.
+    if (p.xw) {
+        unsigned short* const xt = reinterpret_cast<unsigned short*>(np_lds);
+        const int RS = p.CPR * 8, CS = H * RS + 8;
+        const int row = (4 * t) / W, c0 = 4 * t - row * W;
+        const int CBLK = p.C >> 6, FX = p.Hx * p.CPR;
+        const int nwords = 8 * FX;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned short u[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[e] = (unsigned short)(((pl ? lw[e][j >> 1] : hw[e][j >> 1]) >> (16 * (j & 1))) & 0xffffu);
+                    unsigned short* const r = xt + j * CS + row * RS + c0 + 1;       // padded pixel = column + 1
+                    r[0] = u[0];
+                    *reinterpret_cast<unsigned*>(r + 1) = (unsigned)u[1] | ((unsigned)u[2] << 16);
+                    r[3] = u[3];
+                    if (c0 == 0) r[-1] = u[1];                                       // padded pixel 0 mirrors column 1
+                    if (c0 == W - 4) {
+                        r[4] = u[2];                                                 // padded pixel W + 1 mirrors column W - 2
+                        for (int z = W + 2; z < RS; ++z) xt[j * CS + row * RS + z] = 0;
+                    }
+                }
+            }
+            __syncthreads();
+            u32x4* const dst = p.xw + (pl ? p.xplane16 : 0) + (((size_t)n * CBLK + (cg >> 3)) * FX) * 64 + (cg & 7) * 8;
+            for (int i = t; i < nwords; i += 1024) {
+                const int cc = i & 7, f = i >> 3;
+                const int yp = f / p.CPR, q = f - yp * p.CPR;
+                u32x4 word = u32x4{0u, 0u, 0u, 0u};
+                if (yp <= H + 1) {
+                    const int sr = yp == 0 ? 1 : (yp == H + 1 ? H - 2 : yp - 1);
+                    word = *reinterpret_cast<const u32x4*>(xt + cc * CS + sr * RS + q * 8);
+                }
+                dst[(size_t)f * 64 + cc] = word;
+            }
+        }
+    }
     if (p.maxw) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
@@ -245,6 +298,216 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
             unsigned m = mred[0];
             for (int i = 1; i < 16; ++i) m = max(m, mred[i]);
             p.maxw[p.N + blockIdx.x] = m;
+        }
+    }
+}
+
+
+// ---- backward: InstanceNorm (+ activation, + dropout) gradient that writes the OPERAND PLANES of the two gradient calls of the 3x3
+// convolution in front of it instead of (or besides) the fp32 tensor ------------------------------------------------------------------
+//     g = gy [* dropout mask / (1 - p)] * act'(xhat);   gx = rstd (g - mean(g) - xhat mean(g xhat))          (norm.hip's formula)
+//     -> the data gradient's channel-blocked padded planes of gx (conv_split16.hip, SPLIT16_ZERO or SPLIT16_DGRAD_REFLECT content:
+//        what split_dual_kernel / split_planes_kernel make of the fp32 tensor) and the weight gradient's G_0 planes
+//        (conv_split16_wgrad.hip), both scaled by a power of two from the a-priori bound
+//            |gx| <= rstd_max(sample) (2 + sqrt(HW)) max |g|        (|mean g| <= max |g|, |mean(g xhat)| <= max |g|, |xhat| <= sqrt(HW))
+//        written to scale_words[n]: the consumer's epilogue unscales with it, exactly as with the forward producer's bound;
+//     -> per-plane sums of gx (the convolution's bias gradient is their sum over the batch; mathematically zero, rounding in practice).
+// One workgroup = (sample, 8 channels), 1024 threads x (4 pixels x 8 channels) like the forward kernel; x and gy are read once, the
+// fp32 result goes through an LDS tile [8][HW + 4] from which both layouts (borders, folded rows of the reflect data gradient) are read.
+struct NormBwdPlanesParams {
+    const float* x;            // [N, C, H, W] the forward's input (the convolution's output)
+    const float* stats;        // [N*C, 2]
+    const float* gy;           // [N, C, H, W]
+    const unsigned* gymax;     // per-sample max |gy| words
+    float* gx;                 // fp32 copy or null
+    u32x4* dpl;                // data-gradient planes (hi; lo at + dplane16) or null
+    u32x4* gpl;                // weight-gradient G_0 planes (hi; lo at + gplane16) or null
+    unsigned* scale_words;     // [N] out
+    float* bsum;               // [N * C] out: sum of gx over each plane, or null
+    long long dplane16, gplane16;
+    int N, C, H, W;
+    int CPR, Hg;
+    int reflect;               // data-gradient planes: 1 SPLIT16_DGRAD_REFLECT content, 0 SPLIT16_ZERO
+    int act;
+    float slope, bmul;         // bmul = (2 + sqrt(HW)) [/ (1 - p)]
+    int dropout;
+    unsigned thresh;
+    float dscale;
+    unsigned seed_lo, seed_hi, offset;
+    const unsigned* obase;
+};
+
+__device__ __forceinline__ float np_act_df(float xhat, int act, float slope) {
+    if (act == ACT_RELU) return xhat > 0.f ? 1.f : 0.f;
+    if (act == ACT_LRELU) return xhat > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+__global__ __launch_bounds__(1024) void instnorm_bwd_planes_kernel(NormBwdPlanesParams p) {
+#ifdef NEMAR_HOST_EMULATION
+    __shared__ __attribute__((aligned(16))) float tile[8 * (4096 + 4)];
+#else
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // 8 (HW + 4) floats
+#endif
+    __shared__ float red[136];
+    __shared__ float rmax[16];
+    const int CG = p.C >> 3;
+    const int n = blockIdx.x / CG, cg = blockIdx.x - n * CG;
+    const int HW = p.H * p.W, W = p.W, H = p.H;
+    const int t = threadIdx.x;
+    const bool active = 4 * t < HW;
+    const size_t cbase = ((size_t)n * p.C + (size_t)cg * 8) * HW;
+    float xh[8][4], g[8][4];
+    float s[8], tot[8];
+    // largest rstd of the sample (all C planes): part of the bound
+    {
+        float m = 0.f;
+        for (int c = t; c < p.C; c += 1024) m = fmaxf(m, p.stats[2 * ((size_t)n * p.C + c) + 1]);
+        m = wave_max(m);
+        if ((t & 63) == 0) rmax[t >> 6] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (active) {
+            a = *reinterpret_cast<const float4*>(p.x + cbase + (size_t)j * HW + 4 * t);
+            b = *reinterpret_cast<const float4*>(p.gy + cbase + (size_t)j * HW + 4 * t);
+        }
+        xh[j][0] = a.x; xh[j][1] = a.y; xh[j][2] = a.z; xh[j][3] = a.w;
+        g[j][0] = b.x; g[j][1] = b.y; g[j][2] = b.z; g[j][3] = b.w;
+    }
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const size_t pl = (size_t)n * p.C + (size_t)cg * 8 + j;
+        mean[j] = p.stats[2 * pl];
+        rstd[j] = p.stats[2 * pl + 1];
+    }
+    float s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (p.dropout) {
+            const unsigned long long q = ((unsigned long long)n * p.C + (unsigned long long)cg * 8 + j) * (unsigned long long)(HW >> 2) + t;
+            unsigned r[4];
+            np_philox((unsigned)q, (unsigned)(q >> 32), p.offset + (p.obase ? *p.obase : 0u), 0u, p.seed_lo, p.seed_hi, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[j][e] = r[e] >= p.thresh ? g[j][e] * p.dscale : 0.f;
+        }
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = active ? (xh[j][e] - mean[j]) * rstd[j] : 0.f;
+            const float u = active ? g[j][e] * np_act_df(h, p.act, p.slope) : 0.f;
+            xh[j][e] = h;
+            g[j][e] = u;
+            a += u;
+            b += u * h;
+        }
+        s[j] = a;
+        s2[j] = b;
+    }
+    const float inv = 1.f / (float)HW;
+    float m1[8], m2[8];
+    block_sum8(s, red, tot);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m1[j] = tot[j] * inv;
+    block_sum8(s2, red, tot);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m2[j] = tot[j] * inv;
+    // the bound this sample's planes are scaled by (rmax was written before the first barrier of block_sum8)
+    float rm = rmax[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) rm = fmaxf(rm, rmax[w]);
+    const float bound = rm * p.bmul * __builtin_bit_cast(float, p.gymax[n]);
+    const unsigned bound_bits = __builtin_bit_cast(unsigned, bound);
+    if (cg == 0 && t == 0) p.scale_words[n] = bound_bits;
+    const float scale = np_pow2_scale(bound_bits);
+    const int TS = HW + 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd[j] * (g[j][e] - m1[j] - xh[j][e] * m2[j]);
+        if (active) {
+            if (p.gx) *reinterpret_cast<float4*>(p.gx + cbase + (size_t)j * HW + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(tile + j * TS + 4 * t) = make_float4(o[0] * scale, o[1] * scale, o[2] * scale, o[3] * scale);
+        }
+        s[j] = active ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
+    }
+    if (p.bsum) {
+        block_sum8(s, red, tot);
+        if (t < 8) p.bsum[(size_t)n * p.C + (size_t)cg * 8 + t] = tot[t];
+    }
+    __syncthreads();
+    // ---- data-gradient planes: word (row, slot) = the 8 channels of one plane position (conv_split16.hip plane_value) ----
+    if (p.dpl) {
+        const int Hp = H + 4, Ws = W + 4;
+        u32x4* const hp = p.dpl + ((size_t)n * CG + cg) * (size_t)Hp * Ws;
+        for (int i = t; i < Hp * Ws; i += 1024) {
+            const int row = i / Ws, slot = i - row * Ws;
+            int ya = -1, yb = -1, xa = -1, xb = -1;
+            if (row >= 1 && row <= H) ya = row - 1;
+            else if (p.reflect && row == H + 2) { ya = 0; yb = 2; }
+            else if (p.reflect && row == H + 3) { ya = H - 3; yb = H - 1; }
+            if (slot >= 1 && slot <= W) xa = slot - 1;
+            else if (p.reflect && slot == W + 2) { xa = 0; xb = 2; }
+            else if (p.reflect && slot == W + 3) { xa = W - 3; xb = W - 1; }
+            const bool any = ya >= 0 && xa >= 0;
+            const int yA = max(ya, 0), yB = max(yb, 0), xA = max(xa, 0), xB = max(xb, 0);
+            u32x4 hwd, lwd;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float vv[2];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const float* const tj = tile + (2 * k + z) * TS;
+                    // (scaling by a power of two commutes with the fold sums: the same bits as scaling the folded fp32 value)
+                    float v = tj[yA * W + xA];
+                    if (yb >= 0) v += tj[yB * W + xA];
+                    if (xb >= 0) {
+                        float u = tj[yA * W + xB];
+                        if (yb >= 0) u += tj[yB * W + xB];
+                        v += u;
+                    }
+                    vv[z] = any ? v : 0.f;
+                }
+                f16x2 h, l;
+                h[0] = (_Float16)vv[0];
+                h[1] = (_Float16)vv[1];
+                l[0] = (_Float16)(vv[0] - (float)h[0]);
+                l[1] = (_Float16)(vv[1] - (float)h[1]);
+                hwd[k] = __builtin_bit_cast(unsigned, h);
+                lwd[k] = __builtin_bit_cast(unsigned, l);
+            }
+            hp[i] = hwd;
+            hp[p.dplane16 + i] = lwd;
+        }
+    }
+    // ---- weight-gradient G_0 planes: word ((n KBLK + kblk) F + y CPR + q) 64 + kk = pixels 8 q .. 8 q + 7 of row y of channel kk ----
+    if (p.gpl) {
+        const int KBLK = p.C >> 6, F = p.Hg * p.CPR;
+        u32x4* const dst = p.gpl + (((size_t)n * KBLK + (cg >> 3)) * F) * 64 + (cg & 7) * 8;
+        for (int i = t; i < 8 * F; i += 1024) {
+            const int cc = i & 7, f = i >> 3;
+            const int y = f / p.CPR, q = f - y * p.CPR;
+            u32x4 hwd = u32x4{0u, 0u, 0u, 0u}, lwd = hwd;
+            if (y < H && q * 8 < W) {
+                const float* const src = tile + cc * TS + y * W + q * 8;
+                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                const float vv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f16x2 h, l;
+                    h[0] = (_Float16)vv[2 * k];
+                    h[1] = (_Float16)vv[2 * k + 1];
+                    l[0] = (_Float16)(vv[2 * k] - (float)h[0]);
+                    l[1] = (_Float16)(vv[2 * k + 1] - (float)h[1]);
+                    hwd[k] = __builtin_bit_cast(unsigned, h);
+                    lwd[k] = __builtin_bit_cast(unsigned, l);
+                }
+            }
+            dst[(size_t)f * 64 + cc] = hwd;
+            dst[p.gplane16 + (size_t)f * 64 + cc] = lwd;
         }
     }
 }
@@ -260,10 +523,19 @@ void nemar_norm_planes_debug(int bits) { g_norm_planes_dbg = bits; }
 
 // y (optional) = [residual +] dropout(act(InstanceNorm(x))), stats, AND the fp16 x 3 planes of y for a 3x3 / pad-1 reflect convolution
 // (conv_split16.hip layout, 2 * N * (C/8) * (H+4) * (W+4) 16-byte words), scaled by the a-priori bound written to scale_words[n].
+// wgrad_planes (optional): ALSO the pixel-major X planes the weight gradient of that convolution reads (conv_split16_wgrad.hip layout,
+// nemar_conv2d_x_planes_bytes(N, C, H, W, 3) bytes, same scale) — the layer then needs neither split pass.
+NEMAR_API size_t nemar_conv2d_x_planes_bytes(int N, int C, int H, int W, int KS) {
+    if (KS != 3 || N <= 0 || N > 256 || C <= 0 || C % 64 || H < 4 || W < 8 || W % 8 || H * W > 4096) return 0;
+    const int CPR = (W + 2 + 7) / 8, Hg = (H + 3) / 4 * 4;
+    if (H * CPR * 8 > XT_MAX) return 0;
+    return (size_t)2 * N * C * (Hg + 2) * CPR * 16;
+}
+
 NEMAR_API int nemar_instnorm_fwd_planes(const float* x, const float* residual, const void* residual_max_words, float* y, float* stats,
                                         int N, int C, int H, int W, float eps, int act, float slope, float dropout_p,
                                         unsigned long long seed, unsigned offset, void* planes, void* scale_words, void* max_words,
-                                        void* stream) {
+                                        void* wgrad_planes, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && stats && planes && scale_words, "instnorm_fwd_planes: null pointer");
     NEMAR_REQUIRE(N > 0 && N <= 256 && C > 0 && C % 8 == 0 && C / 8 <= NEMAR_MAX_PARTIALS, "instnorm_fwd_planes: bad N=%d C=%d", N, C);
@@ -286,9 +558,72 @@ NEMAR_API int nemar_instnorm_fwd_planes(const float* x, const float* residual, c
     p.dbg = g_norm_planes_dbg;
     p.obase = g_dropout_base;
     p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32); p.offset = offset;
+    p.xw = (u32x4*)wgrad_planes;
+    p.CPR = (W + 2 + 7) / 8;
+    p.Hx = (H + 3) / 4 * 4 + 2;
+    p.xplane16 = (long long)N * C * p.Hx * p.CPR;
+    NEMAR_REQUIRE(!wgrad_planes || (nemar_conv2d_x_planes_bytes(N, C, H, W, 3) > 0 && ((uintptr_t)wgrad_planes & 15) == 0),
+                  "instnorm_fwd_planes: this shape has no weight-gradient planes (N=%d C=%d %dx%d)", N, C, H, W);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(instnorm_planes_kernel, dim3(N * (C / 8)), dim3(1024), 0, st, p);
     if (max_words) max_words_finalize((unsigned*)max_words, N, C / 8, st);
     NEMAR_CHECK_LAUNCH("instnorm_fwd_planes");
+    return NEMAR_OK;
+}
+
+// gx (optional fp32) = InstanceNorm backward of gy through [dropout ->] act -> InstanceNorm (the order of nemar_instnorm_fwd_planes), AND the
+// operand planes of gx for the two gradient calls of the 3x3 / pad-1 convolution that produced x: `dgrad_planes`
+// (2 N (C/8) (H+4) (W+4) 16-byte words; pad_mode 1: the reflect data gradient's folded content, 0: zero padding) and `wgrad_planes`
+// (nemar_conv2d_gy_planes_bytes: the G_0 planes), scaled by the a-priori bound written to scale_words[n] (pass it as the max words of
+// gx to the two calls).  gy_max_words: per-sample max |gy| (N words).  bias_partials (optional, [N, C]): sum of gx over each plane.
+NEMAR_API int nemar_instnorm_bwd_planes(const float* x, const float* stats, const float* gy, const void* gy_max_words, int N, int C,
+                                        int H, int W, int act, float slope, float dropout_p, unsigned long long seed, unsigned offset,
+                                        int pad_mode, float* gx, void* dgrad_planes, void* wgrad_planes, void* scale_words,
+                                        float* bias_partials, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(x && stats && gy && gy_max_words && scale_words, "instnorm_bwd_planes: null pointer");
+    NEMAR_REQUIRE(dgrad_planes || wgrad_planes, "instnorm_bwd_planes: no planes requested (use nemar_instnorm_bwd)");
+    NEMAR_REQUIRE(N > 0 && N <= 256 && C > 0 && C % 8 == 0, "instnorm_bwd_planes: bad N=%d C=%d", N, C);
+    NEMAR_REQUIRE(H >= 4 && W >= 4 && W % 4 == 0 && H * W <= 4096, "instnorm_bwd_planes: unsupported plane %dx%d (W %% 4 == 0, HW <= 4096)", H, W);
+    NEMAR_REQUIRE(!wgrad_planes || (C % 64 == 0 && W % 8 == 0), "instnorm_bwd_planes: weight-gradient planes need C %% 64 == 0 and W %% 8 == 0");
+    NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_bwd_planes: unsupported act %d", act);
+    NEMAR_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "instnorm_bwd_planes: bad dropout p");
+    NEMAR_REQUIRE(pad_mode == 0 || pad_mode == 1, "instnorm_bwd_planes: bad pad_mode %d", pad_mode);
+    NEMAR_REQUIRE((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)dgrad_planes | (uintptr_t)wgrad_planes) & 15) == 0,
+                  "instnorm_bwd_planes: pointers must be 16-byte aligned");
+    NormBwdPlanesParams p;
+    p.x = x; p.stats = stats; p.gy = gy; p.gymax = (const unsigned*)gy_max_words; p.gx = gx;
+    p.dpl = (u32x4*)dgrad_planes; p.gpl = (u32x4*)wgrad_planes; p.scale_words = (unsigned*)scale_words; p.bsum = bias_partials;
+    p.N = N; p.C = C; p.H = H; p.W = W;
+    p.CPR = (W + 2 + 7) / 8;
+    p.Hg = (H + 3) / 4 * 4;
+    p.dplane16 = (long long)N * (C / 8) * (H + 4) * (W + 4);
+    p.gplane16 = (long long)N * C * p.Hg * p.CPR;
+    p.reflect = pad_mode;
+    p.act = act; p.slope = slope;
+    p.dscale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    p.bmul = (2.f + sqrtf((float)(H * W))) * p.dscale;
+    const double t = (double)dropout_p * 4294967296.0;
+    p.dropout = dropout_p > 0.f ? 1 : 0;
+    p.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    p.obase = g_dropout_base;
+    p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32); p.offset = offset;
+    const size_t lds = nemar_lds_bytes(reinterpret_cast<const void*>(&instnorm_bwd_planes_kernel), (size_t)8 * (H * W + 4) * sizeof(float), false);
+#ifdef NEMAR_HOST_EMULATION
+    hipLaunchKernelGGL(instnorm_bwd_planes_kernel, dim3(N * (C / 8)), dim3(1024), 0, (hipStream_t)stream, p);
+    (void)lds;
+#else
+    hipLaunchKernelGGL(instnorm_bwd_planes_kernel, dim3(N * (C / 8)), dim3(1024), lds, (hipStream_t)stream, p);
+#endif
+    NEMAR_CHECK_LAUNCH("instnorm_bwd_planes");
+    return NEMAR_OK;
+}
+
+// gb[C] += sum over the batch of bias_partials [N, C] (fixed order: bitwise reproducible)
+NEMAR_API int nemar_bias_from_partials(const float* bias_partials, int N, int C, float* gb, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(bias_partials && gb && N > 0 && C > 0, "bias_from_partials: bad arguments");
+    nemar_sum_partials(bias_partials, C, N, gb, C, true, (hipStream_t)stream);
+    NEMAR_CHECK_LAUNCH("bias_from_partials");
     return NEMAR_OK;
 }

@@ -319,6 +319,13 @@ class ResnetBlock(nn.Module):
     def forward(self, x):
         fused_act = ops.ACT_NONE if self.norm else ops.ACT_RELU
         reflect = self.pad_mode == ops.PAD_REFLECT
+        if reflect and self.norm == 'instance':
+            # the whole block as one autograd node where the wide-layer route takes it (ops._ResBlock): producer-written operand planes
+            # for all six convolution calls, the skip gradient added in a data gradient's epilogue
+            out = ops.resnet_block(x, self.c1.weight, self.c1.bias, self.c2.weight, self.c2.bias,
+                                   dropout_p=0.5 if (self.use_dropout and self.training) else 0.0, feeds_block=self.feeds_block)
+            if out is not None:
+                return out
         h = ops.conv2d(x, self.c1.weight, self.c1.bias, 1, 1, self.pad_mode, act=fused_act)
         # (norm + ReLU + Dropout in one pass; where conv2 runs on the fp16 x 3 route its operand planes come out of the same pass)
         h = _norm_act(h, self.norm, ops.ACT_RELU, planes=reflect, dropout_p=0.5 if (self.use_dropout and self.training) else 0.0)

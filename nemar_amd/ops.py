@@ -275,11 +275,15 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
     return slot[0], slot
 
 
-def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None):
+def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None, addend=None, out_max=None):
     """nemar_conv_extras for one call: the side inputs of the wide-layer route, or None when there are none"""
     if arena is None and src_max is None and src2_max is None and planes is None:
         return None
     e = _lib.ConvExtras()
+    if addend is not None:
+        e.addend = addend.data_ptr()
+    if out_max is not None:
+        e.out_max_words = out_max.data_ptr()
     if arena is not None:
         e.scratch, e.scratch_bytes = arena.data_ptr(), arena.numel() * 4
     if src_max is not None:
@@ -414,6 +418,8 @@ def tune(key, value):
     L.tune(key, value)
     _scratch_need.clear()
     _gplanes_need.clear()            # (the gy-planes hand-over depends on the route switches too)
+    _fusable.clear()
+    _xplanes_need.clear()
     invalidate_packed_weights()
 
 
@@ -533,6 +539,9 @@ class _Conv2d(Function):
                 L.conv2d_fwd_ex(_p(x), C0, _p(x2), C1, _p(w), _p(b), _p(y), N, H, W, K, R, S, stride, pad, pad_mode, act,
                                 slope, _p(ws), wsb, hit, _stream(), _extras(arena, xmax, None, ready[0] if ready is not None else None))
         ctx.xmax = xmax
+        # the producer's pixel-major planes of x (same scale words as `ready`): the weight gradient then skips its split pass over x
+        xp = _xplanes_of(x) if ready is not None else None
+        ctx.xplanes = xp[0] if (xp is not None and xp[1] is ready[1]) else None
         ctx.grad_from = int(getattr(x, '_nemar_grad_from', 0)) if x2 is None else 0
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         ctx.weight, ctx.bias = weight, bias
@@ -614,19 +623,25 @@ class _Conv2d(Function):
             if not (need_x or need_x2):
                 _use = False
             gwbuf = _grad_buffer(ctx.weight)
+            gbbuf = _grad_buffer(ctx.bias) if want_b else None       # (the bias gradient rides along with the weight gradient: same lane)
             if _use and _side_on[0]:
                 _side_touched.add(id(gwbuf))
+                if gbbuf is not None:
+                    _side_touched.add(id(gbbuf))
             else:
                 _main_lane_grad(gwbuf, g.device)
+                if gbbuf is not None:
+                    _main_lane_grad(gbbuf, g.device)
             rbw = K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT
-            with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl) if _use else contextlib.nullcontext()), \
+            xpl = getattr(ctx, 'xplanes', None)
+            with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl, xpl) if _use else contextlib.nullcontext()), \
                     (_span('wgrad_resblock') if rbw else contextlib.nullcontext()):
                 gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
                 wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
                 arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
                 L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(gwbuf), _p(gb), N, H, W, K, OH, OW,
                                        R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, _stream(),
-                                       _extras(arena, ctx.xmax, gmax, src2_planes=gpl))
+                                       _extras(arena, ctx.xmax, gmax, planes=xpl, src2_planes=gpl))
                 if gslot is not None and _side_on[0]:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(g.device))
@@ -635,7 +650,9 @@ class _Conv2d(Function):
                 if want_b:
                     grad_ready(ctx.bias)
         elif want_b:
-            _bias_grad(g, _grad_buffer(ctx.bias), N, K, OH * OW, st)
+            gbbuf = _grad_buffer(ctx.bias)
+            _main_lane_grad(gbbuf, g.device)          # (a bias the side lane has accumulated into in this pass: order behind it first)
+            _bias_grad(g, gbbuf, N, K, OH * OW, st)
             grad_ready(ctx.bias)
         return gx, gx2, None, None, None, None, None, None, None, None
 
@@ -763,6 +780,29 @@ def _planes_of(t):
     return have if have is not None and have[2] == t._version else None
 
 
+def _xplanes_of(t):
+    have = getattr(t, '_nemar_xplanes', None)
+    return have if have is not None and have[2] == t._version else None
+
+
+_xplanes_on = [os.environ.get("NEMAR_XPLANES", "1") != "0"]      # A/B: the forward producers also write the weight gradient's X planes
+_xplanes_need = {}
+
+
+def _x_planes_buffer(N, C, H, W, device):
+    """-> a fresh buffer for the weight gradient's X planes of a [N, C, H, W] activation (3x3 reflect consumer), or None where the
+    producer has no such output.  A tensor of its own (not an arena): it lives until the layer's backward pass has read it."""
+    if not _xplanes_on[0]:
+        return None
+    key = (N, C, H, W)
+    need = _xplanes_need.get(key)
+    if need is None:
+        need = _xplanes_need[key] = L.conv2d_x_planes_bytes(N, C, H, W, 3)
+    if not need:
+        return None
+    return torch.empty(int(need), dtype=torch.uint8, device=device)
+
+
 class _InstanceNorm(Function):
     @staticmethod
     def forward(ctx, x, residual, act, slope, eps, planes, drop_p):
@@ -782,10 +822,13 @@ class _InstanceNorm(Function):
                 _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
                 seed, off = _dropout_state["seed"], _dropout_state["offset"]
                 ctx.drop = (drop_p, seed, off)
+            xbuf = _x_planes_buffer(N, C, H, W, x.device)        # the weight gradient's pixel-major planes from the same pass
             L.instnorm_fwd_planes(_p(x), _p(residual), _p(_absmax_word(residual)) if residual is not None else None, _p(y), _p(stats),
-                                  N, C, H, W, eps, act, slope, drop_p, seed, off, _p(buf), _p(scale_words), _p(words), _stream())
+                                  N, C, H, W, eps, act, slope, drop_p, seed, off, _p(buf), _p(scale_words), _p(words), _p(xbuf), _stream())
             _tag_max(y, words)
             y._nemar_planes = (buf, scale_words, y._version)
+            if xbuf is not None:
+                y._nemar_xplanes = (xbuf, scale_words, y._version)
         else:
             if _wants_max(x) and drop_p <= 0.0:
                 words = _max_words(N, x.device)
@@ -838,6 +881,209 @@ def instance_norm(x, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5, planes=Fa
     """(residual +) dropout(act(InstanceNorm2d(x))) with affine=False, track_running_stats=False.  planes=True: the consumer is a
     3x3 / pad-1 reflect convolution — where the wide-layer fp16 x 3 route applies, its operand planes are written in the same pass."""
     return _InstanceNorm.apply(x, residual, act, slope, eps, bool(planes), float(dropout_p))
+
+
+# ---- one ResnetBlock of the wide route as ONE autograd node (round 6) -------------------------------------------------------------------
+# x + IN(conv3x3(reflect(drop(relu(IN(conv3x3(reflect(x)))))))) — reference models/networks.py:418-446.  As separate nodes the backward pass of
+# a block costs, besides its four matrix-pipe kernels: two InstanceNorm backward passes that write fp32 gradients, two split passes that
+# read them back (split_dual_kernel), two split passes over the saved activations (split_wgrad_x_kernel), a dropout backward, two bias
+# reductions over the fp32 gradients and autograd's add of the skip gradient.  As one node:
+#   forward   conv1 -> [IN + ReLU + dropout: planes of conv2's operand AND of its weight gradient's, no fp32 tensor] -> conv2 ->
+#             [IN + skip: fp32 output, planes for the next block's conv1 and its weight gradient]
+#   backward  [IN2 backward: operand planes of conv2's two gradient calls + bias sums, no fp32 tensor] -> conv2 data gradient (epilogue
+#             publishes its per-sample maxima) -> [dropout + ReLU + IN1 backward: planes + bias sums] -> conv1 data gradient
+#             (epilogue adds the skip gradient and publishes the maxima the previous block's IN2 backward scales by)
+#   the two weight gradients run on the side stream from producer-written planes on both operands: no split pass at all.
+_fused_block_on = [os.environ.get("NEMAR_FUSED_BLOCK", "1") != "0"]
+_fusable = {}
+
+
+def fused_blocks(on=None):
+    """Switch the one-node ResnetBlock on / off (A/B; returns the previous setting)"""
+    prev = _fused_block_on[0]
+    if on is not None:
+        _fused_block_on[0] = bool(on)
+    return prev
+
+
+def _block_fusable(x, C):
+    if not (_fused_block_on[0] and _planes_on[0] and _xplanes_on[0] and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        return False
+    N, Cx, H, W = x.shape
+    if Cx != C:
+        return False
+    key = (N, C, H, W, L.config_epoch())
+    ok = _fusable.get(key)
+    if ok is None:
+        ok = (_wants_max(x) and W % 8 == 0 and H >= 4 and H * W <= 4096
+              and L.conv2d_bwd_data_fusable(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT) == 1
+              and L.conv2d_x_planes_bytes(N, C, H, W, 3) > 0
+              and L.conv2d_scratch(N, H, W, C, C, 3, 3, 1, 1) > 0)
+        _fusable[key] = bool(ok)
+    return ok
+
+
+def _chan_planes_buffer(N, C, H, W, device):
+    return torch.empty(2 * N * (C // 8) * (H + 4) * (W + 4) * 16, dtype=torch.uint8, device=device)
+
+
+class _ResBlock(Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop_p, feeds_block, eps):
+        x = _c(x)
+        N, C, H, W = x.shape
+        dev = x.device
+        st = _stream()
+        arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
+        wsb = L.conv2d_fwd_workspace(N, H, W, C, C, 3, 3, 1, 1)
+
+        def conv(src_key, planes, words, weight, bias, y):
+            ws, hit, plan = _packed(weight, ('fwd', 1, 1, N, H, W), wsb)
+            with _span('igemm_fwd_resblock'), _record(plan):
+                L.conv2d_fwd_ex(src_key, C, None, 0, _p(weight), _p(bias), _p(y), N, H, W, C, 3, 3, 1, 1, PAD_REFLECT, ACT_NONE, 0.2,
+                                _p(ws), wsb, hit, st, _extras(arena, words, None, planes))
+
+        # conv1: operand planes from the producer of x where it wrote them (the previous block / the down-sampling stage's InstanceNorm)
+        ready = _planes_of(x)
+        xp0 = _xplanes_of(x)
+        if ready is not None:
+            x_words = ready[1]
+            if xp0 is not None and xp0[1] is not ready[1]:
+                xp0 = None
+        else:
+            x_words, xp0 = _absmax_word(x), None
+        y1 = torch.empty_like(x)
+        conv(_p(x), ready[0] if ready is not None else None, x_words, w1, b1, y1)
+        # IN1 + ReLU + dropout: planes only
+        stats1 = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
+        p1 = _chan_planes_buffer(N, C, H, W, dev)
+        xp1 = _x_planes_buffer(N, C, H, W, dev)
+        scale1 = torch.empty(N, dtype=torch.int32, device=dev)
+        seed = off = 0
+        if drop_p > 0.0:
+            _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
+            seed, off = _dropout_state["seed"], _dropout_state["offset"]
+        L.instnorm_fwd_planes(_p(y1), None, None, None, _p(stats1), N, C, H, W, eps, ACT_RELU, 0.2, drop_p, seed, off, _p(p1), _p(scale1),
+                              None, _p(xp1), st)
+        # conv2 reads the planes; the (never written) fp32 tensor they stand for is only a key: the planes' own address serves
+        y2 = torch.empty_like(x)
+        conv(_p(p1), p1, scale1, w2, b2, y2)
+        del p1
+        # IN2 + skip
+        out = torch.empty_like(x)
+        stats2 = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
+        words = _max_words(N, dev)
+        if feeds_block:
+            pout = _chan_planes_buffer(N, C, H, W, dev)
+            xpout = _x_planes_buffer(N, C, H, W, dev)
+            scale_out = torch.empty(N, dtype=torch.int32, device=dev)
+            L.instnorm_fwd_planes(_p(y2), _p(x), _p(_absmax_word(x)), _p(out), _p(stats2), N, C, H, W, eps, ACT_NONE, 0.2, 0.0, 0, 0,
+                                  _p(pout), _p(scale_out), _p(words), _p(xpout), st)
+            out._nemar_planes = (pout, scale_out, out._version)
+            out._nemar_xplanes = (xpout, scale_out, out._version)
+        else:
+            L.instnorm_fwd_max(_p(y2), _p(x), _p(out), _p(stats2), N * C, H * W, eps, ACT_NONE, 0.2, _p(words), C, st)
+        _tag_max(out, words)
+        ctx.save_for_backward(y1, stats1, y2, stats2, w1, w2)
+        # conv1's weight gradient takes the producer's X planes of x where they exist, else x itself
+        ctx.x0 = None if xp0 is not None else x
+        ctx.xp0 = xp0[0] if xp0 is not None else None
+        ctx.x_words, ctx.xp1, ctx.scale1 = x_words, xp1, scale1
+        ctx.params = (w1, b1, w2, b2)
+        ctx.drop = (drop_p, seed, off)
+        for prm in (w1, b1, w2, b2):
+            if prm is not None:
+                _note_use(prm)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        y1, stats1, y2, stats2, w1v, w2v = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        g_out = _c(g_out)
+        N, C, H, W = g_out.shape
+        dev = g_out.device
+        st = _stream()
+        need_x = ctx.needs_input_grad[0]
+        need = [ctx.needs_input_grad[1], ctx.needs_input_grad[2] and b1 is not None, ctx.needs_input_grad[3],
+                ctx.needs_input_grad[4] and b2 is not None]
+        drop_p, seed, off = ctx.drop
+        gbytes = _gplanes_need.get((N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT))
+        if gbytes is None:
+            gbytes = _gplanes_need[(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)] = L.conv2d_gy_planes_bytes(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)
+        arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
+        dwsb = L.conv2d_bwd_data_workspace(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)
+
+        def norm_bwd(xin, stats, g, gwords, act, p, sd, of, want_d, want_g, want_bias):
+            d = _chan_planes_buffer(N, C, H, W, dev) if want_d else None
+            gp = torch.empty(int(gbytes), dtype=torch.uint8, device=dev) if want_g else None
+            scale = torch.empty(N, dtype=torch.int32, device=dev)
+            bsum = torch.empty((N, C), dtype=torch.float32, device=dev) if want_bias else None
+            L.instnorm_bwd_planes(_p(xin), _p(stats), _p(g), _p(gwords), N, C, H, W, act, 0.2, p, sd, of, 1, None, _p(d), _p(gp), _p(scale),
+                                  _p(bsum), st)
+            return d, gp, scale, bsum
+
+        def dgrad(d, scale, weight, dst, addend, out_words):
+            ws, hit, plan = _packed(weight, ('dgrad', 1, 1, PAD_REFLECT, True, N, H, W), dwsb)
+            with _record(plan), _span('dgrad_resblock'):
+                L.conv2d_bwd_data_ex(_p(d), _p(weight), None, ACT_NONE, 0.0, _p(dst), C, None, 0, N, H, W, C, H, W, 3, 3, 1, 1, PAD_REFLECT,
+                                     _p(ws), dwsb, hit, st, _extras(arena, scale, planes=d, addend=addend, out_max=out_words))
+
+        def wgrad(x_t, xpl, x_words, gp, g_scale, weight, bias, bsum, want_w, want_b):
+            """side stream: the weight gradient from planes on both operands; the bias gradient from the producer's per-plane sums"""
+            if not (want_w or want_b):
+                return
+            gw = _grad_buffer(weight) if want_w else None
+            gb = _grad_buffer(bias) if want_b else None
+            if _side_on[0]:
+                for buf in (gw, gb):
+                    if buf is not None:
+                        _side_touched.add(id(buf))
+            else:
+                for buf in (gw, gb):
+                    if buf is not None:
+                        _main_lane_grad(buf, dev)
+            with _on_side(dev, x_t, xpl, x_words, gp, g_scale, bsum), _span('wgrad_resblock'):
+                if want_w:
+                    wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, C, H, W, 3, 3, 1, 1)
+                    side_arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
+                    key = x_t if x_t is not None else xpl           # (with planes the fp32 operand is only a key)
+                    L.conv2d_bwd_weight_ex(_p(key), C, None, 0, _p(gp), _p(gw), None, N, H, W, C, H, W, 3, 3, 1, 1, PAD_REFLECT,
+                                           _p(_workspace(wsb, dev)), wsb, _stream(),
+                                           _extras(side_arena, x_words, g_scale, planes=xpl, src2_planes=gp))
+                    grad_ready(weight)
+                if want_b:
+                    L.bias_from_partials(_p(bsum), N, C, _p(gb), _stream())
+                    grad_ready(bias)
+
+        # IN2 backward (no activation, the skip path passes g_out on unchanged)
+        gwords = _absmax_word(g_out)
+        d2, gp2, scale2, bsum2 = norm_bwd(y2, stats2, g_out, gwords, ACT_NONE, 0.0, 0, 0, True, need[2], need[3])
+        gmid = torch.empty_like(g_out)
+        mid_words = _max_words(N, dev)
+        dgrad(d2, scale2, w2v, gmid, None, mid_words)
+        del d2
+        wgrad(None, ctx.xp1, ctx.scale1, gp2, scale2, w2, b2, bsum2, need[2], need[3])
+        # dropout + ReLU + IN1 backward
+        d1, gp1, scale1b, bsum1 = norm_bwd(y1, stats1, gmid, mid_words[:N], ACT_RELU, drop_p, seed, off, need_x or not need[0], need[0], need[1])
+        gin = None
+        if need_x:
+            gin = torch.empty_like(g_out)
+            in_words = _max_words(N, dev)
+            dgrad(d1, scale1b, w1v, gin, g_out, in_words)          # + the skip gradient, in the epilogue
+            _tag_max(gin, in_words)
+        del d1
+        wgrad(ctx.x0, ctx.xp0, ctx.x_words, gp1, scale1b, w1, b1, bsum1, need[0], need[1])
+        return gin, None, None, None, None, None, None, None
+
+
+def resnet_block(x, w1, b1, w2, b2, dropout_p=0.0, feeds_block=False, eps=1e-5):
+    """One reflect-padded, instance-normalised ResnetBlock as a single autograd node where the wide-layer route takes it
+    (None: the caller composes it from conv2d / instance_norm)."""
+    if not _block_fusable(x, w1.shape[0]) or tuple(w1.shape) != (x.shape[1], x.shape[1], 3, 3) or tuple(w2.shape) != tuple(w1.shape):
+        return None
+    return _ResBlock.apply(x, w1, b1, w2, b2, float(dropout_p), bool(feeds_block), float(eps))
 
 
 class _MaxPool2(Function):

@@ -856,7 +856,7 @@ def case_instnorm_planes(be, act, use_residual, drop_p, N=2, C=16, H=6, W=8, see
     planes = be.bytes_buf(2 * N * (C // 8) * (H + 4) * (W + 4) * 16)
     scale_w, max_w = be.bytes_buf(4 * N), be.bytes_buf(4 * N * 2049)
     be.lib.instnorm_fwd_planes(be.ptr(d_x), be.ptr(d_res), be.ptr(resmax), be.ptr(d_y), be.ptr(d_st), N, C, H, W, 1e-5, act, 0.2,
-                               drop_p, 424242, 5, be.ptr(planes), be.ptr(scale_w), be.ptr(max_w), be.stream)
+                               drop_p, 424242, 5, be.ptr(planes), be.ptr(scale_w), be.ptr(max_w), None, be.stream)
     be.sync()
     y = be.np(d_y)
     assert np.array_equal(y != 0, keep & (y != 0)) and np.abs(y - want).max() < 2e-5 * max(1.0, np.abs(want).max()), np.abs(y - want).max()
@@ -897,7 +897,7 @@ def case_conv_from_producer_planes(be, N=3, C=128, H=8, W=32, K=128, seed=0):
     nb = 2 * N * (C // 8) * (H + 4) * (W + 4) * 16
     planes, scale_w = be.bytes_buf(nb), be.bytes_buf(4 * N)
     be.lib.instnorm_fwd_planes(be.ptr(d_x), None, None, be.ptr(d_h), be.ptr(d_st), N, C, H, W, 1e-5, 1, 0.2, 0.0, 0, 0, be.ptr(planes),
-                               be.ptr(scale_w), None, be.stream)
+                               be.ptr(scale_w), None, None, be.stream)
     outs = []
     with scratch_arena(be, need):
         for mode in ('planes', 'own passes', 'zeroed planes'):
@@ -923,6 +923,184 @@ def case_conv_from_producer_planes(be, N=3, C=128, H=8, W=32, K=128, seed=0):
         lim = 4e-6 * mag + 3e-11 * bound * wsum + 1e-30
         assert np.all(np.abs(y - want) <= lim), (who, float((np.abs(y - want) / lim).max()))
     assert np.all(outs[2] == 0), "the convolution did not read the hinted planes"
+
+
+def _decode_pixel_planes(raw, N, C, rows, CPR):
+    """conv_split16_wgrad.hip's pixel-major layout (X or G_0 planes) -> float64 [2 (hi, lo)][N][C][rows][8 CPR]"""
+    a = raw.view(np.float16).astype(np.float64).reshape(2, N, C // 64, rows, CPR, 64, 8)
+    return a.transpose(0, 1, 2, 5, 3, 4, 6).reshape(2, N, C, rows, CPR * 8)
+
+
+def _dgrad_plane_content(g, reflect):
+    """what conv_split16.hip's plane_value makes of g [N, C, H, W]: [N, C, H+4, W+4] (zero padding, or the reflect data gradient's
+    folded border rows / slots)"""
+    N, C, H, W = g.shape
+    out = np.zeros((N, C, H + 4, W + 4), dtype=np.float64)
+    rows = {r: [r - 1] for r in range(1, H + 1)}
+    cols = {c: [c - 1] for c in range(1, W + 1)}
+    if reflect:
+        rows[H + 2], rows[H + 3] = [0, 2], [H - 3, H - 1]
+        cols[W + 2], cols[W + 3] = [0, 2], [W - 3, W - 1]
+    for r, ys in rows.items():
+        for c, xs in cols.items():
+            out[:, :, r, c] = sum(g[:, :, y, x] for y in ys for x in xs)
+    return out
+
+
+def case_resblock_planes_chain(be, pad_mode, act, drop_p, N=2, C=128, H=8, W=32, seed=0):
+    """The producer-fused chain of a ResnetBlock convolution (round 6): the InstanceNorm pass in front writes the weight gradient's X
+    planes too (nemar_instnorm_fwd_planes wgrad_planes), the InstanceNorm BACKWARD behind writes the operand planes of both gradient
+    calls instead of the fp32 tensor (nemar_instnorm_bwd_planes), the data gradient adds the skip gradient and publishes the per-sample
+    maximum of its result in the epilogue (nemar_conv_extras.addend / .out_max_words) — every piece against float64, the planes decoded
+    word by word."""
+    from nemar_amd._lib import ConvExtras
+    import ctypes
+    lib = be.lib
+    rng = np.random.default_rng(seed)
+    K = C
+    reflect = pad_mode == PAD_REFLECT
+    mags = np.array([1.0, 30.0, 1e-2]).reshape(3, 1, 1, 1)[:N]
+    # ---- forward producer: y = dropout(act(IN(x0))) with both plane sets ----
+    x0 = (rng.standard_normal((N, C, H, W)) * 3 + 1).astype(np.float32)
+    d_x0 = be.dev(x0)
+    d_y, d_st0 = be.full(x0.shape, np.nan), be.full((N * C, 2), np.nan)
+    CPR, Hg = (W + 2 + 7) // 8, (H + 3) // 4 * 4
+    Hx = Hg + 2
+    xbytes = lib.conv2d_x_planes_bytes(N, C, H, W, 3)
+    assert xbytes == 2 * N * C * Hx * CPR * 16
+    cplanes = be.bytes_buf(2 * N * (C // 8) * (H + 4) * (W + 4) * 16)
+    xplanes = be.bytes_buf(xbytes)
+    fscale, fmax = be.bytes_buf(4 * N), be.bytes_buf(4 * N * 2049)
+    lib.instnorm_fwd_planes(be.ptr(d_x0), None, None, be.ptr(d_y), be.ptr(d_st0), N, C, H, W, 1e-5, act, 0.2, drop_p, 777, 3,
+                            be.ptr(cplanes), be.ptr(fscale), be.ptr(fmax), be.ptr(xplanes), be.stream)
+    be.sync()
+    y = be.np(d_y).astype(np.float64)
+    fb = be.raw(fscale)[:4 * N].view(np.float32).astype(np.float64)
+    fs = (2.0 ** (11 - np.floor(np.log2(fb)))).reshape(N, 1, 1, 1)
+    xp = _decode_pixel_planes(be.raw(xplanes)[:xbytes], N, C, Hx, CPR)
+    val = (xp[0] + xp[1]) / fs
+    ypad = np.pad(y, ((0, 0), (0, 0), (1, 1), (1, 1)), mode='reflect')
+    err = np.abs(val[:, :, :H + 2, :W + 2] - ypad)
+    assert np.all(err <= 2.0 ** -21 * np.abs(ypad) + 2.0 ** -24 / fs), ("X planes", err.max())
+    assert np.all(xp[:, :, :, H + 2:, :] == 0) and np.all(xp[:, :, :, :, W + 2:] == 0), "X planes: spare rows / columns must be zero"
+    # the channel-blocked planes of the same call hold the same values
+    cp = _decode_planes(be.raw(cplanes)[:2 * N * (C // 8) * (H + 4) * (W + 4) * 16], N, C, H, W)
+    assert np.array_equal(cp[:, :, :, :H + 2, :W + 2], xp[:, :, :, :H + 2, :W + 2]), "the two layouts of one producer differ"
+
+    # ---- backward producer: the InstanceNorm in front of which the convolution sits (x1 = the convolution's output) ----
+    x1 = (rng.standard_normal((N, C, H, W)) * np.linspace(0.5, 4.0, C).reshape(1, C, 1, 1) - 0.5).astype(np.float32)
+    gy = (rng.standard_normal((N, C, H, W)) * mags).astype(np.float32)
+    mean = x1.astype(np.float64).mean(axis=(2, 3), keepdims=True)
+    var = x1.astype(np.float64).var(axis=(2, 3), keepdims=True)
+    rstd = 1.0 / np.sqrt(var + 1e-5)
+    st1 = np.stack([mean[..., 0, 0], rstd[..., 0, 0]], axis=-1).astype(np.float32)        # [N, C, 2] as the forward would have saved it
+    xhat = (x1 - st1[..., 0].reshape(N, C, 1, 1).astype(np.float64)) * st1[..., 1].reshape(N, C, 1, 1).astype(np.float64)
+    g = gy.astype(np.float64)
+    if drop_p > 0:
+        ones, m = be.dev(np.ones_like(x1)), be.full(x1.shape, np.nan)
+        lib.dropout(be.ptr(ones), be.ptr(m), x1.size, drop_p, 4242, 9, be.stream)
+        g = np.where(be.np(m) != 0, g / (1 - drop_p), 0.0)
+    if act == 1:
+        g = g * (xhat > 0)
+    elif act == 2:
+        g = g * np.where(xhat > 0, 1.0, 0.2)
+    r64 = st1[..., 1].reshape(N, C, 1, 1).astype(np.float64)
+    want_gx = r64 * (g - g.mean(axis=(2, 3), keepdims=True) - xhat * (g * xhat).mean(axis=(2, 3), keepdims=True))
+    d_x1, d_st1, d_gy = be.dev(x1), be.dev(st1.reshape(N * C, 2)), be.dev(gy)
+    gymax = be.dev(np.abs(gy).reshape(N, -1).max(axis=1).astype(np.float32))
+    d_gx = be.full(x1.shape, np.nan)
+    dbytes = 2 * N * (C // 8) * (H + 4) * (W + 4) * 16
+    lib.tune(23, 0)
+    lib.tune(39, 1)                  # (a few-tile test shape would split its reduction over workgroups: no fused epilogue there)
+    try:
+        gbytes = lib.conv2d_gy_planes_bytes(N, C, H, W, K, 3, 3, 1, 1, pad_mode)
+        assert gbytes == 2 * N * K * Hg * CPR * 16, gbytes
+        assert lib.conv2d_bwd_data_fusable(N, C, H, W, K, 3, 3, 1, 1, pad_mode) == 1
+    finally:
+        lib.tune(23, 2000)
+        lib.tune(39, 8)
+    dplanes, gplanes = be.bytes_buf(dbytes), be.bytes_buf(gbytes)
+    bscale, bsum = be.bytes_buf(4 * N), be.full((N, C), np.nan)
+    lib.instnorm_bwd_planes(be.ptr(d_x1), be.ptr(d_st1), be.ptr(d_gy), be.ptr(gymax), N, C, H, W, act, 0.2, drop_p, 4242, 9,
+                            1 if reflect else 0, be.ptr(d_gx), be.ptr(dplanes), be.ptr(gplanes), be.ptr(bscale), be.ptr(bsum), be.stream)
+    be.sync()
+    gx = be.np(d_gx).astype(np.float64)
+    smax = np.abs(want_gx).reshape(N, -1).max(axis=1).reshape(N, 1, 1, 1)
+    assert np.all(np.abs(gx - want_gx) <= 2e-5 * smax), ("gx", float((np.abs(gx - want_gx) / smax).max()))
+    bb = be.raw(bscale)[:4 * N].view(np.float32).astype(np.float64)
+    want_bb = st1[..., 1].max(axis=1).astype(np.float64) * (2 + np.sqrt(H * W)) / (1 - drop_p) * np.abs(gy).reshape(N, -1).max(axis=1)
+    assert np.allclose(bb, want_bb, rtol=1e-6), (bb, want_bb)
+    assert np.all(bb >= np.abs(gx).reshape(N, -1).max(axis=1)), "the bound is not a bound"
+    bs = (2.0 ** (11 - np.floor(np.log2(bb)))).reshape(N, 1, 1, 1)
+    dp = _decode_planes(be.raw(dplanes)[:dbytes], N, C, H, W)
+    want_dp = _dgrad_plane_content(gx, reflect)
+    err = np.abs((dp[0] + dp[1]) / bs - want_dp)
+    mag_dp = _dgrad_plane_content(np.abs(gx), reflect)           # (the folded rows / slots are fp32 sums of up to four terms)
+    assert np.all(err <= 2.0 ** -21 * mag_dp + 2.0 ** -23 / bs), ("data-gradient planes", float((err / (2.0 ** -21 * mag_dp + 2.0 ** -23 / bs)).max()))
+    gp = _decode_pixel_planes(be.raw(gplanes)[:gbytes], N, C, Hg, CPR)
+    want_gp = np.zeros((N, C, Hg, CPR * 8))
+    want_gp[:, :, :H, :W] = gx
+    err = np.abs((gp[0] + gp[1]) / bs - want_gp)
+    assert np.all(err <= 2.0 ** -21 * np.abs(want_gp) + 2.0 ** -24 / bs), ("weight-gradient planes", float(err.max()))
+    got_bsum = be.np(bsum).astype(np.float64)
+    assert np.all(np.abs(got_bsum - gx.sum(axis=(2, 3))) <= 1e-5 * np.abs(gx).sum(axis=(2, 3)) + 1e-30), "bias partials"
+
+    # ---- the convolution's two gradient calls on those planes: w [K, C, 3, 3], layer input = y (the forward producer's output) ----
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    skip = (rng.standard_normal((N, C, H, W)) * mags * 0.1).astype(np.float32)
+    d_w, d_skip = be.dev(w), be.dev(skip)
+    need = split16_scratch(be, N, H, W, K, C, 3, 3, 1, 1)
+    arena = be.bytes_buf(need)
+    lib.tune(23, 0)
+    lib.tune(39, 1)
+    try:
+        wsd, wsdb = _ws(be, lib.conv2d_bwd_data_workspace(N, C, H, W, K, 3, 3, 1, 1, pad_mode))
+        wsw, wswb = _ws(be, lib.conv2d_bwd_weight_workspace(N, C, H, W, K, H, W, 3, 3, 1, 1))
+        d_gin = be.full((N, C, H, W), np.nan)
+        omax = be.bytes_buf(4 * N * 2049)
+        ghost = be.full((N, C, H, W), np.nan)            # the fp32 gx the planes stand for: must not be read
+        e = ConvExtras()
+        e.scratch, e.scratch_bytes = be.ptr(arena).value, need
+        e.src_max_words, e.src_max_count = be.ptr(bscale).value, N
+        e.src_planes = be.ptr(dplanes).value
+        e.addend = be.ptr(d_skip).value
+        e.out_max_words = be.ptr(omax).value
+        lib.conv2d_bwd_data_ex(be.ptr(ghost), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gin), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1,
+                               pad_mode, be.ptr(wsd), wsdb, 0, be.stream, ctypes.byref(e))
+        assert lib.last_route() == 2
+        be.sync()
+        gin = be.np(d_gin)
+        want_gin, want_gw, _ = O.conv2d_bwd(y, w.astype(np.float64), gx, 1, 1, _PM[pad_mode])
+        mag = O.conv2d_bwd(np.abs(y), np.abs(w.astype(np.float64)), np.abs(gx), 1, 1, _PM[pad_mode])[0]
+        wsum = np.abs(w.astype(np.float64)).sum(axis=(0, 2, 3)).reshape(1, C, 1, 1)
+        lim = 4e-6 * mag + 3e-11 * bb.reshape(N, 1, 1, 1) * wsum + 2e-7 * np.abs(skip) + 1e-30
+        assert np.all(np.abs(gin - (want_gin + skip)) <= lim), ("data gradient from planes + skip", float((np.abs(gin - (want_gin + skip)) / lim).max()))
+        got_omax = be.raw(omax)[:4 * N].view(np.uint32)
+        assert np.array_equal(got_omax, np.abs(gin).reshape(N, -1).max(axis=1).astype(np.float32).view(np.uint32)), "epilogue max words"
+        # weight gradient: both operands as planes
+        d_gw = be.full((K, C, 3, 3), 0.25)
+        ghost_x = be.full((N, C, H, W), np.nan)
+        e2 = ConvExtras()
+        e2.scratch, e2.scratch_bytes = be.ptr(arena).value, need
+        e2.src_max_words, e2.src_max_count = be.ptr(fscale).value, N
+        e2.src2_max_words, e2.src2_max_count = be.ptr(bscale).value, N
+        e2.src2_planes = be.ptr(gplanes).value
+        if reflect:
+            e2.src_planes = be.ptr(xplanes).value
+            xsrc = ghost_x
+        else:
+            xsrc = d_y                                    # (the X planes carry the reflect border: a zero-padded layer splits x itself)
+        lib.conv2d_bwd_weight_ex(be.ptr(xsrc), C, None, 0, be.ptr(ghost), be.ptr(d_gw), None, N, H, W, K, H, W, 3, 3, 1, 1, pad_mode,
+                                 be.ptr(wsw), wswb, be.stream, ctypes.byref(e2))
+        assert lib.last_route() == 2
+        be.sync()
+        gw = be.np(d_gw).astype(np.float64) - 0.25
+        wmag = O.conv2d_bwd(np.abs(y), np.abs(w.astype(np.float64)), np.abs(gx), 1, 1, _PM[pad_mode])[1]
+        lim = 6e-6 * wmag + 1e-6 * np.abs(want_gw).max() + 1e-30
+        assert np.all(np.abs(gw - want_gw) <= lim), ("weight gradient from planes", float((np.abs(gw - want_gw) / lim).max()))
+    finally:
+        lib.tune(23, 2000)
+        lib.tune(39, 8)
 
 
 def case_pointwise(be, seed=0):

@@ -533,6 +533,12 @@ def test_conv_from_producer_planes(be):
     K.case_conv_from_producer_planes(be)
 
 
+@pytest.mark.parametrize("pad_mode,act,drop", [(K.PAD_REFLECT, 1, 0.5), (K.PAD_REFLECT, 0, 0.0), (K.PAD_ZERO, 2, 0.0)])
+def test_resblock_planes_chain(be, pad_mode, act, drop):
+    """Round 6: producer-written operand planes for all three calls of a wide layer + the data gradient's fused epilogue (kernel_cases)."""
+    K.case_resblock_planes_chain(be, pad_mode, act, drop)
+
+
 def test_producer_max_words(be):
     K.case_producer_max_words(be)
 

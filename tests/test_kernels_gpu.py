@@ -505,6 +505,18 @@ def test_conv_from_producer_planes(be):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pad_mode,act,drop", [(K.PAD_REFLECT, 1, 0.5), (K.PAD_REFLECT, 0, 0.0), (K.PAD_ZERO, 2, 0.0)])
+def test_resblock_planes_chain(be, pad_mode, act, drop):
+    """Round 6: producer-written operand planes for all three calls of a wide layer + the data gradient's fused epilogue (kernel_cases)."""
+    K.case_resblock_planes_chain(be, pad_mode, act, drop)
+
+@pytest.mark.gpu
+def test_resblock_planes_chain_bench_shape(be):
+    """... at the residual blocks' own plane size (64 x 64: the 1024-thread workgroups are full, the LDS tiles at their largest)"""
+    K.case_resblock_planes_chain(be, K.PAD_REFLECT, 1, 0.5, N=2, C=128, H=64, W=64)
+
+
+@pytest.mark.gpu
 def test_producer_max_words(be):
     K.case_producer_max_words(be)
 
