@@ -154,11 +154,64 @@ elif VICTIM == 'wgrad2':
     torch.cuda.synchronize()
     print('victim %s: route %d' % (VICTIM, L.last_route()))
     refs = {True: gws[0].clone(), False: gws[0].clone()}
+elif VICTIM in ('wide_dgrad', 's16g_dgrad', 'fused_dgrad'):
+    # data-gradient calls on the side stream.  wide_dgrad: igemm_split16_kernel with the reflect fold, behind its own split pass;
+    # fused_dgrad: the round-6 form (planes from nemar_instnorm_bwd_planes, skip gradient + max words in the epilogue: igemm_split16_kernel<.., 2>);
+    # s16g_dgrad: s16g_kernel's parity classes (the translation net's 64 -> 128 stride-2 layer)
+    if VICTIM == 's16g_dgrad':
+        vN, vC, vK, vH, vs, vmode = N, 64, 128, 256, 2, 0
+        vw = (torch.rand(vK, vC, 3, 3, device=dev, generator=g0) * 2 - 1) * 0.05
+        vg = (torch.rand(vN, vK, vH // 2, vH // 2, device=dev, generator=g0) * 2 - 1) * 0.01
+        varena, vgm = None, None
+    else:
+        vN, vC, vK, vH, vs, vmode = N, C, K, H, 1, 1
+        vw, vg, varena, vgm = w, gy, arena_s, gmax
+    voh = vg.shape[2]
+    vdb = L.conv2d_bwd_data_workspace(vN, vC, vH, vH, vK, 3, 3, vs, 1, vmode)
+    vdw = torch.empty(vdb // 4 + 64, device=dev)
+    fused = None
+    if VICTIM == 'fused_dgrad':
+        assert L.conv2d_bwd_data_fusable(vN, vC, vH, vH, vK, 3, 3, 1, 1, 1) == 1, "N too small for the fused epilogue (reduction split over workgroups)"
+        stats_v = torch.empty(vN * vK, 2, device=dev)
+        yv = torch.empty_like(vg)
+        xin = torch.rand(vN, vK, vH, vH, device=dev, generator=g0) * 2 - 1
+        L.instnorm_fwd(p(xin), None, p(yv), p(stats_v), vN * vK, vH * vH, 1e-5, 0, 0.0, ctypes.c_void_p(main.cuda_stream))
+        dpl = torch.empty(2 * vN * (vK // 8) * (vH + 4) * (vH + 4) * 4, device=dev)
+        gpl_v = torch.empty(gpb // 4 + 64, device=dev)
+        bscale = torch.empty(vN, dtype=torch.int32, device=dev)
+        L.instnorm_bwd_planes(p(xin), p(stats_v), p(vg), p(gmax), vN, vK, vH, vH, 0, 0.0, 0.0, 0, 0, 1, None, p(dpl), p(gpl_v), p(bscale), None,
+                              ctypes.c_void_p(main.cuda_stream))
+        skip = torch.rand(vN, vC, vH, vH, device=dev, generator=g0) * 0.01
+        owords = torch.empty(vN * 2049, dtype=torch.int32, device=dev)
+        fused = (dpl, bscale, skip, owords)
+        torch.cuda.synchronize()
+
+    def victim(out, handover, hit=1):
+        e = None
+        if fused is not None:
+            e = extras(varena, fused[1])
+            e.src_planes, e.addend, e.out_max_words = fused[0].data_ptr(), fused[2].data_ptr(), fused[3].data_ptr()
+        elif varena is not None:
+            e = extras(varena, vgm)
+        L.conv2d_bwd_data_ex(p(vg), p(vw), None, 0, 0.0, p(out), vC, None, 0, vN, vH, vH, vK, voh, voh, 3, 3, vs, 1, vmode, p(vdw), vdb, hit,
+                             ctypes.c_void_p(side.cuda_stream), ctypes.byref(e) if e is not None else None)
+
+    gws = [torch.empty(vN, vC, vH, vH, device=dev) for _ in range(NV)]
+    with torch.cuda.stream(side):
+        victim(gws[0], False, 0)
+    torch.cuda.synchronize()
+    print('victim %s: route %d' % (VICTIM, L.last_route()))
+    refs = {True: gws[0].clone(), False: gws[0].clone()}
 else:
     # other LDS-DMA staged kernels as the victim: a forward call on the side stream (DIAG_VICTIM = wide_fwd: igemm_split16_kernel, the same
-    # layer; s16g_fwd: s16g_kernel, 64 -> 128 3x3 stride 2 at 256 x 256, the translation net's first down-sampling layer)
+    # layer; s16g_fwd: s16g_kernel, 64 -> 128 3x3 stride 2 at 256 x 256, the translation net's first down-sampling layer; exact_fwd:
+    # igemm_kernel of the exact-fp32 route, the registration net's 64 -> 64 layer at 16 x 16)
     if VICTIM == 'wide_fwd':
         vx, vw, vs, vp, vmode, vK = x, w, 1, 1, 1, K
+    elif VICTIM == 'exact_fwd':
+        vx = torch.rand(8, 64, 16, 16, device=dev, generator=g0) * 2 - 1
+        vw = (torch.rand(64, 64, 3, 3, device=dev, generator=g0) * 2 - 1) * 0.05
+        vs, vp, vmode, vK = 1, 1, 1, 64
     else:
         vx = torch.rand(N, 64, 256, 256, device=dev, generator=g0) * 2 - 1
         vw = (torch.rand(128, 64, 3, 3, device=dev, generator=g0) * 2 - 1) * 0.05
@@ -239,8 +292,14 @@ def co_chain_dual():
 
 
 AGG = None
-if os.path.exists(os.path.join(ROOT, 'tools', 'probes', '_build', 'liblds_aggressors.so')):
-    AGG = ctypes.CDLL(os.path.join(ROOT, 'tools', 'probes', '_build', 'liblds_aggressors.so'))
+_agg_so = os.path.join(ROOT, 'tests', 'emu', '_build', 'liblds_aggressors.so')        # (a build directory that is neither in git nor in the GPU snapshot's ignore list)
+if only and any(n.startswith('agg_') for n in only) and not os.path.exists(_agg_so):
+    import subprocess
+    os.makedirs(os.path.dirname(_agg_so), exist_ok=True)
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', os.path.join(ROOT, 'tools', 'probes', 'lds_aggressors.hip'), '-o', _agg_so],
+                   check=True)
+if os.path.exists(_agg_so):
+    AGG = ctypes.CDLL(_agg_so)
     AGG.launch_aggressor.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
 
 

@@ -42,3 +42,22 @@ def test_product_library_refuses_a_switch_on_the_gpu_box():
             "try:\n    ops.tune(20, 0)\nexcept _lib.NemarHipError as e:\n    print('REFUSED', e)\n" % os.path.dirname(HERE))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "REFUSED" in r.stdout and "NEMAR_AB" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
+SOAK_STEPS = 300
+
+
+@pytest.mark.parametrize("name", ["c2_b8", "c3_full", "c5_full"])
+def test_side_stream_soak_product_library_dropout_on(name):
+    """What bench.py times — product library, dropout on, weight-gradient branch on the side stream — against the single-stream order:
+    SOAK_STEPS consecutive steps, every step's three gradient buffers compared on the device (tests/side_stream_soak.py; the reference's
+    step is repeatable, models/nemar_model.py:266-288).  Round 5 had this only as a tool (tools/diag_step_events.py) and only without dropout."""
+    env = dict(os.environ, NEMAR_AB_LIBRARY="0", NEMAR_SIDE_STREAM="1")
+    env.pop("NEMAR_TUNE", None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "side_stream_soak.py"), name, str(SOAK_STEPS)], env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["library"] == "libnemar_hip.so" and d["dropout"], d
+    assert d["single_stream_repeats"] == 5, d
+    assert d["steps"] >= SOAK_STEPS and d["events"] == 0, d
