@@ -44,7 +44,9 @@ extern "C" {
  *   36 reduction-split forward layers keep a fused ReLU / LeakyReLU (activation in the sum pass; 0)
  *   37 kernel families whose workgroups claim the whole CU's LDS (bit mask: 1 LDS-DMA forms of wgrad_split16_kernel (default), 2 igemm_split16_kernel,
  *      4 s16g_kernel — csrc/common.h)                                38 wide 3x3 weight gradient stages through registers (1, default) / by LDS-DMA (0)
- *   39 most reduction runs per tile of the wide-layer kernel (8; 1 = never split: small test shapes with the fused data-gradient epilogue) */
+ *   39 most reduction runs per tile of the wide-layer kernel (8; 1 = never split: small test shapes with the fused data-gradient epilogue)
+ *   40 most 64-channel blocks one s16g_kernel workgroup runs on one converted halo (4; 1 = one workgroup per channel block, rounds 3-5)
+ *   41 ... as long as the grid keeps this many workgroups (256; tests: 0) */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/timeline_*.py), NULL = off */
 /* grad_input variant for A/B measurements: 0 (default) = gather + fixed point (needs the workspace), 1 = fp32 atomics through an

@@ -63,7 +63,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-_AB_WORDS = re.compile(r"\bNEMAR_(AB|SWITCH|AB_ONLY)\b")
+_AB_WORDS = re.compile(r"\b(NEMAR_(AB|SWITCH|AB_ONLY)|g_lds_claim)\b")      # (g_lds_claim: a switch variable DECLARED in common.h — its users change with -DNEMAR_AB too)
 
 
 def ab_sensitive(src):

@@ -1436,6 +1436,8 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 34) { nemar_split16_wgrad_tune(value); return NEMAR_OK; }      // wide weight gradient: 1 one gy copy (default), 0 KS shifted copies
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
+    if (key == 40) { nemar_s16g_tune(2, value); return NEMAR_OK; }
+    if (key == 41) { nemar_s16g_tune(3, value); return NEMAR_OK; }      // ... while the grid keeps this many workgroups (256)      // most channel blocks per s16g workgroup (4; 1 = one workgroup per block)
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = value == 3 ? 3 : 4; return NEMAR_OK; }      // packed images made under the other setting are stale
     if (key == 16) { g_adir = value != 0; return NEMAR_OK; }

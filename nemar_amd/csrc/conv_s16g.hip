@@ -235,7 +235,12 @@ struct RegS16gPack {
 // MT x 32 output channels, NT x 32 pixels per wave (four waves side by side in the pixel direction); SX = source stride.
 // LDS (dynamic: exactly what the layer needs, so that narrow layers keep several workgroups per CU): [weights of one chunk,
 // p.aw16 words][halo planes, 4 p.hp16 words]
-template <int MT, int NT, int SX, int NS4MAX>          // NS4MAX: 4-pixel halo groups per loader thread (1: tiles of <= 128 groups)
+// MBL (round 6): channel blocks per workgroup.  The grid used to hold one workgroup per (tile, channel block): a layer with 128 / 256
+// output channels loaded, reduced and converted every halo chunk two / four times, and those phases — not the MFMAs — are most of a
+// chunk (timeline: max + barrier 3000, conversion 3300, loads + barrier 1500 cycles beside 3000 cycles of taps).  With MBL > 1 a
+// workgroup keeps MBL accumulator sets and runs the taps of MBL channel blocks on ONE converted halo; their weights alternate between two
+// LDS regions (the next block's copies are issued before the current block's taps).
+template <int MT, int NT, int SX, int NS4MAX, int MBL = 1>          // NS4MAX: 4-pixel halo groups per loader thread (1: tiles of <= 128 groups)
 __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     constexpr int MB = 32 * MT, NPW = 32 * NT;
 #ifdef NEMAR_HOST_EMULATION
@@ -245,15 +250,15 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
 #endif
     __shared__ unsigned red[4];
     u32x4* const As = smem;
-    u32x4* const Bs = smem + p.aw16;
+    u32x4* const Bs = smem + (MBL > 1 ? 2 : 1) * p.aw16;          // MBL > 1: two weight regions
 
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid; consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous run of (tile, class, channel block)
     // triples, so that the channel blocks / classes of a tile (same halo) and neighbouring tiles (shared halo rows) share one L2
     int t = blockIdx.x;
     if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
-    const int mblk = t % p.mblks;
-    t /= p.mblks;
+    const int mblk = (t % (p.mblks / MBL)) * MBL;              // first channel block of this workgroup
+    t /= p.mblks / MBL;
     const int cls = t % p.ncls;
     t /= p.ncls;
     const int txi = t % p.tiles_x;
@@ -345,10 +350,11 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     const int acopies = ntaps * 2 * MT;                        // ntaps * 4 * MB / 64
     const u32x4* const wcls = p.wp + (size_t)cls * p.cls_words + (size_t)mblk * ntaps * 4 * MB;
     const size_t wchunk = (size_t)p.mblks * ntaps * 4 * MB;
-#define S16G_WEIGHTS(ch_)                                                                                               \
+#define S16G_WEIGHTS(ch_, mb_)                                        /* block mb_ of the workgroup -> region mb_ & 1 */ \
     {                                                                                                                   \
-        const u32x4* const a_ = wcls + (size_t)(ch_) * wchunk + lane;                                                   \
-        if (!(p.dbg & 8)) for (int q = wid; q < acopies; q += 4) glds16(a_ + 64 * q, As + 64 * q);                      \
+        const u32x4* const a_ = wcls + (size_t)(ch_) * wchunk + (size_t)(mb_) * (ntaps * 4 * MB) + lane;                \
+        u32x4* const d_ = As + ((mb_) & 1) * p.aw16;                                                                    \
+        if (!(p.dbg & 8)) for (int q = wid; q < acopies; q += 4) glds16(a_ + 64 * q, d_ + 64 * q);                      \
     }
 
     // ---- MFMA role ----
@@ -361,15 +367,26 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         oyx[nt] = ((oy0 + ty) << 16) | (ox0 + tx);
     }
     const int abase = lhi * MB + l31;
-    f32x16 acc[MT][NT];
+    f32x16 acc[MBL][MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mb = 0; mb < MBL; ++mb)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][mt][nt][r] = 0.f;
 
     int E = 0;                                             // running biased exponent of the tile's source maximum
+    // halo word offsets of this class's taps, lane t = tap t: the tap loop takes them with v_readlane.  (Round 6: as p.tapoff[...] the
+    // offset was an s_load_dword PER TAP — scalar memory shares the lgkm counter with LDS, so the s_waitcnt lgkmcnt(0) behind it also
+    // drained the fragment reads in flight: ~250 exposed cycles per tap beside 192 - 384 cycles of MFMAs.)
+#ifndef NEMAR_HOST_EMULATION
+    const int tapv = p.tapoff[min(cls * S16G_CLS_TAPS + lane, S16G_MAX_TAPS - 1)];
+#define S16G_TAPOFF(tap_) __builtin_amdgcn_readlane(tapv, (tap_))
+#else
+#define S16G_TAPOFF(tap_) p.tapoff[cls * S16G_CLS_TAPS + (tap_)]
+#endif
 #ifdef NEMAR_TIMELINE
 #define S16G_STAMP(i_) if (p.tl != nullptr && blockIdx.x == 8 && lane == 0 && chunk < 8) p.tl[(wid * 8 + chunk) * 8 + (i_)] = clock64();
 #else
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the max word is written
         if (!(p.dbg & 32)) __builtin_amdgcn_s_barrier();   // (also: every wave has left the previous chunk's tap loop)
         S16G_STAMP(1)
-        S16G_WEIGHTS(chunk)                                // land during the conversion below
+        S16G_WEIGHTS(chunk, 0)                             // land during the conversion below
         {
             const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
             const int e = max_exponent(m);
@@ -421,11 +438,13 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
                 if (chunk > 0) {
                     const float f = pow2f(127 + E - e);    // exact (power of two); accumulators far below the new scale flush
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                    for (int mb = 0; mb < MBL; ++mb)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= f;
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[mb][mt][nt][r] *= f;
                 }
                 E = e;
             }
@@ -470,36 +489,47 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         S16G_STAMP(2)
         wait_vmem();
         S16G_STAMP(3)
+        if (MBL > 1) S16G_WEIGHTS(chunk, 1)                // the second block's weights: in flight during the first block's taps
         if (chunk + 1 < p.nchunks) S16G_LOAD(chunk + 1)
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's halo words are written
         __builtin_amdgcn_s_barrier();                      // halo planes + weights of this chunk are in LDS for every wave
         S16G_STAMP(4)
         // fragments of tap t + 1 are read while the MFMAs of tap t issue (two register sets)
         u32x4 fa[2][MT][2], fb[2][NT][2];
-#define S16G_READ(set_, tap_)                                                                                           \
+#define S16G_READ(set_, tap_, mb_)                                                                                      \
         {                                                                                                               \
-            const int to_ = p.tapoff[cls * S16G_CLS_TAPS + (tap_)];                                                     \
+            const int to_ = S16G_TAPOFF(tap_);                                                                          \
+            const u32x4* const A_ = As + ((mb_) & 1) * p.aw16;                                                          \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                           \
                 _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) fb[set_][nt][pl] = Bs[pl * 2 * p.hp16 + bbase[nt] + to_]; \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
-                _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) fa[set_][mt][pl] = As[((tap_) * 2 + pl) * 2 * MB + abase + mt * 32]; \
+                _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) fa[set_][mt][pl] = A_[((tap_) * 2 + pl) * 2 * MB + abase + mt * 32]; \
         }
         // partial products, smallest first: (l h') (h l') (h h')
-#define S16G_MMA(set_)                                                                                                  \
+#define S16G_MMA(set_, mb_)                                                                                             \
         _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                                   \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
                 _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                       \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set_][mt][q == 0 ? 1 : 0]), \
-                                                                         __builtin_bit_cast(f16x8, fb[set_][nt][q == 1 ? 1 : 0]), \
-                                                                         acc[mt][nt], 0, 0, 0);
-        S16G_READ(0, 0)
-        for (int tap = 0; tap + 1 < ntaps && !(p.dbg & 1); tap += 2) {
-            S16G_READ(1, tap + 1)
-            S16G_MMA(0)
-            if (tap + 2 < ntaps) S16G_READ(0, tap + 2)
-            S16G_MMA(1)
+                    acc[mb_][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set_][mt][q == 0 ? 1 : 0]), \
+                                                                              __builtin_bit_cast(f16x8, fb[set_][nt][q == 1 ? 1 : 0]), \
+                                                                              acc[mb_][mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MBL; ++mb) {
+            if (mb > 0) {
+                // block mb's weights (issued before block mb - 1's taps) have landed for every wave; region (mb + 1) & 1 is free again
+                wait_vmem();
+                __builtin_amdgcn_s_barrier();
+                if (mb + 1 < MBL) S16G_WEIGHTS(chunk, mb + 1)
+            }
+            S16G_READ(0, 0, mb)
+            for (int tap = 0; tap + 1 < ntaps && !(p.dbg & 1); tap += 2) {
+                S16G_READ(1, tap + 1, mb)
+                S16G_MMA(0, mb)
+                if (tap + 2 < ntaps) S16G_READ(0, tap + 2, mb)
+                S16G_MMA(1, mb)
+            }
+            if (ntaps & 1) { S16G_MMA(0, mb) }
         }
-        if (ntaps & 1) { S16G_MMA(0) }
         S16G_STAMP(5)
 #undef S16G_READ
 #undef S16G_MMA
@@ -508,56 +538,61 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
 #undef S16G_LOAD
 #undef S16G_MASK
 #undef S16G_WEIGHTS
+#undef S16G_TAPOFF
 
     // ---- epilogue: take the two power-of-two scales out (exact), bias, activation ----
     if (p.dbg & 128) return;
     const float u1 = pow2f(E - TEXP), u2 = 1.f / weight_scale(absmax_of_partials(p.wmax));
     const size_t plane = (size_t)p.OHf * p.OWf;
     const int M1 = p.M - p.M0;
-    float bv[MT][16];                  // the bias of this lane's rows: all loads in flight at once (one wait, not one per row)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mblk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            bv[mt][r] = p.bias ? p.bias[m < p.M ? m : 0] : 0.f;
-        }
-    // full channel block into one destination (every layer of the three nets; ragged blocks below): plain stores, the activation
-    // chosen once per wave — three compact store loops (an inlined tanhf per element made this epilogue 30 000 instructions and
-    // instruction-fetch bound: 24 of 160 us; tanh layers have <= 4 output channels and never come here)
-    const bool plain = (mblk + 1) * MB <= p.M && ((mblk + 1) * MB <= p.M0 || mblk * MB >= p.M0);
-    float* const dplain = mblk * MB >= p.M0 ? p.dst1 + ((size_t)n * M1 + (mblk * MB - p.M0)) * plane : p.dst0 + ((size_t)n * p.M0 + mblk * MB) * plane;
-    const float u12 = u1 * u2;                               // (both powers of two; their product is a normal number for any finite result)
-    const bool one_mul = u12 != 0.f && u12 < 3.0e38f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
-        if (oy >= OH || ox >= OW) continue;
-        const size_t opix = (size_t)(oy * p.osy + p.ooy[cls]) * p.OWf + (size_t)(ox * p.osx + p.oox[cls]);
-        if (plain) {
-            float* const d0 = dplain + opix + (size_t)(4 * lhi) * plane;
-#define S16G_STORES(EXPR_)                                                                                              \
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-                    const float o_ = (one_mul ? acc[mt][nt][r] * u12 : (acc[mt][nt][r] * u1) * u2) + bv[mt][r];         \
-                    d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * plane] = (EXPR_);                                   \
-                }
-            if (p.act == ACT_RELU) { S16G_STORES(fmaxf(o_, 0.f)) }
-            else if (p.act == ACT_LRELU) { S16G_STORES(o_ > 0.f ? o_ : o_ * p.slope) }
-            else { S16G_STORES(o_) }
-#undef S16G_STORES
-            continue;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
+    for (int mb = 0; mb < MBL; ++mb) {                     // (MBL > 1: the channel blocks of this workgroup, one after the other)
+    const int mbk = mblk + mb;
+        float bv[MT][16];                  // the bias of this lane's rows: all loads in flight at once (one wait, not one per row)
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mblk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m >= p.M) continue;
-                float o = (acc[mt][nt][r] * u1) * u2 + bv[mt][r];
-                o = p.act == ACT_RELU ? fmaxf(o, 0.f) : (p.act == ACT_LRELU ? (o > 0.f ? o : o * p.slope) : o);
-                float* const d = m < p.M0 ? p.dst0 + ((size_t)n * p.M0 + m) * plane : p.dst1 + ((size_t)n * M1 + (m - p.M0)) * plane;
-                d[opix] = o;
+                const int m = mbk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                bv[mt][r] = p.bias ? p.bias[m < p.M ? m : 0] : 0.f;
+            }
+        // full channel block into one destination (every layer of the three nets; ragged blocks below): plain stores, the activation
+        // chosen once per wave — three compact store loops (an inlined tanhf per element made this epilogue 30 000 instructions and
+        // instruction-fetch bound: 24 of 160 us; tanh layers have <= 4 output channels and never come here)
+        const bool plain = (mbk + 1) * MB <= p.M && ((mbk + 1) * MB <= p.M0 || mbk * MB >= p.M0);
+        float* const dplain = mbk * MB >= p.M0 ? p.dst1 + ((size_t)n * M1 + (mbk * MB - p.M0)) * plane : p.dst0 + ((size_t)n * p.M0 + mbk * MB) * plane;
+        const float u12 = u1 * u2;                               // (both powers of two; their product is a normal number for any finite result)
+        const bool one_mul = u12 != 0.f && u12 < 3.0e38f;
+    #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
+            if (oy >= OH || ox >= OW) continue;
+            const size_t opix = (size_t)(oy * p.osy + p.ooy[cls]) * p.OWf + (size_t)(ox * p.osx + p.oox[cls]);
+            if (plain) {
+                float* const d0 = dplain + opix + (size_t)(4 * lhi) * plane;
+    #define S16G_STORES(EXPR_)                                                                                              \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                        const float o_ = (one_mul ? acc[mb][mt][nt][r] * u12 : (acc[mb][mt][nt][r] * u1) * u2) + bv[mt][r];         \
+                        d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * plane] = (EXPR_);                                   \
+                    }
+                if (p.act == ACT_RELU) { S16G_STORES(fmaxf(o_, 0.f)) }
+                else if (p.act == ACT_LRELU) { S16G_STORES(o_ > 0.f ? o_ : o_ * p.slope) }
+                else { S16G_STORES(o_) }
+    #undef S16G_STORES
+                continue;
+            }
+    #pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (m >= p.M) continue;
+                    float o = (acc[mb][mt][nt][r] * u1) * u2 + bv[mt][r];
+                    o = p.act == ACT_RELU ? fmaxf(o, 0.f) : (p.act == ACT_LRELU ? (o > 0.f ? o : o * p.slope) : o);
+                    float* const d = m < p.M0 ? p.dst0 + ((size_t)n * p.M0 + m) * plane : p.dst1 + ((size_t)n * M1 + (m - p.M0)) * plane;
+                    d[opix] = o;
+                }
             }
         }
     }
@@ -602,10 +637,14 @@ int nemar_s16g_timer_read(double* total_ms, double* total_flop) {
 static NEMAR_SWITCH(int, g_s16g_maxmt, 2);      // widest channel tile (x 32): nemar_s16g_tune(0, v).  64 channels: the step is 1.3 % faster than with 128-channel
                                    // tiles (36.4-36.7 vs 37.0-37.2 ms, A/B on one box) — their fragment sets leave no room for latency hiding
 static NEMAR_SWITCH(int, g_s16g_lds_pref, 0);   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
+static NEMAR_SWITCH(int, g_s16g_mbl_wgs, 256);  // ... as long as the grid keeps this many workgroups: nemar_s16g_tune(3, v) (tests: 0)
+static NEMAR_SWITCH(int, g_s16g_maxmbl, 4);     // most channel blocks per workgroup (1: one workgroup per channel block, the rounds 3-5 form): nemar_s16g_tune(2, v)
 #ifdef NEMAR_AB
 void nemar_s16g_tune(int key, int value) {
     if (key == 0) g_s16g_maxmt = value == 1 || value == 4 ? value : 2;
     if (key == 1) g_s16g_lds_pref = value;
+    if (key == 2) g_s16g_maxmbl = value >= 4 ? 4 : 1;
+    if (key == 3) g_s16g_mbl_wgs = value;
 }
 #endif
 
@@ -760,7 +799,22 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
             const int ddy = q.dy[c][t] - pl.dymin, ddx = q.dx[c][t] + p.OFS;      // LDS column = image column - ox0 SX + OFS
             p.tapoff[c * S16G_CLS_TAPS + t] = ddy * pl.HCP + (q.sstride == 2 ? (ddx & 1) * pl.HCH + (ddx >> 1) : ddx);
         }
-    const dim3 g(pl.tiles_x * pl.tiles_y * q.N * pl.mblks * q.ncls), b(256);
+    int maxtaps = 0;
+    for (int c = 0; c < q.ncls; ++c) maxtaps = q.ntaps[c] > maxtaps ? q.ntaps[c] : maxtaps;
+    p.aw16 = maxtaps * 4 * 32 * pl.MT;
+    // channel blocks per workgroup: FOUR 64-channel blocks on 128-pixel tiles (MBL x MT x NT = 8 accumulator tiles), where two weight regions fit
+    // next to the halo and the grid keeps >= 256 workgroups.  Measured stand-alone at batch 16 (profiles/r6_s16g_mbl_microbench.txt): the
+    // translation net's 128 -> 256 stride-2 layer 199 -> 170 us.  TWO blocks per workgroup were measured too and lost (64 -> 128 stride 2:
+    // 228 -> 243 us; stride-1 data gradients with 128 / 256 rows: 336 -> 437, 448 -> 530 us): half the conversions saved do not pay for
+    // the second workgroup the CU loses to 384 registers per wave and the doubled weight region — those shapes keep one block per workgroup.
+    int mbl = 1;
+    {
+        const long long wgs = (long long)pl.tiles_x * pl.tiles_y * q.N * (pl.mblks / 4) * q.ncls;
+        if (g_s16g_maxmbl >= 4 && pl.MT == 2 && pl.NT == 1 && pl.mblks % 4 == 0 && wgs >= g_s16g_mbl_wgs &&
+            ((size_t)2 * p.aw16 + 4 * (size_t)p.hp16) * 16 <= (size_t)160 * 1024 - 2048)
+            mbl = 4;
+    }
+    const dim3 g(pl.tiles_x * pl.tiles_y * q.N * (pl.mblks / mbl) * q.ncls), b(256);
     p.ncls = q.ncls;
     p.xcd = g.x % 8 == 0 ? 1 : 0;
     const bool tm = g_timing && g_tev_used < MAX_TIMED;
@@ -772,20 +826,23 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
         }
         (void)hipEventRecord(g_tev[g_tev_used][0], st);
     }
-    int maxtaps = 0;
-    for (int c = 0; c < q.ncls; ++c) maxtaps = q.ntaps[c] > maxtaps ? q.ntaps[c] : maxtaps;
-    p.aw16 = maxtaps * 4 * 32 * pl.MT;
-    const size_t lds = ((size_t)p.aw16 + 4 * (size_t)p.hp16) * 16;
+    const size_t lds = ((size_t)(mbl > 1 ? 2 : 1) * p.aw16 + 4 * (size_t)p.hp16) * 16;
 #ifdef NEMAR_HOST_EMULATION
-#define S16G_GO1(MT_, NT_, SX_, NS_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds, st, p); }
+#define S16G_GO2(MT_, NT_, SX_, NS_, MBL_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_, MBL_>), g, b, lds, st, p); }
 #else
     // more than 64 KiB of dynamic LDS needs the attribute (nemar_lds_bytes sets it once per instantiation; whole-CU claim: common.h)
-#define S16G_GO1(MT_, NT_, SX_, NS_)                                                                                    \
+#define S16G_GO2(MT_, NT_, SX_, NS_, MBL_)                                                                              \
     {                                                                                                                   \
-        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_, NS_>), lds, (g_lds_claim & 4) != 0);       \
-        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_>), g, b, lds_, st, p);                                       \
+        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&s16g_kernel<MT_, NT_, SX_, NS_, MBL_>), lds, (g_lds_claim & 4) != 0);       \
+        hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_, MBL_>), g, b, lds_, st, p);                                 \
     }
 #endif
+    // (MBL = 4 is instantiated for the 64-channel x 128-pixel tile only)
+#define S16G_GO1(MT_, NT_, SX_, NS_)                                                                                    \
+    {                                                                                                                   \
+        if (MT_ == 2 && NT_ == 1 && mbl == 4) S16G_GO2(2, 1, SX_, NS_, 4)                                               \
+        else S16G_GO2(MT_, NT_, SX_, NS_, 1)                                                                            \
+    }
 #define S16G_GO(MT_, NT_, SX_) { if (pl.HR * p.GPR <= 128) S16G_GO1(MT_, NT_, SX_, 1) else S16G_GO1(MT_, NT_, SX_, 2) }
 #define S16G_BY_TILE(MT_)                                           \
     if (sx == 1 && pl.NT == 2) S16G_GO(MT_, 2, 1)                   \
@@ -800,6 +857,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
 #undef S16G_BY_TILE
 #undef S16G_GO
 #undef S16G_GO1
+#undef S16G_GO2
     if (tm) {
         (void)hipEventRecord(g_tev[g_tev_used++][1], st);
         g_tev_flop += flop;

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd4_kernel(const float* __r
     }
     const float rstd = uniform_f(1.f / sqrtf(block_sum(q, red) * inv + eps));
     // (the residual is fetched in groups of four float4 per thread: all PER4 at once would double the register footprint)
-    constexpr int RG = PER4 >= 16 ? 1 : (PER4 < 4 ? PER4 : 4);
+    constexpr int RG = PER4 >= 16 ? 1 : (PER4 < 4 ? PER4 : (PER4 % 4 == 0 ? 4 : (PER4 % 2 == 0 ? 2 : 1)));
+    static_assert(PER4 % RG == 0, "residual groups must tile the float4s of a thread");
 #pragma unroll
     for (int k0 = 0; k0 < PER4; k0 += RG) {
         f32x4n r[RG];
@@ -341,6 +342,10 @@ static int instnorm_fwd_impl(const float* x, const float* residual, float* y, fl
         hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 8, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (vec && HW == 1024 * 64)
         hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 16, true>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    else if (vec && HW <= 1024 * 48)        // 32768 < HW <= 49152 (200 x 200, 208 x 208 ...): register-cached as well
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 12, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+    else if (vec && HW <= 1024 * 56)        // ... <= 57344 (224 x 224, 232 x 232); a <1024, 16, false> instance spills 20 registers
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 14, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 64 * 8)
         hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
     else if (HW <= 256 * 16)

@@ -117,6 +117,7 @@ _side_streams = {}
 _side_keep = collections.deque()     # (event recorded on the side stream behind a branch | None inside a capture, the tensors it reads)
 _side_touched = set()                # id() of the gradient buffers the side lane has accumulated into since the last join
 _side_busy = [False]
+_event_pool = []                     # completed branch events, reused (a fresh torch.cuda.Event per backward convolution is a hipEventCreate each)
 _main_streams = {}     # device -> the compute stream the last branch forked from
 _side_cb = [False]     # join_side is queued as an end-of-backward callback of the running autograd pass
 
@@ -153,7 +154,7 @@ class _on_side:
         side.wait_stream(main)
         if not torch.cuda.is_current_stream_capturing() and not _KEEP_ALL:
             while _side_keep and _side_keep[0][0] is not None and _side_keep[0][0].query():
-                _side_keep.popleft()                               # that branch has run: its tensors may go back to the allocator
+                _event_pool.append(_side_keep.popleft()[0])        # that branch has run: its tensors may go back to the allocator
         self.kept = [t for t in self.keep if t is not None]
         _side_busy[0] = True
         if not _side_cb[0]:
@@ -169,7 +170,7 @@ class _on_side:
         if self.ctx is not None:
             ev = None
             if not torch.cuda.is_current_stream_capturing():
-                ev = torch.cuda.Event()
+                ev = _event_pool.pop() if _event_pool else torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
             _side_keep.append((ev, self.kept))
             _lane[0] = 0

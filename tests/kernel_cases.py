@@ -205,21 +205,26 @@ class s16g_route:
     """Lift the work threshold of the general 16-bit-pipe route (csrc/conv_s16g.hip: in-kernel operand split) for small test shapes;
     `on=False` forces the exact-fp32 kernels instead."""
 
-    def __init__(self, be, on=True):
-        self.be, self.on = be, on
+    def __init__(self, be, on=True, mbl=None):
+        self.be, self.on, self.mbl = be, on, mbl
 
     def __enter__(self):
         self.be.lib.tune(24, 1 if self.on else 0)
         self.be.lib.tune(25, 0)
+        if self.mbl is not None:          # channel blocks per workgroup (round 6): force the grouping on the tests' few-tile shapes
+            self.be.lib.tune(40, self.mbl)
+            self.be.lib.tune(41, 0)
         return self
 
     def __exit__(self, *a):
         self.be.sync()
         self.be.lib.tune(24, 1)
         self.be.lib.tune(25, 30)
+        self.be.lib.tune(40, 4)
+        self.be.lib.tune(41, 256)
 
 
-def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NONE, bias=True, seed=0, xscale=None):
+def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NONE, bias=True, seed=0, xscale=None, mbl=None):
     """Forward through nemar_conv2d_fwd on the general 16-bit-pipe route; `xscale` [N] or [N, C] multiplies the source per sample /
     per channel (dynamic-range cases: the block scale is per tile and per 16-channel chunk)."""
     rng = np.random.default_rng(seed)
@@ -239,7 +244,7 @@ def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.A
     d_x1 = be.dev(x[:, C0:]) if C1 else None
     d_w, d_b = be.dev(w), (be.dev(b) if bias else None)
     d_y = be.full((N, K, OH, OW), np.nan)
-    with s16g_route(be):
+    with s16g_route(be, mbl=mbl):
         ws, wsb = _ws(be, be.lib.conv2d_fwd_workspace(N, H, W, K, C, R, R, stride, pad))
         be.lib.conv2d_fwd(be.ptr(d_x0), C0, be.ptr(d_x1), C1, be.ptr(d_w), be.ptr(d_b), be.ptr(d_y), N, H, W, K, R, R,
                           stride, pad, pad_mode, act, 0.2, be.ptr(ws), wsb, 0, be.stream)
@@ -252,8 +257,8 @@ def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.A
         raise AssertionError("conv2d_fwd (s16g): err %.3e > %.3e at %s (got %.6g want %.6g)" % (err[i], lim[i], i, got[i], want[i]))
 
 
-def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO):
-    with s16g_route(be):
+def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO, mbl=None):
+    with s16g_route(be, mbl=mbl):
         case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=skip0, seed=seed)
         assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
 

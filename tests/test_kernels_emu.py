@@ -539,6 +539,24 @@ def test_resblock_planes_chain(be, pad_mode, act, drop):
     K.case_resblock_planes_chain(be, pad_mode, act, drop)
 
 
+@pytest.mark.parametrize("mbl", [1, 4])
+def test_conv_s16g_channel_blocks_per_workgroup(be, mbl):
+    """Round 6: one s16g_kernel workgroup runs the taps of four 64-channel blocks on one converted halo (two weight regions in LDS,
+    four accumulator sets) where the layer has a multiple of 256 output rows and 128-pixel tiles.  Same results as one workgroup per block (mbl = 1) within the kernel's bound: forward with several chunks and
+    a rescale between them, 128 and 256 output channels, stride 1 / 2 / 4x4, data gradient (a forward over the transposed weights) and a
+    transposed convolution's parity classes."""
+    chan = 10.0 ** np.linspace(3, -4, 48)
+    K.case_conv_s16g_fwd(be, 1, 48, 0, 4, 32, 256, 3, 1, 1, K.PAD_ZERO, act=2, xscale=np.stack([chan]), mbl=mbl)       # chunks shrink: no rescale
+    K.case_conv_s16g_fwd(be, 1, 48, 0, 4, 32, 256, 3, 1, 1, K.PAD_ZERO, xscale=np.stack([chan[::-1]]), mbl=mbl)        # chunks grow: every block's accumulators rescale
+    K.case_conv_s16g_fwd(be, 2, 16, 16, 8, 64, 128, 3, 2, 1, K.PAD_ZERO, act=1, mbl=mbl)                               # stride 2, two sources
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 8, 64, 128, 4, 2, 1, K.PAD_ZERO, mbl=mbl)                                       # 4x4 stride 2 (discriminator)
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 8, 64, 256, 3, 2, 1, K.PAD_ZERO, act=1, mbl=mbl)                                # the translation net's second down-sampling layer (four blocks)
+    K.case_conv_s16g_fwd(be, 1, 16, 0, 8, 64, 512, 4, 2, 1, K.PAD_ZERO, mbl=mbl)                                       # eight blocks: two workgroups of four
+    K.case_conv_s16g_fwd(be, 1, 32, 0, 6, 40, 192, 3, 1, 1, K.PAD_REFLECT, mbl=mbl)                                    # 3 blocks: falls back to fewer per workgroup
+    K.case_conv_s16g_bwd_data(be, 1, 256, 0, 4, 32, 32, 3, 1, 1, mbl=mbl)                                              # data gradient: 256 "output" channels
+    K.case_conv_s16g_bwd_data(be, 1, 128, 0, 8, 64, 32, 3, 2, 1, mbl=mbl)                                              # stride-2 data gradient: parity classes
+
+
 def test_producer_max_words(be):
     K.case_producer_max_words(be)
 
