@@ -16,7 +16,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                       launch duration, measured with HIP events on the launch stream inside the library (nemar_kernel_timer) in
                       two extra steps right after the timed region; peak = 2500 TF dense fp16 MFMA / 3 products;
                       traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same batch-16 launch from separate rocprofv3 --pmc passes
-                      (profiles/r5_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
+                      (profiles/r6_pmc_traffic.json).  Under this kernel the chip clocks at ~1.75 GHz, not the 2.4 GHz the
                       peak assumes (profiles/r3_clock_trace.txt); a pure MFMA loop on random operands sustains 1730 TFLOP/s,
                       on all-zero operands 2530 (profiles/r4_mfma_peak_modes.txt): `frac_of_sustained_mfma` is priced on the former
   roofline_grid_sample   BASELINE's second metric: grid_sample fwd+bwd algorithmic bytes / event-timed duration vs 8 TB/s
@@ -43,7 +43,7 @@ F16_MFMA_SUSTAINED_TF = 1730.0   # measured on the MI355X of this pool: back-to-
                                  # RANDOM operands, 2 waves / SIMD: the clock settles at ~1.75 GHz.  The same loop on all-zero / all-one
                                  # operands holds 2.37-2.43 GHz = 2450-2530 TFLOP/s — the guide's peak is a trivial-operand figure, the
                                  # power limit depends on the data (tools/probes/mfma_peak_modes.hip, profiles/r4_mfma_peak_modes.txt)
-PMC_FILE = "profiles/r5_pmc_traffic.json"
+PMC_FILE = "profiles/r6_pmc_traffic.json"
 
 
 def build_opt(batch, size, extra=()):
@@ -588,7 +588,7 @@ def main():
         out["dist_buckets_launched"] = buckets
     C = 256
     hw = (a.size // 4) ** 2
-    # HBM traffic comes from separate rocprofv3 --pmc passes over the same kernels (tools/profile_round.sh); it is
+    # HBM traffic comes from separate rocprofv3 --pmc passes over the same kernels (tools/profile_evidence.sh); it is
     # only attached when the bench runs the shape those passes measured.
     pmc, std = {}, (a.size == 256 and a.batch == 8)
     try:
@@ -638,6 +638,15 @@ def main():
         tot = sum(v["avg_call_us"] for v in rb.values())
         rb["all_three"] = {"avg_us_per_layer": tot, "frac": sum(2.0 * (2 * a.batch) * C * hw * C * 9 for _ in range(len(rb))) / (tot * 1e-6) / 1e12 / (F16_MFMA_PEAK_TF / 3.0)}
         rb["peak_basis"] = "2500 TFLOP/s dense fp16 MFMA / 3 products per fp32 product; 256->256 3x3 reflect layer, %d images per call" % (2 * a.batch)
+        # Round 6: inside the one-node ResnetBlock the three calls run on producer-written operand planes (no split / max passes inside them
+        # any more): what used to be their support passes now sits in the InstanceNorm passes on either side.  The honest per-layer price
+        # therefore includes those two producers (one InstanceNorm forward + one InstanceNorm backward per convolution layer).
+        prod = {nm: spans[tag][1] * 1e6 for tag, nm in (('in_fwd_planes_resblock', 'instnorm_fwd_planes'), ('in_bwd_planes_resblock', 'instnorm_bwd_planes')) if tag in spans}
+        if len(prod) == 2 and len(rb) >= 5:
+            tot2 = tot + sum(prod.values())
+            rb["with_producers"] = {"avg_call_us": prod, "avg_us_per_layer": tot2,
+                                    "frac": 3 * 2.0 * (2 * a.batch) * C * hw * C * 9 / (tot2 * 1e-6) / 1e12 / (F16_MFMA_PEAK_TF / 3.0),
+                                    "note": "three convolution calls + the InstanceNorm forward and backward passes that write their operand planes"}
         out["roofline_operator"] = rb
     px = a.batch * a.size * a.size
     gs = {}

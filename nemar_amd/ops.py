@@ -964,8 +964,9 @@ class _ResBlock(Function):
         if drop_p > 0.0:
             _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
             seed, off = _dropout_state["seed"], _dropout_state["offset"]
-        L.instnorm_fwd_planes(_p(y1), None, None, None, _p(stats1), N, C, H, W, eps, ACT_RELU, 0.2, drop_p, seed, off, _p(p1), _p(scale1),
-                              None, _p(xp1), st)
+        with _span('in_fwd_planes_resblock'):
+            L.instnorm_fwd_planes(_p(y1), None, None, None, _p(stats1), N, C, H, W, eps, ACT_RELU, 0.2, drop_p, seed, off, _p(p1), _p(scale1),
+                                  None, _p(xp1), st)
         # conv2 reads the planes; the (never written) fp32 tensor they stand for is only a key: the planes' own address serves
         y2 = torch.empty_like(x)
         conv(_p(p1), p1, scale1, w2, b2, y2)
@@ -978,8 +979,9 @@ class _ResBlock(Function):
             pout = _chan_planes_buffer(N, C, H, W, dev)
             xpout = _x_planes_buffer(N, C, H, W, dev)
             scale_out = torch.empty(N, dtype=torch.int32, device=dev)
-            L.instnorm_fwd_planes(_p(y2), _p(x), _p(_absmax_word(x)), _p(out), _p(stats2), N, C, H, W, eps, ACT_NONE, 0.2, 0.0, 0, 0,
-                                  _p(pout), _p(scale_out), _p(words), _p(xpout), st)
+            with _span('in_fwd_planes_resblock'):
+                L.instnorm_fwd_planes(_p(y2), _p(x), _p(_absmax_word(x)), _p(out), _p(stats2), N, C, H, W, eps, ACT_NONE, 0.2, 0.0, 0, 0,
+                                      _p(pout), _p(scale_out), _p(words), _p(xpout), st)
             out._nemar_planes = (pout, scale_out, out._version)
             out._nemar_xplanes = (xpout, scale_out, out._version)
         else:
@@ -1021,8 +1023,9 @@ class _ResBlock(Function):
             gp = torch.empty(int(gbytes), dtype=torch.uint8, device=dev) if want_g else None
             scale = torch.empty(N, dtype=torch.int32, device=dev)
             bsum = torch.empty((N, C), dtype=torch.float32, device=dev) if want_bias else None
-            L.instnorm_bwd_planes(_p(xin), _p(stats), _p(g), _p(gwords), N, C, H, W, act, 0.2, p, sd, of, 1, None, _p(d), _p(gp), _p(scale),
-                                  _p(bsum), st)
+            with _span('in_bwd_planes_resblock'):
+                L.instnorm_bwd_planes(_p(xin), _p(stats), _p(g), _p(gwords), N, C, H, W, act, 0.2, p, sd, of, 1, None, _p(d), _p(gp), _p(scale),
+                                      _p(bsum), st)
             return d, gp, scale, bsum
 
         def dgrad(d, scale, weight, dst, addend, out_words):

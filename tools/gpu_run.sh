@@ -8,6 +8,8 @@
 #   stats[:ENV=V,...]               rocprofv3 --kernel-trace --stats of 6 eager steps (NEMAR_SIDE_STREAM=0 unless given) -> kernel_stats_<tag>.csv
 #   layers                          tools/microbench_conv.py per-layer table
 #   py:<script.py args>             any tools/ script
+#   pmc:<script.py args>            rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (SEPARATE passes, kernel trace only) over a tools/ script ->
+#                                   pmc_<tag>.txt: per kernel, KiB per launch (FETCH_SIZE counts 64 B per 128-B request on gfx950: x 2 for bytes)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$1; mkdir -p $O; shift
 cd $R
 for step in "$@"; do
@@ -41,5 +43,12 @@ PY
       python tools/microbench_conv.py --iters 20 > $O/layers.jsonl 2>/dev/null; tail -3 $O/layers.jsonl | cut -c1-300 ;;
     py)
       timeout 1500 python $arg > $O/py_$tag.txt 2>&1; tail -30 $O/py_$tag.txt ;;
+    pmc)
+      ( cd /tmp && export TMPDIR=/tmp
+        for c in FETCH_SIZE WRITE_SIZE; do
+          rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/p_$c -- python $R/$arg > /dev/null 2>&1
+          echo "=== $c (KiB per launch)"; python $R/tools/pmc_summary.py $O/p_$c | grep -v "distribution\|fillBuffer"
+        done ) > $O/pmc_$tag.txt 2>&1
+      rm -rf $O/p_FETCH_SIZE $O/p_WRITE_SIZE; grep -A1 "planes\|igemm\|wgrad_split\|sum_partials" $O/pmc_$tag.txt | head -60 ;;
   esac
 done

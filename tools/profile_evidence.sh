@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round-5 evidence run (on the GPU box, via gpurun): the default bench line (with its extras), rocprofv3 kernel stats of the same command
-# on two streams and on one, the traffic / SQ PMC passes of the dominant kernel (separate passes, no trace domains next to --pmc), the
-# per-layer convolution table, the grid_sample micro-benchmark.
+# The round's evidence run (on the GPU box, via gpurun: `tools/profile_evidence.sh <out-name>`): the default bench line (with its extras),
+# rocprofv3 kernel stats of the same command on two streams and on one, the traffic / SQ PMC passes of the dominant kernel (separate
+# passes, no trace domains next to --pmc), the per-layer convolution table, the grid_sample micro-benchmark.  Copy what is to be judged
+# from gpurun_out/<out-name>/ into profiles/ (named per round).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$1
 mkdir -p $O
@@ -29,6 +30,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "=== instnorm $c"; python $R/tools/pmc_summary.py $O/pmc_warp_$c instnorm
 done
 } > $O/pmc_summary.txt 2>&1
+# the one-node ResnetBlock (forward + backward, batch 16, dropout on): HBM bytes per kernel
+{
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_block_$c -- python $R/tools/pmc_block.py 4 1 > /dev/null 2>&1
+  echo "=== one-node ResnetBlock $c (KiB per launch; FETCH_SIZE x 2 = bytes)"; python $R/tools/pmc_summary.py $O/pmc_block_$c | grep -v "distribution\|fillBuffer"
+done
+} > $O/pmc_block.txt 2>&1
+rm -rf $O/pmc_block_*
 python $R/tools/microbench.py > $O/microbench.jsonl 2>/dev/null
 cd $R
 timeout 600 python tools/trace_convs.py > $O/conv_trace.jsonl 2> $O/trace.err
