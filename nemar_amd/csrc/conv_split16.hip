@@ -609,61 +609,69 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
         // add per store; the 16 bias values of a group are four aligned 16-byte loads (round 6: the per-element form — a guarded scalar
         // load and a 64-bit multiply per store — cost 15 us of a 200 us launch)
         const bool with_bias = p.bias != nullptr && zsplit == 0;
+        // the two 32-pixel halves of a lane pair (nt = 0, 1) are neighbouring 128-byte runs of the same channel row: stored back to back
+        float* d0[2];
+        bool ok[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            if (KS != 3 && (y0 + row[nt] >= p.OH || col[nt] >= p.OW)) continue;      // the row / column beyond the valid output
-            float* const d0 = p.dst + (size_t)zsplit * p.slab_stride + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt] +
-                              (size_t)(mblk * 128 + 4 * lhi) * HW;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                float bv[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (with_bias) {
-                        const float* const bp = p.bias + mblk * 128 + 4 * lhi + mt * 32 + 8 * q;
-                        b4 = p.bias_al ? *reinterpret_cast<const float4*>(bp) : make_float4(bp[0], bp[1], bp[2], bp[3]);
-                    }
-                    bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[mt][nt][r];
-                    if (NPL == 2) v *= unscale;
-                    v += bv[r];
-                    d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW] = v;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            ok[nt] = KS == 3 || (y0 + row[nt] < p.OH && col[nt] < p.OW);                 // (4x4: the row / column beyond the valid output)
+            d0[nt] = p.dst + (size_t)zsplit * p.slab_stride + (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt] +
+                     (size_t)(mblk * 128 + 4 * lhi) * HW;
         }
-        return;
-    }
-    // ---- EPI: result [+ addend (the skip gradient)] -> dst, and the tile's max |result| into its partial word (max_words.h).  Eight groups
-    // of 16 elements, each [its addend loads][add, max, stores], fenced: at most 16 loads' worth of extra registers.  Element (mt, r) of a
-    // lane lies a wave-uniform (32 mt + (r & 3) + 8 (r >> 2)) HW floats behind the lane's first one.
-    unsigned omax = 0;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const size_t o0 = (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt] + (size_t)(mblk * 128 + 4 * lhi) * HW;
-        float* const d0 = p.dst + o0;
-        const float* const a0 = p.addend + o0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            float ad[16];
-            if (EPI == 2) {
+            float bv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ad[r] = a0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW];
-                __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) {
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (with_bias) {
+                    const float* const bp = p.bias + mblk * 128 + 4 * lhi + mt * 32 + 8 * q;
+                    b4 = p.bias_al ? *reinterpret_cast<const float4*>(bp) : make_float4(bp[0], bp[1], bp[2], bp[3]);
+                }
+                bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[mt][nt][r] * unscale;
-                if (EPI == 2) v += ad[r];
-                d0[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW] = v;
-                omax = max(omax, finite_bits(__builtin_bit_cast(unsigned, v)));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float v = acc[mt][nt][r];
+                    if (NPL == 2) v *= unscale;
+                    v += bv[r];
+                    if (ok[nt]) d0[nt][(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW] = v;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        return;
+    }
+    // ---- EPI: result [+ addend (the skip gradient)] -> dst, and the tile's max |result| into its partial word (max_words.h).  Four groups
+    // of 32 elements (both 32-pixel halves of 16 channel rows), each [its addend loads][add, max, stores], fenced: at most 32 loads' worth of extra registers.  Element (mt, r) of a
+    // lane lies a wave-uniform (32 mt + (r & 3) + 8 (r >> 2)) HW floats behind the lane's first one.
+    unsigned omax = 0;
+    size_t o0[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        o0[nt] = (size_t)n * p.M * HW + (size_t)(y0 + row[nt]) * p.OW + col[nt] + (size_t)(mblk * 128 + 4 * lhi) * HW;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float ad[2][16];
+        if (EPI == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) ad[nt][r] = p.addend[o0[nt] + (size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v = acc[mt][nt][r] * unscale;
+                if (EPI == 2) v += ad[nt][r];
+                p.dst[o0[nt] + (size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * HW] = v;
+                omax = max(omax, finite_bits(__builtin_bit_cast(unsigned, v)));
+            }
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (p.maxw) {
         __shared__ unsigned mred[4];
