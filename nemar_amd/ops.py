@@ -134,7 +134,9 @@ def side_stream(on=None):
 def _side_stream_of(device):
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        # (NEMAR_SIDE_PRIORITY: tools/prio_experiment.py — HIP queue priorities, two levels on this stack, move the step by <= 1 %)
+        prio = os.environ.get("NEMAR_SIDE_PRIORITY")
+        st = _side_streams[device] = torch.cuda.Stream(device=device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device=device)
     return st
 
 
