@@ -22,6 +22,31 @@ from . import _lib
 
 L = _lib.load()          # raises NemarHipError when the extension is missing: no CPU / eager fallback
 
+
+
+class _SizeQueries:
+    """The library's workspace-size queries are pure functions of their integer arguments (and, in the measurement build, of the switch
+    state: ops.tune() forgets the memo) — ~700 ctypes round trips per step otherwise."""
+
+    def __init__(self, lib):
+        self._lib, self._memo = lib, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        memo = self._memo
+
+        def q(*a):
+            key = (name, a)
+            v = memo.get(key)
+            if v is None:
+                v = memo[key] = fn(*a)
+            return v
+        self.__dict__[name] = q
+        return q
+
+
+Q = _SizeQueries(L)
+
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 GRID_EXPLICIT, GRID_UNET, GRID_AFFINE = 0, 1, 2
@@ -32,7 +57,13 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)      # (the raw handle without building a torch.cuda.Stream object:
+                                                                         # 768 calls per step at ~9 us each were 1.2 ms of host time)
+
+
 def _stream():
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -419,6 +450,7 @@ def invalidate_packed_weights():
 def tune(key, value):
     """nemar_tune through the packed-weight cache: several switches (tile family, split-16 route) change the packed image."""
     L.tune(key, value)
+    Q._memo.clear()
     _scratch_need.clear()
     _gplanes_need.clear()            # (the gy-planes hand-over depends on the route switches too)
     _fusable.clear()
@@ -529,7 +561,7 @@ class _Conv2d(Function):
         OH = (H + 2 * pad - R) // stride + 1
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
-        wsb = L.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
+        wsb = Q.conv2d_fwd_workspace(N, H, W, K, C, R, S, stride, pad)
         ws, hit, plan = _packed(weight, ('fwd', stride, pad, N, H, W), wsb)
         arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, x.device) if x2 is None else None
         tag = 'igemm_fwd_resblock' if (K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT) else None
@@ -586,7 +618,7 @@ class _Conv2d(Function):
             if x2 is not None and gx2 is None:
                 # kernel splits channels [0,C0) | [C0,C); a missing second half still needs a destination
                 gx2 = torch.empty_like(x2)
-            wsb = L.conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode)
+            wsb = Q.conv2d_bwd_data_workspace(N, C, H, W, K, R, S, stride, pad, pad_mode)
             if pad_mode == PAD_REFLECT and pad > 0 and x2 is not None:
                 raise NotImplementedError("reflect-padded conv over a concatenated input has no data-gradient kernel")
             # the packed image depends on which source halves are differentiated (channel skip) and on the geometry
@@ -598,7 +630,7 @@ class _Conv2d(Function):
                 Nd, gd, gxd = N - n0, g[n0:], gx[n0:]
             else:
                 Nd, gd, gxd = N, g, gx
-            wsb = L.conv2d_bwd_data_workspace(Nd, C, H, W, K, R, S, stride, pad, pad_mode)
+            wsb = Q.conv2d_bwd_data_workspace(Nd, C, H, W, K, R, S, stride, pad, pad_mode)
             ws, hit, plan = _packed(ctx.weight, ('dgrad', stride, pad, pad_mode, need_x, Nd, H, W), wsb)
             arena = _conv_scratch(Nd, H, W, K, C, R, S, stride, pad, g.device)
             if arena is not None and need_w and Nd == N and gmax is not None and x2 is None:
@@ -640,7 +672,7 @@ class _Conv2d(Function):
             with (_on_side(g.device, x, x2, g, gmax, ctx.xmax, gpl, xpl) if _use else contextlib.nullcontext()), \
                     (_span('wgrad_resblock') if rbw else contextlib.nullcontext()):
                 gb = _grad_buffer(ctx.bias) if want_b else None      # bias gradient rides along in the same pass
-                wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
+                wsb = Q.conv2d_bwd_weight_workspace(N, C, H, W, K, OH, OW, R, S, stride, pad)
                 arena = _conv_scratch(N, H, W, K, C, R, S, stride, pad, g.device)
                 L.conv2d_bwd_weight_ex(_p(x), C0, _p(x2), C1, _p(g), _p(gwbuf), _p(gb), N, H, W, K, OH, OW,
                                        R, S, stride, pad, pad_mode, _p(_workspace(wsb, g.device)), wsb, _stream(),
@@ -661,7 +693,7 @@ class _Conv2d(Function):
 
 
 def _bias_grad(g, gb, N, C, HW, st):
-    wsb = L.bias_grad_workspace(N, C, HW)
+    wsb = Q.bias_grad_workspace(N, C, HW)
     L.bias_grad(_p(g), _p(gb), N, C, HW, _p(_workspace(wsb, g.device)), wsb, st)
 
 
@@ -684,7 +716,7 @@ class _ConvTranspose2d(Function):
         Ho = (H - 1) * stride - 2 * pad + R + out_pad
         Wo = (W - 1) * stride - 2 * pad + S + out_pad
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
-        wsb = L.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO)
+        wsb = Q.conv2d_bwd_data_workspace(N, Co, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO)
         ws, hit, plan = _packed(weight, ('convT_fwd', stride, pad, N, Ho, Wo), wsb)
         with _record(plan):
             L.conv2d_bwd_data(_p(x), _p(w), _p(b), act, slope, _p(y), Co, None, 0, N, Ho, Wo, Ci, H, W, R, S, stride, pad,
@@ -715,7 +747,7 @@ class _ConvTranspose2d(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            wsb = L.conv2d_fwd_workspace(N, Ho, Wo, Ci, Co, R, S, stride, pad)
+            wsb = Q.conv2d_fwd_workspace(N, Ho, Wo, Ci, Co, R, S, stride, pad)
             ws, hit, plan = _packed(ctx.weight, ('convT_bwd', stride, pad, N, Ho, Wo), wsb)
             with _record(plan):
                 L.conv2d_fwd(_p(g), Co, None, 0, _p(w), None, _p(gx), N, Ho, Wo, Ci, R, S, stride, pad, PAD_ZERO, ACT_NONE,
@@ -725,7 +757,7 @@ class _ConvTranspose2d(Function):
                 _side_touched.add(id(_grad_buffer(ctx.weight)))
             with _on_side(g.device, g, x):                 # the weight-gradient branch: side stream (see _Conv2d)
                 if ctx.needs_input_grad[1]:
-                    wsb = L.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
+                    wsb = Q.conv2d_bwd_weight_workspace(N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad)
                     L.conv2d_bwd_weight(_p(g), Co, None, 0, _p(x), _p(_grad_buffer(ctx.weight)), None, N, Ho, Wo, Ci, H, W, R,
                                         S, stride, pad, PAD_ZERO, _p(_workspace(wsb, g.device)), wsb, _stream())
                     grad_ready(ctx.weight)
@@ -825,7 +857,8 @@ class _InstanceNorm(Function):
                 _dropout_state["offset"] = (_dropout_state["offset"] + 1) & 0xFFFFFFFF
                 seed, off = _dropout_state["seed"], _dropout_state["offset"]
                 ctx.drop = (drop_p, seed, off)
-            xbuf = _x_planes_buffer(N, C, H, W, x.device)        # the weight gradient's pixel-major planes from the same pass
+            # the weight gradient's pixel-major planes from the same pass (not in no_grad / inference forward passes)
+            xbuf = _x_planes_buffer(N, C, H, W, x.device) if any(ctx.needs_input_grad[:2]) else None
             L.instnorm_fwd_planes(_p(x), _p(residual), _p(_absmax_word(residual)) if residual is not None else None, _p(y), _p(stats),
                                   N, C, H, W, eps, act, slope, drop_p, seed, off, _p(buf), _p(scale_words), _p(words), _p(xbuf), _stream())
             _tag_max(y, words)
@@ -938,7 +971,7 @@ class _ResBlock(Function):
         dev = x.device
         st = _stream()
         arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
-        wsb = L.conv2d_fwd_workspace(N, H, W, C, C, 3, 3, 1, 1)
+        wsb = Q.conv2d_fwd_workspace(N, H, W, C, C, 3, 3, 1, 1)
 
         def conv(src_key, planes, words, weight, bias, y):
             ws, hit, plan = _packed(weight, ('fwd', 1, 1, N, H, W), wsb)
@@ -960,7 +993,9 @@ class _ResBlock(Function):
         # IN1 + ReLU + dropout: planes only
         stats1 = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
         p1 = _chan_planes_buffer(N, C, H, W, dev)
-        xp1 = _x_planes_buffer(N, C, H, W, dev)
+        # (the weight gradient's planes only when a backward pass can follow: inference / no_grad forward passes skip 78 MB per activation)
+        train = any(ctx.needs_input_grad[:5])
+        xp1 = _x_planes_buffer(N, C, H, W, dev) if train else None
         scale1 = torch.empty(N, dtype=torch.int32, device=dev)
         seed = off = 0
         if drop_p > 0.0:
@@ -979,13 +1014,14 @@ class _ResBlock(Function):
         words = _max_words(N, dev)
         if feeds_block:
             pout = _chan_planes_buffer(N, C, H, W, dev)
-            xpout = _x_planes_buffer(N, C, H, W, dev)
+            xpout = _x_planes_buffer(N, C, H, W, dev) if train else None
             scale_out = torch.empty(N, dtype=torch.int32, device=dev)
             with _span('in_fwd_planes_resblock'):
                 L.instnorm_fwd_planes(_p(y2), _p(x), _p(_absmax_word(x)), _p(out), _p(stats2), N, C, H, W, eps, ACT_NONE, 0.2, 0.0, 0, 0,
                                       _p(pout), _p(scale_out), _p(words), _p(xpout), st)
             out._nemar_planes = (pout, scale_out, out._version)
-            out._nemar_xplanes = (xpout, scale_out, out._version)
+            if xpout is not None:
+                out._nemar_xplanes = (xpout, scale_out, out._version)
         else:
             L.instnorm_fwd_max(_p(y2), _p(x), _p(out), _p(stats2), N * C, H * W, eps, ACT_NONE, 0.2, _p(words), C, st)
         _tag_max(out, words)
@@ -1018,7 +1054,7 @@ class _ResBlock(Function):
         if gbytes is None:
             gbytes = _gplanes_need[(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)] = L.conv2d_gy_planes_bytes(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)
         arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
-        dwsb = L.conv2d_bwd_data_workspace(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)
+        dwsb = Q.conv2d_bwd_data_workspace(N, C, H, W, C, 3, 3, 1, 1, PAD_REFLECT)
 
         def norm_bwd(xin, stats, g, gwords, act, p, sd, of, want_d, want_g, want_bias):
             d = _chan_planes_buffer(N, C, H, W, dev) if want_d else None
@@ -1052,7 +1088,7 @@ class _ResBlock(Function):
                         _main_lane_grad(buf, dev)
             with _on_side(dev, x_t, xpl, x_words, gp, g_scale, bsum), _span('wgrad_resblock'):
                 if want_w:
-                    wsb = L.conv2d_bwd_weight_workspace(N, C, H, W, C, H, W, 3, 3, 1, 1)
+                    wsb = Q.conv2d_bwd_weight_workspace(N, C, H, W, C, H, W, 3, 3, 1, 1)
                     side_arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
                     key = x_t if x_t is not None else xpl           # (with planes the fp32 operand is only a key)
                     L.conv2d_bwd_weight_ex(_p(key), C, None, 0, _p(gp), _p(gw), None, N, H, W, C, H, W, 3, 3, 1, 1, PAD_REFLECT,
@@ -1266,7 +1302,7 @@ class _Warp(Function):
             go = _c(go)
             N, C, H, W = img.shape
             gin = torch.empty_like(img) if need_img else None
-            wsb = L.grid_sample_bwd_workspace(N, C, H, W)
+            wsb = Q.grid_sample_bwd_workspace(N, C, H, W)
             ws = _zeroed_workspace(wsb, (img.device, N, C, H, W))    # leading part: all-zero in, all-zero out; rest: scratch
             with _span('grid_sample_bwd_gin' if need_img else 'grid_sample_bwd_nogin'):
                 L.grid_sample_bwd(_p(img), _p(gs), mode, _p(go), _p(gin), 0, _p(ggs), 0 if first else 1, N, C, H, W,
@@ -1312,7 +1348,7 @@ class _Smoothness(Function):
         N, _, H, W = d.shape
         Ci = 0 if img is None else img.shape[1]
         loss = torch.empty((1,), dtype=torch.float32, device=d.device)
-        wsb = L.smoothness_workspace(N, H, W)
+        wsb = Q.smoothness_workspace(N, H, W)
         ws = _workspace(wsb, d.device)
         L.smoothness_fwd(_p(d), _p(img), Ci, alpha, factor, _p(loss), 0, _p(ws), wsb, N, H, W, _stream())
         ctx.save_for_backward(d, img)
@@ -1342,7 +1378,7 @@ class _L1(Function):
     def forward(ctx, a, b, weight):
         a, b = _c(a), _c(b)
         loss = torch.empty((1,), dtype=torch.float32, device=a.device)
-        wsb = L.loss_workspace()
+        wsb = Q.loss_workspace()
         ws = _workspace(wsb, a.device)
         L.l1_loss_fwd(_p(a), _p(b), a.numel(), weight, _p(loss), 0, _p(ws), wsb, _stream())
         ctx.save_for_backward(a, b)
@@ -1370,7 +1406,7 @@ class _GanLoss(Function):
     def forward(ctx, x, mode, real, weight):
         x = _c(x)
         loss = torch.empty((1,), dtype=torch.float32, device=x.device)
-        wsb = L.loss_workspace()
+        wsb = Q.loss_workspace()
         ws = _workspace(wsb, x.device)
         L.gan_loss_fwd(_p(x), x.numel(), mode, real, weight, _p(loss), 0, _p(ws), wsb, _stream())
         ctx.save_for_backward(x)
