@@ -463,6 +463,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     __shared__ float red[16];
     __shared__ unsigned s_far[GT_W * GT_H];
     __shared__ unsigned s_nfar;
+    __shared__ unsigned s_rt;                          // round 6: the radius this tile's gathered pixels actually need (1 .. GT_R)
     constexpr int GT_TPT = GT_W * GT_H / GT_THREADS;   // vertically adjacent texels per thread in the gather phase
     const int n = blockIdx.z;
     const int tx0 = blockIdx.x * GT_W, ty0 = blockIdx.y * GT_H;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     const size_t plane = (size_t)H * W;
     const float* inN = in + (size_t)n * C * plane;
     const float* goN = gout + (size_t)n * C * plane;
-    if (tid == 0) s_nfar = 0u;
+    if (tid == 0) { s_nfar = 0u; s_rt = 1u; }
     __syncthreads();
     const int tiles_x = gridDim.x, tiles_n = gridDim.x * gridDim.y;
     const int* const toffN = ws.toff + 2 * (size_t)n * tiles_n;                 // this image's offset table
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     const int rx0 = tx0 - ox - GT_R, ry0 = ty0 - oy - GT_R;                     // pixel at staged index (0, 0)
     float acc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gmax = 0.f;
+    unsigned myrt = 1u;                                // the largest radius a pixel this thread staged needs (-> s_rt, one LDS atomic per wave)
     // Local arrays are only ever indexed by unrolled constants (a run-time channel index would put them in scratch memory).
     // ---- stage 1: the tile's own pixels (4 per thread, independent iterations: their loads overlap): geometry + gout -> LDS,
     //      d loss / d grid -> global, far pixels -> list ------------------------------------------------------------------------
@@ -513,7 +515,13 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
                 if (fm) s_far[atomicAdd(&s_nfar, 1u)] = (unsigned)(((size_t)n * H + h) * W + w) | (fm << 28);
             }
             const bool near = s.x0 - w >= -GT_R && s.x0 - w <= GT_R - 1 && s.y0 - h >= -GT_R && s.y0 - h <= GT_R - 1;   // (o = 0 form)
-            if (any && near) key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+            if (any && near) {
+                key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+                // displacement (dx, dy) in [-r, r - 1]^2 needs radius r: identity, the linspace zoom and sub-pixel fields need 1
+                const int ddx = s.x0 - w, ddy = s.y0 - h;
+                const int rn = max(ddx >= 0 ? ddx + 1 : -ddx, ddy >= 0 ? ddy + 1 : -ddy);
+                if (!shifted) myrt = max(myrt, (unsigned)rn);
+            }
             // d loss / d grid (same arithmetic as grid_sample_bwd_kernel)
             const int o = s.y0 * W + s.x0;
             const float ex = 1.f - s.tx, ey = 1.f - s.ty;
@@ -596,6 +604,8 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
                 for (int c = 0; c < GT_CH; ++c)
                     if (c < C) g[c] = goN[(size_t)c * plane + it];
                 key = ((s.y0 - ty0 + 2 * GT_R) << 16) | ((s.x0 - tx0 + 2 * GT_R) & 0xffff);
+                const int rn = max(dx >= 0 ? dx + 1 : -dx, dy >= 0 ? dy + 1 : -dy);
+                myrt = max(myrt, (unsigned)rn);
             }
         }
         s_key[idx] = key;
@@ -604,6 +614,9 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
 #pragma unroll
         for (int c = 0; c < GT_CH; ++c) s_g[c][idx] = g[c];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) myrt = max(myrt, (unsigned)__shfl_xor((int)myrt, o, 64));
+    if ((tid & 63) == 0 && myrt > 1u) atomicMax(&s_rt, myrt);
     __syncthreads();
     // far pixels of this tile -> the tile's own list segment (no global counter), and the tile's max |gout| -> the scale of the
     // fixed-point scatter.  Only tiles that HAVE far pixels touch the two global words, and only when that would change them
@@ -642,31 +655,57 @@ __global__ __launch_bounds__(GT_THREADS) void grid_sample_bwd_gather_kernel(cons
     for (int i = 0; i < GT_TPT; ++i)
 #pragma unroll
         for (int c = 0; c < GT_CH; ++c) sum[i][c] = 0.f;
-    for (int rr = 0; rr < GT_TPT + 2 * GT_R; ++rr) {
-        const int rowbase = (GT_TPT * rg + rr) * GT_RW + lx;
+    // Round 6: only the staged pixels that CAN touch these texels are visited.  Every gathered pixel of the tile has its corner base within
+    // [-rt, rt - 1] of its own position (relative to the window offset), rt = s_rt <= GT_R found while staging; the others — the outer
+    // GT_R - rt rows / columns of the 7 x (TPT + 6) walk — would fail the test below anyway.  Same pixels, same order, same sums: bitwise
+    // what the full walk gives; identity / the reference's linspace zoom / sub-pixel fields have rt = 1 (12 instead of 56 visits per thread).
+    const int rt = (int)s_rt, skip = GT_R - rt;
+#define GT_VISIT                                                                                                        \
+            const int k = s_key[rowbase + dx]; \
+            const int ex = xt - (int)(short)(k & 0xffff); \
+            const int a = (k >> 16) - yt0; \
+            if ((unsigned)ex <= 1u && a >= -1 && a <= GT_TPT - 1) { \
+                const float ftx = s_tx[rowbase + dx], fty = s_ty[rowbase + dx]; \
+                const float wx = ex ? ftx : 1.f - ftx; \
+                const float wtop = wx * (1.f - fty), wbot = wx * fty; \
+                float g[GT_CH]; \
+_Pragma("unroll") \
+                for (int c = 0; c < GT_CH; ++c) g[c] = s_g[c][rowbase + dx]; \
+_Pragma("unroll") \
+                for (int i = 0; i < GT_TPT; ++i) { \
+                    const float wgt = (i == a) ? wtop : wbot; \
+                    if (i == a || i == a + 1) { \
+_Pragma("unroll") \
+                        for (int c = 0; c < GT_CH; ++c) sum[i][c] += g[c] * wgt; \
+                    } \
+                } \
+            }
+    if (rt == GT_R) {                                  // rough fields: the full walk, fully unrolled as before
+        for (int rr = 0; rr < GT_TPT + 2 * GT_R; ++rr) {
+            const int rowbase = (GT_TPT * rg + rr) * GT_RW + lx;
 #pragma unroll
-        for (int dx = 0; dx <= 2 * GT_R; ++dx) {
-            const int k = s_key[rowbase + dx];
-            const int ex = xt - (int)(short)(k & 0xffff);       // 0: the texel column is the pixel's left corner, 1: its right one
-            const int a = (k >> 16) - yt0;                      // texel a is the pixel's top corner row, a + 1 its bottom one
-            if ((unsigned)ex <= 1u && a >= -1 && a <= GT_TPT - 1) {
-                const float ftx = s_tx[rowbase + dx], fty = s_ty[rowbase + dx];
-                const float wx = ex ? ftx : 1.f - ftx;
-                const float wtop = wx * (1.f - fty), wbot = wx * fty;   // == ex*ey / tx*ey / ex*ty / tx*ty of the scatter form
-                float g[GT_CH];
+            for (int dx = 0; dx <= 2 * GT_R; ++dx) {
+                GT_VISIT
+            }
+        }
+    } else if (rt == 1) {                              // identity, the reference's linspace zoom, sub-pixel fields: 3 x (TPT + 2) visits
 #pragma unroll
-                for (int c = 0; c < GT_CH; ++c) g[c] = s_g[c][rowbase + dx];
+        for (int rr = GT_R - 1; rr < GT_TPT + GT_R + 1; ++rr) {
+            const int rowbase = (GT_TPT * rg + rr) * GT_RW + lx;
 #pragma unroll
-                for (int i = 0; i < GT_TPT; ++i) {
-                    const float wgt = (i == a) ? wtop : wbot;
-                    if (i == a || i == a + 1) {
-#pragma unroll
-                        for (int c = 0; c < GT_CH; ++c) sum[i][c] += g[c] * wgt;
-                    }
-                }
+            for (int dx = GT_R - 1; dx <= GT_R + 1; ++dx) {
+                GT_VISIT
+            }
+        }
+    } else {
+        for (int rr = skip; rr < GT_TPT + 2 * GT_R - skip; ++rr) {
+            const int rowbase = (GT_TPT * rg + rr) * GT_RW + lx;
+            for (int dx = skip; dx <= 2 * GT_R - skip; ++dx) {
+                GT_VISIT
             }
         }
     }
+#undef GT_VISIT
     float* ginN = gin + (size_t)n * C * plane;
     const int x = tx0 + lx;
 #pragma unroll
