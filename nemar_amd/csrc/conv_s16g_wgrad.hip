@@ -419,45 +419,46 @@ __global__ __launch_bounds__(256) void s16g_wgrad_kernel(WgGParams p) {
     }
 }
 
-// gw[k][c][tap] += sum over the slabs of part[slab][tap][k][c] (coalesced slab reads, one pass).  A workgroup = 64 (k, c) pairs x 4
-// waves; wave w adds slabs w, w + 4, ... in order, the four partial sums meet in LDS in wave order: a fixed association order.
-// Workgroups beyond the (k, c) range add the bias partials: gb[k] += sum_slab partb[slab][k].
+// gw[k][c][tap] += sum over the slabs of part[slab][tap][k][c] (coalesced slab reads, one pass).  A workgroup = 64 (k, c) pairs of ONE
+// tap (grid.y) x 4 waves; wave w adds slabs w, w + 4, ... in order (eight loads in flight), the four partial sums meet in LDS in wave
+// order: a fixed association order.  (Round 6: one workgroup per 64 pairs ran all NT taps with one slab's loads in flight — 16
+// workgroups and 64 dependent steps for the registration net's 32 x 32 layers: 17.7 us per call; the sums are bitwise what that form gave.)
+// Workgroups beyond the (k, c) range (tap 0 only) add the bias partials: gb[k] += sum_slab partb[slab][k].
 template <int NT>
 __global__ __launch_bounds__(256) void s16g_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int KC, int nslab,
                                                                 const float* __restrict__ partb, float* __restrict__ gb, int K) {
-    __shared__ float red[3][NT][64];
+    __shared__ float red[3][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nkc = (KC + 63) / 64;
     if ((int)blockIdx.x >= nkc) {                          // bias rows
+        if (blockIdx.y != 0) return;
         const int k = ((int)blockIdx.x - nkc) * 64 + lane;
         float b = 0.f;
         if (k < K)
             for (int sl = w; sl < nslab; sl += 4) b += partb[(size_t)sl * K + k];
-        if (w > 0) red[w - 1][0][lane] = b;
+        if (w > 0) red[w - 1][lane] = b;
         __syncthreads();
-        if (w == 0 && k < K) gb[k] += ((b + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+        if (w == 0 && k < K) gb[k] += ((b + red[0][lane]) + red[1][lane]) + red[2][lane];
         return;
     }
+    const int tp = blockIdx.y;
     const int i = blockIdx.x * 64 + lane;
-    float a[NT];
+    float a = 0.f;
+    if (i < KC) {
+        const float* const q = part + (size_t)tp * KC + i;
+        const size_t ss = (size_t)NT * KC;
+        for (int sl = w; sl < nslab; sl += 32) {
+            float v[8];
 #pragma unroll
-    for (int tp = 0; tp < NT; ++tp) a[tp] = 0.f;
-    if (i < KC)
-        for (int sl = w; sl < nslab; sl += 4) {
-            const float* const q = part + (size_t)sl * NT * KC + i;
+            for (int j = 0; j < 8; ++j) v[j] = q[(size_t)min(sl + 4 * j, nslab - 1) * ss];      // unconditional: all eight in flight
 #pragma unroll
-            for (int tp = 0; tp < NT; ++tp) a[tp] += q[(size_t)tp * KC];
+            for (int j = 0; j < 8; ++j)
+                if (sl + 4 * j < nslab) a += v[j];
         }
-    if (w > 0) {
-#pragma unroll
-        for (int tp = 0; tp < NT; ++tp) red[w - 1][tp][lane] = a[tp];
     }
+    if (w > 0) red[w - 1][lane] = a;
     __syncthreads();
-    if (w == 0 && i < KC) {
-        float* const o = gw + (size_t)i * NT;
-#pragma unroll
-        for (int tp = 0; tp < NT; ++tp) o[tp] += ((a[tp] + red[0][tp][lane]) + red[1][tp][lane]) + red[2][tp][lane];
-    }
+    if (w == 0 && i < KC) gw[(size_t)i * NT + tp] += ((a + red[0][lane]) + red[1][lane]) + red[2][lane];
 }
 
 }  // namespace
@@ -539,8 +540,8 @@ void nemar_s16g_wgrad(const float* x0, int C0, const float* x1, int C1, const fl
 #undef WG_GO
     const int KC = K * C;
     const int rgrid = (KC + 63) / 64 + (gb ? (K + 63) / 64 : 0);
-    if (KS == 3) hipLaunchKernelGGL((s16g_wgrad_reduce_kernel<9>), dim3(rgrid), dim3(256), 0, st, (const float*)part, gw, KC, nslab,
+    if (KS == 3) hipLaunchKernelGGL((s16g_wgrad_reduce_kernel<9>), dim3(rgrid, 9), dim3(256), 0, st, (const float*)part, gw, KC, nslab,
                                     (const float*)p.partb, gb, K);
-    else hipLaunchKernelGGL((s16g_wgrad_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, st, (const float*)part, gw, KC, nslab,
+    else hipLaunchKernelGGL((s16g_wgrad_reduce_kernel<1>), dim3(rgrid, 1), dim3(256), 0, st, (const float*)part, gw, KC, nslab,
                             (const float*)p.partb, gb, K);
 }

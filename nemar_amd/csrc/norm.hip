@@ -244,6 +244,80 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd4_kernel(const float* __r
     if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
 }
 
+// HW == 4 THREADS PER4 exactly, too large for x AND gy in registers (256 x 256 planes: the registration net's 32-channel layers, the
+// translation net's stem): gy stays in registers, x is read twice — the second time from the memory-side cache —
+// with four 16-byte loads in flight per thread (g is recomputed in the second pass: gy is never rewritten in its registers).  Four tensor passes of 16-byte accesses instead of the streaming kernel's five passes of
+// 4-byte ones (130 us per call on 256 planes of 256 x 256: 1.5 TB/s).
+template <int THREADS, int PER4>
+__global__ __launch_bounds__(THREADS) void instnorm_bwd4s_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gy, float* __restrict__ gx, int HW, int act,
+                                                                 float slope, unsigned* maxw, int pps) {
+    static_assert(PER4 % 4 == 0, "x is fetched four float4 at a time");
+    __shared__ float red[16];
+    unsigned omax = 0;
+    const size_t base = (size_t)blockIdx.x * HW;
+    const f32x4n* xp = reinterpret_cast<const f32x4n*>(x + base);
+    const f32x4n* gp = reinterpret_cast<const f32x4n*>(gy + base);
+    f32x4n* op = reinterpret_cast<f32x4n*>(gx + base);
+    const float mean = stats[2 * (size_t)blockIdx.x], rstd = stats[2 * (size_t)blockIdx.x + 1];
+    const float inv = 1.f / (float)HW;
+    const float dneg = act == ACT_RELU ? 0.f : (act == ACT_LRELU ? slope : 1.f);       // act'(xhat <= 0), chosen once (act_df per element: a branch each)
+    f32x4n g[PER4];
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) g[k] = gp[threadIdx.x + k * THREADS];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < PER4; k0 += 4) {
+        f32x4n xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = xp[threadIdx.x + (k0 + k) * THREADS];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (xv[k][e] - mean) * rstd;
+                const float t = g[k0 + k][e] * (h > 0.f ? 1.f : dneg);
+                s1 += t;
+                s2 += t * h;
+            }
+            // one float4 at a time: hipcc otherwise hoists all sixteen x loads above the arithmetic, or runs the whole s1 chain before
+            // the s2 chain with every xhat alive in between (142 / 39 spilled registers)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#ifndef NEMAR_HOST_EMULATION
+    asm volatile("" : "+v"(s1), "+v"(s2));                 // both sums complete HERE (hipcc otherwise sinks the s2 chain below the first reduction,
+#endif                                                     // with every product's operands spilled to scratch on the way)
+    const float m1 = uniform_f(block_sum(s1, red) * inv);
+    const float m2 = uniform_f(block_sum(s2, red) * inv);
+    // the second read of x must BE a read: through an opaque copy of the pointer (hipcc otherwise keeps the first pass's 64 values per
+    // thread alive across the reduction — 144 spilled registers)
+    const f32x4n* xp2 = xp;
+#ifndef NEMAR_HOST_EMULATION
+    asm volatile("" : "+s"(xp2));
+#endif
+#pragma unroll
+    for (int k0 = 0; k0 < PER4; k0 += 4) {
+        f32x4n xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = xp2[threadIdx.x + (k0 + k) * THREADS];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4n o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (xv[k][e] - mean) * rstd;
+                const float t = g[k0 + k][e] * (h > 0.f ? 1.f : dneg);
+                o[e] = rstd * (t - m1 - h * m2);
+                omax = max(omax, finite_mag(o[e]));
+            }
+            op[threadIdx.x + (k0 + k) * THREADS] = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+}
+
 template <int THREADS, int PER>
 __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ stats,
@@ -390,6 +464,8 @@ static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy
         hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 4>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (vec)
         hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 8>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+    else if (HW == 1024 * 64 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0)
+        hipLaunchKernelGGL((instnorm_bwd4s_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (HW <= 64 * 8)
         hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     else if (HW <= 256 * 16)

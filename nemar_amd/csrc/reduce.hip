@@ -55,6 +55,33 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     }
 }
 
+// Few slabs (<= 16: the 16-slab sums of the wide weight gradient — 18 per step, 37.7 MB each — and most bias / split sums), 16-byte
+// columns: one thread = one column, all slabs' words in flight at once, no LDS, no barrier.  SAME association order as the general
+// kernel below ((0 + s0) + s1) + ... [+ dst]: bit-identical results.  (Round 6: in the general kernel a thread had ONE 16-byte load in
+// flight per 16 columns and 240 of 256 threads idled through the second phase: 48 us = 0.8 TB/s for the wide layers' sums.)
+__global__ __launch_bounds__(256) void sum_partials_few_kernel(const float* __restrict__ part, long long stride, int splits,
+                                                               float* __restrict__ dst, long long n, int accumulate, int act, float slope) {
+    const long long cols = n >> 2;
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+        f32x4 v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)                       // unconditional loads (slots beyond the last slab re-read slab 0)
+            v[s] = *reinterpret_cast<const f32x4*>(part + (long long)(s < splits ? s : 0) * stride + 4 * c);
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        t += v[0];
+#pragma unroll
+        for (int s = 1; s < 16; ++s)
+            if (s < splits) t += v[s];
+        f32x4* d = reinterpret_cast<f32x4*>(dst + 4 * c);
+        if (accumulate) t += *d;
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : (act == 1 ? 0.f : t[e] * slope);
+        }
+        *d = t;
+    }
+}
+
 // the slabs hold [N][C0 + C1][HW]; channels < C0 go to d0 [N][C0][HW], the rest to d1 [N][C1][HW] (data gradient of a two-source layer);
 // slabs added in ascending order
 __global__ __launch_bounds__(256) void sum_partials_two_kernel(const float* __restrict__ part, long long stride, int splits, float* __restrict__ d0,
@@ -86,7 +113,12 @@ static void sum_partials_launch(const float* part, long long stride, int splits,
     long long blocks = (cols + 15) / 16;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
-    if (vec)
+    if (vec && splits >= 1 && splits <= 16) {
+        long long fb = (cols + 255) / 256;
+        if (fb > 2048) fb = 2048;
+        hipLaunchKernelGGL(sum_partials_few_kernel, dim3((unsigned)fb), dim3(256), 0, st, part, stride, splits, dst, n, accumulate ? 1 : 0, act,
+                           slope);
+    } else if (vec)
         hipLaunchKernelGGL((sum_partials_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, dst, n,
                            accumulate ? 1 : 0, act, slope);
     else

@@ -321,6 +321,12 @@ def test_instnorm(be, H, W, act):
     K.case_instnorm(be, 2, 3, H, W, act, residual=(act == K.O.ACT_NONE))
 
 
+def test_instnorm_256x256_planes_gy_in_registers(be):
+    """HW == 65536: the backward kernel that keeps gy in registers and reads x twice (norm.hip instnorm_bwd4s_kernel)."""
+    K.case_instnorm(be, 1, 2, 256, 256, K.O.ACT_RELU)
+    K.case_instnorm(be, 1, 1, 256, 256, K.O.ACT_LRELU)
+
+
 def test_pointwise(be):
     K.case_pointwise(be)
 
