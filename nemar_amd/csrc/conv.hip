@@ -1437,6 +1437,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 30) { g_s16g_fold = value != 0; return NEMAR_OK; }
     if (key == 28) { nemar_s16g_tune(1, value); return NEMAR_OK; }
     if (key == 40) { nemar_s16g_tune(2, value); return NEMAR_OK; }
+    if (key == 42) { nemar_s16g_tune(4, value); return NEMAR_OK; }      // class-fused stride-2 data gradients (conv_s16g.hip CF): 0 off, 1 on (default), 2 on + required
     if (key == 41) { nemar_s16g_tune(3, value); return NEMAR_OK; }      // ... while the grid keeps this many workgroups (256)      // most channel blocks per s16g workgroup (4; 1 = one workgroup per block)
     if (key == 23) { g_split16_min_mmac = value < 0 ? 0 : value; return NEMAR_OK; }
     if (key == 21) { g_split16_variant = value == 3 ? 3 : 4; return NEMAR_OK; }      // packed images made under the other setting are stale

@@ -36,6 +36,7 @@ struct S16gPlan {
     int TW, RT, tiles_x, tiles_y, mblks, nchunks;
     int HR, HC, HCP, HCH, dymin, dxmin;
     size_t pack_words_per_class;                           // 16-byte words of one class's packed weights
+    int CF;                                                // four classes fused into one workgroup per tile (conv_s16g.hip: s16g_kernel<..., CF = 1>)
 };
 S16gPlan nemar_s16g_plan(const S16gProblem& q);
 size_t nemar_s16g_pack_bytes(const S16gProblem& q, const S16gPlan& pl);           // all classes + the max word

@@ -113,6 +113,7 @@ struct S16gParams {
     int OHf, OWf, osy, osx;
     int border, act; float slope;
     int ncls, xcd;
+    int pair;                                // class-fused kernel: the two column parities of an output pixel pair are stored as one 8-byte word
     long long* tl;                           // NEMAR_TIMELINE builds: cycle stamps of one workgroup (tools/timeline_s16g.py)
     int dbg;                                 // ablation bits (nemar_tune key 2, tools/ only): 1 no tap loop, 2 no source loads, 4 no conversion
     int TW, RT, wshift, tiles_x, tiles_y, mblks, nchunks;
@@ -240,9 +241,16 @@ struct RegS16gPack {
 // chunk (timeline: max + barrier 3000, conversion 3300, loads + barrier 1500 cycles beside 3000 cycles of taps).  With MBL > 1 a
 // workgroup keeps MBL accumulator sets and runs the taps of MBL channel blocks on ONE converted halo; their weights alternate between two
 // LDS regions (the next block's copies are issued before the current block's taps).
-template <int MT, int NT, int SX, int NS4MAX, int MBL = 1>          // NS4MAX: 4-pixel halo groups per loader thread (1: tiles of <= 128 groups)
+// CF (round 6): CLASS-FUSED form of a four-class problem (the output-parity classes of a stride-2 data gradient / ConvTranspose2d: 1 + 2 + 2 + 4
+// taps of a 3x3 filter, 4 x 4 of a 4x4 one).  One workgroup per (tile, class) loaded, reduced and converted the SAME halo four times for
+// nine taps' worth of MFMAs — those phases, not the taps, are most of a chunk (above).  With CF a workgroup keeps one accumulator set per
+// class and runs all classes' taps on ONE converted halo; the chunk's weights of the four classes sit side by side in the one weight
+// region (as many words as a plain 3x3 / 4x4 layer's), and the epilogue stores the two column parities of a pixel pair as one 8-byte word
+// (a class's own stores are 4 bytes every 8).
+template <int MT, int NT, int SX, int NS4MAX, int MBL = 1, int CF = 0>          // NS4MAX: 4-pixel halo groups per loader thread (1: tiles of <= 128 groups)
 __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
-    constexpr int MB = 32 * MT, NPW = 32 * NT;
+    static_assert(!CF || (MBL == 1 && NT == 1 && SX == 1), "class-fused form: four accumulator sets of one 128-pixel tile, stride-1 source");
+    constexpr int MB = 32 * MT, NPW = 32 * NT, NSET = CF ? 4 : MBL;
 #ifdef NEMAR_HOST_EMULATION
     __shared__ __attribute__((aligned(16))) u32x4 smem[49 * 4 * 32 * 4 + BWORDS];      // (the emulator has no dynamic LDS)
 #else
@@ -259,13 +267,13 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     if (p.xcd) t = (t & 7) * ((int)gridDim.x >> 3) + (t >> 3);
     const int mblk = (t % (p.mblks / MBL)) * MBL;              // first channel block of this workgroup
     t /= p.mblks / MBL;
-    const int cls = t % p.ncls;
-    t /= p.ncls;
+    const int cls = CF ? 0 : t % p.ncls;               // (CF: class 0 = parity (0, 0) has the largest extents — the tile test below)
+    if (!CF) t /= p.ncls;
     const int txi = t % p.tiles_x;
     t /= p.tiles_x;
     const int tyi = t % p.tiles_y, n = t / p.tiles_y;
     const int oy0 = tyi * p.RT, ox0 = txi * p.TW;
-    const int ntaps = p.ntaps[cls];
+    const int ntaps = CF ? p.ntaps[0] + p.ntaps[1] + p.ntaps[2] + p.ntaps[3] : p.ntaps[cls];      // CF: all classes' taps, class after class
     const int OH = p.OH[cls], OW = p.OW[cls];
     if (oy0 >= OH || ox0 >= OW) return;                    // (classes of an odd-sized plane differ by one row / column of tiles)
     const int C = p.C0 + p.C1;
@@ -351,11 +359,20 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     const u32x4* const wcls = p.wp + (size_t)cls * p.cls_words + (size_t)mblk * ntaps * 4 * MB;
     const size_t wchunk = (size_t)p.mblks * ntaps * 4 * MB;
 #define S16G_WEIGHTS(ch_, mb_)                                        /* block mb_ of the workgroup -> region mb_ & 1 */ \
-    {                                                                                                                   \
+    { if (CF) {                                           /* the four classes' runs of this chunk, side by side */      \
+        int pre_ = 0;                                                                                                   \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                              \
+            const int nt_ = p.ntaps[c_];                                                                                \
+            const u32x4* const a_ = p.wp + (size_t)c_ * p.cls_words + ((size_t)(ch_) * p.mblks + mblk) * (nt_ * 4 * MB) + lane; \
+            u32x4* const d_ = As + pre_ * 4 * MB;                                                                       \
+            for (int q = wid; q < nt_ * 2 * MT; q += 4) glds16(a_ + 64 * q, d_ + 64 * q);                               \
+            pre_ += nt_;                                                                                                \
+        }                                                                                                               \
+    } else {                                                                                                            \
         const u32x4* const a_ = wcls + (size_t)(ch_) * wchunk + (size_t)(mb_) * (ntaps * 4 * MB) + lane;                \
         u32x4* const d_ = As + ((mb_) & 1) * p.aw16;                                                                    \
         if (!(p.dbg & 8)) for (int q = wid; q < acopies; q += 4) glds16(a_ + 64 * q, d_ + 64 * q);                      \
-    }
+    } }
 
     // ---- MFMA role ----
     int bbase[NT], oyx[NT];
@@ -367,9 +384,9 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         oyx[nt] = ((oy0 + ty) << 16) | (ox0 + tx);
     }
     const int abase = lhi * MB + l31;
-    f32x16 acc[MBL][MT][NT];
+    f32x16 acc[NSET][MT][NT];
 #pragma unroll
-    for (int mb = 0; mb < MBL; ++mb)
+    for (int mb = 0; mb < NSET; ++mb)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     // offset was an s_load_dword PER TAP — scalar memory shares the lgkm counter with LDS, so the s_waitcnt lgkmcnt(0) behind it also
     // drained the fragment reads in flight: ~250 exposed cycles per tap beside 192 - 384 cycles of MFMAs.)
 #ifndef NEMAR_HOST_EMULATION
-    const int tapv = p.tapoff[min(cls * S16G_CLS_TAPS + lane, S16G_MAX_TAPS - 1)];
+    const int tapv = p.tapoff[min(cls * S16G_CLS_TAPS + lane, S16G_MAX_TAPS - 1)];       // (CF: cls == 0, the host wrote the classes' taps back to back)
 #define S16G_TAPOFF(tap_) __builtin_amdgcn_readlane(tapv, (tap_))
 #else
 #define S16G_TAPOFF(tap_) p.tapoff[cls * S16G_CLS_TAPS + (tap_)]
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
                 if (chunk > 0) {
                     const float f = pow2f(127 + E - e);    // exact (power of two); accumulators far below the new scale flush
 #pragma unroll
-                    for (int mb = 0; mb < MBL; ++mb)
+                    for (int mb = 0; mb < NSET; ++mb)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -513,6 +530,23 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
                     acc[mb_][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set_][mt][q == 0 ? 1 : 0]), \
                                                                               __builtin_bit_cast(f16x8, fb[set_][nt][q == 1 ? 1 : 0]), \
                                                                               acc[mb_][mt][nt], 0, 0, 0);
+        if constexpr (CF != 0) {
+            // class after class on the one converted halo: set c = class c's accumulators, taps g0 .. g0 + ntaps[c] - 1 of the flat table
+            int g0 = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int nt_c = p.ntaps[c];
+                S16G_READ(0, g0, 0)
+                for (int tap = 0; tap + 1 < nt_c && !(p.dbg & 1); tap += 2) {
+                    S16G_READ(1, g0 + tap + 1, 0)
+                    S16G_MMA(0, c)
+                    if (tap + 2 < nt_c) S16G_READ(0, g0 + tap + 2, 0)
+                    S16G_MMA(1, c)
+                }
+                if (nt_c & 1) { S16G_MMA(0, c) }
+                g0 += nt_c;
+            }
+        } else {
 #pragma unroll
         for (int mb = 0; mb < MBL; ++mb) {
             if (mb > 0) {
@@ -530,6 +564,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
             }
             if (ntaps & 1) { S16G_MMA(0, mb) }
         }
+        }
         S16G_STAMP(5)
 #undef S16G_READ
 #undef S16G_MMA
@@ -545,9 +580,44 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     const float u1 = pow2f(E - TEXP), u2 = 1.f / weight_scale(absmax_of_partials(p.wmax));
     const size_t plane = (size_t)p.OHf * p.OWf;
     const int M1 = p.M - p.M0;
+    const float u12 = u1 * u2;                               // (both powers of two; their product is a normal number for any finite result)
+    const bool one_mul = u12 != 0.f && u12 < 3.0e38f;
+    if constexpr (CF != 0) {
+        // (the plan offers this form only for full channel blocks into one destination each and classes (ph, 0), (ph, 1) of equal extents:)
+        // element pairs (2 ox, 2 ox + 1) of destination row 2 oy + ph as one aligned 8-byte store (p.pair: the host checked the alignment;
+        // otherwise two 4-byte stores)
+        {
+            float* const dplain = mblk * MB >= p.M0 ? p.dst1 + ((size_t)n * M1 + (mblk * MB - p.M0)) * plane : p.dst0 + ((size_t)n * p.M0 + mblk * MB) * plane;
+            const int oy = oyx[0] >> 16, ox = oyx[0] & 0xffff;
 #pragma unroll
-    for (int mb = 0; mb < MBL; ++mb) {                     // (MBL > 1: the channel blocks of this workgroup, one after the other)
-    const int mbk = mblk + mb;
+            for (int ph = 0; ph < 2; ++ph) {
+                if (oy >= p.OH[2 * ph] || ox >= p.OW[2 * ph]) continue;
+                float* const d0 = dplain + (size_t)(oy * 2 + ph) * p.OWf + (size_t)(ox * 2) + (size_t)(4 * lhi) * plane;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float bv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bv[r] = p.bias ? p.bias[mblk * MB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float o0 = (one_mul ? acc[2 * ph][mt][0][r] * u12 : (acc[2 * ph][mt][0][r] * u1) * u2) + bv[r];
+                        float o1 = (one_mul ? acc[2 * ph + 1][mt][0][r] * u12 : (acc[2 * ph + 1][mt][0][r] * u1) * u2) + bv[r];
+                        if (p.act == ACT_RELU) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); }
+                        else if (p.act == ACT_LRELU) { o0 = o0 > 0.f ? o0 : o0 * p.slope; o1 = o1 > 0.f ? o1 : o1 * p.slope; }
+                        float* const d = d0 + (size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * plane;
+                        if (p.pair) *reinterpret_cast<float2*>(d) = make_float2(o0, o1);
+                        else { d[0] = o0; d[1] = o1; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // (one group of 32 accumulators at a time out of the accumulator file)
+                }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int mb = 0; mb < NSET; ++mb) {                    // (MBL > 1: the channel blocks of this workgroup, one after the other; CF: its classes)
+    const int mbk = CF ? mblk : mblk + mb;
+    const int ec = CF ? mb : cls;
+    const int OHe = p.OH[ec], OWe = p.OW[ec];
         float bv[MT][16];                  // the bias of this lane's rows: all loads in flight at once (one wait, not one per row)
     #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -561,13 +631,11 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
         // instruction-fetch bound: 24 of 160 us; tanh layers have <= 4 output channels and never come here)
         const bool plain = (mbk + 1) * MB <= p.M && ((mbk + 1) * MB <= p.M0 || mbk * MB >= p.M0);
         float* const dplain = mbk * MB >= p.M0 ? p.dst1 + ((size_t)n * M1 + (mbk * MB - p.M0)) * plane : p.dst0 + ((size_t)n * p.M0 + mbk * MB) * plane;
-        const float u12 = u1 * u2;                               // (both powers of two; their product is a normal number for any finite result)
-        const bool one_mul = u12 != 0.f && u12 < 3.0e38f;
     #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int oy = oyx[nt] >> 16, ox = oyx[nt] & 0xffff;
-            if (oy >= OH || ox >= OW) continue;
-            const size_t opix = (size_t)(oy * p.osy + p.ooy[cls]) * p.OWf + (size_t)(ox * p.osx + p.oox[cls]);
+            if (oy >= OHe || ox >= OWe) continue;
+            const size_t opix = (size_t)(oy * p.osy + p.ooy[ec]) * p.OWf + (size_t)(ox * p.osx + p.oox[ec]);
             if (plain) {
                 float* const d0 = dplain + opix + (size_t)(4 * lhi) * plane;
     #define S16G_STORES(EXPR_)                                                                                              \
@@ -595,6 +663,7 @@ __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
                 }
             }
         }
+    }
     }
 }
 
@@ -638,6 +707,8 @@ static NEMAR_SWITCH(int, g_s16g_maxmt, 2);      // widest channel tile (x 32): n
                                    // tiles (36.4-36.7 vs 37.0-37.2 ms, A/B on one box) — their fragment sets leave no room for latency hiding
 static NEMAR_SWITCH(int, g_s16g_lds_pref, 0);   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
 static NEMAR_SWITCH(int, g_s16g_mbl_wgs, 256);  // ... as long as the grid keeps this many workgroups: nemar_s16g_tune(3, v) (tests: 0)
+static NEMAR_SWITCH(int, g_s16g_cf, 1);         // fuse the four parity classes of a stride-2 data gradient / ConvTranspose2d into one workgroup per tile: nemar_s16g_tune(4, v)
+                                                // (0 off, 1 where the grid keeps >= min(192, key 3) workgroups, 2 = 1 + refuse four-class problems that do not fuse: tests)
 static NEMAR_SWITCH(int, g_s16g_maxmbl, 4);     // most channel blocks per workgroup (1: one workgroup per channel block, the rounds 3-5 form): nemar_s16g_tune(2, v)
 #ifdef NEMAR_AB
 void nemar_s16g_tune(int key, int value) {
@@ -645,12 +716,14 @@ void nemar_s16g_tune(int key, int value) {
     if (key == 1) g_s16g_lds_pref = value;
     if (key == 2) g_s16g_maxmbl = value >= 4 ? 4 : 1;
     if (key == 3) g_s16g_mbl_wgs = value;
+    if (key == 4) g_s16g_cf = value;
 }
 #endif
 
 S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     S16gPlan pl;
     pl.ok = 0;
+    pl.CF = 0;
     const int C = q.C0 + q.C1;
     if (q.ncls < 1 || q.ncls > S16G_MAX_CLS || (q.sstride != 1 && q.sstride != 2) || q.M < 5 || C < 1) return pl;       // (<= 4 rows: the narrow VALU kernels)
     if (q.ncls > 1 && q.sstride != 1) return pl;
@@ -683,9 +756,20 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     pl.nchunks = (C + 15) / 16;
     // pixel tile: 128 NT pixels as RT rows x TW columns; the smallest halo that fits wins
     const int sx = q.sstride, ey = dymax - dymin, ex = dxmax - dxmin;
+    // class-fused form (s16g_kernel<..., CF = 1>): the four parity classes of a stride-2 data gradient on one converted halo — one 128-pixel
+    // tile, four accumulator sets, all classes' taps of a chunk in the one weight region
+    int alltaps = 0;
+    for (int c = 0; c < q.ncls; ++c) alltaps += q.ntaps[c];
+    bool cf = g_s16g_cf && q.ncls == 4 && sx == 1 && pl.MT <= 2 && alltaps <= 16 && q.osy == 2 && q.osx == 2 && q.border != BORDER_REFLECT &&
+              q.M % MB == 0 && (q.M0 >= q.M || q.M0 % MB == 0);            // full channel blocks, each into one destination
+    for (int c = 0; cf && c < 4; ++c) cf = q.ooy[c] == (c >> 1) && q.oox[c] == (c & 1) && q.OH[c] <= q.OH[0] && q.OW[c] <= q.OW[0];
+    cf = cf && q.OW[0] == q.OW[1] && q.OW[2] == q.OW[3] && q.OH[0] == q.OH[1] && q.OH[2] == q.OH[3];      // (even destination extents)
     long long best = -1;
+  for (int attempt = cf ? 0 : 1; attempt < 2 && best < 0; ++attempt) {
+    cf = attempt == 0;
+    const int wtaps = cf ? alltaps : maxtaps, wcls = cf ? 1 : q.ncls;
     // (128 channels x 256 pixels per workgroup — MT 4, NT 2 — needs 280 VGPRs: 144 of them spilled to scratch; that tile is not offered)
-    for (int NT = (sx == 2 || pl.MT == 4 ? 1 : 2); NT >= 1; --NT) {
+    for (int NT = (sx == 2 || pl.MT == 4 || cf ? 1 : 2); NT >= 1; --NT) {
         const int NP = 128 * NT;
         for (int TW = 32; TW <= NP; TW *= 2) {
             if (TW > 32 && TW / 2 >= OW) break;              // wider than the rows: pure waste
@@ -695,15 +779,16 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
             // is a whole number of groups (stride 2: even | odd columns, half each)
             const int OFS = dxmin < 0 ? (-dxmin + 3) / 4 * 4 : 0;
             const int GPR = (OFS + (TW - 1) * sx + dxmax + 1 + 3) / 4, HCP = 4 * GPR, HCH = HCP / 2;
-            if (4 * HR * HCP > BWORDS || HR * GPR > 128 * NS4LIM) continue;
-            if (maxtaps * 4 * MB + 4 * HR * HCP > 10200) continue;            // weights of a chunk + halo planes within the 160 KiB of LDS
+            if (4 * HR * HCP > BWORDS || HR * GPR > 128 * (cf ? 1 : NS4LIM)) continue;
+            if (wtaps * 4 * MB + 4 * HR * HCP > 10200) continue;              // weights of a chunk + halo planes within the 160 KiB of LDS
             const int tx = (OW + TW - 1) / TW, ty = (OH + RT - 1) / RT;
             // cost: halo elements loaded + converted per launch (short rows coalesce badly: 16 elements of overhead per row),
             // plus the masked part of the tiles
             long long cost = (long long)tx * ty * (HR * HC + 16 * HR + NP / 2);
-            if (g_s16g_lds_pref && (maxtaps * 4 * MB + 4 * HR * HCP) * 16 > 80 * 1024 - 256) cost = cost * 3 / 2;      // one workgroup per CU only
-            const long long wgs = (long long)tx * ty * q.N * pl.mblks * q.ncls;
+            if (g_s16g_lds_pref && (wtaps * 4 * MB + 4 * HR * HCP) * 16 > 80 * 1024 - 256) cost = cost * 3 / 2;      // one workgroup per CU only
+            const long long wgs = (long long)tx * ty * q.N * pl.mblks * wcls;
             if (NT == 2 && wgs < 256) continue;              // few tiles: prefer the smaller tile
+            if (cf && wgs < (g_s16g_mbl_wgs < 192 ? g_s16g_mbl_wgs : 192)) continue;      // (fused classes: a quarter of the workgroups — small problems keep one per class)
             if (best < 0 || cost < best) {
                 best = cost;
                 pl.NT = NT; pl.TW = TW; pl.RT = RT; pl.tiles_x = tx; pl.tiles_y = ty;
@@ -712,7 +797,10 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
         }
         if (best >= 0) break;
     }
+    pl.CF = (cf && best >= 0) ? 1 : 0;
+  }
     if (best < 0) return pl;
+    if (g_s16g_cf == 2 && q.ncls == 4 && !pl.CF) return pl;      // (tests: a four-class problem that does not fuse is refused — the caller's route check fails)
     if ((long long)pl.tiles_x * pl.tiles_y * q.N * pl.mblks * q.ncls >= (1ll << 31)) return pl;
     if ((long long)q.Hs * q.Ws >= (1ll << 30)) return pl;
     pl.dymin = dymin;
@@ -794,27 +882,36 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
         if (on) flop += 2.0 * q.N * q.OH[c] * q.OW[c] * (double)q.M * (q.C0 + q.C1) * q.ntaps[c];
     }
     for (int i = 0; i < S16G_MAX_TAPS; ++i) p.tapoff[i] = 0;
-    for (int c = 0; c < q.ncls; ++c)
+    int maxtaps = 0, alltaps = 0;
+    for (int c = 0; c < q.ncls; ++c) {
         for (int t = 0; t < q.ntaps[c]; ++t) {
             const int ddy = q.dy[c][t] - pl.dymin, ddx = q.dx[c][t] + p.OFS;      // LDS column = image column - ox0 SX + OFS
-            p.tapoff[c * S16G_CLS_TAPS + t] = ddy * pl.HCP + (q.sstride == 2 ? (ddx & 1) * pl.HCH + (ddx >> 1) : ddx);
+            // (class-fused kernel: one flat table, the classes' taps back to back — the order of its weight region)
+            p.tapoff[pl.CF ? alltaps + t : c * S16G_CLS_TAPS + t] = ddy * pl.HCP + (q.sstride == 2 ? (ddx & 1) * pl.HCH + (ddx >> 1) : ddx);
         }
-    int maxtaps = 0;
-    for (int c = 0; c < q.ncls; ++c) maxtaps = q.ntaps[c] > maxtaps ? q.ntaps[c] : maxtaps;
-    p.aw16 = maxtaps * 4 * 32 * pl.MT;
+        maxtaps = q.ntaps[c] > maxtaps ? q.ntaps[c] : maxtaps;
+        alltaps += q.ntaps[c];
+    }
+    p.aw16 = (pl.CF ? alltaps : maxtaps) * 4 * 32 * pl.MT;
+    // class-fused epilogue: 8-byte stores of the column-parity pairs (aligned destinations, equal widths of the two column classes)
+    p.pair = 0;
+    if (pl.CF) {
+        const size_t planef = (size_t)q.OHf * q.OWf;
+        p.pair = (q.OWf % 2 == 0 && planef % 2 == 0 && ((reinterpret_cast<uintptr_t>(q.dst0) | reinterpret_cast<uintptr_t>(q.dst1)) & 7) == 0) ? 1 : 0;
+    }
     // channel blocks per workgroup: FOUR 64-channel blocks on 128-pixel tiles (MBL x MT x NT = 8 accumulator tiles), where two weight regions fit
     // next to the halo and the grid keeps >= 256 workgroups.  Measured stand-alone at batch 16 (profiles/r6_s16g_mbl_microbench.txt): the
     // translation net's 128 -> 256 stride-2 layer 199 -> 170 us.  TWO blocks per workgroup were measured too and lost (64 -> 128 stride 2:
     // 228 -> 243 us; stride-1 data gradients with 128 / 256 rows: 336 -> 437, 448 -> 530 us): half the conversions saved do not pay for
     // the second workgroup the CU loses to 384 registers per wave and the doubled weight region — those shapes keep one block per workgroup.
     int mbl = 1;
-    {
+    if (!pl.CF) {
         const long long wgs = (long long)pl.tiles_x * pl.tiles_y * q.N * (pl.mblks / 4) * q.ncls;
         if (g_s16g_maxmbl >= 4 && pl.MT == 2 && pl.NT == 1 && pl.mblks % 4 == 0 && wgs >= g_s16g_mbl_wgs &&
             ((size_t)2 * p.aw16 + 4 * (size_t)p.hp16) * 16 <= (size_t)160 * 1024 - 2048)
             mbl = 4;
     }
-    const dim3 g(pl.tiles_x * pl.tiles_y * q.N * (pl.mblks / mbl) * q.ncls), b(256);
+    const dim3 g(pl.tiles_x * pl.tiles_y * q.N * (pl.mblks / mbl) * (pl.CF ? 1 : q.ncls)), b(256);
     p.ncls = q.ncls;
     p.xcd = g.x % 8 == 0 ? 1 : 0;
     const bool tm = g_timing && g_tev_used < MAX_TIMED;
@@ -829,6 +926,15 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     const size_t lds = ((size_t)(mbl > 1 ? 2 : 1) * p.aw16 + 4 * (size_t)p.hp16) * 16;
 #ifdef NEMAR_HOST_EMULATION
 #define S16G_GO2(MT_, NT_, SX_, NS_, MBL_) { hipLaunchKernelGGL((s16g_kernel<MT_, NT_, SX_, NS_, MBL_>), g, b, lds, st, p); }
+#define S16G_GOCF(MT_) { hipLaunchKernelGGL((s16g_kernel<MT_, 1, 1, 1, 1, 1>), g, b, lds, st, p); }
+#else
+#define S16G_GOCF(MT_)                                                                                                  \
+    {                                                                                                                   \
+        const size_t lds_ = nemar_lds_bytes(reinterpret_cast<const void*>(&s16g_kernel<MT_, 1, 1, 1, 1, 1>), lds, (g_lds_claim & 4) != 0);  \
+        hipLaunchKernelGGL((s16g_kernel<MT_, 1, 1, 1, 1, 1>), g, b, lds_, st, p);                                       \
+    }
+#endif
+#ifdef NEMAR_HOST_EMULATION
 #else
     // more than 64 KiB of dynamic LDS needs the attribute (nemar_lds_bytes sets it once per instantiation; whole-CU claim: common.h)
 #define S16G_GO2(MT_, NT_, SX_, NS_, MBL_)                                                                              \
@@ -849,6 +955,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     else if (sx == 1) S16G_GO(MT_, 1, 1)                            \
     else S16G_GO(MT_, 1, 2)
     const int sx = q.sstride;
+    if (pl.CF) { if (pl.MT == 2) S16G_GOCF(2) else S16G_GOCF(1) } else
 #ifdef NEMAR_AB
     if (pl.MT == 4) { S16G_BY_TILE(4) } else       // (128-channel tiles: nemar_tune(27, 4) only — the plan caps MT at g_s16g_maxmt)
 #endif
@@ -858,6 +965,7 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
 #undef S16G_GO
 #undef S16G_GO1
 #undef S16G_GO2
+#undef S16G_GOCF
     if (tm) {
         (void)hipEventRecord(g_tev[g_tev_used++][1], st);
         g_tev_flop += flop;

@@ -205,14 +205,17 @@ class s16g_route:
     """Lift the work threshold of the general 16-bit-pipe route (csrc/conv_s16g.hip: in-kernel operand split) for small test shapes;
     `on=False` forces the exact-fp32 kernels instead."""
 
-    def __init__(self, be, on=True, mbl=None):
-        self.be, self.on, self.mbl = be, on, mbl
+    def __init__(self, be, on=True, mbl=None, cf=None):
+        self.be, self.on, self.mbl, self.cf = be, on, mbl, cf
 
     def __enter__(self):
         self.be.lib.tune(24, 1 if self.on else 0)
         self.be.lib.tune(25, 0)
         if self.mbl is not None:          # channel blocks per workgroup (round 6): force the grouping on the tests' few-tile shapes
             self.be.lib.tune(40, self.mbl)
+            self.be.lib.tune(41, 0)
+        if self.cf is not None:           # class-fused stride-2 data gradients (round 6): 0 off, 2 required (whatever the grid size)
+            self.be.lib.tune(42, self.cf)
             self.be.lib.tune(41, 0)
         return self
 
@@ -222,6 +225,7 @@ class s16g_route:
         self.be.lib.tune(25, 30)
         self.be.lib.tune(40, 4)
         self.be.lib.tune(41, 256)
+        self.be.lib.tune(42, 1)
 
 
 def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NONE, bias=True, seed=0, xscale=None, mbl=None):
@@ -257,8 +261,8 @@ def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.A
         raise AssertionError("conv2d_fwd (s16g): err %.3e > %.3e at %s (got %.6g want %.6g)" % (err[i], lim[i], i, got[i], want[i]))
 
 
-def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO, mbl=None):
-    with s16g_route(be, mbl=mbl):
+def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO, mbl=None, cf=None):
+    with s16g_route(be, mbl=mbl, cf=cf):
         case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=skip0, seed=seed)
         assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
 

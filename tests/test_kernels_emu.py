@@ -482,6 +482,31 @@ def test_conv_s16g_data_gradient(be, case):
     K.case_conv_s16g_bwd_data(be, *case)
 
 
+S16G_DGRAD_FUSED = [
+    # N, C0, C1, H,  W,  K,  R, stride, pad          (C0 = the output rows: whole 32 / 64-row blocks; even extents)
+    (1, 64, 0, 8, 64, 32, 3, 2, 1),                     # 64-row tile, classes of 1 / 2 / 2 / 4 taps, two chunks
+    (2, 32, 0, 10, 72, 16, 4, 2, 1),                    # 32-row tile, 4x4: four classes of four taps, ragged tile (5 x 36 class pixels)
+    (1, 128, 0, 6, 128, 48, 3, 2, 1),                   # two 64-row blocks, three chunks, tiles of 2 x 64 class pixels (last row of tiles ragged)
+]
+
+
+@pytest.mark.parametrize("case", S16G_DGRAD_FUSED)
+def test_conv_s16g_data_gradient_class_fused(be, case):
+    """Stride-2 data gradients with the four output-parity classes in ONE workgroup per tile (conv_s16g.hip, CF): one converted halo, four
+    accumulator sets, column-parity pairs stored as 8-byte words.  tune(42, 2): a problem that does not fuse fails the route check."""
+    K.case_conv_s16g_bwd_data(be, *case, cf=2)
+    K.case_conv_s16g_bwd_data(be, *case, cf=0)           # (one workgroup per class, the rounds 3-5 form: still there for odd extents)
+
+
+@pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
+def test_conv_s16g_transpose_forward_class_fused(be, R, op):
+    with K.s16g_route(be, cf=2):
+        K.case_conv_transpose_fwd(be, 2, 32, 64, 8, 32, R, op)                       # bias + ReLU in the paired epilogue
+        assert be.lib.last_route() == 3
+        K.case_conv_transpose_fwd(be, 1, 16, 32, 5, 36, R, op, act=K.O.ACT_LRELU)    # 32-row tile, ragged class tile
+        assert be.lib.last_route() == 3
+
+
 def test_conv_s16g_data_gradient_skip_first_source(be):
     K.case_conv_s16g_bwd_data(be, 1, 16, 16, 4, 32, 24, 3, 1, 1, skip0=True)
 
