@@ -48,8 +48,8 @@ extern "C" {
  *   40 most 64-channel blocks one s16g_kernel workgroup runs on one converted halo (4; 1 = one workgroup per channel block, rounds 3-5)
  *   41 ... as long as the grid keeps this many workgroups (256; tests: 0)
  *   42 the four output-parity classes of a stride-2 data gradient / ConvTranspose2d in ONE s16g_kernel workgroup per tile, on one converted
- *      halo (1, default, where the grid keeps min(192, key 41) workgroups; 0 = one workgroup per (tile, class), rounds 3-5; 2 = 1 and a
- *      four-class problem that cannot fuse leaves the route: tests) */
+ *      halo (0, default = one workgroup per (tile, class): the fused form measured 10-30 % slower, csrc/conv_s16g.hip; 1 = where the grid
+ *      keeps min(192, key 41) workgroups; 2 = 1 and a four-class problem that cannot fuse leaves the route: tests) */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/timeline_*.py), NULL = off */
 /* grad_input variant for A/B measurements: 0 (default) = gather + fixed point (needs the workspace), 1 = fp32 atomics through an

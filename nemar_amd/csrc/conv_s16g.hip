@@ -241,12 +241,15 @@ struct RegS16gPack {
 // chunk (timeline: max + barrier 3000, conversion 3300, loads + barrier 1500 cycles beside 3000 cycles of taps).  With MBL > 1 a
 // workgroup keeps MBL accumulator sets and runs the taps of MBL channel blocks on ONE converted halo; their weights alternate between two
 // LDS regions (the next block's copies are issued before the current block's taps).
-// CF (round 6): CLASS-FUSED form of a four-class problem (the output-parity classes of a stride-2 data gradient / ConvTranspose2d: 1 + 2 + 2 + 4
+// CF (round 6, measurement build only — it LOST): CLASS-FUSED form of a four-class problem (the output-parity classes of a stride-2 data gradient / ConvTranspose2d: 1 + 2 + 2 + 4
 // taps of a 3x3 filter, 4 x 4 of a 4x4 one).  One workgroup per (tile, class) loaded, reduced and converted the SAME halo four times for
 // nine taps' worth of MFMAs — those phases, not the taps, are most of a chunk (above).  With CF a workgroup keeps one accumulator set per
 // class and runs all classes' taps on ONE converted halo; the chunk's weights of the four classes sit side by side in the one weight
 // region (as many words as a plain 3x3 / 4x4 layer's), and the epilogue stores the two column parities of a pixel pair as one 8-byte word
-// (a class's own stores are 4 bytes every 8).
+// (a class's own stores are 4 bytes every 8).  Measured at batch 16 / 24 (profiles/r6_s16g_class_fused.txt): the translation net's 64 <- 128 stride-2
+// data gradient 309 -> 345 us, 128 <- 256: 261 -> 281 us, the discriminator's 64 <- 128 4x4: 118 -> 153 us.  Four accumulator sets of a
+// 64-row tile take 332 registers: ONE workgroup per CU, and what hides a workgroup's load / exchange / convert phases is the OTHER
+// workgroups of its CU, not fewer conversions.  (The 32-row form, 204 registers, is even: 163 vs 165 us.)
 template <int MT, int NT, int SX, int NS4MAX, int MBL = 1, int CF = 0>          // NS4MAX: 4-pixel halo groups per loader thread (1: tiles of <= 128 groups)
 __global__ __launch_bounds__(256) void s16g_kernel(S16gParams p) {
     static_assert(!CF || (MBL == 1 && NT == 1 && SX == 1), "class-fused form: four accumulator sets of one 128-pixel tile, stride-1 source");
@@ -707,8 +710,9 @@ static NEMAR_SWITCH(int, g_s16g_maxmt, 2);      // widest channel tile (x 32): n
                                    // tiles (36.4-36.7 vs 37.0-37.2 ms, A/B on one box) — their fragment sets leave no room for latency hiding
 static NEMAR_SWITCH(int, g_s16g_lds_pref, 0);   // prefer pixel tiles that leave room for two workgroups per CU: nemar_s16g_tune(1, v)
 static NEMAR_SWITCH(int, g_s16g_mbl_wgs, 256);  // ... as long as the grid keeps this many workgroups: nemar_s16g_tune(3, v) (tests: 0)
-static NEMAR_SWITCH(int, g_s16g_cf, 1);         // fuse the four parity classes of a stride-2 data gradient / ConvTranspose2d into one workgroup per tile: nemar_s16g_tune(4, v)
-                                                // (0 off, 1 where the grid keeps >= min(192, key 3) workgroups, 2 = 1 + refuse four-class problems that do not fuse: tests)
+static NEMAR_SWITCH(int, g_s16g_cf, 0);         // fuse the four parity classes of a stride-2 data gradient / ConvTranspose2d into one workgroup per tile: nemar_s16g_tune(4, v)
+                                                // (0 off = default: MEASURED SLOWER, below; 1 where the grid keeps >= min(192, key 3) workgroups, 2 = 1 + refuse four-class
+                                                // problems that do not fuse: tests).  Measurement build only.
 static NEMAR_SWITCH(int, g_s16g_maxmbl, 4);     // most channel blocks per workgroup (1: one workgroup per channel block, the rounds 3-5 form): nemar_s16g_tune(2, v)
 #ifdef NEMAR_AB
 void nemar_s16g_tune(int key, int value) {
@@ -955,8 +959,8 @@ void nemar_s16g_conv(const S16gProblem& q, const S16gPlan& pl, const void* packe
     else if (sx == 1) S16G_GO(MT_, 1, 1)                            \
     else S16G_GO(MT_, 1, 2)
     const int sx = q.sstride;
-    if (pl.CF) { if (pl.MT == 2) S16G_GOCF(2) else S16G_GOCF(1) } else
 #ifdef NEMAR_AB
+    if (pl.CF) { if (pl.MT == 2) S16G_GOCF(2) else S16G_GOCF(1) } else
     if (pl.MT == 4) { S16G_BY_TILE(4) } else       // (128-channel tiles: nemar_tune(27, 4) only — the plan caps MT at g_s16g_maxmt)
 #endif
     if (pl.MT == 2) { S16G_BY_TILE(2) }

@@ -225,7 +225,7 @@ class s16g_route:
         self.be.lib.tune(25, 30)
         self.be.lib.tune(40, 4)
         self.be.lib.tune(41, 256)
-        self.be.lib.tune(42, 1)
+        self.be.lib.tune(42, 0)
 
 
 def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NONE, bias=True, seed=0, xscale=None, mbl=None):

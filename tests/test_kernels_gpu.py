@@ -453,7 +453,6 @@ def test_conv_s16g_data_gradient(be, case):
     K.case_conv_s16g_bwd_data(be, *case)
 
 
-@pytest.mark.gpu
 S16G_DGRAD_FUSED = [
     # N, C0, C1, H,  W,  K,  R, stride, pad          (C0 = the output rows: whole 32 / 64-row blocks; even extents)
     (1, 64, 0, 8, 64, 32, 3, 2, 1),                     # 64-row tile, classes of 1 / 2 / 2 / 4 taps, two chunks
@@ -462,6 +461,7 @@ S16G_DGRAD_FUSED = [
 ]
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", S16G_DGRAD_FUSED)
 def test_conv_s16g_data_gradient_class_fused(be, case):
     """Stride-2 data gradients with the four output-parity classes in ONE workgroup per tile (conv_s16g.hip, CF): one converted halo, four
@@ -470,6 +470,7 @@ def test_conv_s16g_data_gradient_class_fused(be, case):
     K.case_conv_s16g_bwd_data(be, *case, cf=0)           # (one workgroup per class, the rounds 3-5 form: still there for odd extents)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,op", [(3, 1), (4, 0)])
 def test_conv_s16g_transpose_forward_class_fused(be, R, op):
     with K.s16g_route(be, cf=2):
@@ -479,6 +480,7 @@ def test_conv_s16g_transpose_forward_class_fused(be, R, op):
         assert be.lib.last_route() == 3
 
 
+@pytest.mark.gpu
 def test_conv_s16g_data_gradient_skip_first_source(be):
     K.case_conv_s16g_bwd_data(be, 1, 16, 16, 4, 32, 24, 3, 1, 1, skip0=True)
 

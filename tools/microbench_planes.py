@@ -27,12 +27,14 @@ for N in (8, 16):
     pls = [torch.empty(2 * N * (C // 8) * (H + 4) * (W + 4) * 16, dtype=torch.uint8, device=dev) for _ in range(K)]
     stats = torch.empty(N * C, 2, device=dev); sw = torch.zeros(N, dtype=torch.int32, device=dev)
     mw = torch.zeros(N * 2049, dtype=torch.int32, device=dev)
+    xbytes = L.conv2d_x_planes_bytes(N, C, H, W, 3)
+    xws = [torch.empty(xbytes, dtype=torch.uint8, device=dev) for _ in range(K)]
     rmax = torch.full((N,), 5.0, device=dev)
     i = [0]
-    def run(res, y, drop, maxw):
+    def run(res, y, drop, maxw, xw=0):
         k = i[0] = (i[0] + 1) % K
         L.instnorm_fwd_planes(p(xs[k]), p(rs[k]) if res else None, p(rmax) if res else None, p(ys[k]) if y else None, p(stats), N, C, H, W,
-                              1e-5, 1, 0.0, 0.5 if drop else 0.0, 1234, 7, p(pls[k]), p(sw), p(mw) if maxw else None, st)
+                              1e-5, 1, 0.0, 0.5 if drop else 0.0, 1234, 7, p(pls[k]), p(sw), p(mw) if maxw else None, p(xws[k]) if xw else None, st)
     def plain(res):
         k = i[0] = (i[0] + 1) % K
         L.instnorm_fwd(p(xs[k]), p(rs[k]) if res else None, p(ys[k]), p(stats), N * C, H * W, 1e-5, 1, 0.0, st)
@@ -43,5 +45,11 @@ for N in (8, 16):
         L.tune(31, bits)
         print('  ablation bits %2d (1 no plane stores, 2 no transpose, 4 no statistics, 8 no fp32 stores): y+max %6.1f us' % (bits, timeit(lambda: run(0, 1, 0, 1))))
     L.tune(31, 0)
-    for res, y, drop, maxw in ((0, 1, 0, 1), (0, 1, 1, 1), (1, 1, 0, 1), (0, 0, 0, 0), (0, 0, 0, 1), (0, 1, 0, 0)):
-        print('  planes: residual %d  fp32 y %d  dropout %d  max words %d   %6.1f us' % (res, y, drop, maxw, timeit(lambda: run(res, y, drop, maxw))))
+    for res, y, drop, maxw, xw in ((0, 1, 0, 1, 0), (0, 1, 1, 1, 0), (1, 1, 0, 1, 0), (0, 0, 0, 0, 0), (0, 0, 0, 1, 0), (0, 1, 0, 0, 0),
+                                   (0, 0, 1, 0, 1), (1, 1, 0, 1, 1), (0, 0, 0, 0, 1)):
+        print('  planes: residual %d  fp32 y %d  dropout %d  max words %d  X planes %d   %6.1f us' % (res, y, drop, maxw, xw, timeit(lambda: run(res, y, drop, maxw, xw))))
+    # the step's two forms under the ablation bits: mid-block (dropout, planes + X planes only) and block end (residual, fp32 y, planes + X planes)
+    for bits in (0, 1, 2, 4, 8):
+        L.tune(31, bits)
+        print('  ablation bits %2d: mid-block %6.1f us   block end %6.1f us' % (bits, timeit(lambda: run(0, 0, 1, 0, 1)), timeit(lambda: run(1, 1, 0, 1, 1))))
+    L.tune(31, 0)
