@@ -93,7 +93,7 @@ struct NormPlanesParams {
 constexpr int XT_MAX = 64 * 72;                    // H * CPR * 8 of the largest plane served (64 x 64)
 constexpr int NP_LDS_BYTES = 8 * (XT_MAX + 8) * 2 > 16 * 256 * 16 ? 8 * (XT_MAX + 8) * 2 : 16 * 256 * 16;
 
-// sums of eight per-thread values over the workgroup -> tot[0..7] (all threads)
+// sums of eight per-thread values over the workgroup -> tot[0..7] (all threads; wave-uniform: they live in scalar registers)
 __device__ __forceinline__ void block_sum8(float* s, float* red, float* tot) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -111,7 +111,17 @@ __device__ __forceinline__ void block_sum8(float* s, float* red, float* tot) {
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tot[j] = red[128 + j];
+    for (int j = 0; j < 8; ++j) tot[j] = uniform_f(red[128 + j]);
+}
+
+// Workgroup id -> (sample, 8-channel group).  Consecutive workgroup ids sit on consecutive XCDs, and the eight channel groups of one
+// 64-channel block each write a 128-byte piece of every 1 KiB run of the pixel-major planes ([flat chunk][64 channels][8 pixels]): with the
+// plain order those eight pieces leave eight different L2s as eight separate 128-byte write-backs.  Eight consecutive ids OF ONE XCD get the
+// eight groups of one block instead, so the pieces meet in that XCD's L2 (round 6b; needs a whole number of 64-unit rounds).
+__device__ __forceinline__ int np_unit_of_block(int b, int total) {
+    if (total & 63) return b;
+    const int x = b & 7, r = b >> 3;
+    return (((r >> 3) << 3) + x) * 8 + (r & 7);
 }
 
 __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams p) {
@@ -120,7 +130,8 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
     __shared__ __attribute__((aligned(16))) unsigned char np_lds[NP_LDS_BYTES];
     u32x4 (*const xpose)[256] = reinterpret_cast<u32x4 (*)[256]>(np_lds);      // per wave: 256 plane words in flight between the two orders
     const int CG = p.C >> 3;
-    const int n = blockIdx.x / CG, cg = blockIdx.x - n * CG;
+    const int unit = np_unit_of_block((int)blockIdx.x, (int)gridDim.x);
+    const int n = unit / CG, cg = unit - n * CG;
     const int HW = p.H * p.W, W = p.W, H = p.H;
     const int t = threadIdx.x;
     const bool active = 4 * t < HW;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
         if (t == 0) {
             unsigned m = mred[0];
             for (int i = 1; i < 16; ++i) m = max(m, mred[i]);
-            p.maxw[p.N + blockIdx.x] = m;
+            p.maxw[p.N + unit] = m;
         }
     }
 }
@@ -343,49 +354,69 @@ __device__ __forceinline__ float np_act_df(float xhat, int act, float slope) {
     return 1.f;
 }
 
-__global__ __launch_bounds__(1024) void instnorm_bwd_planes_kernel(NormBwdPlanesParams p) {
+// LDS bytes of the backward producer: the 16-bit tile [8][HW + 8], or the fp32 border rows / columns of the reflect fold where those are larger
+// (planes of a few rows only)
+static size_t np_bwd_lds_bytes(int H, int W) {
+    const size_t tile = (size_t)8 * (H * W + 8) * 2, side = (size_t)4 * 8 * (W + H) * sizeof(float);
+    return tile > side ? tile : side;
+}
+
+// Round 6b: the result used to go through an fp32 tile [8][HW + 4] (131 KB: ONE workgroup per CU, its load / reduce / store phases exposed
+// — 74 us stand-alone, 2.7 x that beside the side stream's weight gradients).  Now each value is split ONCE in the registers of the thread
+// that computed it and the tile holds ONE 16-bit plane at a time ([8][HW + 8] halves, 66 KB: two workgroups per CU): hi plane -> both
+// layouts, then lo plane -> both layouts.  The folded border sums of the reflect data gradient need fp32 operands: the four border rows
+// and columns they are made of go through the same memory first (16 KB), the sums in the order plane_value (conv_split16.hip) adds them —
+// the planes are bit for bit what the fp32-tile form wrote.
+// 4 * threadIdx.x, recomputed where it is used (one shift): as one value hipcc parks it in scratch across the kernel — the one register
+// the 64 of two workgroups per CU do not have
+__device__ __forceinline__ unsigned np_t4() {
 #ifdef NEMAR_HOST_EMULATION
-    __shared__ __attribute__((aligned(16))) float tile[8 * (4096 + 4)];
+    return 4u * threadIdx.x;
 #else
-    extern __shared__ __attribute__((aligned(16))) float tile[];       // 8 (HW + 4) floats
+    unsigned v;
+    asm volatile("v_lshlrev_b32 %0, 2, %1" : "=v"(v) : "v"((unsigned)threadIdx.x));
+    return v;
 #endif
-    __shared__ float red[136];
+}
+
+// Registers (round 6b): a thread keeps ONE array of 32 values — g = gy [x mask] act'(xhat), later the scaled result — and reads x twice (the
+// second time from the caches: its own workgroup fetched those 128 KB microseconds ago); statistics, means and scales are wave-uniform
+// (scalar registers); every per-channel sum goes wave sum -> LDS at once instead of waiting in eight registers.  <= 64 registers x 1024
+// threads and 66 KB of LDS: two of these workgroups share a CU, or one shares it with a 64 KB / ~300-register weight-gradient workgroup
+// of the side stream (the fp32-tile form, 131 KB / 107 registers, could do neither: 74 us stand-alone, 203 us beside the side stream).
+__global__ __launch_bounds__(1024, 8) void instnorm_bwd_planes_kernel(NormBwdPlanesParams p) {
+#ifdef NEMAR_HOST_EMULATION
+    __shared__ __attribute__((aligned(16))) unsigned short tile16[8 * (4096 + 8)];
+#else
+    extern __shared__ __attribute__((aligned(16))) unsigned short tile16[];       // 8 (HW + 8) halves (np_bwd_lds_bytes)
+#endif
+    __shared__ float red[16 * 16 + 16];                    // [wave][sum 1 of channel 0..7 | sum 2 of channel 0..7], then the 16 totals
     __shared__ float rmax[16];
     const int CG = p.C >> 3;
-    const int n = blockIdx.x / CG, cg = blockIdx.x - n * CG;
+    const int unit = np_unit_of_block((int)blockIdx.x, (int)gridDim.x);
+    const int n = unit / CG, cg = unit - n * CG;
     const int HW = p.H * p.W, W = p.W, H = p.H;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const bool active = 4 * t < HW;
     const size_t cbase = ((size_t)n * p.C + (size_t)cg * 8) * HW;
-    float xh[8][4], g[8][4];
-    float s[8], tot[8];
+    #define NP_TOFF (active ? np_t4() : 0u)                 /* (inactive threads load element 0 and use nothing of it) */
+    float g[8][4];
     // largest rstd of the sample (all C planes): part of the bound
     {
         float m = 0.f;
         for (int c = t; c < p.C; c += 1024) m = fmaxf(m, p.stats[2 * ((size_t)n * p.C + c) + 1]);
         m = wave_max(m);
-        if ((t & 63) == 0) rmax[t >> 6] = m;
+        if (lane == 0) rmax[wid] = m;
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (active) {
-            a = *reinterpret_cast<const float4*>(p.x + cbase + (size_t)j * HW + 4 * t);
-            b = *reinterpret_cast<const float4*>(p.gy + cbase + (size_t)j * HW + 4 * t);
-        }
-        xh[j][0] = a.x; xh[j][1] = a.y; xh[j][2] = a.z; xh[j][3] = a.w;
-        g[j][0] = b.x; g[j][1] = b.y; g[j][2] = b.z; g[j][3] = b.w;
-    }
-    float mean[8], rstd[8];
+    const float dneg = p.act == ACT_RELU ? 0.f : (p.act == ACT_LRELU ? p.slope : 1.f);      // act'(xhat <= 0)
+    // ---- pass 1: g and the two sums of every channel ----
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const size_t pl = (size_t)n * p.C + (size_t)cg * 8 + j;
-        mean[j] = p.stats[2 * pl];
-        rstd[j] = p.stats[2 * pl + 1];
-    }
-    float s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
+        const float mean = p.stats[2 * pl], rstd = p.stats[2 * pl + 1];
+        const float4 a = *reinterpret_cast<const float4*>(p.x + cbase + (size_t)j * HW + NP_TOFF);
+        const float4 b = *reinterpret_cast<const float4*>(p.gy + cbase + (size_t)j * HW + NP_TOFF);
+        g[j][0] = b.x; g[j][1] = b.y; g[j][2] = b.z; g[j][3] = b.w;
         if (p.dropout) {
             const unsigned long long q = ((unsigned long long)n * p.C + (unsigned long long)cg * 8 + j) * (unsigned long long)(HW >> 2) + t;
             unsigned r[4];
@@ -393,83 +424,141 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_planes_kernel(NormBwdPlanes
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[j][e] = r[e] >= p.thresh ? g[j][e] * p.dscale : 0.f;
         }
-        float a = 0.f, b = 0.f;
+        const float xv[4] = {a.x, a.y, a.z, a.w};
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float h = active ? (xh[j][e] - mean[j]) * rstd[j] : 0.f;
-            const float u = active ? g[j][e] * np_act_df(h, p.act, p.slope) : 0.f;
-            xh[j][e] = h;
+            const float h = active ? (xv[e] - mean) * rstd : 0.f;
+            const float u = active ? g[j][e] * (h > 0.f ? 1.f : dneg) : 0.f;
             g[j][e] = u;
-            a += u;
-            b += u * h;
+            s1 += u;
+            s2 += u * h;
         }
-        s[j] = a;
-        s2[j] = b;
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { red[wid * 16 + j] = s1; red[wid * 16 + 8 + j] = s2; }
     }
-    const float inv = 1.f / (float)HW;
-    float m1[8], m2[8];
-    block_sum8(s, red, tot);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m1[j] = tot[j] * inv;
-    block_sum8(s2, red, tot);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m2[j] = tot[j] * inv;
-    // the bound this sample's planes are scaled by (rmax was written before the first barrier of block_sum8)
+    __syncthreads();
+    if (t < 16) {
+        float tt = 0.f;
+        for (int w = 0; w < 16; ++w) tt += red[w * 16 + t];          // wave order: a fixed association
+        red[256 + t] = tt;
+    }
+    __syncthreads();
+    // the bound this sample's planes are scaled by (rmax was written before the first barrier)
     float rm = rmax[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) rm = fmaxf(rm, rmax[w]);
     const float bound = rm * p.bmul * __builtin_bit_cast(float, p.gymax[n]);
     const unsigned bound_bits = __builtin_bit_cast(unsigned, bound);
     if (cg == 0 && t == 0) p.scale_words[n] = bound_bits;
-    const float scale = np_pow2_scale(bound_bits);
-    const int TS = HW + 4;
+    const float scale = uniform_f(np_pow2_scale(bound_bits));
+    const float inv = 1.f / (float)HW;
+    // ---- pass 2: x again (a real read: through an opaque copy of the pointer), the result, its per-plane sums; g <- scaled result ----
+    const float* x2 = p.x;
+#ifndef NEMAR_HOST_EMULATION
+    asm volatile("" : "+s"(x2));
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        const size_t pl = (size_t)n * p.C + (size_t)cg * 8 + j;
+        const float mean = p.stats[2 * pl], rstd = p.stats[2 * pl + 1];
+        const float m1 = uniform_f(red[256 + j] * inv), m2 = uniform_f(red[256 + 8 + j] * inv);
+        const float4 a = *reinterpret_cast<const float4*>(x2 + cbase + (size_t)j * HW + NP_TOFF);
+        const float xv[4] = {a.x, a.y, a.z, a.w};
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd[j] * (g[j][e] - m1[j] - xh[j][e] * m2[j]);
-        if (active) {
-            if (p.gx) *reinterpret_cast<float4*>(p.gx + cbase + (size_t)j * HW + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<float4*>(tile + j * TS + 4 * t) = make_float4(o[0] * scale, o[1] * scale, o[2] * scale, o[3] * scale);
+        for (int e = 0; e < 4; ++e) {
+            const float h = active ? (xv[e] - mean) * rstd : 0.f;
+            o[e] = rstd * (g[j][e] - m1 - h * m2);
         }
-        s[j] = active ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
+        if (active && p.gx) *reinterpret_cast<float4*>(p.gx + cbase + (size_t)j * HW + NP_TOFF) = make_float4(o[0], o[1], o[2], o[3]);
+        if (p.bsum) {                                      // (red[0 .. 255] was last read before the barrier above; the totals sit behind it)
+            const float bsj = wave_sum(active ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f);
+            if (lane == 0) red[wid * 16 + j] = bsj;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[j][e] = active ? o[e] * scale : 0.f;
     }
     if (p.bsum) {
-        block_sum8(s, red, tot);
-        if (t < 8) p.bsum[(size_t)n * p.C + (size_t)cg * 8 + t] = tot[t];
+        __syncthreads();
+        if (t < 8) {
+            float tt = 0.f;
+            for (int w = 0; w < 16; ++w) tt += red[w * 16 + t];
+            p.bsum[(size_t)n * p.C + (size_t)cg * 8 + t] = tt;
+        }
     }
-    __syncthreads();
-    // ---- data-gradient planes: word (row, slot) = the 8 channels of one plane position (conv_split16.hip plane_value) ----
-    if (p.dpl) {
-        const int Hp = H + 4, Ws = W + 4;
-        u32x4* const hp = p.dpl + ((size_t)n * CG + cg) * (size_t)Hp * Ws;
-        for (int i = t; i < Hp * Ws; i += 1024) {
-            const int row = i / Ws, slot = i - row * Ws;
-            int ya = -1, yb = -1, xa = -1, xb = -1;
-            if (row >= 1 && row <= H) ya = row - 1;
-            else if (p.reflect && row == H + 2) { ya = 0; yb = 2; }
-            else if (p.reflect && row == H + 3) { ya = H - 3; yb = H - 1; }
-            if (slot >= 1 && slot <= W) xa = slot - 1;
-            else if (p.reflect && slot == W + 2) { xa = 0; xb = 2; }
-            else if (p.reflect && slot == W + 3) { xa = W - 3; xb = W - 1; }
-            const bool any = ya >= 0 && xa >= 0;
-            const int yA = max(ya, 0), yB = max(yb, 0), xA = max(xa, 0), xB = max(xb, 0);
+    const int Hp = H + 4, Ws = W + 4;
+    u32x4* const hp = p.dpl ? p.dpl + ((size_t)n * CG + cg) * (size_t)Hp * Ws : nullptr;
+    const int row = active ? (int)np_t4() / W : 0, c0 = (int)np_t4() - row * W;
+    // ---- phase 0 (reflect data gradient only): the folded rows H + 2, H + 3 and slots W + 2, W + 3 of the data-gradient planes from the fp32
+    // border rows {0, 2, H - 3, H - 1} and columns {0, 2, W - 3, W - 1}: rb[4][8][W], cb[4][8][H] ----
+    if (p.dpl && p.reflect) {
+        float* const rb = reinterpret_cast<float*>(tile16);
+        float* const cb = rb + 4 * 8 * W;
+        __syncthreads();
+        if (active) {
+            const int ri = row == 0 ? 0 : (row == 2 ? 1 : (row == H - 3 ? 2 : (row == H - 1 ? 3 : -1)));
+            // (first match, as the reader below looks them up: H == 5 / W == 5 name one row / column twice)
+            if (ri >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<float4*>(rb + (ri * 8 + j) * W + c0) = make_float4(g[j][0], g[j][1], g[j][2], g[j][3]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = c0 + e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int want = k == 0 ? 0 : (k == 1 ? 2 : (k == 2 ? W - 3 : W - 1));
+                    if (col == want) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) cb[(k * 8 + j) * H + row] = g[j][e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // aux positions: (H + 2 | H + 3, slot 1 .. W and W + 2, W + 3) and (row 1 .. H, slot W + 2 | W + 3)
+        const int naux = 2 * (W + 2) + 2 * H;
+        for (int i = t; i < naux; i += 1024) {
+            int prow, pslot;
+            if (i < 2 * (W + 2)) {
+                prow = H + 2 + i / (W + 2);
+                const int q = i - (i / (W + 2)) * (W + 2);
+                pslot = q < W ? q + 1 : (q == W ? W + 2 : W + 3);
+            } else {
+                const int q = i - 2 * (W + 2);
+                prow = 1 + (q >> 1);
+                pslot = W + 2 + (q & 1);
+            }
+            // operands as plane_value names them: rows ya (+ yb), columns xa (+ xb)
+            const int ya = prow == H + 2 ? 0 : (prow == H + 3 ? H - 3 : prow - 1), yb = prow == H + 2 ? 2 : (prow == H + 3 ? H - 1 : -1);
+            const int xa = pslot == W + 2 ? 0 : (pslot == W + 3 ? W - 3 : pslot - 1), xb = pslot == W + 2 ? 2 : (pslot == W + 3 ? W - 1 : -1);
+            auto at = [&](int ch, int y, int x) -> float {
+                // (y, x) is in a border row or a border column by construction
+                if (yb >= 0) {          // folded row: both rows are border rows
+                    const int ri = y == 0 ? 0 : (y == 2 ? 1 : (y == H - 3 ? 2 : 3));
+                    return rb[(ri * 8 + ch) * W + x];
+                }
+                const int ci = x == 0 ? 0 : (x == 2 ? 1 : (x == W - 3 ? 2 : 3));
+                return cb[(ci * 8 + ch) * H + y];
+            };
             u32x4 hwd, lwd;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float vv[2];
 #pragma unroll
                 for (int z = 0; z < 2; ++z) {
-                    const float* const tj = tile + (2 * k + z) * TS;
-                    // (scaling by a power of two commutes with the fold sums: the same bits as scaling the folded fp32 value)
-                    float v = tj[yA * W + xA];
-                    if (yb >= 0) v += tj[yB * W + xA];
+                    const int ch = 2 * k + z;
+                    float v = at(ch, ya, xa);
+                    if (yb >= 0) v += at(ch, yb, xa);
                     if (xb >= 0) {
-                        float u = tj[yA * W + xB];
-                        if (yb >= 0) u += tj[yB * W + xB];
+                        float u = at(ch, ya, xb);
+                        if (yb >= 0) u += at(ch, yb, xb);
                         v += u;
                     }
-                    vv[z] = any ? v : 0.f;
+                    vv[z] = v;
                 }
                 f16x2 h, l;
                 h[0] = (_Float16)vv[0];
@@ -479,38 +568,64 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_planes_kernel(NormBwdPlanes
                 hwd[k] = __builtin_bit_cast(unsigned, h);
                 lwd[k] = __builtin_bit_cast(unsigned, l);
             }
-            hp[i] = hwd;
-            hp[p.dplane16 + i] = lwd;
+            hp[(size_t)prow * Ws + pslot] = hwd;
+            hp[p.dplane16 + (size_t)prow * Ws + pslot] = lwd;
         }
     }
-    // ---- weight-gradient G_0 planes: word ((n KBLK + kblk) F + y CPR + q) 64 + kk = pixels 8 q .. 8 q + 7 of row y of channel kk ----
-    if (p.gpl) {
-        const int KBLK = p.C >> 6, F = p.Hg * p.CPR;
-        u32x4* const dst = p.gpl + (((size_t)n * KBLK + (cg >> 3)) * F) * 64 + (cg & 7) * 8;
-        for (int i = t; i < 8 * F; i += 1024) {
-            const int cc = i & 7, f = i >> 3;
-            const int y = f / p.CPR, q = f - y * p.CPR;
-            u32x4 hwd = u32x4{0u, 0u, 0u, 0u}, lwd = hwd;
-            if (y < H && q * 8 < W) {
-                const float* const src = tile + cc * TS + y * W + q * 8;
-                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-                const float vv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    // ---- the split in the registers that hold the values: element pairs (e, e + 1) of channel j as one dword of plane pl ----
+    auto halves = [&](int pl, int j, int k) -> unsigned {
+        f16x2 h;
+        h[0] = (_Float16)g[j][2 * k];
+        h[1] = (_Float16)g[j][2 * k + 1];
+        if (pl) {
+            f16x2 l;
+            l[0] = (_Float16)(g[j][2 * k] - (float)h[0]);
+            l[1] = (_Float16)(g[j][2 * k + 1] - (float)h[1]);
+            return __builtin_bit_cast(unsigned, l);
+        }
+        return __builtin_bit_cast(unsigned, h);
+    };
+    const int TS = HW + 8;
+    const int KBLK = p.C >> 6, F = p.Hg * p.CPR;
+    u32x4* const gdst = p.gpl ? p.gpl + (((size_t)n * KBLK + (cg >> 3)) * F) * 64 + (cg & 7) * 8 : nullptr;
+#pragma unroll 1                                           // (side by side, hipcc keeps the hi halves of the first pass for the second)
+    for (int pl = 0; pl < 2; ++pl) {
+        __syncthreads();                                   // (the previous phase's readers are done with the memory)
+        if (active) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f16x2 h, l;
-                    h[0] = (_Float16)vv[2 * k];
-                    h[1] = (_Float16)vv[2 * k + 1];
-                    l[0] = (_Float16)(vv[2 * k] - (float)h[0]);
-                    l[1] = (_Float16)(vv[2 * k + 1] - (float)h[1]);
-                    hwd[k] = __builtin_bit_cast(unsigned, h);
-                    lwd[k] = __builtin_bit_cast(unsigned, l);
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<uint2*>(tile16 + j * TS + np_t4()) = make_uint2(halves(pl, j, 0), halves(pl, j, 1));
+        }
+        __syncthreads();
+        // data-gradient planes: word (row, slot) = the 8 channels of one plane position; the folded rows / slots were written in phase 0
+        if (p.dpl) {
+            u32x4* const dst = hp + (pl ? p.dplane16 : 0);
+            for (int i = t; i < Hp * Ws; i += 1024) {
+                const int prow = i / Ws, pslot = i - prow * Ws;
+                const bool inner = prow >= 1 && prow <= H && pslot >= 1 && pslot <= W;
+                if (!inner && p.reflect && (prow >= H + 2 ? (pslot >= 1 && pslot != W + 1) : (prow >= 1 && prow <= H && pslot >= W + 2))) continue;
+                u32x4 word = u32x4{0u, 0u, 0u, 0u};
+                if (inner) {
+                    const unsigned short* const src = tile16 + (prow - 1) * W + (pslot - 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) word[k] = (unsigned)src[(2 * k) * TS] | ((unsigned)src[(2 * k + 1) * TS] << 16);
                 }
+                dst[i] = word;
             }
-            dst[(size_t)f * 64 + cc] = hwd;
-            dst[p.gplane16 + (size_t)f * 64 + cc] = lwd;
+        }
+        // weight-gradient G_0 planes: word ((n KBLK + kblk) F + y CPR + q) 64 + kk = pixels 8 q .. 8 q + 7 of row y of channel kk
+        if (p.gpl) {
+            u32x4* const dst = gdst + (pl ? p.gplane16 : 0);
+            for (int i = t; i < 8 * F; i += 1024) {
+                const int cc = i & 7, f = i >> 3;
+                const int y = f / p.CPR, q = f - y * p.CPR;
+                u32x4 word = u32x4{0u, 0u, 0u, 0u};
+                if (y < H && q * 8 < W) word = *reinterpret_cast<const u32x4*>(tile16 + cc * TS + y * W + q * 8);
+                dst[(size_t)f * 64 + cc] = word;
+            }
         }
     }
 }
+#undef NP_TOFF
 
 NEMAR_SWITCH(int, g_norm_planes_dbg, 0);
 }  // namespace
@@ -608,7 +723,7 @@ NEMAR_API int nemar_instnorm_bwd_planes(const float* x, const float* stats, cons
     p.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     p.obase = g_dropout_base;
     p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32); p.offset = offset;
-    const size_t lds = nemar_lds_bytes(reinterpret_cast<const void*>(&instnorm_bwd_planes_kernel), (size_t)8 * (H * W + 4) * sizeof(float), false);
+    const size_t lds = nemar_lds_bytes(reinterpret_cast<const void*>(&instnorm_bwd_planes_kernel), np_bwd_lds_bytes(H, W), false);
 #ifdef NEMAR_HOST_EMULATION
     hipLaunchKernelGGL(instnorm_bwd_planes_kernel, dim3(N * (C / 8)), dim3(1024), 0, (hipStream_t)stream, p);
     (void)lds;

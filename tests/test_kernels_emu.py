@@ -570,6 +570,14 @@ def test_resblock_planes_chain(be, pad_mode, act, drop):
     K.case_resblock_planes_chain(be, pad_mode, act, drop)
 
 
+def test_resblock_planes_chain_xcd_order(be):
+    """64 (sample, 8-channel group) units = one whole round of the XCD-aware workgroup order of the two producers (norm_planes.hip
+    np_unit_of_block: the eight groups of a 64-channel block on consecutive workgroups of ONE XCD); H == 5 rows: the reflect fold's border
+    rows 2 and H - 3 coincide."""
+    K.case_resblock_planes_chain(be, K.PAD_REFLECT, 1, 0.5, N=4, C=128, H=8, W=32)
+    K.case_resblock_planes_chain(be, K.PAD_REFLECT, 2, 0.0, N=1, C=64, H=5, W=16, producers_only=True)
+
+
 @pytest.mark.parametrize("mbl", [1, 4])
 def test_conv_s16g_channel_blocks_per_workgroup(be, mbl):
     """Round 6: one s16g_kernel workgroup runs the taps of four 64-channel blocks on one converted halo (two weight regions in LDS,

@@ -537,6 +537,15 @@ def test_resblock_planes_chain(be, pad_mode, act, drop):
     """Round 6: producer-written operand planes for all three calls of a wide layer + the data gradient's fused epilogue (kernel_cases)."""
     K.case_resblock_planes_chain(be, pad_mode, act, drop)
 
+
+@pytest.mark.gpu
+def test_resblock_planes_chain_xcd_order(be):
+    """64 (sample, 8-channel group) units = one whole round of the XCD-aware workgroup order of the two producers (norm_planes.hip
+    np_unit_of_block: the eight groups of a 64-channel block on consecutive workgroups of ONE XCD); H == 5 rows: the reflect fold's border
+    rows 2 and H - 3 coincide."""
+    K.case_resblock_planes_chain(be, K.PAD_REFLECT, 1, 0.5, N=4, C=128, H=8, W=32)
+    K.case_resblock_planes_chain(be, K.PAD_REFLECT, 2, 0.0, N=1, C=64, H=5, W=16, producers_only=True)
+
 @pytest.mark.gpu
 def test_resblock_planes_chain_bench_shape(be):
     """... at the residual blocks' own plane size (64 x 64: the 1024-thread workgroups are full, the LDS tiles at their largest)"""
