@@ -32,7 +32,7 @@ extern "C" {
 #define NEMAR_EWORKSPACE (-3)
 
 /* library */
-int nemar_version(void);              /* major*10000 + minor*100 + patch; 600 = this header (0.4.x exported nemar_tune*) */
+int nemar_version(void);              /* major*10000 + minor*100 + patch; 601 = this header (0.4.x exported nemar_tune*) */
 const char* nemar_last_error(void);   /* thread-local message of the last failing call */
 
 /* ---- K9/K10/K11: sampling-grid generation fused into bilinear grid_sample ------------------------------
@@ -200,6 +200,13 @@ int nemar_last_route(void);
  * function of the shape and of the library's measurement switches.  This library has none: always 0.  In the measurement build
  * (nemar_hip_ab.h) it is a counter bumped by every nemar_tune call, and a caller that caches packed workspaces keys them with it. */
 int nemar_config_epoch(void);
+/* Per calling thread, 1 / 0, returns the previous setting (0.6.1).  While on, the two producers of per-sample maxima on the residual blocks'
+ * path — nemar_instnorm_fwd_planes (max_words) and nemar_conv2d_bwd_data_ex (nemar_conv_extras.out_max_words) — do NOT launch the reduction
+ * of their per-workgroup partial words; word n of the buffer holds a marker (0xFFFF0000 | partials) instead.  Such a buffer may ONLY be
+ * passed on as nemar_instnorm_fwd_planes residual_max_words or nemar_instnorm_bwd_planes gy_max_words, which reduce a sample's partials
+ * themselves; every other consumer of max words needs finalized words (the default).  One launch less per producer call: 4 us on one
+ * stream, 12 us beside a second stream, 25 times per training step on the chain the rest of the step waits for. */
+int nemar_set_max_words_lazy(int on);
 /* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data / nemar_conv2d_bwd_weight.  The wide stride-1 / pad-1
  * layers (the 3x3 ResnetBlock convolutions, reference models/networks.py:418-439, and the discriminator's 256->512 4x4 layer,
  * :576-597; >= 128 channels, >= 2 G multiply-adds) run on the 16-bit matrix pipe at fp32 accuracy: each fp32 operand is split into

@@ -61,6 +61,7 @@ SIGNATURES = {
     "nemar_last_route": (_i, []),
     "nemar_last_gy_planes": (_i, []),
     "nemar_config_epoch": (_i, []),
+    "nemar_set_max_words_lazy": (_i, [_i]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
@@ -163,7 +164,7 @@ class Library:
                                     "(libnemar_hip_ab.so; set NEMAR_AB_LIBRARY=1 before nemar_amd is imported)" % (self.__dict__.get("path"), full))
             raise AttributeError(name)
         fn = fns[full]
-        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty", "nemar_conv2d_bwd_data_fusable"):
+        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_set_max_words_lazy", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty", "nemar_conv2d_bwd_data_fusable"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

@@ -292,6 +292,7 @@ struct Split16Params {
     long long* tl;             // NEMAR_TIMELINE builds: cycle stamps of workgroup 0 (tools/timeline_split16.py)
     const float* addend;       // [N, M, OH, OW] added to the result in the epilogue (the ResnetBlock skip gradient), or null (ksplit == 1 only)
     unsigned* maxw;            // NEMAR_MAX_WORDS(N) buffer: this workgroup's max |result| into its partial word, or null (ksplit == 1 only)
+    int maxw_lazy;             // the consumer reduces the partial words: result word n = the marker (max_words.h)
 };
 
 __device__ __forceinline__ void glds16(const u32x4* g, u32x4* lds) {
@@ -682,6 +683,7 @@ __global__ __launch_bounds__(256) void igemm_split16_kernel(Split16Params p) {
         if (tid == 0) {
             const int parts = p.tiles_per_img * p.mblks;
             p.maxw[p.N + (size_t)n * parts + (ptile - n * p.tiles_per_img) * p.mblks + mblk] = max(max(mred[0], mred[1]), max(mred[2], mred[3]));
+            if (p.maxw_lazy && ptile == n * p.tiles_per_img && mblk == 0) p.maxw[n] = NEMAR_MAX_LAZY_MARK | (unsigned)parts;
         }
     }
 }
@@ -961,6 +963,7 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
     const bool fuse = p.ksplit == 1 && variant == 4 && KS == 3 && !bias && (g_s16_addend || g_s16_maxw);
     p.addend = fuse ? g_s16_addend : nullptr;
     p.maxw = fuse ? g_s16_maxw : nullptr;
+    p.maxw_lazy = (p.maxw && nemar_max_words_lazy() && p.tiles_per_img * p.mblks <= 0xFFFF) ? 1 : 0;
     g_s16_epilogue_done = fuse ? 1 : 0;
     float* const final_dst = dst;
     if (p.ksplit > 1) p.dst = (float*)((char*)scratch + nemar_split16_scratch_bytes(N, Cred, H, W));       // slabs behind the planes
@@ -1006,7 +1009,7 @@ bool nemar_split16_conv(const float* src, const void* packed, const float* bias,
             else if (nbw == 2) S16_GO(2, 2, 3, 4)
             else S16_GO(3, 2, 3, 4))
         if (p.ksplit > 1) nemar_sum_partials(p.dst, p.slab_stride, p.ksplit, final_dst, p.slab_stride, false, st);
-        if (p.maxw) max_words_finalize(p.maxw, N, p.tiles_per_img * p.mblks, st);
+        if (p.maxw && !p.maxw_lazy) max_words_finalize(p.maxw, N, p.tiles_per_img * p.mblks, st);
         return dual_written;
     }
 #ifdef NEMAR_AB      // nemar_tune(21, 3): bf16 x 6 products

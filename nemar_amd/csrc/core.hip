@@ -49,12 +49,22 @@ size_t nemar_lds_bytes(const void* kernel, size_t need, bool claim) {
 #endif
 }
 
-#define NEMAR_HIP_VERSION 600  // major*10000 + minor*100 + patch  (0.6.0: round 6 — producer-written operand planes for all three calls of the
+#define NEMAR_HIP_VERSION 601  // major*10000 + minor*100 + patch  (0.6.1: nemar_set_max_words_lazy; 0.6.0: round 6 — producer-written operand planes for all three calls of the
                                // wide layers, fused skip-gradient add / max words in the data gradient's epilogue; 0.5.0: round 5 — no nemar_tune* in the product library: the measurement
                                // switches are constants there and live in libnemar_hip_ab.so (-DNEMAR_AB, include/nemar_hip_ab.h);
                                // 0.4.0: side inputs per call only, weight-pack plans, nemar_store_words, 7x7 layers on the 16-bit pipe)
 
 static thread_local char g_err[512] = "";
+static thread_local int g_max_words_lazy = 0;
+bool nemar_max_words_lazy() { return g_max_words_lazy != 0; }
+// While on (per calling thread), producers that publish per-sample maxima (nemar_instnorm_fwd_planes max_words, nemar_conv_extras.out_max_words)
+// leave the reduction of their partial words to the consumer: ONLY for words that go to nemar_instnorm_fwd_planes (residual_max_words) /
+// nemar_instnorm_bwd_planes (gy_max_words) — no other entry point understands the marker (csrc/max_words.h).  Returns the previous setting.
+NEMAR_API int nemar_set_max_words_lazy(int on) {
+    const int prev = g_max_words_lazy;
+    g_max_words_lazy = on ? 1 : 0;
+    return prev;
+}
 
 void nemar_set_error(const char* fmt, ...) {
     va_list ap;

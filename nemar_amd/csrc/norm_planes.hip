@@ -82,6 +82,7 @@ struct NormPlanesParams {
     float dscale;
     unsigned seed_lo, seed_hi, offset;
     const unsigned* obase;     // nemar_set_dropout_base word (added to offset) or null
+    int lazy;                  // the consumer reduces the partial maxima (nemar_set_max_words_lazy)
     int dbg;                   // measurement only (nemar_tune(31, bits)): 1 no plane stores, 2 no LDS transpose, 4 no statistics, 8 no fp32 stores
     u32x4* xw;                 // the weight gradient's pixel-major X planes of y (conv_split16_wgrad.hip layout, reflect border) or null
     long long xplane16;        // 16-byte words per X plane
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
         }
     // the bound this sample's planes are scaled by
     float bound = p.bound0;
-    if (p.residual) bound += __builtin_bit_cast(float, p.resmax[n]);
+    if (p.residual) bound += __builtin_bit_cast(float, sample_max_word(p.resmax, n, p.N));
     const unsigned bound_bits = __builtin_bit_cast(unsigned, bound);
     if (cg == 0 && t == 0) p.scale_words[n] = bound_bits;
     const float scale = np_pow2_scale(bound_bits);
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams 
             unsigned m = mred[0];
             for (int i = 1; i < 16; ++i) m = max(m, mred[i]);
             p.maxw[p.N + unit] = m;
+            if (p.lazy && cg == 0) p.maxw[n] = NEMAR_MAX_LAZY_MARK | (unsigned)CG;       // (no reduction launch: max_words.h)
         }
     }
 }
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(1024, 8) void instnorm_bwd_planes_kernel(NormBwdPla
     float rm = rmax[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) rm = fmaxf(rm, rmax[w]);
-    const float bound = rm * p.bmul * __builtin_bit_cast(float, p.gymax[n]);
+    const float bound = rm * p.bmul * __builtin_bit_cast(float, sample_max_word(p.gymax, n, p.N));
     const unsigned bound_bits = __builtin_bit_cast(unsigned, bound);
     if (cg == 0 && t == 0) p.scale_words[n] = bound_bits;
     const float scale = uniform_f(np_pow2_scale(bound_bits));
@@ -671,6 +673,7 @@ NEMAR_API int nemar_instnorm_fwd_planes(const float* x, const float* residual, c
     p.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     p.dscale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     p.dbg = g_norm_planes_dbg;
+    p.lazy = (max_words && nemar_max_words_lazy() && C / 8 <= 0xFFFF) ? 1 : 0;
     p.obase = g_dropout_base;
     p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32); p.offset = offset;
     p.xw = (u32x4*)wgrad_planes;
@@ -681,7 +684,7 @@ NEMAR_API int nemar_instnorm_fwd_planes(const float* x, const float* residual, c
                   "instnorm_fwd_planes: this shape has no weight-gradient planes (N=%d C=%d %dx%d)", N, C, H, W);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(instnorm_planes_kernel, dim3(N * (C / 8)), dim3(1024), 0, st, p);
-    if (max_words) max_words_finalize((unsigned*)max_words, N, C / 8, st);
+    if (max_words && !p.lazy) max_words_finalize((unsigned*)max_words, N, C / 8, st);
     NEMAR_CHECK_LAUNCH("instnorm_fwd_planes");
     return NEMAR_OK;
 }

@@ -351,16 +351,46 @@ def _wants_max(t):
     return t.dim() == 4 and 128 <= t.shape[1] <= MAX_PARTIALS and t.shape[1] % 16 == 0 and t.shape[0] <= 256
 
 
-def _tag_max(t, words):
+def _tag_max(t, words, lazy=False):
     # (with the tensor's version: autograd may accumulate another gradient INTO this tensor in place — the words are then stale)
-    t._nemar_absmax = (words[:t.shape[0]], t._version)
+    # lazy: the producer ran under _lazy_max() — the words hold the marker, not the maxima (csrc/max_words.h): a tag of its own that only
+    # the consumers which reduce the partial words themselves (the two InstanceNorm producers of the residual blocks) ask for
+    if lazy:
+        t._nemar_absmax_lazy = (words[:t.shape[0]], t._version)
+    else:
+        t._nemar_absmax = (words[:t.shape[0]], t._version)
 
 
-def _absmax_word(t):
+def _absmax_word(t, lazy_ok=False):
+    if lazy_ok:
+        have = getattr(t, '_nemar_absmax_lazy', None)
+        if have is not None and have[1] == t._version and have[0].numel() == t.shape[0]:
+            return have[0]
     have = getattr(t, '_nemar_absmax', None)
     if have is not None and have[1] == t._version and have[0].numel() == t.shape[0]:
         return have[0]
     return _absmax_word_compute(t)
+
+
+_LAZY_MAX = os.environ.get("NEMAR_LAZY_MAX", "1") != "0"      # (0: every producer finalizes its words — for A/B runs)
+
+
+class _lazy_max:
+    """`with _lazy_max(on)`: producers of per-sample maxima called inside leave the reduction of their partial words to the consumer
+    (nemar_set_max_words_lazy; one launch less per call on the chain the step waits for).  Only where the consumer is known to be
+    nemar_instnorm_fwd_planes / nemar_instnorm_bwd_planes."""
+
+    def __init__(self, on=True):
+        self.on = on and _LAZY_MAX
+
+    def __enter__(self):
+        if self.on:
+            L.set_max_words_lazy(1)
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            L.set_max_words_lazy(0)
 
 
 def _absmax_word_compute(t):
@@ -1016,15 +1046,16 @@ class _ResBlock(Function):
             pout = _chan_planes_buffer(N, C, H, W, dev)
             xpout = _x_planes_buffer(N, C, H, W, dev) if train else None
             scale_out = torch.empty(N, dtype=torch.int32, device=dev)
-            with _span('in_fwd_planes_resblock'):
-                L.instnorm_fwd_planes(_p(y2), _p(x), _p(_absmax_word(x)), _p(out), _p(stats2), N, C, H, W, eps, ACT_NONE, 0.2, 0.0, 0, 0,
+            # (the next block's IN2 + skip producer is the one consumer of these maxima: it reduces the partial words itself)
+            with _span('in_fwd_planes_resblock'), _lazy_max():
+                L.instnorm_fwd_planes(_p(y2), _p(x), _p(_absmax_word(x, lazy_ok=True)), _p(out), _p(stats2), N, C, H, W, eps, ACT_NONE, 0.2, 0.0, 0, 0,
                                       _p(pout), _p(scale_out), _p(words), _p(xpout), st)
             out._nemar_planes = (pout, scale_out, out._version)
             if xpout is not None:
                 out._nemar_xplanes = (xpout, scale_out, out._version)
         else:
             L.instnorm_fwd_max(_p(y2), _p(x), _p(out), _p(stats2), N * C, H * W, eps, ACT_NONE, 0.2, _p(words), C, st)
-        _tag_max(out, words)
+        _tag_max(out, words, lazy=feeds_block and _LAZY_MAX)
         ctx.save_for_backward(y1, stats1, y2, stats2, w1, w2)
         # conv1's weight gradient takes the producer's X planes of x where they exist, else x itself
         ctx.x0 = None if xp0 is not None else x
@@ -1100,11 +1131,12 @@ class _ResBlock(Function):
                     grad_ready(bias)
 
         # IN2 backward (no activation, the skip path passes g_out on unchanged)
-        gwords = _absmax_word(g_out)
+        gwords = _absmax_word(g_out, lazy_ok=True)
         d2, gp2, scale2, bsum2 = norm_bwd(y2, stats2, g_out, gwords, ACT_NONE, 0.0, 0, 0, True, need[2], need[3])
         gmid = torch.empty_like(g_out)
         mid_words = _max_words(N, dev)
-        dgrad(d2, scale2, w2v, gmid, None, mid_words)
+        with _lazy_max():                      # (consumed by this block's own IN1 backward producer, below)
+            dgrad(d2, scale2, w2v, gmid, None, mid_words)
         del d2
         wgrad(None, ctx.xp1, ctx.scale1, gp2, scale2, w2, b2, bsum2, need[2], need[3])
         # dropout + ReLU + IN1 backward
@@ -1113,8 +1145,11 @@ class _ResBlock(Function):
         if need_x:
             gin = torch.empty_like(g_out)
             in_words = _max_words(N, dev)
-            dgrad(d1, scale1b, w1v, gin, g_out, in_words)          # + the skip gradient, in the epilogue
-            _tag_max(gin, in_words)
+            # the block's input came with producer planes = from another block's end: gin goes to THAT block's backward producer and to nothing else
+            lazy_in = ctx.xp0 is not None and _LAZY_MAX
+            with _lazy_max(lazy_in):
+                dgrad(d1, scale1b, w1v, gin, g_out, in_words)      # + the skip gradient, in the epilogue
+            _tag_max(gin, in_words, lazy=lazy_in)
         del d1
         wgrad(ctx.x0, ctx.xp0, ctx.x_words, gp1, scale1b, w1, b1, bsum1, need[0], need[1])
         return gin, None, None, None, None, None, None, None

@@ -995,6 +995,32 @@ def case_resblock_planes_chain(be, pad_mode, act, drop_p, N=2, C=128, H=8, W=32,
     # the channel-blocked planes of the same call hold the same values
     cp = _decode_planes(be.raw(cplanes)[:2 * N * (C // 8) * (H + 4) * (W + 4) * 16], N, C, H, W)
     assert np.array_equal(cp[:, :, :, :H + 2, :W + 2], xp[:, :, :, :H + 2, :W + 2]), "the two layouts of one producer differ"
+    # ---- lazy maximum words (nemar_set_max_words_lazy): the same call leaves the marker instead of launching the reduction; the next producer
+    # (IN + skip: residual_max_words) reduces the partial words itself and must come out bit for bit as with finalized words ----
+    fmax_lazy = be.bytes_buf(4 * N * 2049)
+    cplanes2, xplanes2, fscale2 = be.bytes_buf(2 * N * (C // 8) * (H + 4) * (W + 4) * 16), be.bytes_buf(xbytes), be.bytes_buf(4 * N)
+    d_y2 = be.full(x0.shape, np.nan)
+    assert lib.set_max_words_lazy(1) == 0
+    try:
+        lib.instnorm_fwd_planes(be.ptr(d_x0), None, None, be.ptr(d_y2), be.ptr(d_st0), N, C, H, W, 1e-5, act, 0.2, drop_p, 777, 3,
+                                be.ptr(cplanes2), be.ptr(fscale2), be.ptr(fmax_lazy), be.ptr(xplanes2), be.stream)
+    finally:
+        assert lib.set_max_words_lazy(0) == 1
+    be.sync()
+    wl, we = be.raw(fmax_lazy)[:4 * N * 2049].view(np.uint32), be.raw(fmax)[:4 * N * 2049].view(np.uint32)
+    assert np.all(wl[:N] == (0xFFFF0000 | (C // 8))), [hex(int(v)) for v in wl[:N]]
+    assert np.array_equal(wl[N:N + N * (C // 8)], we[N:N + N * (C // 8)]), "lazy / eager partial words differ"
+    assert np.array_equal(we[:N], we[N:N + N * (C // 8)].reshape(N, C // 8).max(axis=1)), "finalized words are not the maxima of the partials"
+    x9 = (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32)
+    d_x9 = be.dev(x9)
+    outs = []
+    for words in (fmax, fmax_lazy):
+        o9, st9, pl9, sc9 = be.full(x0.shape, np.nan), be.full((N * C, 2), np.nan), be.bytes_buf(2 * N * (C // 8) * (H + 4) * (W + 4) * 16), be.bytes_buf(4 * N)
+        lib.instnorm_fwd_planes(be.ptr(d_x9), be.ptr(d_y), be.ptr(words), be.ptr(o9), be.ptr(st9), N, C, H, W, 1e-5, 0, 0.2, 0.0, 0, 0,
+                                be.ptr(pl9), be.ptr(sc9), None, None, be.stream)
+        be.sync()
+        outs.append((be.np(o9).copy(), be.raw(sc9)[:4 * N].copy(), be.raw(pl9)[:2 * N * (C // 8) * (H + 4) * (W + 4) * 16].copy()))
+    assert all(np.array_equal(a, b) for a, b in zip(*outs)), "a consumer of lazy residual words differs from one of finalized words"
 
     # ---- backward producer: the InstanceNorm in front of which the convolution sits (x1 = the convolution's output) ----
     x1 = (rng.standard_normal((N, C, H, W)) * np.linspace(0.5, 4.0, C).reshape(1, C, 1, 1) - 0.5).astype(np.float32)
@@ -1089,6 +1115,29 @@ def case_resblock_planes_chain(be, pad_mode, act, drop_p, N=2, C=128, H=8, W=32,
         assert np.all(np.abs(gin - (want_gin + skip)) <= lim), ("data gradient from planes + skip", float((np.abs(gin - (want_gin + skip)) / lim).max()))
         got_omax = be.raw(omax)[:4 * N].view(np.uint32)
         assert np.array_equal(got_omax, np.abs(gin).reshape(N, -1).max(axis=1).astype(np.float32).view(np.uint32)), "epilogue max words"
+        # ... and lazily: marker words, the same partial words, the same result; the backward producer fed with either comes out the same
+        omax_lazy, d_gin2 = be.bytes_buf(4 * N * 2049), be.full((N, C, H, W), np.nan)
+        e.out_max_words = be.ptr(omax_lazy).value
+        lib.set_max_words_lazy(1)
+        try:
+            lib.conv2d_bwd_data_ex(be.ptr(ghost), be.ptr(d_w), None, 0, 0.0, be.ptr(d_gin2), C, None, 0, N, H, W, K, H, W, 3, 3, 1, 1,
+                                   pad_mode, be.ptr(wsd), wsdb, 1, be.stream, ctypes.byref(e))
+        finally:
+            lib.set_max_words_lazy(0)
+        be.sync()
+        parts = (H // (256 // W)) * (C // 128)
+        ol, oe = be.raw(omax_lazy)[:4 * N * 2049].view(np.uint32), be.raw(omax)[:4 * N * 2049].view(np.uint32)
+        assert np.array_equal(be.np(d_gin2), gin)
+        assert np.all(ol[:N] == (0xFFFF0000 | parts)), [hex(int(v)) for v in ol[:N]]
+        assert np.array_equal(ol[N:N + N * parts], oe[N:N + N * parts]) and np.array_equal(oe[:N], oe[N:N + N * parts].reshape(N, parts).max(axis=1))
+        res = []
+        for words in (omax, omax_lazy):
+            dpl, gpl, bsc = be.bytes_buf(dbytes), be.bytes_buf(gbytes), be.bytes_buf(4 * N)
+            lib.instnorm_bwd_planes(be.ptr(d_x1), be.ptr(d_st1), be.ptr(d_gin), be.ptr(words), N, C, H, W, act, 0.2, 0.0, 0, 0,
+                                    1 if reflect else 0, None, be.ptr(dpl), be.ptr(gpl), be.ptr(bsc), None, be.stream)
+            be.sync()
+            res.append((be.raw(bsc)[:4 * N].copy(), be.raw(dpl)[:dbytes].copy(), be.raw(gpl)[:gbytes].copy()))
+        assert all(np.array_equal(a, b) for a, b in zip(*res)), "the backward producer on lazy gradient words differs from the one on finalized words"
         # weight gradient: both operands as planes
         d_gw = be.full((K, C, 3, 3), 0.25)
         ghost_x = be.full((N, C, H, W), np.nan)
