@@ -25,6 +25,7 @@ SHAPES = [  # name, C0, C1, K, R, stride, pad, pad_mode, H
     ("R.up2 128->64 k3 @128", 64, 64, 64, 3, 1, 1, 0, 128),
     ("D.l1 6->64 k4s2 @256", 3, 3, 64, 4, 2, 1, 0, 256),
     ("D.l2 64->128 k4s2 @128", 64, 0, 128, 4, 2, 1, 0, 128),
+    ("D.l3 128->256 k4s2 @64", 128, 0, 256, 4, 2, 1, 0, 64),
     ("D.l4 256->512 k4s1 @32", 256, 0, 512, 4, 1, 1, 0, 32),
 ]
 
