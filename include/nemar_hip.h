@@ -247,12 +247,6 @@ int nemar_instnorm_fwd(const float* x, const float* residual, float* y, float* s
                        float eps, int act, float slope, void* stream);
 int nemar_instnorm_bwd(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW,
                        int act, float slope, void* stream);
-/* nemar_instnorm_bwd for planes too large for one workgroup's registers (>= 32768 pixels: the 256 x 256 layers), as two launches of small
- * workgroups with a workspace of nemar_instnorm_bwd_workspace(planes, HW) bytes (0: this shape has no such form) between them — a footprint
- * that fits next to a second stream's kernels (0.6.1).  Without a workspace, or for smaller planes, it is nemar_instnorm_bwd. */
-size_t nemar_instnorm_bwd_workspace(int planes, int HW);
-int nemar_instnorm_bwd_ws(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW, int act, float slope,
-                          void* workspace, size_t ws_bytes, void* stream);
 /* The same, and max |output| (finite elements) of every SAMPLE into max_words[sample]: what nemar_absmax_samples would compute in a
  * pass of its own — the producer has the values in registers.  The words are what nemar_conv_extras.src_max_words takes (the
  * fp16 x 3 convolutions consume them).  max_words is a buffer of NEMAR_MAX_WORDS(samples) 4-byte words, no initialisation needed: the first

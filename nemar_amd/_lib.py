@@ -64,8 +64,6 @@ SIGNATURES = {
     "nemar_set_max_words_lazy": (_i, [_i]),
     "nemar_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp]),
     "nemar_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp]),
-    "nemar_instnorm_bwd_workspace": (_sz, [_i, _i]),
-    "nemar_instnorm_bwd_ws": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _sz, _vp]),
     "nemar_instnorm_fwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _fl, _i, _fl, _vp, _i, _vp]),
     "nemar_instnorm_fwd_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _fl, _i, _fl, _fl, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
     "nemar_instnorm_bwd_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _fl, _fl, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

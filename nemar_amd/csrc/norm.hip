@@ -379,95 +379,6 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __re
     if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
 }
 
-// ---- large planes in TWO launches (round 6b: nemar_instnorm_bwd_ws) ---------------------------------------------------------------------------
-// A 256 x 256 plane in one workgroup is 1024 threads x 120 registers (instnorm_bwd4s_kernel): fast alone (88 us per 67 MB tensor), but a
-// workgroup that needs a CU's whole register file waits for one while the side stream's weight gradients hold them (148 us in the two-stream
-// step).  Here every plane is cut into BS_SPLIT parts of a 256-thread workgroup each: launch 1 leaves the two sums of every part in a small
-// workspace, launch 2 adds a plane's parts in order (a fixed association) and applies them — x and gy are read twice (the second time mostly
-// from the memory-side cache), with a footprint that fits next to anything.
-constexpr int BS_SPLIT = 4;
-
-__global__ __launch_bounds__(256) void instnorm_bwd_part_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                                const float* __restrict__ gy, float* __restrict__ part, int HW, int act, float slope) {
-    __shared__ float red[16];
-    const int plane = blockIdx.x / BS_SPLIT, sp = blockIdx.x - plane * BS_SPLIT;
-    const int per4 = (HW >> 2) / BS_SPLIT;
-    const f32x4n* xp = reinterpret_cast<const f32x4n*>(x + (size_t)plane * HW) + (size_t)sp * per4;
-    const f32x4n* gp = reinterpret_cast<const f32x4n*>(gy + (size_t)plane * HW) + (size_t)sp * per4;
-    const float mean = stats[2 * (size_t)plane], rstd = stats[2 * (size_t)plane + 1];
-    const float dneg = act == ACT_RELU ? 0.f : (act == ACT_LRELU ? slope : 1.f);
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < per4; i += 4 * 256) {
-        f32x4n xv[4], gv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // unconditional loads from clamped addresses: eight 16-byte loads in flight
-            const int j = min(i + k * 256, per4 - 1);
-            xv[k] = xp[j];
-            gv[k] = gp[j];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i + k * 256 < per4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float h = (xv[k][e] - mean) * rstd;
-                    const float t = gv[k][e] * (h > 0.f ? 1.f : dneg);
-                    s1 += t;
-                    s2 += t * h;
-                }
-            }
-        }
-    }
-    s1 = block_sum(s1, red);
-    s2 = block_sum(s2, red);
-    if (threadIdx.x == 0) {
-        part[2 * (size_t)blockIdx.x] = s1;
-        part[2 * (size_t)blockIdx.x + 1] = s2;
-    }
-}
-
-__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                                 const float* __restrict__ gy, const float* __restrict__ part,
-                                                                 float* __restrict__ gx, int HW, int act, float slope) {
-    const int plane = blockIdx.x / BS_SPLIT, sp = blockIdx.x - plane * BS_SPLIT;
-    const int per4 = (HW >> 2) / BS_SPLIT;
-    const f32x4n* xp = reinterpret_cast<const f32x4n*>(x + (size_t)plane * HW) + (size_t)sp * per4;
-    const f32x4n* gp = reinterpret_cast<const f32x4n*>(gy + (size_t)plane * HW) + (size_t)sp * per4;
-    f32x4n* op = reinterpret_cast<f32x4n*>(gx + (size_t)plane * HW) + (size_t)sp * per4;
-    const float mean = stats[2 * (size_t)plane], rstd = stats[2 * (size_t)plane + 1];
-    const float dneg = act == ACT_RELU ? 0.f : (act == ACT_LRELU ? slope : 1.f);
-    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < BS_SPLIT; ++q) {                    // the plane's parts in order
-        t1 += part[2 * ((size_t)plane * BS_SPLIT + q)];
-        t2 += part[2 * ((size_t)plane * BS_SPLIT + q) + 1];
-    }
-    const float inv = 1.f / (float)HW;
-    const float m1 = t1 * inv, m2 = t2 * inv;
-    for (int i = threadIdx.x; i < per4; i += 4 * 256) {
-        f32x4n xv[4], gv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = min(i + k * 256, per4 - 1);
-            xv[k] = xp[j];
-            gv[k] = gp[j];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i + k * 256 < per4) {
-                f32x4n o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float h = (xv[k][e] - mean) * rstd;
-                    const float t = gv[k][e] * (h > 0.f ? 1.f : dneg);
-                    o[e] = rstd * (t - m1 - h * m2);
-                }
-                op[i + k * 256] = o;
-            }
-        }
-    }
-}
-
 }  // namespace
 
 // x, y, residual (nullable): [planes, HW] with planes = N*C;  stats: [planes, 2] = (mean, rstd)
@@ -567,28 +478,5 @@ static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy
         hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
     if (maxw) max_words_finalize(maxw, planes / pps, pps, st);
     NEMAR_CHECK_LAUNCH("instnorm_bwd");
-    return NEMAR_OK;
-}
-
-// nemar_instnorm_bwd with a workspace: planes too large for one workgroup's registers run as two launches of small workgroups (above);
-// everything else — and every call without a workspace — takes nemar_instnorm_bwd's kernels.  Same results up to the association of the sums.
-NEMAR_API size_t nemar_instnorm_bwd_workspace(int planes, int HW) {
-    if (planes <= 0 || HW < 32768 || HW % (4 * BS_SPLIT) != 0) return 0;
-    return (size_t)planes * BS_SPLIT * 2 * sizeof(float);
-}
-
-NEMAR_API int nemar_instnorm_bwd_ws(const float* x, const float* stats, const float* gy, float* gx, int planes, int HW, int act, float slope,
-                                    void* workspace, size_t ws_bytes, void* stream) {
-    const size_t need = nemar_instnorm_bwd_workspace(planes, HW);
-    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0;
-    if (need == 0 || !workspace || ws_bytes < need || !al || (long long)planes * BS_SPLIT >= (1ll << 31))
-        return instnorm_bwd_impl(x, stats, gy, gx, planes, HW, act, slope, nullptr, 1, stream);
-    NEMAR_CLEAR_HIP_ERROR();
-    NEMAR_REQUIRE(x && stats && gy && gx, "instnorm_bwd_ws: null pointer");
-    NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_bwd_ws: unsupported act %d", act);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(instnorm_bwd_part_kernel, dim3(planes * BS_SPLIT), dim3(256), 0, st, x, stats, gy, (float*)workspace, HW, act, slope);
-    hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(planes * BS_SPLIT), dim3(256), 0, st, x, stats, gy, (const float*)workspace, gx, HW, act, slope);
-    NEMAR_CHECK_LAUNCH("instnorm_bwd_ws");
     return NEMAR_OK;
 }

@@ -372,7 +372,6 @@ def _absmax_word(t, lazy_ok=False):
     return _absmax_word_compute(t)
 
 
-_IN_BWD_WS = os.environ.get("NEMAR_IN_BWD_WS", "1") != "0"      # (0: the one-workgroup-per-plane kernels for 256 x 256 planes — for A/B runs)
 _LAZY_MAX = os.environ.get("NEMAR_LAZY_MAX", "1") != "0"      # (0: every producer finalizes its words — for A/B runs)
 
 
@@ -932,11 +931,7 @@ class _InstanceNorm(Function):
                 L.instnorm_bwd_max(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _p(words), C, _stream())
                 _tag_max(gx, words)
             else:
-                wsb = Q.instnorm_bwd_workspace(N * C, H * W) if _IN_BWD_WS else 0
-                if wsb:        # 256 x 256 planes: two launches of small workgroups (a footprint that fits beside the side stream's kernels)
-                    L.instnorm_bwd_ws(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _p(_workspace(wsb, x.device)), wsb, _stream())
-                else:
-                    L.instnorm_bwd(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _stream())
+                L.instnorm_bwd(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _stream())
         gres = gy if ctx.needs_input_grad[1] else None
         return gx, gres, None, None, None, None, None
 

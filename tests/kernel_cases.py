@@ -700,37 +700,6 @@ def case_instnorm(be, N, C, H, W, act, residual=False, seed=0):
     _assert_close(be.np(d_gx), want_gx, atol=3e-5 * np.abs(want_gx).max(), rtol=1e-4, what="instnorm_bwd")
 
 
-def case_instnorm_bwd_ws(be, N, C, H, W, act, seed=0):
-    """nemar_instnorm_bwd_ws: large planes as two launches of small workgroups with a workspace in between (csrc/norm.hip) — against float64,
-    against nemar_instnorm_bwd within rounding, twice the same bits; a shape without that form falls back to nemar_instnorm_bwd exactly."""
-    rng = np.random.default_rng(seed)
-    x = (rng.standard_normal((N, C, H, W)) * 2 + rng.standard_normal((N, C, 1, 1)) * 3).astype(np.float32)
-    gy = rng.standard_normal((N, C, H, W)).astype(np.float32)
-    x64 = x.astype(np.float64)
-    xhat, m, rstd = O.instance_norm_fwd(x64)
-    g = gy.astype(np.float64) * (O.act_bwd(np.ones_like(xhat), O.act_fwd(xhat, act), act))
-    want_gx = O.instance_norm_bwd(x64, g)
-    d_x, d_gy = be.dev(x), be.dev(gy)
-    d_y, d_st = be.full((N, C, H, W), np.nan), be.full((N * C, 2), np.nan)
-    be.lib.instnorm_fwd(be.ptr(d_x), None, be.ptr(d_y), be.ptr(d_st), N * C, H * W, 1e-5, act, 0.2, be.stream)
-    wsb = be.lib.instnorm_bwd_workspace(N * C, H * W)
-    outs = []
-    for rep in range(2):
-        ws = be.bytes_buf(max(wsb, 16))
-        d_gx = be.full((N, C, H, W), np.nan)
-        be.lib.instnorm_bwd_ws(be.ptr(d_x), be.ptr(d_st), be.ptr(d_gy), be.ptr(d_gx), N * C, H * W, act, 0.2, be.ptr(ws), wsb, be.stream)
-        outs.append(be.np(d_gx))
-    assert np.array_equal(outs[0], outs[1]), "not bitwise reproducible"
-    _assert_close(outs[0], want_gx, atol=3e-5 * np.abs(want_gx).max(), rtol=1e-4, what="instnorm_bwd_ws")
-    d_ref = be.full((N, C, H, W), np.nan)
-    be.lib.instnorm_bwd(be.ptr(d_x), be.ptr(d_st), be.ptr(d_gy), be.ptr(d_ref), N * C, H * W, act, 0.2, be.stream)
-    if wsb == 0:
-        assert np.array_equal(outs[0], be.np(d_ref)), "without a split form the call must be nemar_instnorm_bwd"
-    else:
-        assert wsb == N * C * 4 * 2 * 4
-        _assert_close(outs[0], be.np(d_ref).astype(np.float64), atol=2e-6 * np.abs(want_gx).max(), rtol=1e-5, what="instnorm_bwd_ws vs instnorm_bwd")
-
-
 def case_producer_max_words(be, seed=0):
     """InstanceNorm forward / backward and dropout with the per-sample maximum of their output as a by-product (the words the fp16 x 3
     convolutions scale by): same outputs as the plain entry points, words == numpy's per-sample finite maximum."""

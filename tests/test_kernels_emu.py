@@ -327,14 +327,6 @@ def test_instnorm_256x256_planes_gy_in_registers(be):
     K.case_instnorm(be, 1, 1, 256, 256, K.O.ACT_LRELU)
 
 
-def test_instnorm_backward_large_planes_in_two_launches(be):
-    """256 x 256 / 192 x 256 planes through nemar_instnorm_bwd_ws (parts of a plane in 256-thread workgroups, sums through a workspace); a small
-    plane takes nemar_instnorm_bwd's kernel bit for bit."""
-    K.case_instnorm_bwd_ws(be, 1, 2, 256, 256, K.O.ACT_RELU)
-    K.case_instnorm_bwd_ws(be, 2, 1, 192, 256, K.O.ACT_LRELU)
-    K.case_instnorm_bwd_ws(be, 1, 3, 40, 30, K.O.ACT_NONE)
-
-
 def test_pointwise(be):
     K.case_pointwise(be)
 
