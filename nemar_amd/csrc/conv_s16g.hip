@@ -773,7 +773,11 @@ S16gPlan nemar_s16g_plan(const S16gProblem& q) {
     cf = attempt == 0;
     const int wtaps = cf ? alltaps : maxtaps, wcls = cf ? 1 : q.ncls;
     // (128 channels x 256 pixels per workgroup — MT 4, NT 2 — needs 280 VGPRs: 144 of them spilled to scratch; that tile is not offered)
+#ifdef NEMAR_S16G_NT1          /* variant build for an A/B run (tools/build_variant.py): 128-pixel tiles only */
+    for (int NT = 1; NT >= 1; --NT) {
+#else
     for (int NT = (sx == 2 || pl.MT == 4 || cf ? 1 : 2); NT >= 1; --NT) {
+#endif
         const int NP = 128 * NT;
         for (int TW = 32; TW <= NP; TW *= 2) {
             if (TW > 32 && TW / 2 >= OW) break;              // wider than the rows: pure waste

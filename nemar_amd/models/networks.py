@@ -12,6 +12,7 @@ Only instance normalisation (the reference default, `--norm instance`) and `--no
 raises NotImplementedError (cross-sample statistics are outside the per-sample hot path).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -410,6 +411,12 @@ class NLayerDiscriminator(nn.Module):
         self.layers.append((m.put(idx, ConvParams(ndf * prev, ndf * nf, 4, bias=use_bias)), 1, True))
         idx += per
         _ref(self, 'final', m.put(idx, ConvParams(ndf * nf, 1, 4, bias=True)))
+        # Schedule hint (ops._Conv2d backward): D's backward chain is short (four data gradients) and its weight gradients long (the 4x4
+        # stride-2 layers run on the exact-fp32 kernels), so with all of them on the side stream the compute stream waited 0.53 ms per step
+        # at the join before D's Adam step (tools/side_tail.py).  The second layer's weight gradient stays on the compute stream: the two
+        # lanes then end together.  NEMAR_D_WGRAD_MAIN=0 switches the hint off (A/B of the schedule; the results are the same bits).
+        if len(self.layers) >= 3 and os.environ.get('NEMAR_D_WGRAD_MAIN', '1') != '0':
+            self.layers[1][0].weight._nemar_wgrad_main = True
 
     def forward(self, x, x2=None):
         """`x2`: optional second tensor, logically concatenated after `x` along channels (the (real_A, image)

@@ -687,6 +687,10 @@ class _Conv2d(Function):
             # gradient there — it is the last one of the pass, and the compute stream would only wait for it at the join
             if not (need_x or need_x2):
                 _use = False
+            # schedule hint of the model (NLayerDiscriminator: the side lane is the longer one of the D phase, the compute stream idles at
+            # its join): this layer's weight gradient stays on the compute stream.  Same kernels, same accumulation order: same bits.
+            if getattr(ctx.weight, '_nemar_wgrad_main', False):
+                _use = False
             gwbuf = _grad_buffer(ctx.weight)
             gbbuf = _grad_buffer(ctx.bias) if want_b else None       # (the bias gradient rides along with the weight gradient: same lane)
             if _use and _side_on[0]:
