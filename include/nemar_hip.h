@@ -32,7 +32,7 @@ extern "C" {
 #define NEMAR_EWORKSPACE (-3)
 
 /* library */
-int nemar_version(void);              /* major*10000 + minor*100 + patch; 601 = this header (0.4.x exported nemar_tune*) */
+int nemar_version(void);              /* major*10000 + minor*100 + patch; 602 = this header (0.4.x exported nemar_tune*) */
 const char* nemar_last_error(void);   /* thread-local message of the last failing call */
 
 /* ---- K9/K10/K11: sampling-grid generation fused into bilinear grid_sample ------------------------------
@@ -307,6 +307,14 @@ int nemar_act_bwd(const float* gy, const float* y, float* gx, long long n, int a
 /* y = act(x) as a stand-alone pass (nn.ReLU / nn.LeakyReLU / nn.Tanh where no producer epilogue can carry it: the U-Net
  * generator's skip path, reference models/networks.py:516-553).  Backward = nemar_act_bwd on the output. */
 int nemar_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream);
+/* (ABI 602) dst = [piece 0 | piece 1 | ... | piece k-1] (k <= 8 contiguous pieces of counts[i] floats; `pieces` / `counts` are HOST arrays,
+ * read during the call; a NULL piece contributes zeros).  The concatenation along the batch of the model's batched passes
+ * (torch.cat of reference models/nemar_model.py:181,220 evaluated once for several images) and, with the incoming gradients as pieces, the
+ * backward of slicing such a batch — instead of autograd's cat / zero-fill / copy / add kernels. */
+int nemar_concat_pieces(const float* const* pieces, const long long* counts, int k, float* dst, void* stream);
+/* (ABI 602) out = a + b (out may alias a or b): the sum of the gradients of a tensor with two consumers (a ResnetBlock's input, a U-Net skip:
+ * reference models/networks.py:443-446, models/stn/unet_stn.py:80-97), which autograd would add with an ATen kernel. */
+int nemar_add2(const float* a, const float* b, float* out, long long n, void* stream);
 /* nn.MaxPool2d(2) — reference models/stn/layers.py:174.  x [planes,H,W] -> y [planes,H/2,W/2].
  * bwd: gx = (addend ? addend : 0) + unpool(gy); the argmax (first maximum, row-major) is recomputed from x. */
 int nemar_maxpool2_fwd(const float* x, float* y, int planes, int H, int W, void* stream);

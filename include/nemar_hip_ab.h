@@ -41,7 +41,7 @@ extern "C" {
  *   33 the 7x7 stem / head layers on the 16-bit matrix pipe (csrc/conv_k7.hip; 1)
  *   34 wide weight gradient: one copy of the gy planes + shifted operands built in registers (1) / KS shifted copies in HBM (0)
  *   35 the wide data gradient's split pass also writes the weight gradient's gy planes (1)
- *   36 reduction-split forward layers keep a fused ReLU / LeakyReLU (activation in the sum pass; 0)
+ *   36 reduction-split forward layers keep a fused ReLU / LeakyReLU (activation in the sum pass; 1 since round 6c, 0 = such layers are not split)
  *   37 kernel families whose workgroups claim the whole CU's LDS (bit mask: 1 LDS-DMA forms of wgrad_split16_kernel (default), 2 igemm_split16_kernel,
  *      4 s16g_kernel — csrc/common.h)                                38 wide 3x3 weight gradient stages through registers (1, default) / by LDS-DMA (0)
  *   39 most reduction runs per tile of the wide-layer kernel (8; 1 = never split: small test shapes with the fused data-gradient epilogue)
@@ -49,7 +49,9 @@ extern "C" {
  *   41 ... as long as the grid keeps this many workgroups (256; tests: 0)
  *   42 the four output-parity classes of a stride-2 data gradient / ConvTranspose2d in ONE s16g_kernel workgroup per tile, on one converted
  *      halo (0, default = one workgroup per (tile, class): the fused form measured 10-30 % slower, csrc/conv_s16g.hip; 1 = where the grid
- *      keeps min(192, key 41) workgroups; 2 = 1 and a four-class problem that cannot fuse leaves the route: tests) */
+ *      keeps min(192, key 41) workgroups; 2 = 1 and a four-class problem that cannot fuse leaves the route: tests)
+ *   43 stride-1 reflect data gradients of tiny maps on the exact-fp32 kernels: one split launch over the padded domain + a sum-and-fold pass
+ *      (1, default) / interior + border-ring launches with their sums and a gather (0) */
 int nemar_tune(int key, int value);
 int nemar_tune_ptr(void* timeline_buffer);   /* device buffer for per-stage cycle stamps (tools/timeline_*.py), NULL = off */
 /* grad_input variant for A/B measurements: 0 (default) = gather + fixed point (needs the workspace), 1 = fp32 atomics through an

@@ -86,6 +86,8 @@ SIGNATURES = {
     "nemar_instnorm_bwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _i, _vp]),
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),
+    "nemar_concat_pieces": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "nemar_add2": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "nemar_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "nemar_maxpool2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "nemar_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

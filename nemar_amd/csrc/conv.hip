@@ -47,6 +47,8 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
                          int target_blocks, bool vec_ok, int dbg, float* part, hipStream_t st);
 // reduce.hip: dst (+)= sum of `splits` slabs in split order (the deterministic second stage of every split reduction)
+void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
+                             hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st);
 
@@ -83,7 +85,8 @@ static thread_local const void* t_x_wplanes = nullptr;        // bwd_weight_ex: 
 static thread_local const float* t_addend = nullptr;          // bwd_data_ex: tensor added to gx0 in the epilogue (extras.addend)
 static thread_local void* t_out_max = nullptr;                // bwd_data_ex: per-sample max |gx0| words (extras.out_max_words)
 static thread_local int t_fused_epilogue = 0;                 // did the last bwd_data_ex call honour them?
-static NEMAR_SWITCH(int, g_split_act, 0);          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
+static NEMAR_SWITCH(int, g_split_act, 1);          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
+static NEMAR_SWITCH(int, g_fold_small, 1);         // key 43: stride-1 reflect data gradients of tiny maps on the exact route: padded domain + sum-and-fold pass
 static NEMAR_SWITCH(int, g_dual_gy, 1);            // key 35: the data-gradient call's split pass also writes the weight gradient's gy planes
 static thread_local int t_gy_planes_written = 0;      // did the last bwd_data_ex call on this thread fill gy_planes_out?
 #define g_scratch t_scratch
@@ -710,7 +713,7 @@ void k7_mf_run(const K7MfPlan& m_, const float* src, const float* w, int Ks, int
 struct DgradLayout {
     size_t pack_stride, padded_off, w2_off, ring_off, ring_slab_off, slab_off, aux_rows_off, aux_cols_off, total;
     int ring_len, ksplit, ring_ksplit;
-    bool ring, fold, fold16;
+    bool ring, fold, fold16, fold_small;
 };
 DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
     DgradLayout L;
@@ -745,6 +748,12 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
             if (b > L.pack_stride) L.pack_stride = b;
         }
     }
+    // Tiny stride-1 reflect layers that stay on the exact-fp32 kernels (the <= 16 x 16 maps of the registration net's ResnetBlocks): the
+    // padded-domain form as well — ONE implicit-GEMM launch over the (H + 2p) x (W + 2p) domain with its reduction split into slabs, then ONE
+    // pass that sums the slabs and folds the mirrored border (nemar_sum_partials_fold).  The ring form of the same layer is five
+    // launches of 4 - 8 us each on the step's critical chain: interior, its slab sum, border ring, its slab sum, gather.
+    L.fold_small = L.ring && !L.fold16 && g_fold_small && g_ksplit && C > 4 && (H + 2 * pad) * (W + 2 * pad) <= 1296;
+    if (L.fold_small) { L.ring = false; L.fold = true; }
     size_t o = L.pack_stride * (size_t)(stride * stride);
     L.padded_off = o;
     if (L.fold || L.fold16) o += (size_t)N * C * (H + 2 * pad) * (W + 2 * pad);
@@ -768,8 +777,9 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
     // 128x128 tiles (D's 256->512 k4 layer: 128 tiles x 512 stages) get one workgroup per CU; tiny deep problems on the
     // generic kernels (the 2x2 .. 32x32-pixel layers of the registration net) ~256 workgroups of >= 4 stages
     L.ksplit = 1;
-    if (g_ksplit && stride == 1 && !L.fold && C > 4) {
-        const int P = N * H * W, Kred = K * R * S, stages = nemar_cdiv(Kred, BK);
+    const int Hs = L.fold_small ? H + 2 * pad : H, Wsl = L.fold_small ? W + 2 * pad : W;      // the domain the split launch covers
+    if (g_ksplit && stride == 1 && (!L.fold || L.fold_small) && C > 4) {
+        const int P = N * Hs * Wsl, Kred = K * R * S, stages = nemar_cdiv(Kred, BK);
         if (g_cfg128 == 0 && C > 64 && K % BK == 0) {
             const long long tiles = (long long)nemar_cdiv(C, 128) * nemar_cdiv(P, 128);
             if (tiles < 200 && stages >= 256) {
@@ -782,7 +792,7 @@ DgradLayout dgrad_layout(int N, int C, int H, int W, int K, int R, int S, int st
         L.ksplit = normalize_ksplit(Kred, L.ksplit);
     }
     L.slab_off = o;
-    if (L.ksplit > 1) o += (size_t)L.ksplit * N * C * H * W;
+    if (L.ksplit > 1) o += (size_t)L.ksplit * N * C * Hs * Wsl;
     // side buffers of the ring-free reflect data gradient (source = gy [N,K,H,W] for a 3x3 / pad 1 layer)
     L.aux_rows_off = o;
     if (L.ring && pad == 1 && R == 3 && S == 3) o += 6ull * N * K * W;
@@ -932,9 +942,9 @@ NEMAR_API int nemar_conv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     p.N = N; p.P = N * OH * OW;
     p.sy = stride; p.sx = stride; p.border = pad_mode; p.act = act; p.slope = slope; p.pad = pad;
     p.fd_ohw = make_fastdiv(OH * OW); p.fd_ow = make_fastdiv(OW); p.fd_cs = make_fastdiv(C);
-    // (a split with the activation applied by the sum pass — nemar_sum_partials_act — is wired but off: it changes the summation order of
-    // the registration net's decoder layers, and the reduced-width parity test then sits on a different LeakyReLU knife edge of D
-    // (tests/step_parity.py); 0.2 ms per step were not worth re-measuring every allowance.  nemar_tune(36, 1) switches it on.)
+    // A layer with a fused ReLU / LeakyReLU splits too: the activation is applied by the sum pass (nemar_sum_partials_act).  The registration
+    // net's decoder and first-of-level layers at <= 16 x 16 (72 .. 144 serial stages in one or two workgroups: 33 / 57 us per call) take
+    // ~10 us + the sum; same-box A/B 27.41 -> 27.07 ms per step (profiles/r6_d_wgrad_lane_and_split_act_ab.txt).  nemar_tune(36, 0): off.
     const bool split_act = g_split_act && (act == ACT_RELU || act == ACT_LRELU);
     if (FL.ksplit > 1 && (act == ACT_NONE || split_act)) {      // slab 0 carries the bias; an activation follows the sum (ReLU / LeakyReLU)
         p.ksplit = FL.ksplit;
@@ -1081,6 +1091,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
     // reflect convolutions (not on the hot path) keep the simple form: differentiate on the padded domain into
     // scratch, then fold.
     const bool ring = L.ring, fold = L.fold;
+    bool folded = false;                  // fold_small: the slab sum folded the border already
     const int Hd = fold ? H + 2 * pad : H, Wd = fold ? W + 2 * pad : W;
     const int padd = fold ? 0 : pad;
     float* padded = fold ? wsf + L.padded_off : nullptr;
@@ -1136,10 +1147,10 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 nemar_narrow_fwd(gy, w2, nullptr, gx0, N, K, OH, OW, C, R, R - 1 - pad, BORDER_ZERO, ACT_NONE, 0.f, nullptr, 0, st);
             } else {
                 // split reductions (see dgrad_layout): each split stores its partial gradient to its own slab, summed in order
-                if (L.ksplit > 1 && !bias && act == ACT_NONE && mskip == 0 && (gx1 == nullptr || (gx0 != nullptr && !ring))) {
+                if (L.ksplit > 1 && !bias && act == ACT_NONE && mskip == 0 && (fold ? (gx0 != nullptr && gx1 == nullptr) : (gx1 == nullptr || (gx0 != nullptr && !ring)))) {
                     p.ksplit = L.ksplit;
                     p.part = wsf + L.slab_off;
-                    p.part_stride = (long long)N * C * H * W;
+                    p.part_stride = (long long)N * C * Hd * Wd;       // (fold_small: slabs of the padded domain)
                     if (gx1) { p.M0 = C; p.dst1 = nullptr; }      // two destinations: the slabs hold all C rows, the sum pass parts them
                 }
                 // 3x3 reflect layers that run on the wave-specialised 16-byte-load kernel fold the border INTO the main launch
@@ -1154,7 +1165,11 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                     ring_done = true;
                 }
                 launch_igemm(p, st);
-                if (p.ksplit > 1 && gx1) nemar_sum_partials_two(p.part, p.part_stride, p.ksplit, gx0, gx1, N, C0, C1, H * W, st);
+                if (p.ksplit > 1 && fold) {                       // slabs of the padded domain -> sum + fold in one pass (gx1 == nullptr: checked above)
+                    nemar_sum_partials_fold(p.part, p.part_stride, p.ksplit, gx0, (long long)N * C, H, W, pad, st);
+                    folded = true;
+                }
+                else if (p.ksplit > 1 && gx1) nemar_sum_partials_two(p.part, p.part_stride, p.ksplit, gx0, gx1, N, C0, C1, H * W, st);
                 else if (p.ksplit > 1) nemar_sum_partials(p.part, p.part_stride, p.ksplit, gx0, p.part_stride, false, st);
                 p.rf = 0;
             }
@@ -1185,7 +1200,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                                        (const float*)ring_buf, gx0 ? gx0 : gx1, H, W, pad, ring_len, band, planes);
             }
         }
-    if (fold) {
+    if (fold && !folded) {
         const long long total = (long long)N * C * H * W;
         hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st,
                            (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total);
@@ -1429,6 +1444,7 @@ NEMAR_API int nemar_tune(int key, int value) {
     if (key == 32) { g_split16_ring3 = value != 0; return NEMAR_OK; }
     if (key == 33) { g_k7 = value != 0; return NEMAR_OK; }
     if (key == 36) { g_split_act = value != 0; return NEMAR_OK; }
+    if (key == 43) { g_fold_small = value != 0; return NEMAR_OK; }      // tiny stride-1 reflect data gradients: padded domain + sum-and-fold (1) / interior + ring (0)
     if (key == 37) { g_lds_claim = value; return NEMAR_OK; }      // kernel families whose workgroups claim the whole CU's LDS (common.h)
     if (key == 38) { g_wg_xreg = value != 0; return NEMAR_OK; }   // wide 3x3 weight gradient: X pieces through registers
     if (key == 39) { g_split16_ksplit_cap = value < 1 ? 1 : (value > 8 ? 8 : value); return NEMAR_OK; }      // most reduction runs per tile of the wide-layer kernel

@@ -49,7 +49,7 @@ size_t nemar_lds_bytes(const void* kernel, size_t need, bool claim) {
 #endif
 }
 
-#define NEMAR_HIP_VERSION 601  // major*10000 + minor*100 + patch  (0.6.1: nemar_set_max_words_lazy; 0.6.0: round 6 — producer-written operand planes for all three calls of the
+#define NEMAR_HIP_VERSION 602  // major*10000 + minor*100 + patch  (0.6.2: nemar_concat_pieces, nemar_add2; 0.6.1: nemar_set_max_words_lazy; 0.6.0: round 6 — producer-written operand planes for all three calls of the
                                // wide layers, fused skip-gradient add / max words in the data gradient's epilogue; 0.5.0: round 5 — no nemar_tune* in the product library: the measurement
                                // switches are constants there and live in libnemar_hip_ab.so (-DNEMAR_AB, include/nemar_hip_ab.h);
                                // 0.4.0: side inputs per call only, weight-pack plans, nemar_store_words, 7x7 layers on the 16-bit pipe)

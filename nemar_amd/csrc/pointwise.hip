@@ -325,6 +325,80 @@ NEMAR_API int nemar_act_bwd(const float* gy, const float* y, float* gx, long lon
     return NEMAR_OK;
 }
 
+// ---- batch concatenation / gradient of batch slices, and the sum of two gradients (ABI 602) ----------------------------------------
+// The batched passes of the model (T on [real_A ; R(real_A)], D on [real ; fake ; fake]: reference models/nemar_model.py:161-206 evaluates
+// them as separate calls) concatenate along the batch and slice the result; autograd's own cat / zero-fill + copy + add kernels for that
+// are the only ATen arithmetic a step would launch — and ATen's elementwise kernels use the packed-FP32 instruction forms this library is
+// built without.  dst = [piece 0 | piece 1 | ...]; a NULL piece contributes zeros (a slice no loss term reads).
+namespace {
+constexpr int CONCAT_MAX = 8;
+struct ConcatArgs { const float* src[CONCAT_MAX]; long long end[CONCAT_MAX]; int k; };
+template <bool VEC>
+__global__ __launch_bounds__(256) void concat_pieces_kernel(ConcatArgs a, float* __restrict__ dst, long long total) {
+    const long long units = VEC ? (total >> 2) : total;
+    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+        const long long idx = VEC ? (u << 2) : u;
+        int j = 0;
+        long long beg = 0;
+#pragma unroll
+        for (int i = 0; i < CONCAT_MAX - 1; ++i)
+            if (i + 1 < a.k && idx >= a.end[i]) { j = i + 1; beg = a.end[i]; }
+        // (no dynamically indexed private array: select the pointer with a chain of compares)
+        const float* s = a.src[0];
+#pragma unroll
+        for (int i = 1; i < CONCAT_MAX; ++i)
+            if (j == i) s = a.src[i];
+        if (VEC) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s) v = *reinterpret_cast<const float4*>(s + (idx - beg));
+            *reinterpret_cast<float4*>(dst + idx) = v;
+        } else {
+            dst[idx] = s ? s[idx - beg] : 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void add2_kernel(const float* a, const float* b, float* out, long long n) {      // (out may alias a or b: same element)
+    const long long n4 = n >> 2;
+    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < n4; u += (long long)gridDim.x * 256) {
+        const float4 x = reinterpret_cast<const float4*>(a)[u], y = reinterpret_cast<const float4*>(b)[u];
+        reinterpret_cast<float4*>(out)[u] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+}  // namespace
+
+NEMAR_API int nemar_concat_pieces(const float* const* pieces, const long long* counts, int k, float* dst, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(pieces && counts && dst && k >= 1 && k <= CONCAT_MAX, "concat_pieces: 1..8 pieces");
+    ConcatArgs a;
+    long long total = 0;
+    bool vec = ((uintptr_t)dst & 15) == 0;
+    for (int i = 0; i < CONCAT_MAX; ++i) {
+        a.src[i] = i < k ? pieces[i] : nullptr;
+        if (i < k) {
+            NEMAR_REQUIRE(counts[i] > 0, "concat_pieces: empty piece");
+            vec = vec && (counts[i] & 3) == 0 && ((uintptr_t)pieces[i] & 15) == 0;
+            total += counts[i];
+        }
+        a.end[i] = total;
+    }
+    a.k = k;
+    const long long units = vec ? total / 4 : total;
+    if (vec) hipLaunchKernelGGL((concat_pieces_kernel<true>), dim3(nemar_stream_grid(units, 256)), dim3(256), 0, (hipStream_t)stream, a, dst, total);
+    else hipLaunchKernelGGL((concat_pieces_kernel<false>), dim3(nemar_stream_grid(units, 256)), dim3(256), 0, (hipStream_t)stream, a, dst, total);
+    NEMAR_CHECK_LAUNCH("concat_pieces");
+    return NEMAR_OK;
+}
+
+NEMAR_API int nemar_add2(const float* a, const float* b, float* out, long long n, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(a && b && out && n > 0, "add2: bad arguments");
+    NEMAR_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "add2: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(add2_kernel, dim3(nemar_stream_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    NEMAR_CHECK_LAUNCH("add2");
+    return NEMAR_OK;
+}
+
 NEMAR_API int nemar_act_fwd(const float* x, float* y, long long n, int act, float slope, void* stream) {
     NEMAR_CLEAR_HIP_ERROR();
     NEMAR_REQUIRE(x && y && n > 0, "act_fwd: bad arguments");

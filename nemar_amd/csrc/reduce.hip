@@ -97,7 +97,57 @@ __global__ __launch_bounds__(256) void sum_partials_two_kernel(const float* __re
     }
 }
 
+// Second stage of a reduction-split stride-1 REFLECT data gradient computed on the padded domain (conv.hip fold_small): the slabs hold
+// [planes][H + 2 pad][W + 2 pad]; gx[plane][h][w] = the slab sums (ascending slab order, ((0 + s0) + s1) + ...) of every padded position that
+// mirrors onto (h, w), added in reflect_fold_kernel's order (rows: own, upper mirror, lower mirror; within a row: own, left, right).  Up to
+// 16 slabs of a position are in flight at once (a serial chain of dependent loads would cost a cache miss per slab).
+__global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __restrict__ part, long long stride, int splits, float* __restrict__ gx,
+                                                                int H, int W, int pad, long long total) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int w = (int)(idx % W);
+        const long long t = idx / W;
+        const int h = (int)(t % H);
+        const long long nc = t / H;
+        const float* q = part + nc * (long long)Hp * Wp;
+        const int y0 = h + pad, x0 = w + pad;
+        const int y1 = (h >= 1 && h <= pad) ? pad - h : -1, y2 = (h <= H - 2 && h >= H - 1 - pad) ? 2 * (H - 1) - h + pad : -1;
+        const int x1 = (w >= 1 && w <= pad) ? pad - w : -1, x2 = (w <= W - 2 && w >= W - 1 - pad) ? 2 * (W - 1) - w + pad : -1;
+        auto at = [&](int y, int x) {
+            const float* r = q + (long long)y * Wp + x;
+            float acc = 0.f;
+            for (int s0 = 0; s0 < splits; s0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) v[s] = r[(long long)(s0 + s < splits ? s0 + s : 0) * stride];      // unconditional loads
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    if (s0 + s < splits) acc += v[s];
+            }
+            return acc;
+        };
+        auto rowsum = [&](int y) {
+            float v = at(y, x0);
+            if (x1 >= 0) v += at(y, x1);
+            if (x2 >= 0) v += at(y, x2);
+            return v;
+        };
+        float sum = rowsum(y0);
+        if (y1 >= 0) sum += rowsum(y1);
+        if (y2 >= 0) sum += rowsum(y2);
+        gx[idx] = sum;
+    }
+}
+
 }  // namespace
+
+void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad, hipStream_t st) {
+    const long long total = planes * H * W;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sum_partials_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, gx, H, W, pad, total);
+}
 
 void nemar_sum_partials_two(const float* part, long long stride, int splits, float* d0, float* d1, int N, int C0, int C1, int HW, hipStream_t st) {
     const long long total = (long long)N * (C0 + C1) * HW;

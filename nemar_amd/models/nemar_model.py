@@ -195,13 +195,15 @@ class NEMARModel(BaseModel):
             # [T(a) ; T(R(a))].  Every T layer then launches once on 2x the pixels (full second round of workgroups,
             # one weight-gradient reduction instead of two).
             n = self.real_A.size(0)
-            field = self.netR.predict(self.real_A, self.real_B)
-            self.registered_real_A = self.netR.warp(field, [self.real_A])[0]
+            # (the field has three consumers — two warps and the regulariser —, the batch of T two sources and two slices: the library's own
+            # nodes for fan-out, concatenation and slicing, ops.fork / cat_batch / split_batch, instead of autograd's ATen kernels)
+            (f_a, f_b), f_reg = self.netR.fork_field(self.netR.predict(self.real_A, self.real_B), 2)
+            self.registered_real_A = self.netR.warp(f_a, [self.real_A])[0]
             # (only the second half is differentiated: the stem's data gradient runs on it alone)
-            both = self.netT(ops.grad_from(torch.cat([self.real_A, self.registered_real_A], 0), n))
-            self.fake_B, self.fake_TR_B = both[:n], both[n:]
-            self.fake_RT_B = self.netR.warp(field, [self.fake_B])[0]
-            self.stn_reg_term = self.netR.regularization(field, self.registered_real_A)
+            both = self.netT(ops.grad_from(ops.cat_batch([self.real_A, self.registered_real_A]), n))
+            self.fake_B, self.fake_TR_B = ops.split_batch(both, 2)
+            self.fake_RT_B = self.netR.warp(f_b, [self.fake_B])[0]
+            self.stn_reg_term = self.netR.regularization(f_reg, self.registered_real_A)
         self._resized = {}
         if self.tb_visualizer is not None:
             # the reference runs netR a second time here (get_grid, :172-173); the field of the pass above is the same tensor
@@ -224,15 +226,18 @@ class NEMARModel(BaseModel):
         images as one batch (no cross-sample op in D), the loss terms are taken on the per-image slices."""
         k, n = len(specs), self.real_A.size(0)
         imgs = [(im.detach() if det else im) for (im, _, _, _, det) in specs]
-        a_rep = torch.cat([self.real_A] * k, 0)
-        out = self.netD(a_rep, torch.cat(imgs, 0))
-        terms = [[self.criterionGAN(out[i * n:(i + 1) * n], tr, w)] for i, (_, _, tr, w, _) in enumerate(specs)]
+        # an image every discriminator reads: one handle per reader (ops.fork: the readers' gradients are added by the library's kernel)
+        readers = 1 + len(self.netD_multiresolution)
+        handles = [ops.fork(im, readers) for im in imgs]
+        a_rep = ops.cat_batch([self.real_A] * k)
+        out = ops.split_batch(self.netD(a_rep, ops.cat_batch([h[0] for h in handles])), k)
+        terms = [[self.criterionGAN(out[i], tr, w)] for i, (_, _, tr, w, _) in enumerate(specs)]
         for lvl, netD_S in enumerate(self.netD_multiresolution):
             a_r = self._half('real_A', self.real_A, lvl + 1)
-            img_r = [self._half(name, im, lvl + 1) for im, (_, name, _, _, det) in zip(imgs, specs)]
-            out = netD_S(torch.cat([a_r] * k, 0), torch.cat(img_r, 0))
+            img_r = [self._half(name, h[lvl + 1], lvl + 1) for h, (_, name, _, _, det) in zip(handles, specs)]
+            out = ops.split_batch(netD_S(ops.cat_batch([a_r] * k), ops.cat_batch(img_r)), k)
             for i, (_, _, tr, w, _) in enumerate(specs):
-                terms[i].append(self.criterionGAN(out[i * n:(i + 1) * n], tr, w))
+                terms[i].append(self.criterionGAN(out[i], tr, w))
         return terms
 
     def _d_terms(self, image, image_name, target_is_real, weight, detach):
@@ -268,14 +273,17 @@ class NEMARModel(BaseModel):
     # ---- translation + registration step ----------------------------------------------------------------------
     def backward_T_and_R(self):
         opt = self.opt
-        l1_tr = self.criterionL1(self.fake_TR_B, self.real_B, opt.lambda_recon)
-        l1_rt = self.criterionL1(self.fake_RT_B, self.real_B, opt.lambda_recon)
+        # each generated image is read by its L1 term and by the discriminators: two handles (ops.fork)
+        tr_l1, tr_d = ops.fork(self.fake_TR_B, 2)
+        rt_l1, rt_d = ops.fork(self.fake_RT_B, 2)
+        l1_tr = self.criterionL1(tr_l1, self.real_B, opt.lambda_recon)
+        l1_rt = self.criterionL1(rt_l1, self.real_B, opt.lambda_recon)
         if self._batched:
-            gan_tr, gan_rt = self._d_terms_batched([(self.fake_TR_B, None, True, opt.lambda_GAN, False),
-                                                    (self.fake_RT_B, None, True, opt.lambda_GAN, False)])
+            gan_tr, gan_rt = self._d_terms_batched([(tr_d, None, True, opt.lambda_GAN, False),
+                                                    (rt_d, None, True, opt.lambda_GAN, False)])
         else:
-            gan_tr = self._d_terms(self.fake_TR_B, None, True, opt.lambda_GAN, detach=False)
-            gan_rt = self._d_terms(self.fake_RT_B, None, True, opt.lambda_GAN, detach=False)
+            gan_tr = self._d_terms(tr_d, None, True, opt.lambda_GAN, detach=False)
+            gan_rt = self._d_terms(rt_d, None, True, opt.lambda_GAN, detach=False)
         self.loss_L1_TR = _LazyLoss([(l1_tr, 1.0)])
         self.loss_GAN_TR = _LazyLoss([(t, 1.0) for t in gan_tr])
         self.loss_L1_RT = _LazyLoss([(l1_rt, 1.0)])

@@ -77,13 +77,18 @@ class AffineSTN(nn.Module):
     def warp(self, field, imgs):
         return ops.warp_affine(field, list(imgs))
 
+    def fork_field(self, field, n_warps):
+        """-> ([one theta handle per warp() call], the handle for regularization()) — ops.fork, as UnetSTN.fork_field"""
+        hs = ops.fork(field, n_warps + 1)
+        return list(hs[:n_warps]), hs[n_warps]
+
     def regularization(self, field, warped_first=None):
         return self._calculate_regularization_term(field)
 
     def forward(self, img_a, img_b, apply_on=None):
-        field = self.predict(img_a, img_b)
-        warped = self.warp(field, [img_a] if apply_on is None else apply_on)
-        return warped, self.regularization(field, warped[0])
+        (f_warp,), f_reg = self.fork_field(self.predict(img_a, img_b), 1)
+        warped = self.warp(f_warp, [img_a] if apply_on is None else apply_on)
+        return warped, self.regularization(f_reg, warped[0])
 
     def _calculate_regularization_term(self, theta):
         """mean|dtheta| (reference :136-138)."""

@@ -128,5 +128,7 @@ class DownBlock(nn.Module):
         if self.conv_1 is not None:
             x = skip = self.conv_1(x)
         if self.pool:
+            if self.skip:
+                x, skip = ops.fork(x, 2)         # two consumers (the pooling and the decoder): the library adds their gradients
             x = ops.max_pool2(x)
         return (x, skip) if self.skip else x

@@ -134,14 +134,24 @@ class UnetSTN(nn.Module):
     def warp(self, field, imgs):
         return ops.warp_unet(field[1], list(imgs))
 
+    def fork_field(self, field, n_warps):
+        """-> ([one field per warp() call], the field for regularization()): handles of the same tensors (ops.fork), so that the
+        consumers' gradients are added by the library's kernel instead of autograd's accumulation."""
+        d, d_up = field
+        if d_up is d:
+            hs = ops.fork(d, n_warps + 1)
+            return [(h, h) for h in hs[:n_warps]], (hs[n_warps], hs[n_warps])
+        ups = ops.fork(d_up, n_warps)
+        return [(d, u) for u in ups], (d, d_up)
+
     def regularization(self, field, warped_first):
         return self._calculate_regularization_term(field[0], warped_first)
 
     def forward(self, img_a, img_b, apply_on=None):
         """-> (list of warped tensors in `apply_on` order (default [img_a]), regularisation term)."""
-        field = self.predict(img_a, img_b)
-        warped = self.warp(field, [img_a] if apply_on is None else apply_on)
-        return warped, self.regularization(field, warped[0])
+        (f_warp,), f_reg = self.fork_field(self.predict(img_a, img_b), 1)
+        warped = self.warp(f_warp, [img_a] if apply_on is None else apply_on)
+        return warped, self.regularization(f_reg, warped[0])
 
     def _calculate_regularization_term(self, deformation, img):
         """sum_i 2^-i * smoothness(resize(d, /2^i), resize(img.detach(), /2^i), alpha) — reference :179-201."""

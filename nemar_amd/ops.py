@@ -656,7 +656,7 @@ class _Conv2d(Function):
             if 0 < n0 < N:
                 # only samples [n0:] of the input are differentiated (ops.grad_from: T's batch [real_A ; R(real_A)]): the data
                 # gradient of the others is never read — run the kernel on the sub-batch
-                gx[:n0].zero_()
+                _zero(gx[:n0])
                 Nd, gd, gxd = N - n0, g[n0:], gx[n0:]
             else:
                 Nd, gd, gxd = N, g, gx
@@ -1299,6 +1299,133 @@ def dropout(x, p=0.5, training=True):
     return _Dropout.apply(x, float(p))
 
 
+# ---- batch concatenation / batch slices / fan-out of a tensor, with the library's own kernels in BOTH directions ----------------------
+# The batched passes (T on [real_A ; R(real_A)], D on [real ; fakes]) concatenate along the batch and slice the result; tensors with two
+# consumers (a ResnetBlock's input, a U-Net skip, a generated image read by a loss and by D, the deformation field) have their gradients
+# added.  Left to autograd these are ATen kernels — cat, zero-fill + copy + add_ per slice, add per fan-out: 49 launches per step of the
+# bench configuration (tools/aten_on_path.py), the only arithmetic on the path that is not this library's, and built WITH the packed-FP32
+# instruction forms that miscompute beside another kernel's MFMAs.  As autograd nodes of their own they run
+# nemar_concat_pieces / nemar_add2 instead, and a slice no loss reads costs nothing (no zero-filled gradient is materialised).
+_TAGS = ('_nemar_absmax', '_nemar_absmax_lazy', '_nemar_planes', '_nemar_xplanes', '_nemar_grad_from')
+_own_nodes = os.environ.get("NEMAR_OWN_NODES", "1") != "0"       # 0: autograd's own cat / slices / accumulation (A/B of the schedule only)
+
+
+def _zero(t):
+    """t[...] = 0 for a contiguous fp32 tensor, by the library's kernel (a NULL piece of nemar_concat_pieces)"""
+    if t.numel():
+        _concat_launch([None], [t.numel()], t)
+    return t
+
+
+def _concat_launch(pieces, counts, dst):
+    k = len(pieces)
+    ptrs = (ctypes.c_void_p * k)(*[None if t is None else t.data_ptr() for t in pieces])
+    cnts = (ctypes.c_longlong * k)(*counts)
+    L.concat_pieces(ptrs, cnts, k, _p(dst), _stream())
+
+
+class _CatBatch(Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [_c(t) for t in ts]
+        ctx.sizes = [t.shape[0] for t in ts]
+        out = torch.empty((sum(ctx.sizes),) + tuple(ts[0].shape[1:]), dtype=torch.float32, device=ts[0].device)
+        _concat_launch(ts, [t.numel() for t in ts], out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g)
+        out, o = [], 0
+        for i, n in enumerate(ctx.sizes):
+            out.append(g[o:o + n] if ctx.needs_input_grad[i] else None)       # (views: contiguous pieces of the batch)
+            o += n
+        return tuple(out)
+
+
+def cat_batch(tensors):
+    """torch.cat(tensors, 0) of contiguous fp32 tensors of one trailing shape"""
+    tensors = list(tensors)
+    if len(tensors) == 1:
+        return tensors[0]
+    if not _own_nodes:
+        return torch.cat(tensors, 0)
+    if len(tensors) > 8:
+        return cat_batch([cat_batch(tensors[:8])] + tensors[8:])
+    return _CatBatch.apply(*tensors)
+
+
+class _SplitBatch(Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        n = x.shape[0] // k
+        ctx.k, ctx.n, ctx.shape = k, n, tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(x[i * n:(i + 1) * n] for i in range(k))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        gs = [_c(g) for g in gs]
+        ref = next(g for g in gs if g is not None)
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=ref.device)
+        per = ref.numel()
+        _concat_launch(gs, [per] * ctx.k, out)
+        return out, None
+
+
+def split_batch(x, k):
+    """(x[0:n], x[n:2n], ...) for k equal pieces of the batch; the backward pass assembles the pieces' gradients in one launch"""
+    if k == 1:
+        return (x,)
+    if x.shape[0] % k or k > 8:
+        raise ValueError("split_batch: %d pieces of a batch of %d" % (k, x.shape[0]))
+    if not _own_nodes:
+        n = x.shape[0] // k
+        return tuple(x[i * n:(i + 1) * n] for i in range(k))
+    return _SplitBatch.apply(_c(x), int(k))
+
+
+class _Fork(Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        acc = None
+        for g in gs:
+            if g is None:
+                continue
+            g = _c(g)
+            if acc is None:
+                acc = g
+            else:
+                out = torch.empty_like(acc)
+                L.add2(_p(acc), _p(g), _p(out), acc.numel(), _stream())
+                acc = out
+        return acc, None
+
+
+def fork(x, n=2):
+    """n handles of one tensor for n consumers: the consumers' gradients are added by nemar_add2 (in consumer order) instead of
+    autograd's accumulation.  The handles keep the producer's side information (maximum words, operand planes)."""
+    if not (_own_nodes and torch.is_grad_enabled() and x.requires_grad) or n < 2:
+        return (x,) * n
+    outs = _Fork.apply(x, int(n))
+    for name in _TAGS:
+        v = getattr(x, name, None)
+        if v is not None:
+            for o in outs:
+                setattr(o, name, v)
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------------
 _ggs_alloc = torch.empty_like      # (a seam for tools/diag_lost_stores.py: where the grid gradient's buffer comes from)
 
@@ -1511,7 +1638,10 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False):
         join_side()                    # (a weight-gradient branch of an earlier pass must not land after the fill)
-        self.flat_g.zero_()
+        if self.flat_g.is_cuda:
+            _zero(self.flat_g)
+        else:
+            self.flat_g.zero_()        # (host-resident buffers: the gloo tests of the gradient all-reduce; no kernel runs on them)
 
     def step(self):
         join_side()                    # every gradient contribution issued on the side stream is behind the compute stream from here

@@ -1215,6 +1215,32 @@ def case_pointwise(be, seed=0):
         _assert_close(be.np(d_gx), want_g, atol=5e-6, what="bilinear_bwd %s" % ((H, W, Ho, Wo),))
 
 
+def case_concat_and_add(be, seed=0):
+    """nemar_concat_pieces (batch concatenation / the gradient of batch slices, a NULL piece = zeros; 16-byte and scalar forms) and
+    nemar_add2 (the sum of two consumers' gradients; aliasing the output) against numpy — bit for bit: copies and one fp32 add."""
+    import ctypes
+    rng = np.random.default_rng(seed)
+    for counts, null in (((7200, 7200, 7200), None), ((7200, 7200, 7200), 1), ((1027, 5, 4096), None), ((48,), None), ((1030,), 0),
+                         ((64, 64, 64, 64, 64, 64, 64, 64), 7), ((3, 1), 0)):
+        pieces = [rng.standard_normal(c).astype(np.float32) for c in counts]
+        devs = [None if i == null else be.dev(q) for i, q in enumerate(pieces)]
+        want = np.concatenate([np.zeros(c, np.float32) if i == null else q for i, (q, c) in enumerate(zip(pieces, counts))])
+        d_out = be.full((sum(counts),), np.nan)
+        ptrs = (ctypes.c_void_p * len(counts))(*[None if d is None else be.ptr(d).value for d in devs])
+        cnts = (ctypes.c_longlong * len(counts))(*counts)
+        be.lib.concat_pieces(ptrs, cnts, len(counts), be.ptr(d_out), be.stream)
+        got = be.np(d_out)
+        assert got.shape == want.shape and (got == want.astype(np.float64)).all(), "concat_pieces %r null=%r" % (counts, null)
+    for n in (4, 48, 1027, 65536 + 3):
+        a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        want = (a + b).astype(np.float64)
+        d_a, d_b, d_o = be.dev(a.copy()), be.dev(b), be.full((n,), np.nan)
+        be.lib.add2(be.ptr(d_a), be.ptr(d_b), be.ptr(d_o), n, be.stream)
+        assert (be.np(d_o) == want).all(), "add2 n=%d" % n
+        be.lib.add2(be.ptr(d_a), be.ptr(d_b), be.ptr(d_a), n, be.stream)          # in place
+        assert (be.np(d_a) == want).all(), "add2 in place n=%d" % n
+
+
 def case_dropout(be, n=40003, p=0.5):
     x = np.ones(n, dtype=np.float32) * 3
     d_x = be.dev(x)

@@ -218,17 +218,29 @@ def test_conv_ws2_vector_loads(be, mt):
 
 def test_conv_fwd_split_reduction(be):
     """Tiny, deep forward layers (the registration net's 2x2 .. 8x8 maps) split their reduction over grid.z: per-split slabs
-    behind the packed weights, summed in split order (bias in slab 0); with nemar_tune(36, 1) a fused ReLU / LeakyReLU is applied by the sum pass."""
+    behind the packed weights, summed in split order (bias in slab 0); a fused ReLU / LeakyReLU is applied by the sum pass (nemar_tune(36, 0):
+    such layers are not split)."""
     K.case_conv_fwd(be, 1, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT, act=K.O.ACT_NONE)    # STN bottleneck layer, 72 stages
     K.case_conv_fwd(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_NONE, bias=False)
-    K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)        # decoder conv with activation: not split by default
-    be.lib.tune(36, 1)                                                                       # ... split + activation in the sum pass
+    K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)        # decoder conv: split + activation in the sum pass
+    K.case_conv_fwd(be, 1, 64, 0, 8, 8, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_RELU)
+    be.lib.tune(36, 0)                                                                       # ... the unsplit form of the same layers
     try:
         K.case_conv_fwd(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_LRELU)
         K.case_conv_fwd(be, 1, 64, 0, 8, 8, 64, 3, 1, 1, K.PAD_ZERO, act=K.O.ACT_RELU)
     finally:
-        be.lib.tune(36, 0)
-    K.case_conv_bwd_data(be, 2, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT)                  # main pass split + ring split
+        be.lib.tune(36, 1)
+    # tiny stride-1 reflect data gradients: ONE split launch over the padded domain, the sum pass folds the mirrored border (fold_small) ...
+    K.case_conv_bwd_data(be, 2, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT)                  # 2x2: every texel is a border texel
+    K.case_conv_bwd_data(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_REFLECT, seed=1)
+    K.case_conv_bwd_data(be, 1, 64, 0, 6, 10, 64, 3, 1, 1, K.PAD_REFLECT, seed=2)           # non-square
+    K.case_conv_bwd_data(be, 1, 40, 0, 16, 16, 72, 3, 1, 1, K.PAD_REFLECT, seed=3)          # ragged channel tiles
+    be.lib.tune(43, 0)                                                                       # ... and the interior + ring form of the same layers
+    try:
+        K.case_conv_bwd_data(be, 2, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT)              # main pass split + ring split
+        K.case_conv_bwd_data(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_REFLECT, seed=1)
+    finally:
+        be.lib.tune(43, 1)
     K.case_conv_bwd_data(be, 2, 64, 64, 4, 4, 64, 3, 1, 1, K.PAD_ZERO)                      # two destinations: the sum pass parts the rows
 
 
@@ -316,6 +328,10 @@ def test_instnorm(be, H, W, act):
 
 def test_pointwise(be):
     K.case_pointwise(be)
+
+
+def test_concat_pieces_and_add2(be):
+    K.case_concat_and_add(be)
 
 
 def test_crop_flip_normalize(be):
