@@ -142,7 +142,8 @@ int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, int C1, co
  *   addend                      bwd_data only: a tensor of gx0's shape ADDED to the data gradient in the kernel's epilogue (the
  *                               ResnetBlock skip gradient, reference models/networks.py:443-446: out = x + conv_block(x))
  *   out_max_words               bwd_data only: a NEMAR_MAX_WORDS(N) buffer; the epilogue publishes the per-sample max |gx0| (words 0..N-1)
- *                               Both only where nemar_conv2d_bwd_data_fusable(...) says 1 — elsewhere the call fails with NEMAR_EINVAL.
+ *                               Both only where nemar_conv2d_bwd_data_fusable(...) says 1 (the addend alone: where
+ *                               nemar_conv2d_bwd_data_addend_ok(...) says 1) — elsewhere the call fails with NEMAR_EINVAL.
  * A packed-weight workspace (prepacked = 1) must be reused under the same route conditions it was written under (arena present or
  * not, nemar_config_epoch unchanged). */
 typedef struct nemar_conv_extras {
@@ -161,6 +162,9 @@ typedef struct nemar_conv_extras {
 } nemar_conv_extras;
 /* 1: the layer's bwd_data_ex honours addend / out_max_words and takes src_planes, and its bwd_weight_ex takes both operands as planes */
 int nemar_conv2d_bwd_data_fusable(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode);
+/* (ABI 602) 1: the layer's bwd_data_ex (one destination, no bias, no activation) adds extras.addend to gx0 — the wide route's epilogue, or
+ * the fold pass that ends the data gradient of a small stride-1 reflect layer (out_max_words is NOT honoured there: only where _fusable says 1) */
+int nemar_conv2d_bwd_data_addend_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode);
 /* bytes of the pixel-major X planes nemar_instnorm_fwd_planes can write for the weight gradient of a KS x KS / pad-1 reflect layer (0: none) */
 size_t nemar_conv2d_x_planes_bytes(int N, int C, int H, int W, int KS);
 /* bytes of the gy planes a bwd_data call can leave behind for the bwd_weight call of the same layer (0: this layer does not take them) */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "nemar_instnorm_bwd_max": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _i, _vp]),
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),
+    "nemar_conv2d_bwd_data_addend_ok": (_i, [_i] * 10),
     "nemar_concat_pieces": (_i, [_vp, _vp, _i, _vp, _vp]),
     "nemar_add2": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "nemar_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -166,7 +167,7 @@ class Library:
                                     "(libnemar_hip_ab.so; set NEMAR_AB_LIBRARY=1 before nemar_amd is imported)" % (self.__dict__.get("path"), full))
             raise AttributeError(name)
         fn = fns[full]
-        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_set_max_words_lazy", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty", "nemar_conv2d_bwd_data_fusable"):
+        if {**SIGNATURES, **AB_SIGNATURES}[full][0] is not _i or full in ("nemar_version", "nemar_last_route", "nemar_last_gy_planes", "nemar_config_epoch", "nemar_set_max_words_lazy", "nemar_pack_plan_jobs", "nemar_pack_plan_dirty", "nemar_conv2d_bwd_data_fusable", "nemar_conv2d_bwd_data_addend_ok"):
             return fn
 
         if os.environ.get("NEMAR_DEBUG_SYNC"):

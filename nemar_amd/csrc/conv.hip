@@ -48,7 +48,7 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
                          int target_blocks, bool vec_ok, int dbg, float* part, hipStream_t st);
 // reduce.hip: dst (+)= sum of `splits` slabs in split order (the deterministic second stage of every split reduction)
 void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
-                             hipStream_t st);
+                             const float* addend, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st);
 
@@ -85,6 +85,7 @@ static thread_local const void* t_x_wplanes = nullptr;        // bwd_weight_ex: 
 static thread_local const float* t_addend = nullptr;          // bwd_data_ex: tensor added to gx0 in the epilogue (extras.addend)
 static thread_local void* t_out_max = nullptr;                // bwd_data_ex: per-sample max |gx0| words (extras.out_max_words)
 static thread_local int t_fused_epilogue = 0;                 // did the last bwd_data_ex call honour them?
+static thread_local int t_addend_done = 0;                    // ... or at least the addend (the fold pass of a small reflect layer: nemar_conv2d_bwd_data_addend_ok)
 static NEMAR_SWITCH(int, g_split_act, 1);          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
 static NEMAR_SWITCH(int, g_fold_small, 1);         // key 43: stride-1 reflect data gradients of tiny maps on the exact route: padded domain + sum-and-fold pass
 static NEMAR_SWITCH(int, g_dual_gy, 1);            // key 35: the data-gradient call's split pass also writes the weight gradient's gy planes
@@ -440,8 +441,9 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 }
 
 // gx[n,c,h,w] = sum of the padded-domain gradient gp over every padded position that mirrors onto (h,w)
+// (+ addend[n,c,h,w] where given: the skip gradient of a ResnetBlock rides in the pass that writes the data gradient of its first convolution)
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ gp, float* __restrict__ gx, int H,
-                                                           int W, int pad, long long total) {
+                                                           int W, int pad, long long total, const float* __restrict__ addend) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         float s = rowsum(y0);
         if (y1 >= 0) s += rowsum(y1);
         if (y2 >= 0) s += rowsum(y2);
-        gx[idx] = s;
+        gx[idx] = addend ? s + addend[idx] : s;
     }
 }
 
@@ -1020,7 +1022,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             nemar_k7_fm_conv(gy, K, OH, OW, 6, 0, workspace, nullptr, padded, C, N, H + 6, W + 6, ACT_NONE, 0.f, 0, st);
             const long long total = (long long)N * C * H * W;
             hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded, gx0, H, W, pad,
-                               total);
+                               total, (const float*)nullptr);
         } else {
             nemar_k7_fm_conv(gy, K, OH, OW, 3, 0, workspace, nullptr, gx0, C, N, H, W, ACT_NONE, 0.f, 0, st);
         }
@@ -1077,7 +1079,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             nemar_s16g_conv(q, pl, workspace, st);
             const long long total = (long long)N * C * H * W;
             hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded16, gx0, H,
-                               W, pad, total);
+                               W, pad, total, t_addend);
+            if (t_addend) t_addend_done = 1;
             g_last_route = 3;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (16-bit pipe on the padded domain + fold)");
             return NEMAR_OK;
@@ -1166,7 +1169,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 }
                 launch_igemm(p, st);
                 if (p.ksplit > 1 && fold) {                       // slabs of the padded domain -> sum + fold in one pass (gx1 == nullptr: checked above)
-                    nemar_sum_partials_fold(p.part, p.part_stride, p.ksplit, gx0, (long long)N * C, H, W, pad, st);
+                    nemar_sum_partials_fold(p.part, p.part_stride, p.ksplit, gx0, (long long)N * C, H, W, pad, t_addend, st);
+                    if (t_addend) t_addend_done = 1;
                     folded = true;
                 }
                 else if (p.ksplit > 1 && gx1) nemar_sum_partials_two(p.part, p.part_stride, p.ksplit, gx0, gx1, N, C0, C1, H * W, st);
@@ -1202,8 +1206,10 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         }
     if (fold && !folded) {
         const long long total = (long long)N * C * H * W;
+        const float* const add = (gx0 && !gx1) ? t_addend : nullptr;
         hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st,
-                           (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total);
+                           (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total, add);
+        if (add) t_addend_done = 1;
     }
     g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_bwd_data");
@@ -1518,6 +1524,20 @@ NEMAR_API int nemar_conv2d_bwd_data_fusable(int N, int C, int H, int W, int K, i
     return nemar_split16_ksplit(N, H, W, C, K) == 1 ? 1 : 0;
 }
 
+// 1 when nemar_conv2d_bwd_data_ex of this layer (one destination, no bias, no activation) adds nemar_conv_extras.addend to the data gradient:
+// the wide route's fused epilogue, or a stride-1 reflect layer whose data gradient ends with a fold pass (the general 16-bit-pipe kernel
+// on the padded domain + fold; the tiny maps' split launch + sum-and-fold) — the addend is one more term of that pass.
+NEMAR_API size_t nemar_conv2d_scratch(int N, int H, int W, int K, int C, int R, int S, int stride, int pad);
+NEMAR_API int nemar_conv2d_bwd_data_addend_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
+    if (nemar_conv2d_bwd_data_fusable(N, C, H, W, K, R, S, stride, pad, pad_mode)) return 1;
+    if (pad_mode != BORDER_REFLECT || pad <= 0 || stride != 1 || pad >= H || pad >= W || R != S) return 0;
+    if (nemar_conv2d_scratch(N, H, W, K, C, R, S, stride, pad) > 0) return 0;      // a layer the wide route takes when its arena is given
+    if (R == 7) return 0;                                                            // (the 7x7 kernels have their own borders)
+    const DgradLayout L = dgrad_layout(N, C, H, W, K, R, S, stride, pad, pad_mode);
+    return (L.fold16 || L.fold) ? 1 : 0;
+}
+
 // 1 when the last nemar_conv2d_bwd_data_ex call on this thread filled its gy_planes_out buffer (the route it took supports it): only then
 // may the buffer be handed to nemar_conv2d_bwd_weight_ex as src2_planes
 NEMAR_API int nemar_last_gy_planes(void) { return t_gy_planes_written; }
@@ -1541,10 +1561,12 @@ NEMAR_API int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const fl
     ExtrasScope scope(extras ? &e : nullptr, gy, nullptr, N, K, OH, OW, pad_mode == BORDER_REFLECT ? SPLIT16_DGRAD_REFLECT : SPLIT16_ZERO);
     t_gy_planes_written = 0;
     t_fused_epilogue = 0;
+    t_addend_done = 0;
     const int rc = nemar_conv2d_bwd_data(gy, w, bias, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace,
                                          ws_bytes, prepacked, stream);
-    if (rc == NEMAR_OK && extras && (extras->addend || extras->out_max_words) && !t_fused_epilogue) {
-        nemar_set_error("conv2d_bwd_data_ex: this layer's route has no fused epilogue (addend / out_max_words): ask nemar_conv2d_bwd_data_fusable first");
+    if (rc == NEMAR_OK && extras && ((extras->addend && !t_fused_epilogue && !t_addend_done) || (extras->out_max_words && !t_fused_epilogue))) {
+        nemar_set_error("conv2d_bwd_data_ex: this layer's route has no fused epilogue (addend / out_max_words): ask nemar_conv2d_bwd_data_fusable / "
+                        "nemar_conv2d_bwd_data_addend_ok first");
         return NEMAR_EINVAL;
     }
     return rc;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void sum_partials_two_kernel(const float* __re
 // mirrors onto (h, w), added in reflect_fold_kernel's order (rows: own, upper mirror, lower mirror; within a row: own, left, right).  Up to
 // 16 slabs of a position are in flight at once (a serial chain of dependent loads would cost a cache miss per slab).
 __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __restrict__ part, long long stride, int splits, float* __restrict__ gx,
-                                                                int H, int W, int pad, long long total) {
+                                                                int H, int W, int pad, long long total, const float* __restrict__ addend) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int w = (int)(idx % W);
@@ -126,27 +126,38 @@ __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __r
             }
             return acc;
         };
-        auto rowsum = [&](int y) {
-            float v = at(y, x0);
-            if (x1 >= 0) v += at(y, x1);
-            if (x2 >= 0) v += at(y, x2);
-            return v;
-        };
-        float sum = rowsum(y0);
-        if (y1 >= 0) sum += rowsum(y1);
-        if (y2 >= 0) sum += rowsum(y2);
-        gx[idx] = sum;
+        float sum;
+        if ((y1 & y2 & x1 & x2) < 0) {                       // interior texel: its own padded position only
+            sum = at(y0, x0);
+        } else {
+            // border texel: all nine candidate positions are loaded UNCONDITIONALLY (absent mirrors re-read the own row / column) and the
+            // absent ones dropped afterwards — with the loads behind branches a 2x2 map walked four dependent rounds of cache misses
+            const int ya = y1 >= 0 ? y1 : y0, yb = y2 >= 0 ? y2 : y0, xa = x1 >= 0 ? x1 : x0, xb = x2 >= 0 ? x2 : x0;
+            const float a00 = at(y0, x0), a01 = at(y0, xa), a02 = at(y0, xb);
+            const float a10 = at(ya, x0), a11 = at(ya, xa), a12 = at(ya, xb);
+            const float a20 = at(yb, x0), a21 = at(yb, xa), a22 = at(yb, xb);
+            auto rowsum = [&](float v, float l, float r) {
+                if (x1 >= 0) v += l;
+                if (x2 >= 0) v += r;
+                return v;
+            };
+            sum = rowsum(a00, a01, a02);
+            if (y1 >= 0) sum += rowsum(a10, a11, a12);
+            if (y2 >= 0) sum += rowsum(a20, a21, a22);
+        }
+        gx[idx] = addend ? sum + addend[idx] : sum;          // (+ the skip gradient of the ResnetBlock this convolution opens)
     }
 }
 
 }  // namespace
 
-void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad, hipStream_t st) {
+void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
+                             const float* addend, hipStream_t st) {
     const long long total = planes * H * W;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sum_partials_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, gx, H, W, pad, total);
+    hipLaunchKernelGGL(sum_partials_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, gx, H, W, pad, total, addend);
 }
 
 void nemar_sum_partials_two(const float* part, long long stride, int splits, float* d0, float* d1, int N, int C0, int C1, int HW, hipStream_t st) {

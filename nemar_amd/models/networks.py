@@ -327,8 +327,8 @@ class ResnetBlock(nn.Module):
                                    dropout_p=0.5 if (self.use_dropout and self.training) else 0.0, feeds_block=self.feeds_block)
             if out is not None:
                 return out
-        x, x_skip = ops.fork(x, 2)               # the block's input feeds conv1 and the skip: the library adds the two gradients
-        h = ops.conv2d(x, self.c1.weight, self.c1.bias, 1, 1, self.pad_mode, act=fused_act)
+        # the block's input feeds conv1 and the skip: the skip's gradient is added in the last pass of conv1's data gradient
+        h, x_skip = ops.conv2d_with_skip(x, self.c1.weight, self.c1.bias, 1, 1, self.pad_mode, act=fused_act)
         # (norm + ReLU + Dropout in one pass; where conv2 runs on the fp16 x 3 route its operand planes come out of the same pass)
         h = _norm_act(h, self.norm, ops.ACT_RELU, planes=reflect, dropout_p=0.5 if (self.use_dropout and self.training) else 0.0)
         h = ops.conv2d(h, self.c2.weight, self.c2.bias, 1, 1, self.pad_mode)

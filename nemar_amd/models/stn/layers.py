@@ -129,6 +129,8 @@ class DownBlock(nn.Module):
             x = skip = self.conv_1(x)
         if self.pool:
             if self.skip:
-                x, skip = ops.fork(x, 2)         # two consumers (the pooling and the decoder): the library adds their gradients
-            x = ops.max_pool2(x)
+                # two consumers (the pooling and the decoder): the decoder's gradient is the addend of the pooling's backward kernel
+                x, skip = ops.max_pool2_with_skip(x)
+            else:
+                x = ops.max_pool2(x)
         return (x, skip) if self.skip else x

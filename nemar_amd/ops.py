@@ -311,7 +311,7 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
 
 def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None, addend=None, out_max=None):
     """nemar_conv_extras for one call: the side inputs of the wide-layer route, or None when there are none"""
-    if arena is None and src_max is None and src2_max is None and planes is None:
+    if arena is None and src_max is None and src2_max is None and planes is None and addend is None:
         return None
     e = _lib.ConvExtras()
     if addend is not None:
@@ -579,8 +579,11 @@ def _grad_buffer(param):
 # ------------------------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape):
+    def forward(ctx, x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape, with_skip=False):
         x, x2, w, b = _c(x), _c(x2), _c(weight), _c(bias)
+        ctx.with_skip = bool(with_skip)
+        if with_skip:
+            ctx.set_materialize_grads(False)
         if wshape is not None:
             w = w.view(wshape)          # e.g. nn.Linear's [out,in] seen as a 1x1 conv; gradients keep the param's shape
         N, C0, H, W = x.shape
@@ -614,13 +617,20 @@ class _Conv2d(Function):
         if bias is not None:
             _note_use(bias)
         ctx.cfg = (stride, pad, pad_mode, act, slope)
+        if with_skip:
+            # a second handle of the input for the caller's skip connection (ResnetBlock: out = x + conv_block(x)): its gradient comes back
+            # to THIS node and is added inside the data gradient's last pass where the route has one (nemar_conv2d_bwd_data_addend_ok)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, x2, w, y = ctx.saved_tensors
         stride, pad, pad_mode, act, slope = ctx.cfg
+        ctx.gskip = _c(gskip) if (ctx.with_skip and ctx.needs_input_grad[0]) else None
+        if gy is None:                          # (only the skip handle was used)
+            return (ctx.gskip,) + (None,) * 10
         gy = _c(gy)
         N, C0, H, W = x.shape
         C1 = 0 if x2 is None else x2.shape[1]
@@ -667,10 +677,18 @@ class _Conv2d(Function):
                 # wide layer whose weight gradient follows: the pass that splits gy for this call leaves its planes for that one too
                 gpl, gslot = _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, g.device)
             rb = K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT         # (bench.py: operator-level roofline of the residual blocks)
+            gskip = getattr(ctx, 'gskip', None)
+            # (layers the wide route never takes: their data gradient ends with a fold pass or it does not — no arena-dependent routing)
+            ride = (gskip is not None and gx is not None and gx2 is None and Nd == N and arena is None
+                    and Q.conv2d_scratch(N, H, W, K, C, R, S, stride, pad) == 0
+                    and Q.conv2d_bwd_data_addend_ok(N, C, H, W, K, R, S, stride, pad, pad_mode) == 1)
             with _record(plan), (_span('dgrad_resblock') if rb else contextlib.nullcontext()):
                 L.conv2d_bwd_data_ex(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
                                      stride, pad, pad_mode, _p(ws), wsb, hit, st,
-                                     _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax, gy_out=gpl))
+                                     _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax, gy_out=gpl,
+                                             addend=gskip if ride else None))
+            if gskip is not None and gx is not None and not ride:
+                L.add2(_p(gx), _p(gskip), _p(gx), gx.numel(), st)       # (a route without a last pass to ride in: one more launch)
             if gpl is not None and not L.last_gy_planes():
                 gpl = None
             if not need_x2:
@@ -723,7 +741,9 @@ class _Conv2d(Function):
             _main_lane_grad(gbbuf, g.device)          # (a bias the side lane has accumulated into in this pass: order behind it first)
             _bias_grad(g, gbbuf, N, K, OH * OW, st)
             grad_ready(ctx.bias)
-        return gx, gx2, None, None, None, None, None, None, None, None
+        if gx is None and getattr(ctx, 'gskip', None) is not None:
+            gx = ctx.gskip
+        return gx, gx2, None, None, None, None, None, None, None, None, None
 
 
 def _bias_grad(g, gb, N, C, HW, st):
@@ -735,6 +755,19 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NON
     """act(conv2d(pad(cat(x, x2)), weight) + bias).  pad_mode PAD_REFLECT == nn.ReflectionPad2d(pad) + conv.
     `weight` must be the leaf Parameter (its .grad is the accumulation target); `wshape` reinterprets it as 4-D."""
     return _Conv2d.apply(x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape)
+
+
+def conv2d_with_skip(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2):
+    """-> (conv2d(x, ...), a second handle of x for the caller's skip connection).  The skip's gradient returns to the convolution's node
+    and is added in the last pass of its data gradient (one launch less than a separate sum; ops.fork where autograd is off)."""
+    if not (_own_nodes and torch.is_grad_enabled() and x.requires_grad):
+        return _Conv2d.apply(x, None, weight, bias, stride, pad, pad_mode, act, slope, None), x
+    y, skip = _Conv2d.apply(x, None, weight, bias, stride, pad, pad_mode, act, slope, None, True)
+    for name in _TAGS:
+        v = getattr(x, name, None)
+        if v is not None:
+            setattr(skip, name, v)
+    return y, skip
 
 
 class _ConvTranspose2d(Function):
@@ -1190,6 +1223,43 @@ class _MaxPool2(Function):
 
 def max_pool2(x):
     return _MaxPool2.apply(x)
+
+
+class _MaxPool2Skip(Function):
+    """(MaxPool2d(2)(x), a second handle of x) — the U-Net encoder's pooled tensor and its skip connection (reference models/stn/layers.py
+    :174-185).  The skip's gradient is the `addend` of the pooling's backward kernel: gx = g_skip + unpool(gy), one launch."""
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        L.maxpool2_fwd(_p(x), _p(y), N * C, H, W, _stream())
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gskip):
+        (x,) = ctx.saved_tensors
+        if gy is None:
+            return gskip
+        gy, gskip = _c(gy), _c(gskip)
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        L.maxpool2_bwd(_p(x), _p(gy), _p(gskip), _p(gx), N * C, H, W, _stream())
+        return gx
+
+
+def max_pool2_with_skip(x):
+    if not (_own_nodes and torch.is_grad_enabled() and x.requires_grad):
+        return _MaxPool2.apply(x), x
+    y, skip = _MaxPool2Skip.apply(x)
+    for name in _TAGS:
+        v = getattr(x, name, None)
+        if v is not None:
+            setattr(skip, name, v)
+    return y, skip
 
 
 class _Bilinear(Function):

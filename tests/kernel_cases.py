@@ -154,7 +154,9 @@ def case_conv_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.ACT_NO
     _assert_close(be.np(d_y), want, atol=2e-5, rtol=2e-5, what="conv2d_fwd")
 
 
-def case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=False, seed=0):
+def case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=False, seed=0, addend=False):
+    """addend=True: nemar_conv2d_bwd_data_ex with nemar_conv_extras.addend on a layer whose data gradient ends with a fold pass
+    (nemar_conv2d_bwd_data_addend_ok must say 1): gx0 = data gradient + addend."""
     rng = np.random.default_rng(seed)
     C = C0 + C1
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
@@ -166,6 +168,19 @@ def case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=F
     d_g0 = None if (skip0 or C0 == 0) else be.full((N, C0, H, W), np.nan)
     d_g1 = be.full((N, C1, H, W), np.nan) if C1 else None
     ws, wsb = _ws(be, be.lib.conv2d_bwd_data_workspace(N, C, H, W, K, R, R, stride, pad, pad_mode))
+    if addend:
+        import ctypes
+        from nemar_amd._lib import ConvExtras
+        assert C1 == 0 and not skip0
+        assert be.lib.conv2d_bwd_data_addend_ok(N, C, H, W, K, R, R, stride, pad, pad_mode) == 1, "addend_ok"
+        add = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        d_add = be.dev(add)
+        e = ConvExtras()
+        e.addend = be.ptr(d_add).value
+        be.lib.conv2d_bwd_data_ex(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_g0), C0, None, 0, N, H, W, K, OH, OW, R, R, stride, pad,
+                                  pad_mode, be.ptr(ws), wsb, 0, be.stream, ctypes.byref(e))
+        _assert_close(be.np(d_g0), want + add, atol=2e-5, rtol=2e-5, what="conv2d_bwd_data gx0 + addend")
+        return
     be.lib.conv2d_bwd_data(be.ptr(d_gy), be.ptr(d_w), None, 0, 0.0, be.ptr(d_g0), C0, be.ptr(d_g1), C1, N, H, W, K, OH,
                            OW, R, R, stride, pad, pad_mode, be.ptr(ws), wsb, 0, be.stream)
     if d_g0 is not None:
@@ -261,9 +276,9 @@ def case_conv_s16g_fwd(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, act=O.A
         raise AssertionError("conv2d_fwd (s16g): err %.3e > %.3e at %s (got %.6g want %.6g)" % (err[i], lim[i], i, got[i], want[i]))
 
 
-def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO, mbl=None, cf=None):
+def case_conv_s16g_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, skip0=False, seed=0, pad_mode=PAD_ZERO, mbl=None, cf=None, addend=False):
     with s16g_route(be, mbl=mbl, cf=cf):
-        case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=skip0, seed=seed)
+        case_conv_bwd_data(be, N, C0, C1, H, W, K, R, stride, pad, pad_mode, skip0=skip0, seed=seed, addend=addend)
         assert be.lib.last_route() == 3, "the shape did not take the general 16-bit-pipe route"
 
 

@@ -235,6 +235,8 @@ def test_conv_fwd_split_reduction(be):
     K.case_conv_bwd_data(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_REFLECT, seed=1)
     K.case_conv_bwd_data(be, 1, 64, 0, 6, 10, 64, 3, 1, 1, K.PAD_REFLECT, seed=2)           # non-square
     K.case_conv_bwd_data(be, 1, 40, 0, 16, 16, 72, 3, 1, 1, K.PAD_REFLECT, seed=3)          # ragged channel tiles
+    K.case_conv_bwd_data(be, 2, 64, 0, 4, 4, 64, 3, 1, 1, K.PAD_REFLECT, seed=4, addend=True)   # + the skip gradient in the sum-and-fold pass
+    K.case_conv_bwd_data(be, 1, 8, 0, 6, 10, 8, 3, 1, 1, K.PAD_REFLECT, seed=5, addend=True)    # unsplit: the addend rides in the plain fold pass
     be.lib.tune(43, 0)                                                                       # ... and the interior + ring form of the same layers
     try:
         K.case_conv_bwd_data(be, 2, 128, 0, 2, 2, 128, 3, 1, 1, K.PAD_REFLECT)              # main pass split + ring split
@@ -600,6 +602,7 @@ def test_conv_s16g_reflect_data_gradient(be):
     gradient of the padded input on the general 16-bit-pipe kernel, then the fold of the mirrored border."""
     K.case_conv_s16g_bwd_data(be, 2, 32, 0, 8, 32, 32, 3, 1, 1, pad_mode=K.PAD_REFLECT)
     K.case_conv_s16g_bwd_data(be, 1, 64, 0, 6, 40, 48, 3, 1, 1, pad_mode=K.PAD_REFLECT)
+    K.case_conv_s16g_bwd_data(be, 2, 32, 0, 8, 32, 32, 3, 1, 1, pad_mode=K.PAD_REFLECT, seed=7, addend=True)      # + a skip gradient in the fold pass
 
 
 # ---- 7x7 stem / head layers on the 16-bit matrix pipe (csrc/conv_k7.hip) ----
