@@ -27,6 +27,9 @@ SHAPES = [  # name, C0, C1, K, R, stride, pad, pad_mode, H
     ("D.l2 64->128 k4s2 @128", 64, 0, 128, 4, 2, 1, 0, 128),
     ("D.l3 128->256 k4s2 @64", 128, 0, 256, 4, 2, 1, 0, 64),
     ("D.l4 256->512 k4s1 @32", 256, 0, 512, 4, 1, 1, 0, 32),
+    # (padded width a multiple of four floats: the padded-domain reflect data gradient with 16-byte-aligned rows, for comparison)
+    ("X.res 32->32 k3 refl @254", 32, 0, 32, 3, 1, 1, 1, 254),
+    ("X.res 64->64 k3 refl @126", 64, 0, 64, 3, 1, 1, 1, 126),
 ]
 
 
