@@ -159,6 +159,9 @@ typedef struct nemar_conv_extras {
     const void* src2_planes;
     const float* addend;
     void* out_max_words;
+    const float* bias_partials;   /* (ABI 602) bwd_weight only, with gb != NULL on a layer of the wide route: per-plane sums of gy [N, K]
+                                   * (nemar_instnorm_bwd_planes `bias_partials`); gb += their sum over the batch, in batch order, inside the
+                                   * launch that sums the weight gradient's slabs — instead of a nemar_bias_from_partials call of its own */
 } nemar_conv_extras;
 /* 1: the layer's bwd_data_ex honours addend / out_max_words and takes src_planes, and its bwd_weight_ex takes both operands as planes */
 int nemar_conv2d_bwd_data_fusable(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int pad_mode);

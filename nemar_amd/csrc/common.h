@@ -65,6 +65,7 @@ struct nemar_conv_extras {
     const void* src2_planes;
     const float* addend;
     void* out_max_words;
+    const float* bias_partials;
 };
 
 // thread-local so the message survives being raised on autograd's backward thread

@@ -47,6 +47,8 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
                          int target_blocks, bool vec_ok, int dbg, float* part, hipStream_t st);
 // reduce.hip: dst (+)= sum of `splits` slabs in split order (the deterministic second stage of every split reduction)
+void nemar_sum_partials_pair(const float* part_a, long long stride_a, int splits_a, float* dst_a, long long n_a,
+                             const float* part_b, long long stride_b, int splits_b, float* dst_b, long long n_b, bool accumulate, hipStream_t st);
 void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
                              const float* addend, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
@@ -85,6 +87,8 @@ static thread_local const void* t_x_wplanes = nullptr;        // bwd_weight_ex: 
 static thread_local const float* t_addend = nullptr;          // bwd_data_ex: tensor added to gx0 in the epilogue (extras.addend)
 static thread_local void* t_out_max = nullptr;                // bwd_data_ex: per-sample max |gx0| words (extras.out_max_words)
 static thread_local int t_fused_epilogue = 0;                 // did the last bwd_data_ex call honour them?
+static thread_local int t_bias_rode = 0;                       // ... and did the call reduce them (the wide route)?
+static thread_local const float* t_bias_partials = nullptr;   // bwd_weight_ex: per-plane sums of gy [N, K] (extras.bias_partials)
 static thread_local int t_addend_done = 0;                    // ... or at least the addend (the fold pass of a small reflect layer: nemar_conv2d_bwd_data_addend_ok)
 static NEMAR_SWITCH(int, g_split_act, 1);          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
 static NEMAR_SWITCH(int, g_fold_small, 1);         // key 43: stride-1 reflect data gradients of tiny maps on the exact route: padded domain + sum-and-fold pass
@@ -1360,9 +1364,11 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         nemar_split16_wgrad_eligible(N, C0, H, W, K, R, S, stride, pad) &&
         (R == 3 || pad_mode == BORDER_ZERO) && g_scratch && g_scratch_bytes >= nemar_split16_wgrad_scratch_bytes(N, C0, H, W, K, R)) {
         // wide 3x3 stride-1 layers: fp16 x 3 on the 16-bit matrix pipe (conv_split16_wgrad.hip); bias gradient as its own reduction
+        const bool bias_rides = gb && t_bias_partials;           // the producer's per-plane sums: reduced inside the slab-sum launch
+        if (bias_rides) { nemar_split16_wgrad_set_bias(t_bias_partials, gb); t_bias_rode = 1; }
         nemar_split16_wgrad(x0, gy, gw, N, C0, H, W, K, R, pad_mode == BORDER_REFLECT ? 1 : 0, g_scratch, part, g_xcd_map,
                             R == 3 ? t_src2_planes : nullptr, (R == 3 && pad_mode == BORDER_REFLECT) ? t_x_wplanes : nullptr, st);
-        if (gb) {
+        if (gb && !bias_rides) {
             const int chunks = nemar_cdiv(OH * OW, BIAS_CHUNK);
             float* pb = part + (size_t)nemar_split16_wgrad_splits(N, C0, H, W, K, R) * K * J;
             hipLaunchKernelGGL(bias_grad_kernel, dim3(K, N, chunks), dim3(256), 0, st, gy, pb, N, K, OH * OW, BIAS_CHUNK);
@@ -1413,10 +1419,7 @@ NEMAR_API int nemar_conv2d_bwd_weight(const float* x0, int C0, const float* x1, 
         hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
     else
         hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 2>), grid, block, 0, st, p);
-    if (part) {
-        nemar_sum_partials(part, (long long)K * J, splits, gw, (long long)K * J, true, st);
-        if (gb) nemar_sum_partials(p.partb, K, splits, gb, K, true, st);
-    }
+    if (part) nemar_sum_partials_pair(part, (long long)K * J, splits, gw, (long long)K * J, gb ? p.partb : nullptr, K, splits, gb, K, true, st);
     g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_bwd_weight");
     return NEMAR_OK;
@@ -1498,7 +1501,7 @@ struct ExtrasScope {
     ~ExtrasScope() {
         t_scratch = nullptr; t_scratch_bytes = 0;
         t_gy_planes_out = nullptr; t_gy_planes_bytes = 0; t_src2_planes = nullptr;
-        t_addend = nullptr; t_out_max = nullptr; t_x_wplanes = nullptr;
+        t_addend = nullptr; t_out_max = nullptr; t_x_wplanes = nullptr; t_bias_partials = nullptr;
         if (t0) nemar_split16_set_hint(t0, nullptr, 0);
         if (t1) nemar_split16_set_hint(t1, nullptr, 0);
         if (tp) nemar_split16_set_planes_hint(tp, nullptr, 0, 0, 0, 0, 0);
@@ -1580,7 +1583,14 @@ NEMAR_API int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x
     // (extras.src_planes: the weight gradient's X planes of x0 nemar_instnorm_fwd_planes wrote — pixel-major, not a channel-blocked hint)
     ExtrasScope scope(extras ? &e : nullptr, x0, gy, N, C0 + C1, H, W, -1);
     t_x_wplanes = extras ? extras->src_planes : nullptr;
-    return nemar_conv2d_bwd_weight(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes, stream);
+    t_bias_partials = extras ? extras->bias_partials : nullptr;
+    t_bias_rode = 0;
+    const int rc = nemar_conv2d_bwd_weight(x0, C0, x1, C1, gy, gw, gb, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace, ws_bytes, stream);
+    if (rc == NEMAR_OK && extras && extras->bias_partials && gb && !t_bias_rode) {
+        nemar_set_error("conv2d_bwd_weight_ex: bias_partials are only taken on the wide route (nemar_conv2d_bwd_data_fusable); gb was reduced from gy");
+        return NEMAR_EINVAL;
+    }
+    return rc;
 }
 
 // max |t| (finite elements) per sample of a tensor, for callers that feed the same tensor to several split-16 convolution calls

@@ -15,6 +15,9 @@ size_t nemar_k7_wgrad_floats(int N, int C, int H, int W, int K);          // sla
 bool nemar_k7_wgrad(const float* x, const float* gy, float* gw, float* gb, int N, int C, int H, int W, int K, int pad_mode, float* part,
                     hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st);
+void nemar_sum_partials_pair(const float* part_a, long long stride_a, int splits_a, float* dst_a, long long n_a,
+                             const float* part_b, long long stride_b, int splits_b, float* dst_b, long long n_b, bool accumulate, hipStream_t st);
+
 
 // ---- few -> many: out[n][m][y][x] = bias[m] + sum_{c, dy, dx} Wt[m][c][dy][dx] * Small[n][c][y + dy][x + dx]  (stem forward; head data
 // gradient with Wt[c][k][dy][dx] = w[k][c][6 - dy][6 - dx], Small = gy through a zero border).  M = 32 n rows, Cs <= 4.

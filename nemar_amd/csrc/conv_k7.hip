@@ -762,8 +762,7 @@ bool nemar_k7_wgrad(const float* x, const float* gy, float* gw, float* gb, int N
     else K7_WGC(true, false)
 #undef K7_WGC
 #undef K7_WG
-    nemar_sum_partials(part, stride, slabs, gw, J, true, st);
-    if (p.bias_off >= 0) nemar_sum_partials(part + J, stride, slabs, gb, K, true, st);
+    nemar_sum_partials_pair(part, stride, slabs, gw, J, p.bias_off >= 0 ? part + J : nullptr, stride, slabs, gb, K, true, st);
     return p.bias_off >= 0 || !gb;
 }
 

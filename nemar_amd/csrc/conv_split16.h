@@ -34,6 +34,10 @@ void nemar_split16_wgrad_tune(int one_copy);          // nemar_tune(34): 1 (defa
 #endif
 // g_planes != NULL: the G_0 planes of gy already exist (nemar_split16_dual_split wrote them, scaled by the max words hinted for gy)
 // x_planes != NULL: the X planes of x already exist (nemar_instnorm_fwd_planes wrote them, scaled by the max words hinted for x)
+// the NEXT nemar_split16_wgrad call on this thread also reduces gb[K] += sum over the batch of bias_partials [N, K], inside its slab-sum launch
+void nemar_split16_wgrad_set_bias(const float* bias_partials, float* gb);
+void nemar_sum_partials_pair(const float* part_a, long long stride_a, int splits_a, float* dst_a, long long n_a,
+                             const float* part_b, long long stride_b, int splits_b, float* dst_b, long long n_b, bool accumulate, hipStream_t st);
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
                          void* scratch, float* part, int xcd_map, const void* g_planes, const void* x_planes, hipStream_t st);
 size_t nemar_split16_wgrad_g_bytes(int N, int H, int W, int K, int KS);      // bytes of the G_0 planes (two 16-bit planes)

@@ -510,6 +510,10 @@ void nemar_split16_dual_split(const float* gy, void* dplanes, void* gplanes, int
 #undef WG_DUAL
 }
 
+static thread_local const float* t_bias_partials = nullptr;
+static thread_local float* t_bias_dst = nullptr;
+void nemar_split16_wgrad_set_bias(const float* bias_partials, float* gb) { t_bias_partials = bias_partials; t_bias_dst = gb; }
+
 void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int C, int H, int W, int K, int KS, int reflect,
                          void* scratch, float* part, int xcd_map, const void* g_planes, const void* x_planes, hipStream_t st) {
     const int CPR = (W + 2 + 7) / 8, KBLK = K / 64, CBLK = C / 64;
@@ -559,5 +563,7 @@ void nemar_split16_wgrad(const float* x, const float* gy, float* gw, int N, int 
     else if (KS == 3) wg_launch<3, false>(grid, p, st);
     else wg_launch<4, false>(grid, p, st);
 #endif
-    nemar_sum_partials(part, (long long)K * C * KS * KS, splits, gw, (long long)K * C * KS * KS, true, st);
+    // (+ the bias gradient from the backward producer's per-plane sums, where the caller handed them over: one launch for both reductions)
+    nemar_sum_partials_pair(part, (long long)K * C * KS * KS, splits, gw, (long long)K * C * KS * KS, t_bias_partials, K, N, t_bias_dst, K, true, st);
+    t_bias_partials = nullptr; t_bias_dst = nullptr;
 }

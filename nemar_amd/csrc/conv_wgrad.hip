@@ -27,6 +27,8 @@
 // Bias gradient (gb[m] += sum_p gy[m][p]) falls out of the A fragments of column-tile 0.
 #include "common.h"
 
+void nemar_sum_partials_pair(const float* part_a, long long stride_a, int splits_a, float* dst_a, long long n_a,
+                             const float* part_b, long long stride_b, int splits_b, float* dst_b, long long n_b, bool accumulate, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st);
 
@@ -466,8 +468,5 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
     if (BM == 128) launch_wgrad2<2, 2, 2>(p, vec, grid, st);
     else if (BM == 64) launch_wgrad2<2, 1, 2>(p, vec, grid, st);
     else launch_wgrad2<1, 1, 1>(p, vec, grid, st);
-    if (part) {
-        nemar_sum_partials(part, (long long)KJ, splits, gw, (long long)KJ, true, st);
-        if (gb) nemar_sum_partials(p.partb, K, splits, gb, K, true, st);
-    }
+    if (part) nemar_sum_partials_pair(part, (long long)KJ, splits, gw, (long long)KJ, gb ? p.partb : nullptr, K, splits, gb, K, true, st);
 }

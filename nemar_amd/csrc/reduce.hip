@@ -14,14 +14,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // dst.  Workgroup = 16 x 16 threads: x = 16 consecutive float4 (one 256-byte run per slab row: coalesced), y = slab lane —
 // so a reduction over hundreds of small slabs (narrow layers: 341 slabs of 9216 floats) is as parallel as one over a few
 // large ones (256->256 3x3: 14 slabs of 590k floats), instead of one thread walking all slabs at memory latency.
+// (bx, gx: this job's block index and block count — blockIdx.x / gridDim.x for the single-job kernels, a sub-range of the grid for the
+// two-job kernel below)
 template <bool VEC>
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, long long stride, int splits,
-                                                           float* __restrict__ dst, long long n, int accumulate, int act,
-                                                           float slope) {
-    __shared__ f32x4 red[16][17];
+__device__ __forceinline__ void sum_general_body(f32x4 (*red)[17], const float* __restrict__ part, long long stride, int splits,
+                                                 float* __restrict__ dst, long long n, int accumulate, int act, float slope,
+                                                 unsigned bx, unsigned gx) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const long long cols = VEC ? (n >> 2) : n;            // columns of 4 floats (VEC) or 1 float
-    for (long long c0 = (long long)blockIdx.x * 16; c0 < cols; c0 += (long long)gridDim.x * 16) {
+    for (long long c0 = (long long)bx * 16; c0 < cols; c0 += (long long)gx * 16) {
         const long long c = c0 + tx;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (c < cols) {
@@ -54,15 +55,22 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
         __syncthreads();
     }
 }
+template <bool VEC>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, long long stride, int splits,
+                                                           float* __restrict__ dst, long long n, int accumulate, int act,
+                                                           float slope) {
+    __shared__ f32x4 red[16][17];
+    sum_general_body<VEC>(red, part, stride, splits, dst, n, accumulate, act, slope, blockIdx.x, gridDim.x);
+}
 
 // Few slabs (<= 16: the 16-slab sums of the wide weight gradient — 18 per step, 37.7 MB each — and most bias / split sums), 16-byte
 // columns: one thread = one column, all slabs' words in flight at once, no LDS, no barrier.  SAME association order as the general
 // kernel below ((0 + s0) + s1) + ... [+ dst]: bit-identical results.  (Round 6: in the general kernel a thread had ONE 16-byte load in
 // flight per 16 columns and 240 of 256 threads idled through the second phase: 48 us = 0.8 TB/s for the wide layers' sums.)
-__global__ __launch_bounds__(256) void sum_partials_few_kernel(const float* __restrict__ part, long long stride, int splits,
-                                                               float* __restrict__ dst, long long n, int accumulate, int act, float slope) {
+__device__ __forceinline__ void sum_few_body(const float* __restrict__ part, long long stride, int splits, float* __restrict__ dst, long long n,
+                                             int accumulate, int act, float slope, unsigned bx, unsigned gx) {
     const long long cols = n >> 2;
-    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+    for (long long c = (long long)bx * 256 + threadIdx.x; c < cols; c += (long long)gx * 256) {
         f32x4 v[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s)                       // unconditional loads (slots beyond the last slab re-read slab 0)
@@ -80,6 +88,26 @@ __global__ __launch_bounds__(256) void sum_partials_few_kernel(const float* __re
         }
         *d = t;
     }
+}
+__global__ __launch_bounds__(256) void sum_partials_few_kernel(const float* __restrict__ part, long long stride, int splits,
+                                                               float* __restrict__ dst, long long n, int accumulate, int act, float slope) {
+    sum_few_body(part, stride, splits, dst, n, accumulate, act, slope, blockIdx.x, gridDim.x);
+}
+
+// Two reductions in ONE launch (a weight gradient's slabs and its bias gradient's: every weight-gradient call ended with two sum launches):
+// blocks [0, a.blocks) run job a, the rest job b, each with the body — and therefore the association order, bit for bit — its own launch
+// would have used (kind 0: few-slab form, 1: general 16-byte form, 2: general scalar form).
+struct SumJob {
+    const float* part; long long stride; int splits; float* dst; long long n; int accumulate; int kind; unsigned blocks;
+};
+__global__ __launch_bounds__(256) void sum_partials_pair_kernel(SumJob a, SumJob b) {
+    __shared__ f32x4 red[16][17];
+    const bool first = blockIdx.x < a.blocks;
+    const SumJob& j = first ? a : b;
+    const unsigned bx = first ? blockIdx.x : blockIdx.x - a.blocks;
+    if (j.kind == 0) sum_few_body(j.part, j.stride, j.splits, j.dst, j.n, j.accumulate, 0, 0.f, bx, j.blocks);
+    else if (j.kind == 1) sum_general_body<true>(red, j.part, j.stride, j.splits, j.dst, j.n, j.accumulate, 0, 0.f, bx, j.blocks);
+    else sum_general_body<false>(red, j.part, j.stride, j.splits, j.dst, j.n, j.accumulate, 0, 0.f, bx, j.blocks);
 }
 
 // the slabs hold [N][C0 + C1][HW]; channels < C0 go to d0 [N][C0][HW], the rest to d1 [N][C1][HW] (data gradient of a two-source layer);
@@ -167,6 +195,23 @@ void nemar_sum_partials_two(const float* part, long long stride, int splits, flo
     hipLaunchKernelGGL(sum_partials_two_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, d0, d1, C0, C1, HW, total);
 }
 
+// form and grid of one reduction (what sum_partials_launch picks)
+static SumJob sum_job(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate) {
+    const bool vec = (n & 3) == 0 && (stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const long long cols = vec ? (n >> 2) : n;
+    long long blocks = (cols + 15) / 16;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    SumJob j{part, stride, splits, dst, n, accumulate ? 1 : 0, vec ? 1 : 2, (unsigned)blocks};
+    if (vec && splits >= 1 && splits <= 16) {
+        long long fb = (cols + 255) / 256;
+        if (fb > 2048) fb = 2048;
+        if (fb < 1) fb = 1;
+        j.kind = 0; j.blocks = (unsigned)fb;
+    }
+    return j;
+}
+
 static void sum_partials_launch(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, int act, float slope,
                                 hipStream_t st) {
     const bool vec = (n & 3) == 0 && (stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
@@ -189,6 +234,15 @@ static void sum_partials_launch(const float* part, long long stride, int splits,
 
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate, hipStream_t st) {
     sum_partials_launch(part, stride, splits, dst, n, accumulate, 0, 0.f, st);
+}
+
+// the two reductions that end a weight-gradient call (weights: splits_a slabs of n_a floats; bias: splits_b of n_b) in one launch; b's part
+// NULL = the first one alone
+void nemar_sum_partials_pair(const float* part_a, long long stride_a, int splits_a, float* dst_a, long long n_a,
+                             const float* part_b, long long stride_b, int splits_b, float* dst_b, long long n_b, bool accumulate, hipStream_t st) {
+    if (!part_b || !dst_b) { nemar_sum_partials(part_a, stride_a, splits_a, dst_a, n_a, accumulate, st); return; }
+    const SumJob a = sum_job(part_a, stride_a, splits_a, dst_a, n_a, accumulate), b = sum_job(part_b, stride_b, splits_b, dst_b, n_b, accumulate);
+    hipLaunchKernelGGL(sum_partials_pair_kernel, dim3(a.blocks + b.blocks), dim3(256), 0, st, a, b);
 }
 
 // dst = act(sum of the slabs): the second stage of a reduction-split FORWARD convolution (slab 0 carries the bias); act 1 ReLU, 2 LeakyReLU

@@ -309,13 +309,15 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
     return slot[0], slot
 
 
-def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None, addend=None, out_max=None):
+def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None, addend=None, out_max=None, bias_partials=None):
     """nemar_conv_extras for one call: the side inputs of the wide-layer route, or None when there are none"""
     if arena is None and src_max is None and src2_max is None and planes is None and addend is None:
         return None
     e = _lib.ConvExtras()
     if addend is not None:
         e.addend = addend.data_ptr()
+    if bias_partials is not None:
+        e.bias_partials = bias_partials.data_ptr()
     if out_max is not None:
         e.out_max_words = out_max.data_ptr()
     if arena is not None:
@@ -1159,11 +1161,15 @@ class _ResBlock(Function):
                     wsb = Q.conv2d_bwd_weight_workspace(N, C, H, W, C, H, W, 3, 3, 1, 1)
                     side_arena = _conv_scratch(N, H, W, C, C, 3, 3, 1, 1, dev)
                     key = x_t if x_t is not None else xpl           # (with planes the fp32 operand is only a key)
-                    L.conv2d_bwd_weight_ex(_p(key), C, None, 0, _p(gp), _p(gw), None, N, H, W, C, H, W, 3, 3, 1, 1, PAD_REFLECT,
+                    # (the bias gradient — the sum over the batch of the backward producer's per-plane sums — rides in the launch that sums the
+                    # weight gradient's slabs: nemar_conv_extras.bias_partials)
+                    L.conv2d_bwd_weight_ex(_p(key), C, None, 0, _p(gp), _p(gw), _p(gb) if want_b else None, N, H, W, C, H, W, 3, 3, 1, 1, PAD_REFLECT,
                                            _p(_workspace(wsb, dev)), wsb, _stream(),
-                                           _extras(side_arena, x_words, g_scale, planes=xpl, src2_planes=gp))
+                                           _extras(side_arena, x_words, g_scale, planes=xpl, src2_planes=gp, bias_partials=bsum if want_b else None))
                     grad_ready(weight)
-                if want_b:
+                    if want_b:
+                        grad_ready(bias)
+                elif want_b:
                     L.bias_from_partials(_p(bsum), N, C, _p(gb), _stream())
                     grad_ready(bias)
 

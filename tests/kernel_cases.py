@@ -1166,10 +1166,16 @@ def case_resblock_planes_chain(be, pad_mode, act, drop_p, N=2, C=128, H=8, W=32,
             xsrc = ghost_x
         else:
             xsrc = d_y                                    # (the X planes carry the reflect border: a zero-padded layer splits x itself)
-        lib.conv2d_bwd_weight_ex(be.ptr(xsrc), C, None, 0, be.ptr(ghost), be.ptr(d_gw), None, N, H, W, K, H, W, 3, 3, 1, 1, pad_mode,
+        # ... and the bias gradient from the backward producer's per-plane sums, reduced inside the same call's slab-sum launch
+        # (nemar_conv_extras.bias_partials) == nemar_bias_from_partials of the same sums, bit for bit
+        d_gb, d_gb2 = be.full((K,), 0.5), be.full((K,), 0.5)
+        e2.bias_partials = be.ptr(bsum).value
+        lib.conv2d_bwd_weight_ex(be.ptr(xsrc), C, None, 0, be.ptr(ghost), be.ptr(d_gw), be.ptr(d_gb), N, H, W, K, H, W, 3, 3, 1, 1, pad_mode,
                                  be.ptr(wsw), wswb, be.stream, ctypes.byref(e2))
         assert lib.last_route() == 2
+        lib.bias_from_partials(be.ptr(bsum), N, K, be.ptr(d_gb2), be.stream)
         be.sync()
+        assert np.array_equal(be.np(d_gb), be.np(d_gb2)), "bias gradient riding in the slab-sum launch"
         gw = be.np(d_gw).astype(np.float64) - 0.25
         wmag = O.conv2d_bwd(np.abs(y), np.abs(w.astype(np.float64)), np.abs(gx), 1, 1, _PM[pad_mode])[1]
         lim = 6e-6 * wmag + 1e-6 * np.abs(want_gw).max() + 1e-30
