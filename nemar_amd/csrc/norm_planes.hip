@@ -125,7 +125,11 @@ __device__ __forceinline__ int np_unit_of_block(int b, int total) {
     return (((r >> 3) << 3) + x) * 8 + (r & 7);
 }
 
+#ifdef NEMAR_NP_FWD_OCC2          /* variant build (tools/build_variant.py): 8 waves per SIMD = two workgroups per CU, whatever it spills */
+__global__ __launch_bounds__(1024, 8) void instnorm_planes_kernel(NormPlanesParams p) {
+#else
 __global__ __launch_bounds__(1024) void instnorm_planes_kernel(NormPlanesParams p) {
+#endif
     __shared__ float red[136];
     __shared__ unsigned mred[16];
     __shared__ __attribute__((aligned(16))) unsigned char np_lds[NP_LDS_BYTES];

@@ -154,25 +154,17 @@ __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __r
             }
             return acc;
         };
-        float sum;
-        if ((y1 & y2 & x1 & x2) < 0) {                       // interior texel: its own padded position only
-            sum = at(y0, x0);
-        } else {
-            // border texel: all nine candidate positions are loaded UNCONDITIONALLY (absent mirrors re-read the own row / column) and the
-            // absent ones dropped afterwards — with the loads behind branches a 2x2 map walked four dependent rounds of cache misses
-            const int ya = y1 >= 0 ? y1 : y0, yb = y2 >= 0 ? y2 : y0, xa = x1 >= 0 ? x1 : x0, xb = x2 >= 0 ? x2 : x0;
-            const float a00 = at(y0, x0), a01 = at(y0, xa), a02 = at(y0, xb);
-            const float a10 = at(ya, x0), a11 = at(ya, xa), a12 = at(ya, xb);
-            const float a20 = at(yb, x0), a21 = at(yb, xa), a22 = at(yb, xb);
-            auto rowsum = [&](float v, float l, float r) {
-                if (x1 >= 0) v += l;
-                if (x2 >= 0) v += r;
-                return v;
-            };
-            sum = rowsum(a00, a01, a02);
-            if (y1 >= 0) sum += rowsum(a10, a11, a12);
-            if (y2 >= 0) sum += rowsum(a20, a21, a22);
-        }
+        auto rowsum = [&](int y) {
+            float v = at(y, x0);
+            if (x1 >= 0) v += at(y, x1);
+            if (x2 >= 0) v += at(y, x2);
+            return v;
+        };
+        // (loading a border texel's nine candidate positions unconditionally — no dependent rounds of cache misses — measured SLOWER: 14.4 vs
+        // 11.4 us per launch, 144 loads per border thread)
+        float sum = rowsum(y0);
+        if (y1 >= 0) sum += rowsum(y1);
+        if (y2 >= 0) sum += rowsum(y2);
         gx[idx] = addend ? sum + addend[idx] : sum;          // (+ the skip gradient of the ResnetBlock this convolution opens)
     }
 }
