@@ -39,3 +39,13 @@ for (name, where, shapes), n in sorted(rows.items(), key=lambda kv: (-kv[1], kv[
     tot += n
     print('%3d x %-16s %-62s %s' % (n, name, shapes, where[-110:]))
 print('%d ATen ops with device kernels in one step' % tot)
+# every device kernel of the profiled step (the rocprofv3 per-step figures of profiles/ divide a whole process — model set-up included:
+# ~360 one-time init / parameter-copy kernels — by its 11 steps)
+from torch.autograd import DeviceType  # noqa: E402
+kern = collections.Counter()
+for ev in prof.events():
+    if ev.device_type == DeviceType.CUDA:
+        kern[ev.name.split('(')[0][-60:]] += 1
+print('%d device kernels / copies in the step; by name:' % sum(kern.values()))
+for name, n in kern.most_common(12):
+    print('   %4d  %s' % (n, name))
