@@ -225,3 +225,73 @@ def test_resnet_block_one_node_vs_composed(drop):
             # bias gradients in front of InstanceNorm are sums that cancel to rounding noise: both must be negligible against the scale
             # of the weight gradient of the same layer
             assert float(a.abs().max()) < 1e-3 * float(gp_f[k - 1].abs().max()) * H * W
+
+
+def test_own_autograd_nodes_match_autograd():
+    """ops.cat_batch / split_batch / fork (nemar_concat_pieces, nemar_add2) against torch.cat, slices and autograd's own accumulation on the
+    same graph: values and gradients bit for bit (copies, and sums of two terms), a slice nothing reads gets a zero gradient, and no
+    gradient at all is materialised for an input that does not require one."""
+    import torch
+    from nemar_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def graph(cat, split, fork):
+        a = torch.randn(2, 3, 8, 12, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).requires_grad_()
+        b = torch.randn(2, 3, 8, 12, device=dev, generator=torch.Generator(device=dev).manual_seed(2)).requires_grad_()
+        c = torch.randn(2, 3, 8, 12, device=dev, generator=torch.Generator(device=dev).manual_seed(3))          # no gradient
+        w = torch.randn(6, 3, 8, 12, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+        both = cat([a * 2.0, b * 3.0, c]) * w
+        p0, p1, p2 = split(both, 3)
+        f0, f1 = fork(p0)
+        # (two consumers of p0, one gradient term each: a sum of TWO fp32 terms is the same in either order; p2 is read by nothing)
+        loss = (f0 * w[:2]).sum() + f1.sum() * 0.5 + (p1 * 0.25).sum()
+        loss.backward()
+        return both.detach(), a.grad, b.grad
+
+    own = graph(ops.cat_batch, ops.split_batch, lambda x: ops.fork(x, 2))
+    ref = graph(lambda ts: torch.cat(ts, 0), lambda x, k: tuple(x[i * 2:(i + 1) * 2] for i in range(k)), lambda x: (x, x))
+    for what, x, y in zip(('values', 'grad a', 'grad b'), own, ref):
+        assert torch.equal(x, y), (what, float((x - y).abs().max()), int((x != y).sum()), x.numel())
+    assert own[1].abs().max() > 0 and own[2].abs().max() > 0
+
+
+@pytest.mark.parametrize("size", [4, 16, 64])
+def test_skip_gradients_riding_in_another_pass(size):
+    """ops.conv2d_with_skip (the ResnetBlock's skip gradient as the addend of the first convolution's data gradient: the sum-and-fold pass
+    of the tiny maps at 4 x 4 / 16 x 16, the fold pass of the padded-domain data gradient at 64 x 64) and ops.max_pool2_with_skip (the U-Net
+    skip's gradient as the addend of the pooling's backward kernel) against the same graph with autograd's own accumulation: bit for bit
+    — the sum of the same two fp32 terms."""
+    import torch
+    from nemar_amd import ops
+    dev = torch.device('cuda:0')
+    C = 32 if size == 64 else 64
+    gen = lambda s: torch.Generator(device=dev).manual_seed(s)
+    w0 = (torch.randn(C, C, 3, 3, device=dev, generator=gen(1)) * 0.05)
+    b0 = torch.randn(C, device=dev, generator=gen(2)) * 0.1
+    x0 = torch.randn(8, C, size, size, device=dev, generator=gen(3))
+    gy = torch.randn(8, C, size, size, device=dev, generator=gen(4))
+    gs = torch.randn(8, C, size, size, device=dev, generator=gen(5))
+    gp = torch.randn(8, C, size // 2, size // 2, device=dev, generator=gen(6))
+
+    def run(own):
+        x = x0.clone().requires_grad_()
+        w = torch.nn.Parameter(w0.clone())
+        b = torch.nn.Parameter(b0.clone())
+        h = x * 1.5                                        # a producer in front: the summed gradient is what it receives
+        if own:
+            y, skip = ops.conv2d_with_skip(h, w, b, 1, 1, ops.PAD_REFLECT)
+        else:
+            y, skip = ops.conv2d(h, w, b, 1, 1, ops.PAD_REFLECT), h
+        out = y + skip                                     # (the residual sum itself is not under test)
+        if own:
+            pooled, skip2 = ops.max_pool2_with_skip(out)
+        else:
+            pooled, skip2 = ops.max_pool2(out), out
+        torch.autograd.backward([pooled, skip2], [gp, gs + gy])
+        ops.join_side()
+        return x.grad.clone(), w.grad.clone(), b.grad.clone()
+
+    a, r = run(True), run(False)
+    assert torch.equal(a[0], r[0]), float((a[0] - r[0]).abs().max())
+    assert torch.equal(a[1], r[1]) and torch.equal(a[2], r[2])
