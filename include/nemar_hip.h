@@ -214,6 +214,10 @@ int nemar_config_epoch(void);
  * themselves; every other consumer of max words needs finalized words (the default).  One launch less per producer call: 4 us on one
  * stream, 12 us beside a second stream, 25 times per training step on the chain the rest of the step waits for. */
 int nemar_set_max_words_lazy(int on);
+/* (ABI 602) The reduction a lazy producer skipped, on demand: every sample whose result word still holds the marker gets the maximum of its partial
+ * words; finalized words are left alone.  nemar_instnorm_fwd_max / _bwd_max honour the lazy setting too (ABI 602): a binding that publishes maxima
+ * "in case the consumer is a wide-route convolution" pays the reduction only for the tensors such a consumer actually reads. */
+int nemar_max_words_finalize(void* max_words, int samples, void* stream);
 /* Transient scratch arena for nemar_conv2d_fwd / nemar_conv2d_bwd_data / nemar_conv2d_bwd_weight.  The wide stride-1 / pad-1
  * layers (the 3x3 ResnetBlock convolutions, reference models/networks.py:418-439, and the discriminator's 256->512 4x4 layer,
  * :576-597; >= 128 channels, >= 2 G multiply-adds) run on the 16-bit matrix pipe at fp32 accuracy: each fp32 operand is split into

@@ -87,6 +87,7 @@ SIGNATURES = {
     "nemar_act_bwd": (_i, [_vp, _vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_act_fwd": (_i, [_vp, _vp, _ll, _i, _fl, _vp]),
     "nemar_conv2d_bwd_data_addend_ok": (_i, [_i] * 10),
+    "nemar_max_words_finalize": (_i, [_vp, _i, _vp]),
     "nemar_concat_pieces": (_i, [_vp, _vp, _i, _vp, _vp]),
     "nemar_add2": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "nemar_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),

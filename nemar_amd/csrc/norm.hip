@@ -36,7 +36,10 @@ __device__ __forceinline__ unsigned finite_mag(float v) {
     return u < 0x7f800000u ? u : 0u;
 }
 // the workgroup's maximum -> its own partial word (max_words.h)
-__device__ __forceinline__ void publish_max(unsigned m, unsigned* word, unsigned* red) {
+// pps < 0 = LAZY words (max_words.h): no reduction launch follows; the first plane of a sample leaves the marker in the sample's result word
+__device__ __forceinline__ void publish_max(unsigned m, unsigned* maxw, int pps, unsigned* red) {
+    const int P = pps < 0 ? -pps : pps;
+    unsigned* const word = maxw + gridDim.x / P + blockIdx.x;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     __syncthreads();
@@ -46,6 +49,7 @@ __device__ __forceinline__ void publish_max(unsigned m, unsigned* word, unsigned
         const int nw = (blockDim.x + 63) >> 6;
         for (int i = 1; i < nw; ++i) m = max(m, red[i]);
         *word = m;
+        if (pps < 0 && blockIdx.x % P == 0) maxw[blockIdx.x / P] = NEMAR_MAX_LAZY_MARK | (unsigned)P;
     }
 }
 
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd_kernel(const float* __re
         stats[2 * (size_t)blockIdx.x] = mean;
         stats[2 * (size_t)blockIdx.x + 1] = rstd;
     }
-    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw, pps, reinterpret_cast<unsigned*>(red));
 }
 
 // 16-byte form of the register-cached kernels (HW % 4 == 0, 16-byte aligned planes): a thread holds PER4 float4 — a quarter of the load /
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_fwd4_kernel(const float* __r
         stats[2 * (size_t)blockIdx.x] = mean;
         stats[2 * (size_t)blockIdx.x + 1] = rstd;
     }
-    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw, pps, reinterpret_cast<unsigned*>(red));
 }
 
 template <int THREADS, int PER4>
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd4_kernel(const float* __r
             for (int e = 0; e < 4; ++e) omax = max(omax, finite_mag(o[e]));
         }
     }
-    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw, pps, reinterpret_cast<unsigned*>(red));
 }
 
 // HW == 4 THREADS PER4 exactly, too large for x AND gy in registers (256 x 256 planes: the registration net's 32-channel layers, the
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd4s_kernel(const float* __
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw, pps, reinterpret_cast<unsigned*>(red));
 }
 
 template <int THREADS, int PER>
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(THREADS) void instnorm_bwd_kernel(const float* __re
             omax = max(omax, finite_mag(o));
         }
     }
-    if (maxw) publish_max(omax, maxw + gridDim.x / pps + blockIdx.x, reinterpret_cast<unsigned*>(red));
+    if (maxw) publish_max(omax, maxw, pps, reinterpret_cast<unsigned*>(red));
 }
 
 }  // namespace
@@ -406,29 +410,33 @@ static int instnorm_fwd_impl(const float* x, const float* residual, float* y, fl
     NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_fwd: unsupported act %d", act);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(planes);
+    // LAZY words (nemar_set_max_words_lazy): no reduction launch — the kernel leaves the marker and whoever needs the word reduces the
+    // partials (the InstanceNorm producers of norm_planes.hip in their prologue, anyone else through nemar_max_words_finalize)
+    const bool lazy = maxw && nemar_max_words_lazy() && pps <= 0xFFFF;
+    const int pps_k = lazy ? -pps : pps;
     const bool vec = HW % 4 == 0 && HW >= 1024 && HW <= 1024 * 64 &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
     if (vec && HW <= 256 * 16)
-        hipLaunchKernelGGL((instnorm_fwd4_kernel<256, 4, false>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<256, 4, false>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (vec && HW <= 1024 * 16)
-        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 4, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 4, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (vec && HW <= 1024 * 32)
-        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 8, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 8, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (vec && HW == 1024 * 64)
-        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 16, true>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 16, true>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (vec && HW <= 1024 * 48)        // 32768 < HW <= 49152 (200 x 200, 208 x 208 ...): register-cached as well
-        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 12, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 12, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (vec && HW <= 1024 * 56)        // ... <= 57344 (224 x 224, 232 x 232); a <1024, 16, false> instance spills 20 registers
-        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 14, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd4_kernel<1024, 14, false>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (HW <= 64 * 8)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), grid, dim3(64), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (HW <= 256 * 16)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), grid, dim3(256), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else if (HW <= 1024 * 16)
-        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
     else
-        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps);
-    if (maxw) max_words_finalize(maxw, planes / pps, pps, st);
+        hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, residual, y, stats, HW, eps, act, slope, maxw, pps_k);
+    if (maxw && !lazy) max_words_finalize(maxw, planes / pps, pps, st);
     NEMAR_CHECK_LAUNCH("instnorm_fwd");
     return NEMAR_OK;
 }
@@ -456,27 +464,58 @@ static int instnorm_bwd_impl(const float* x, const float* stats, const float* gy
     NEMAR_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LRELU, "instnorm_bwd: unsupported act %d", act);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(planes);
+    // LAZY words (nemar_set_max_words_lazy): no reduction launch — the kernel leaves the marker and whoever needs the word reduces the
+    // partials (the InstanceNorm producers of norm_planes.hip in their prologue, anyone else through nemar_max_words_finalize)
+    const bool lazy = maxw && nemar_max_words_lazy() && pps <= 0xFFFF;
+    const int pps_k = lazy ? -pps : pps;
     const bool vec = HW % 4 == 0 && HW >= 1024 && HW <= 1024 * 32 &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0;
     if (vec && HW <= 256 * 16)
-        hipLaunchKernelGGL((instnorm_bwd4_kernel<256, 4>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd4_kernel<256, 4>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (vec && HW <= 1024 * 16)
-        hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 4>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 4>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (vec)
-        hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 8>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd4_kernel<1024, 8>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (HW == 1024 * 64 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0)
-        hipLaunchKernelGGL((instnorm_bwd4s_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd4s_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (HW <= 64 * 8)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), grid, dim3(64), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (HW <= 256 * 16)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), grid, dim3(256), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (HW <= 1024 * 16)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 16>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else if (HW <= 1024 * 32)
-        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 32>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 32>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
     else
-        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps);
-    if (maxw) max_words_finalize(maxw, planes / pps, pps, st);
+        hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), grid, dim3(1024), 0, st, x, stats, gy, gx, HW, act, slope, maxw, pps_k);
+    if (maxw && !lazy) max_words_finalize(maxw, planes / pps, pps, st);
     NEMAR_CHECK_LAUNCH("instnorm_bwd");
+    return NEMAR_OK;
+}
+
+// The on-demand form of the reduction a lazy producer skipped (nemar_set_max_words_lazy): for every sample whose result word still holds the
+// marker, reduce its partial words into it; words that are maxima already are left alone.  One launch, only when somebody asks.
+namespace {
+__global__ __launch_bounds__(256) void max_words_finalize_lazy_kernel(unsigned* __restrict__ w, int samples) {
+    __shared__ unsigned red[4];
+    const unsigned v = w[blockIdx.x];
+    if ((v & 0xFFFF0000u) != NEMAR_MAX_LAZY_MARK) return;          // (uniform per workgroup)
+    const int partials = (int)(v & 0xFFFFu);
+    const unsigned* src = w + samples + (size_t)blockIdx.x * partials;
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < partials; i += 256) m = max(m, src[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) w[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+}  // namespace
+
+NEMAR_API int nemar_max_words_finalize(void* max_words, int samples, void* stream) {
+    NEMAR_CLEAR_HIP_ERROR();
+    NEMAR_REQUIRE(max_words && samples > 0 && samples <= 65535, "max_words_finalize: bad arguments");
+    hipLaunchKernelGGL(max_words_finalize_lazy_kernel, dim3(samples), dim3(256), 0, (hipStream_t)stream, (unsigned*)max_words, samples);
+    NEMAR_CHECK_LAUNCH("max_words_finalize");
     return NEMAR_OK;
 }

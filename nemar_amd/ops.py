@@ -364,13 +364,20 @@ def _tag_max(t, words, lazy=False):
 
 
 def _absmax_word(t, lazy_ok=False):
-    if lazy_ok:
-        have = getattr(t, '_nemar_absmax_lazy', None)
-        if have is not None and have[1] == t._version and have[0].numel() == t.shape[0]:
-            return have[0]
+    lazy = getattr(t, '_nemar_absmax_lazy', None)
+    if lazy is not None and not (lazy[1] == t._version and lazy[0].numel() == t.shape[0]):
+        lazy = None
+    if lazy_ok and lazy is not None:
+        return lazy[0]
     have = getattr(t, '_nemar_absmax', None)
     if have is not None and have[1] == t._version and have[0].numel() == t.shape[0]:
         return have[0]
+    if lazy is not None:
+        # a producer left the reduction of its partial words to whoever needs the maxima (the InstanceNorm passes publish them "in case the
+        # consumer is a wide-route convolution": most are not): reduce them now, once — nemar_max_words_finalize leaves finalized words alone
+        L.max_words_finalize(_p(lazy[0]), int(t.shape[0]), _stream())
+        t._nemar_absmax = lazy
+        return lazy[0]
     return _absmax_word_compute(t)
 
 
@@ -937,8 +944,9 @@ class _InstanceNorm(Function):
         else:
             if _wants_max(x) and drop_p <= 0.0:
                 words = _max_words(N, x.device)
-                L.instnorm_fwd_max(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _p(words), C, _stream())
-                _tag_max(y, words)
+                with _lazy_max():                 # (the reduction of the partial words: on demand, ops._absmax_word)
+                    L.instnorm_fwd_max(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _p(words), C, _stream())
+                _tag_max(y, words, lazy=_LAZY_MAX)
             else:
                 L.instnorm_fwd(_p(x), _p(residual), _p(y), _p(stats), N * C, H * W, eps, act, slope, _stream())
             if drop_p > 0.0:
@@ -967,8 +975,9 @@ class _InstanceNorm(Function):
             gx = torch.empty_like(x)
             if _wants_max(x):
                 words = _max_words(N, x.device)
-                L.instnorm_bwd_max(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _p(words), C, _stream())
-                _tag_max(gx, words)
+                with _lazy_max():
+                    L.instnorm_bwd_max(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _p(words), C, _stream())
+                _tag_max(gx, words, lazy=_LAZY_MAX)
             else:
                 L.instnorm_bwd(_p(x), _p(stats), _p(g), _p(gx), N * C, H * W, act, slope, _stream())
         gres = gy if ctx.needs_input_grad[1] else None

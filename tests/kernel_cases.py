@@ -745,6 +745,24 @@ def case_producer_max_words(be, seed=0):
         be.lib.instnorm_bwd_max(be.ptr(d_x), be.ptr(st0), be.ptr(d_gy), be.ptr(g1), N * C, H * W, act, 0.2, be.ptr(w), C, be.stream)
         a = np.asarray(be.np(g1), dtype=np.float32)
         assert np.array_equal(be.np(g0), be.np(g1)) and words_of(w) == want(a)
+        # LAZY words (nemar_set_max_words_lazy): the call leaves the marker 0xFFFF0000 | planes-per-sample in each result word, and
+        # nemar_max_words_finalize — on demand, idempotent — turns it into the same maxima
+        for fwd in (True, False):
+            out = be.full(x.shape, np.nan)
+            w = be.bytes_buf(4 * N * 2049)
+            be.lib.set_max_words_lazy(1)
+            try:
+                if fwd:
+                    be.lib.instnorm_fwd_max(be.ptr(d_x), be.ptr(r), be.ptr(out), be.ptr(st1), N * C, H * W, 1e-5, act, 0.2, be.ptr(w), C, be.stream)
+                else:
+                    be.lib.instnorm_bwd_max(be.ptr(d_x), be.ptr(st0), be.ptr(d_gy), be.ptr(out), N * C, H * W, act, 0.2, be.ptr(w), C, be.stream)
+            finally:
+                be.lib.set_max_words_lazy(0)
+            assert words_of(w) == [0xFFFF0000 | C] * N, "lazy marker"
+            a = np.asarray(be.np(out), dtype=np.float32)
+            for _ in range(2):
+                be.lib.max_words_finalize(be.ptr(w), N, be.stream)
+                assert words_of(w) == want(a), "nemar_max_words_finalize"
     y0, y1 = be.full(x.shape, np.nan), be.full(x.shape, np.nan)
     w = be.bytes_buf(4 * N * 2049)
     be.lib.dropout(be.ptr(d_x), be.ptr(y0), x.size, 0.5, 1234567, 9, be.stream)
