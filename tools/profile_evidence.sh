@@ -48,6 +48,10 @@ for tag in ('kernel_stats', 'kernel_stats_single_stream'):
     rows = list(csv.DictReader(open('$O/%s.csv' % tag)))
     tot = sum(float(r['total_us']) for r in rows); calls = sum(int(r['calls']) for r in rows)
     print('%s: kernels %.1f ms over 11 steps (8 + the 3 steps of the roofline / memory pass) = %.2f ms/step, %d launches = %d per step' % (tag, tot / 1e3, tot / 1.1e4, calls, calls // 11))
+    setup = [r for r in rows if 'at::native' in r['name'] or '__amd_rocclr' in r['name']]
+    sc = sum(int(r['calls']) for r in setup)
+    print('   of which %d launches (%.1f ms) are the one-time set-up of the process (ATen weight initialisation, parameter copies into the flat buffers, runtime '
+          'fills): the steps themselves launch (%d - %d) / 11 = %d kernels each' % (sc, sum(float(r['total_us']) for r in setup) / 1e3, calls, sc, (calls - sc) // 11))
     for r in rows[:12]:
         print('   %6.2f%% x%-5s avg %8.1f us  %s' % (float(r['pct']), r['calls'], float(r['avg_us']), r['name'][:100]))
 PY
