@@ -493,6 +493,19 @@ def main():
     lib.kernel_timer_read(ctypes.byref(tk_ms_c), ctypes.byref(tk_fl_c), ctypes.byref(tk_n_c))
     lib.kernel_timer(0)
     tk_ms, tk_flop, tk_n = tk_ms_c.value, tk_fl_c.value, tk_n_c.value
+    # ... and the same launches as the TIMED step runs them: beside the side stream's weight-gradient kernels (the data gradient's launches
+    # share the matrix pipe with them; the forward launches have the chip to themselves)
+    tk2 = None
+    if side_prev and tk_n:
+        lib.kernel_timer(1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        a_ms, a_fl, a_n = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int(0)
+        lib.kernel_timer_read(ctypes.byref(a_ms), ctypes.byref(a_fl), ctypes.byref(a_n))
+        lib.kernel_timer(0)
+        if a_n.value:
+            tk2 = (a_ms.value, a_fl.value, a_n.value)
     rank_ms = [dt / a.steps * 1e3]
     buckets = sum(len(getattr(model, n).launched) for n in ("sync_T", "sync_D", "sync_R"))
     if multi:
@@ -625,6 +638,14 @@ def main():
                            "sustained_mfma_TFLOPs_measured": F16_MFMA_SUSTAINED_TF,
                            "frac_of_sustained_mfma": 3.0 * flop / sec / 1e12 / F16_MFMA_SUSTAINED_TF,
                            "sustained_source": "profiles/r4_mfma_peak_modes.txt (f16, random operands, 2 waves/SIMD, long run)"}
+        if tk2 is not None:
+            sec2 = tk2[0] * 1e-3 / tk2[2]
+            out["roofline"]["in_two_stream_step"] = {
+                "avg_launch_us": sec2 * 1e6, "achieved": tk2[1] / tk2[2] / sec2 / 1e12, "frac": tk2[1] / tk2[2] / sec2 / 1e12 / peak,
+                "launches_timed": tk2[2],
+                "note": "the same launches with the weight-gradient branch on the side stream, as the timed step runs them: the data "
+                        "gradient's launches share the CUs with the side stream's weight-gradient kernels (forward launches do not), so "
+                        "this is a share of the chip, not the kernel's efficiency — `frac` above is that"}
     # Operator level (what the step pays per residual-block layer): the whole C-ABI call — support passes (split / pack / slab sums) + main
     # kernel — event-timed on ONE stream in the same two-step pass; the batch of a call = T's two applications (2 x batch)
     rb = {}
