@@ -127,45 +127,65 @@ __global__ __launch_bounds__(256) void sum_partials_two_kernel(const float* __re
 
 // Second stage of a reduction-split stride-1 REFLECT data gradient computed on the padded domain (conv.hip fold_small): the slabs hold
 // [planes][H + 2 pad][W + 2 pad]; gx[plane][h][w] = the slab sums (ascending slab order, ((0 + s0) + s1) + ...) of every padded position that
-// mirrors onto (h, w), added in reflect_fold_kernel's order (rows: own, upper mirror, lower mirror; within a row: own, left, right).  Up to
-// 16 slabs of a position are in flight at once (a serial chain of dependent loads would cost a cache miss per slab).
+// mirrors onto (h, w), added in reflect_fold_kernel's order (rows: own, upper mirror, lower mirror; within a row: own, left, right) [+ addend].
+// Workgroup = 16 consecutive texels x 16 slab lanes: lane y LOADS slab s0 + y's values of the texel's (up to nine) positions — every load of
+// a round independent of the others —, lane 0 ADDS them in the order above.  (One thread per texel walking its slabs and positions in turn
+// cost 11.4 us per launch on maps of a few hundred texels: dependent rounds of cache misses; this form 5.6 us, the same bits.  Letting each
+// lane sum its own slabs first is as fast but another association order — and the ten-step trajectory test sits close enough to its
+// tolerance at steps 7 - 8 to notice.)
 __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __restrict__ part, long long stride, int splits, float* __restrict__ gx,
                                                                 int H, int W, int pad, long long total, const float* __restrict__ addend) {
+    __shared__ float val[16][9][17];
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int w = (int)(idx % W);
-        const long long t = idx / W;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (long long idx0 = (long long)blockIdx.x * 16; idx0 < total; idx0 += (long long)gridDim.x * 16) {
+        const long long idx = idx0 + tx;
+        const bool live = idx < total;
+        const long long cidx = live ? idx : total - 1;
+        const int w = (int)(cidx % W);
+        const long long t = cidx / W;
         const int h = (int)(t % H);
         const long long nc = t / H;
-        const float* q = part + nc * (long long)Hp * Wp;
         const int y0 = h + pad, x0 = w + pad;
         const int y1 = (h >= 1 && h <= pad) ? pad - h : -1, y2 = (h <= H - 2 && h >= H - 1 - pad) ? 2 * (H - 1) - h + pad : -1;
         const int x1 = (w >= 1 && w <= pad) ? pad - w : -1, x2 = (w <= W - 2 && w >= W - 1 - pad) ? 2 * (W - 1) - w + pad : -1;
-        auto at = [&](int y, int x) {
-            const float* r = q + (long long)y * Wp + x;
-            float acc = 0.f;
-            for (int s0 = 0; s0 < splits; s0 += 16) {
-                float v[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) v[s] = r[(long long)(s0 + s < splits ? s0 + s : 0) * stride];      // unconditional loads
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    if (s0 + s < splits) acc += v[s];
+        // position k = 3 row + column; absent mirrors re-read the own row / column (their values are never added)
+        const int ya = y1 >= 0 ? y1 : y0, yb = y2 >= 0 ? y2 : y0, xa = x1 >= 0 ? x1 : x0, xb = x2 >= 0 ? x2 : x0;
+        const long long pbase = nc * (long long)Hp * Wp;
+        float a00 = 0.f, a01 = 0.f, a02 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f, a20 = 0.f, a21 = 0.f, a22 = 0.f;      // (lane 0: the slab sums per position)
+        for (int s0 = 0; s0 < splits; s0 += 16) {
+            const int sl = s0 + ty;
+            if (sl < splits) {
+                const float* q = part + (long long)sl * stride + pbase;
+                const float* r0 = q + (long long)y0 * Wp;
+                const float* r1 = q + (long long)ya * Wp;
+                const float* r2 = q + (long long)yb * Wp;
+                val[ty][0][tx] = r0[x0]; val[ty][1][tx] = r0[xa]; val[ty][2][tx] = r0[xb];
+                val[ty][3][tx] = r1[x0]; val[ty][4][tx] = r1[xa]; val[ty][5][tx] = r1[xb];
+                val[ty][6][tx] = r2[x0]; val[ty][7][tx] = r2[xa]; val[ty][8][tx] = r2[xb];
             }
-            return acc;
-        };
-        auto rowsum = [&](int y) {
-            float v = at(y, x0);
-            if (x1 >= 0) v += at(y, x1);
-            if (x2 >= 0) v += at(y, x2);
-            return v;
-        };
-        // (loading a border texel's nine candidate positions unconditionally — no dependent rounds of cache misses — measured SLOWER: 14.4 vs
-        // 11.4 us per launch, 144 loads per border thread)
-        float sum = rowsum(y0);
-        if (y1 >= 0) sum += rowsum(y1);
-        if (y2 >= 0) sum += rowsum(y2);
-        gx[idx] = addend ? sum + addend[idx] : sum;          // (+ the skip gradient of the ResnetBlock this convolution opens)
+            __syncthreads();
+            if (ty == 0) {
+                const int n = splits - s0 < 16 ? splits - s0 : 16;
+                for (int y = 0; y < n; ++y) {
+                    a00 += val[y][0][tx]; a01 += val[y][1][tx]; a02 += val[y][2][tx];
+                    a10 += val[y][3][tx]; a11 += val[y][4][tx]; a12 += val[y][5][tx];
+                    a20 += val[y][6][tx]; a21 += val[y][7][tx]; a22 += val[y][8][tx];
+                }
+            }
+            __syncthreads();
+        }
+        if (ty == 0 && live) {
+            auto rowsum = [&](float v, float l, float r) {
+                if (x1 >= 0) v += l;
+                if (x2 >= 0) v += r;
+                return v;
+            };
+            float sum = rowsum(a00, a01, a02);
+            if (y1 >= 0) sum += rowsum(a10, a11, a12);
+            if (y2 >= 0) sum += rowsum(a20, a21, a22);
+            gx[idx] = addend ? sum + addend[idx] : sum;          // (+ the skip gradient of the ResnetBlock this convolution opens)
+        }
     }
 }
 
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __r
 void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
                              const float* addend, hipStream_t st) {
     const long long total = planes * H * W;
-    long long blocks = (total + 255) / 256;
+    long long blocks = (total + 15) / 16;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sum_partials_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, gx, H, W, pad, total, addend);
