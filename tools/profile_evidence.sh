@@ -44,14 +44,15 @@ timeout 600 python tools/trace_convs.py > $O/conv_trace.jsonl 2> $O/trace.err
 timeout 900 python tools/microbench_trace.py $O/conv_trace.jsonl > $O/conv_layers.txt 2> $O/layers.err
 python - <<PY
 import csv, json
-for tag in ('kernel_stats', 'kernel_stats_single_stream'):
+# steps of the profiled process: 2 warm-up + 6 timed + 3 of the roofline / memory pass on one stream (+ 2 of the in-step roofline pass when the side stream is on)
+for tag, ns in (('kernel_stats', 13), ('kernel_stats_single_stream', 11)):
     rows = list(csv.DictReader(open('$O/%s.csv' % tag)))
     tot = sum(float(r['total_us']) for r in rows); calls = sum(int(r['calls']) for r in rows)
-    print('%s: kernels %.1f ms over 11 steps (8 + the 3 steps of the roofline / memory pass) = %.2f ms/step, %d launches = %d per step' % (tag, tot / 1e3, tot / 1.1e4, calls, calls // 11))
+    print('%s: kernels %.1f ms over %d steps = %.2f ms/step, %d launches = %d per step' % (tag, tot / 1e3, ns, tot / 1e3 / ns, calls, calls // ns))
     setup = [r for r in rows if 'at::native' in r['name'] or '__amd_rocclr' in r['name']]
     sc = sum(int(r['calls']) for r in setup)
     print('   of which %d launches (%.1f ms) are the one-time set-up of the process (ATen weight initialisation, parameter copies into the flat buffers, runtime '
-          'fills): the steps themselves launch (%d - %d) / 11 = %d kernels each' % (sc, sum(float(r['total_us']) for r in setup) / 1e3, calls, sc, (calls - sc) // 11))
+          'fills): the steps themselves launch (%d - %d) / %d = %d kernels each' % (sc, sum(float(r['total_us']) for r in setup) / 1e3, calls, sc, ns, (calls - sc) // ns))
     for r in rows[:12]:
         print('   %6.2f%% x%-5s avg %8.1f us  %s' % (float(r['pct']), r['calls'], float(r['avg_us']), r['name'][:100]))
 PY
