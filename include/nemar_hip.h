@@ -159,11 +159,6 @@ typedef struct nemar_conv_extras {
     const void* src2_planes;
     const float* addend;
     void* out_max_words;
-    const float* in_act_y;        /* (ABI 602) bwd_data only, where nemar_conv2d_bwd_data_addend_ok says 1 and the layer is not one of the wide route:
-                                   * the layer's INPUT is the output y of a producer with a fused activation in_act (ReLU / LeakyReLU in_slope) —
-                                   * gx0 = (data gradient [+ addend]) * f'(y), applied in the fold pass: the producer's act_bwd pass is not needed */
-    int in_act;
-    float in_slope;
     const float* bias_partials;   /* (ABI 602) bwd_weight only, with gb != NULL on a layer of the wide route: per-plane sums of gy [N, K]
                                    * (nemar_instnorm_bwd_planes `bias_partials`); gb += their sum over the batch, in batch order, inside the
                                    * launch that sums the weight gradient's slabs — instead of a nemar_bias_from_partials call of its own */

@@ -123,8 +123,7 @@ class ConvExtras(C.Structure):
     _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("src_max_words", C.c_void_p), ("src_max_count", C.c_int),
                 ("src2_max_words", C.c_void_p), ("src2_max_count", C.c_int), ("src_planes", C.c_void_p),
                 ("gy_planes_out", C.c_void_p), ("gy_planes_bytes", C.c_size_t), ("src2_planes", C.c_void_p),
-                ("addend", C.c_void_p), ("out_max_words", C.c_void_p), ("in_act_y", C.c_void_p), ("in_act", C.c_int), ("in_slope", C.c_float),
-                ("bias_partials", C.c_void_p)]
+                ("addend", C.c_void_p), ("out_max_words", C.c_void_p), ("bias_partials", C.c_void_p)]
 
 
 class Library:

@@ -65,9 +65,6 @@ struct nemar_conv_extras {
     const void* src2_planes;
     const float* addend;
     void* out_max_words;
-    const float* in_act_y;
-    int in_act;
-    float in_slope;
     const float* bias_partials;
 };
 

@@ -50,7 +50,7 @@ void nemar_wgrad2_launch(const float* x0, int C0, const float* x1, int C1, const
 void nemar_sum_partials_pair(const float* part_a, long long stride_a, int splits_a, float* dst_a, long long n_a,
                              const float* part_b, long long stride_b, int splits_b, float* dst_b, long long n_b, bool accumulate, hipStream_t st);
 void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
-                             const float* addend, const float* act_y, int act, float slope, hipStream_t st);
+                             const float* addend, hipStream_t st);
 void nemar_sum_partials(const float* part, long long stride, int splits, float* dst, long long n, bool accumulate,
                         hipStream_t st);
 
@@ -89,10 +89,6 @@ static thread_local void* t_out_max = nullptr;                // bwd_data_ex: pe
 static thread_local int t_fused_epilogue = 0;                 // did the last bwd_data_ex call honour them?
 static thread_local int t_bias_rode = 0;                       // ... and did the call reduce them (the wide route)?
 static thread_local const float* t_bias_partials = nullptr;   // bwd_weight_ex: per-plane sums of gy [N, K] (extras.bias_partials)
-static thread_local const float* t_in_act_y = nullptr;          // bwd_data_ex: the producer's activation output (extras.in_act_y) ...
-static thread_local int t_in_act = 0;                          // ... its activation and slope: gx0 *= f'(y) in the fold pass
-static thread_local float t_in_slope = 0.f;
-static thread_local int t_in_act_done = 0;
 static thread_local int t_addend_done = 0;                    // ... or at least the addend (the fold pass of a small reflect layer: nemar_conv2d_bwd_data_addend_ok)
 static NEMAR_SWITCH(int, g_split_act, 1);          // key 36: reduction-split forward layers with a fused ReLU / LeakyReLU (activation in the sum pass)
 static NEMAR_SWITCH(int, g_fold_small, 1);         // key 43: stride-1 reflect data gradients of tiny maps on the exact route: padded domain + sum-and-fold pass
@@ -451,8 +447,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 // gx[n,c,h,w] = sum of the padded-domain gradient gp over every padded position that mirrors onto (h,w)
 // (+ addend[n,c,h,w] where given: the skip gradient of a ResnetBlock rides in the pass that writes the data gradient of its first convolution)
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ gp, float* __restrict__ gx, int H,
-                                                           int W, int pad, long long total, const float* __restrict__ addend,
-                                                           const float* __restrict__ act_y, int act, float slope) {
+                                                           int W, int pad, long long total, const float* __restrict__ addend) {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -476,10 +471,7 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         float s = rowsum(y0);
         if (y1 >= 0) s += rowsum(y1);
         if (y2 >= 0) s += rowsum(y2);
-        if (addend) s += addend[idx];
-        // (* f'(y) of the producer's fused ReLU / LeakyReLU, expressed with its output: exactly nemar_act_bwd's product)
-        if (act_y) s *= act_y[idx] > 0.f ? 1.f : (act == ACT_LRELU ? slope : 0.f);
-        gx[idx] = s;
+        gx[idx] = addend ? s + addend[idx] : s;
     }
 }
 
@@ -1034,7 +1026,7 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             nemar_k7_fm_conv(gy, K, OH, OW, 6, 0, workspace, nullptr, padded, C, N, H + 6, W + 6, ACT_NONE, 0.f, 0, st);
             const long long total = (long long)N * C * H * W;
             hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded, gx0, H, W, pad,
-                               total, (const float*)nullptr, (const float*)nullptr, 0, 0.f);
+                               total, (const float*)nullptr);
         } else {
             nemar_k7_fm_conv(gy, K, OH, OW, 3, 0, workspace, nullptr, gx0, C, N, H, W, ACT_NONE, 0.f, 0, st);
         }
@@ -1091,9 +1083,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
             nemar_s16g_conv(q, pl, workspace, st);
             const long long total = (long long)N * C * H * W;
             hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st, (const float*)padded16, gx0, H,
-                               W, pad, total, t_addend, t_in_act_y, t_in_act, t_in_slope);
+                               W, pad, total, t_addend);
             if (t_addend) t_addend_done = 1;
-            if (t_in_act_y) t_in_act_done = 1;
             g_last_route = 3;
             NEMAR_CHECK_LAUNCH("conv2d_bwd_data (16-bit pipe on the padded domain + fold)");
             return NEMAR_OK;
@@ -1182,9 +1173,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
                 }
                 launch_igemm(p, st);
                 if (p.ksplit > 1 && fold) {                       // slabs of the padded domain -> sum + fold in one pass (gx1 == nullptr: checked above)
-                    nemar_sum_partials_fold(p.part, p.part_stride, p.ksplit, gx0, (long long)N * C, H, W, pad, t_addend, t_in_act_y, t_in_act, t_in_slope, st);
+                    nemar_sum_partials_fold(p.part, p.part_stride, p.ksplit, gx0, (long long)N * C, H, W, pad, t_addend, st);
                     if (t_addend) t_addend_done = 1;
-                    if (t_in_act_y) t_in_act_done = 1;
                     folded = true;
                 }
                 else if (p.ksplit > 1 && gx1) nemar_sum_partials_two(p.part, p.part_stride, p.ksplit, gx0, gx1, N, C0, C1, H * W, st);
@@ -1222,9 +1212,8 @@ NEMAR_API int nemar_conv2d_bwd_data(const float* gy, const float* w, const float
         const long long total = (long long)N * C * H * W;
         const float* const add = (gx0 && !gx1) ? t_addend : nullptr;
         hipLaunchKernelGGL(reflect_fold_kernel, dim3(nemar_stream_grid(total, 256)), dim3(256), 0, st,
-                           (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total, add, (gx0 && !gx1) ? t_in_act_y : nullptr, t_in_act, t_in_slope);
+                           (const float*)padded, gx0 ? gx0 : gx1, H, W, pad, total, add);
         if (add) t_addend_done = 1;
-        if (gx0 && !gx1 && t_in_act_y) t_in_act_done = 1;
     }
     g_last_route = 0;
     NEMAR_CHECK_LAUNCH("conv2d_bwd_data");
@@ -1508,12 +1497,11 @@ struct ExtrasScope {
         t_gy_planes_out = ex->gy_planes_out; t_gy_planes_bytes = ex->gy_planes_bytes;
         t_src2_planes = ex->src2_planes;
         t_addend = ex->addend; t_out_max = ex->out_max_words;
-        t_in_act_y = ex->in_act_y; t_in_act = ex->in_act; t_in_slope = ex->in_slope;
     }
     ~ExtrasScope() {
         t_scratch = nullptr; t_scratch_bytes = 0;
         t_gy_planes_out = nullptr; t_gy_planes_bytes = 0; t_src2_planes = nullptr;
-        t_addend = nullptr; t_out_max = nullptr; t_x_wplanes = nullptr; t_bias_partials = nullptr; t_in_act_y = nullptr; t_in_act = 0;
+        t_addend = nullptr; t_out_max = nullptr; t_x_wplanes = nullptr; t_bias_partials = nullptr;
         if (t0) nemar_split16_set_hint(t0, nullptr, 0);
         if (t1) nemar_split16_set_hint(t1, nullptr, 0);
         if (tp) nemar_split16_set_planes_hint(tp, nullptr, 0, 0, 0, 0, 0);
@@ -1561,7 +1549,7 @@ NEMAR_API int nemar_conv2d_fwd_ex(const float* x0, int C0, const float* x1, int 
                                   int H, int W, int K, int R, int S, int stride, int pad, int pad_mode, int act, float slope,
                                   void* workspace, size_t ws_bytes, int prepacked, void* stream, const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.src2_planes = nullptr; e.addend = nullptr; e.out_max_words = nullptr; e.in_act_y = nullptr; }
+    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.src2_planes = nullptr; e.addend = nullptr; e.out_max_words = nullptr; }
     ExtrasScope scope(extras ? &e : nullptr, x0, nullptr, N, C0 + C1, H, W, SPLIT16_REFLECT);
     return nemar_conv2d_fwd(x0, C0, x1, C1, w, bias, y, N, H, W, K, R, S, stride, pad, pad_mode, act, slope, workspace, ws_bytes, prepacked, stream);
 }
@@ -1577,17 +1565,8 @@ NEMAR_API int nemar_conv2d_bwd_data_ex(const float* gy, const float* w, const fl
     t_gy_planes_written = 0;
     t_fused_epilogue = 0;
     t_addend_done = 0;
-    t_in_act_done = 0;
-    if (extras && extras->in_act_y && extras->in_act != ACT_RELU && extras->in_act != ACT_LRELU) {
-        nemar_set_error("conv2d_bwd_data_ex: in_act must be ReLU or LeakyReLU");
-        return NEMAR_EINVAL;
-    }
     const int rc = nemar_conv2d_bwd_data(gy, w, bias, act, slope, gx0, C0, gx1, C1, N, H, W, K, OH, OW, R, S, stride, pad, pad_mode, workspace,
                                          ws_bytes, prepacked, stream);
-    if (rc == NEMAR_OK && extras && extras->in_act_y && !t_in_act_done) {
-        nemar_set_error("conv2d_bwd_data_ex: this layer's route has no fold pass to apply in_act_y in (nemar_conv2d_bwd_data_addend_ok, not a wide-route layer)");
-        return NEMAR_EINVAL;
-    }
     if (rc == NEMAR_OK && extras && ((extras->addend && !t_fused_epilogue && !t_addend_done) || (extras->out_max_words && !t_fused_epilogue))) {
         nemar_set_error("conv2d_bwd_data_ex: this layer's route has no fused epilogue (addend / out_max_words): ask nemar_conv2d_bwd_data_fusable / "
                         "nemar_conv2d_bwd_data_addend_ok first");
@@ -1600,7 +1579,7 @@ NEMAR_API int nemar_conv2d_bwd_weight_ex(const float* x0, int C0, const float* x
                                          int H, int W, int K, int OH, int OW, int R, int S, int stride, int pad, int pad_mode,
                                          void* workspace, size_t ws_bytes, void* stream, const nemar_conv_extras* extras) {
     nemar_conv_extras e;
-    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.addend = nullptr; e.out_max_words = nullptr; e.in_act_y = nullptr; }
+    if (extras) { e = *extras; e.gy_planes_out = nullptr; e.gy_planes_bytes = 0; e.addend = nullptr; e.out_max_words = nullptr; }
     // (extras.src_planes: the weight gradient's X planes of x0 nemar_instnorm_fwd_planes wrote — pixel-major, not a channel-blocked hint)
     ExtrasScope scope(extras ? &e : nullptr, x0, gy, N, C0 + C1, H, W, -1);
     t_x_wplanes = extras ? extras->src_planes : nullptr;

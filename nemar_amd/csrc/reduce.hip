@@ -134,8 +134,7 @@ __global__ __launch_bounds__(256) void sum_partials_two_kernel(const float* __re
 // lane sum its own slabs first is as fast but another association order — and the ten-step trajectory test sits close enough to its
 // tolerance at steps 7 - 8 to notice.)
 __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __restrict__ part, long long stride, int splits, float* __restrict__ gx,
-                                                                int H, int W, int pad, long long total, const float* __restrict__ addend,
-                                                                const float* __restrict__ act_y, int act, float slope) {
+                                                                int H, int W, int pad, long long total, const float* __restrict__ addend) {
     __shared__ float val[16][9][17];
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -185,9 +184,7 @@ __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __r
             float sum = rowsum(a00, a01, a02);
             if (y1 >= 0) sum += rowsum(a10, a11, a12);
             if (y2 >= 0) sum += rowsum(a20, a21, a22);
-            if (addend) sum += addend[idx];                      // (+ the skip gradient of the ResnetBlock this convolution opens)
-            if (act_y) sum *= act_y[idx] > 0.f ? 1.f : (act == 2 ? slope : 0.f);      // (* f'(y) of the producer's fused ReLU (1) / LeakyReLU (2): nemar_act_bwd's product)
-            gx[idx] = sum;
+            gx[idx] = addend ? sum + addend[idx] : sum;          // (+ the skip gradient of the ResnetBlock this convolution opens)
         }
     }
 }
@@ -195,12 +192,12 @@ __global__ __launch_bounds__(256) void sum_partials_fold_kernel(const float* __r
 }  // namespace
 
 void nemar_sum_partials_fold(const float* part, long long stride, int splits, float* gx, long long planes, int H, int W, int pad,
-                             const float* addend, const float* act_y, int act, float slope, hipStream_t st) {
+                             const float* addend, hipStream_t st) {
     const long long total = planes * H * W;
     long long blocks = (total + 15) / 16;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sum_partials_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, gx, H, W, pad, total, addend, act_y, act, slope);
+    hipLaunchKernelGGL(sum_partials_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, stride, splits, gx, H, W, pad, total, addend);
 }
 
 void nemar_sum_partials_two(const float* part, long long stride, int splits, float* d0, float* d1, int N, int C0, int C1, int HW, hipStream_t st) {

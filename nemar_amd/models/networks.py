@@ -317,12 +317,10 @@ class ResnetBlock(nn.Module):
         second = first + 2 + (1 if use_dropout else 0) + (2 if padding_type == 'reflect' else 1)
         _ref(self, 'c2', self.conv_block.put(second, ConvParams(dim, dim, 3, bias=use_bias)))
 
-    def forward(self, x, input_act=None):
-        """input_act = (act, slope): x is the output of ops.conv2d(..., defer_act_grad=True) — the block's first convolution returns the
-        gradient of that layer's pre-activation (ops.conv2d_with_skip)"""
+    def forward(self, x):
         fused_act = ops.ACT_NONE if self.norm else ops.ACT_RELU
         reflect = self.pad_mode == ops.PAD_REFLECT
-        if reflect and self.norm == 'instance' and input_act is None:
+        if reflect and self.norm == 'instance':
             # the whole block as one autograd node where the wide-layer route takes it (ops._ResBlock): producer-written operand planes
             # for all six convolution calls, the skip gradient added in a data gradient's epilogue
             out = ops.resnet_block(x, self.c1.weight, self.c1.bias, self.c2.weight, self.c2.bias,
@@ -330,7 +328,7 @@ class ResnetBlock(nn.Module):
             if out is not None:
                 return out
         # the block's input feeds conv1 and the skip: the skip's gradient is added in the last pass of conv1's data gradient
-        h, x_skip = ops.conv2d_with_skip(x, self.c1.weight, self.c1.bias, 1, 1, self.pad_mode, act=fused_act, input_act=input_act)
+        h, x_skip = ops.conv2d_with_skip(x, self.c1.weight, self.c1.bias, 1, 1, self.pad_mode, act=fused_act)
         # (norm + ReLU + Dropout in one pass; where conv2 runs on the fp16 x 3 route its operand planes come out of the same pass)
         h = _norm_act(h, self.norm, ops.ACT_RELU, planes=reflect, dropout_p=0.5 if (self.use_dropout and self.training) else 0.0)
         h = ops.conv2d(h, self.c2.weight, self.c2.bias, 1, 1, self.pad_mode)

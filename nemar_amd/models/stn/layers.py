@@ -68,11 +68,9 @@ class ResnetTransformer(nn.Module):
                 c.bias.data.zero_()
         self.n_blocks = n_blocks
 
-    def forward(self, x, input_act=None):
-        """input_act = (act, slope): x comes from a convolution that left the derivative of its fused activation to the first block
-        (ops.conv2d(..., defer_act_grad=True))"""
+    def forward(self, x):
         for i in range(self.n_blocks):
-            x = self.model.at(i)(x, input_act=input_act if i == 0 else None)
+            x = self.model.at(i)(x)
         return x
 
 
@@ -100,12 +98,8 @@ class Conv(nn.Module):
             h = ops.conv2d(x, c.weight, c.bias, self.stride, self.padding, ops.PAD_ZERO, x2=x2)
             h = ops.instance_norm(h, act=self.act, slope=self.slope)
         else:
-            # conv -> ResnetBlock: the derivative of the fused activation rides in the block's first data gradient (one act_bwd pass less)
-            pair = self.resnet_block is not None and ops.pairs_act_grad(self.act)
             h = ops.conv2d(x, c.weight, c.bias, self.stride, self.padding, ops.PAD_ZERO, act=self.act,
-                           slope=self.slope, x2=x2, defer_act_grad=pair)
-            if pair:
-                return self.resnet_block(h, input_act=(self.act, self.slope))
+                           slope=self.slope, x2=x2)
         if self.resnet_block is not None:
             h = self.resnet_block(h)
         return h

@@ -309,14 +309,11 @@ def _gy_planes(N, C, H, W, K, R, S, stride, pad, pad_mode, device):
     return slot[0], slot
 
 
-def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None, addend=None, out_max=None, bias_partials=None,
-            in_act=None):
+def _extras(arena=None, src_max=None, src2_max=None, planes=None, gy_out=None, src2_planes=None, addend=None, out_max=None, bias_partials=None):
     """nemar_conv_extras for one call: the side inputs of the wide-layer route, or None when there are none"""
-    if arena is None and src_max is None and src2_max is None and planes is None and addend is None and in_act is None:
+    if arena is None and src_max is None and src2_max is None and planes is None and addend is None:
         return None
     e = _lib.ConvExtras()
-    if in_act is not None:          # (y, act, slope) of the producer of this layer's input: gx *= f'(y) in the data gradient's fold pass
-        e.in_act_y, e.in_act, e.in_slope = in_act[0].data_ptr(), int(in_act[1]), float(in_act[2])
     if addend is not None:
         e.addend = addend.data_ptr()
     if bias_partials is not None:
@@ -591,13 +588,9 @@ def _grad_buffer(param):
 # ------------------------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape, with_skip=False, defer_act_grad=False, input_act=None):
+    def forward(ctx, x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape, with_skip=False):
         x, x2, w, b = _c(x), _c(x2), _c(weight), _c(bias)
         ctx.with_skip = bool(with_skip)
-        # a PAIR the model declares (layers.Conv -> ResnetBlock): this layer's fused ReLU / LeakyReLU derivative is applied by its consumer's
-        # backward pass (defer_act_grad: no act_bwd launch here), resp. this layer applies its producer's (input_act = (act, slope) of x)
-        ctx.defer_act_grad = bool(defer_act_grad)
-        ctx.input_act = input_act
         if with_skip:
             ctx.set_materialize_grads(False)
         if wshape is not None:
@@ -646,23 +639,18 @@ class _Conv2d(Function):
         stride, pad, pad_mode, act, slope = ctx.cfg
         ctx.gskip = _c(gskip) if (ctx.with_skip and ctx.needs_input_grad[0]) else None
         if gy is None:                          # (only the skip handle was used)
-            gs = ctx.gskip
-            if gs is not None and ctx.input_act is not None:
-                out = torch.empty_like(gs)
-                L.act_bwd(_p(gs), _p(x), _p(out), gs.numel(), ctx.input_act[0], ctx.input_act[1], _stream())
-                gs = out
-            return (gs,) + (None,) * 12
+            return (ctx.gskip,) + (None,) * 10
         gy = _c(gy)
         N, C0, H, W = x.shape
         C1 = 0 if x2 is None else x2.shape[1]
         K, C, R, S = w.shape
         OH, OW = gy.shape[2:]
         st = _stream()
-        if act != ACT_NONE and not ctx.defer_act_grad:
+        if act != ACT_NONE:
             g = torch.empty_like(gy)
             L.act_bwd(_p(gy), _p(y), _p(g), gy.numel(), act, slope, st)
         else:
-            g = gy                        # (deferred: the consumer's backward pass multiplied by f'(y) already)
+            g = gy
         need_x, need_x2, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
             ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gmax = _absmax_word(g) if ctx.xmax is not None else None      # wide layer: max |gy| once for the data and the weight gradient
@@ -700,22 +688,16 @@ class _Conv2d(Function):
             rb = K == 256 and C == 256 and R == 3 and pad_mode == PAD_REFLECT         # (bench.py: operator-level roofline of the residual blocks)
             gskip = getattr(ctx, 'gskip', None)
             # (layers the wide route never takes: their data gradient ends with a fold pass or it does not — no arena-dependent routing)
-            in_act = getattr(ctx, 'input_act', None)
-            fold_ok = (gx is not None and gx2 is None and Nd == N and arena is None
-                       and Q.conv2d_scratch(N, H, W, K, C, R, S, stride, pad) == 0
-                       and Q.conv2d_bwd_data_addend_ok(N, C, H, W, K, R, S, stride, pad, pad_mode) == 1)
-            ride = gskip is not None and fold_ok
-            act_rides = in_act is not None and fold_ok and (gskip is None or ride)
+            ride = (gskip is not None and gx is not None and gx2 is None and Nd == N and arena is None
+                    and Q.conv2d_scratch(N, H, W, K, C, R, S, stride, pad) == 0
+                    and Q.conv2d_bwd_data_addend_ok(N, C, H, W, K, R, S, stride, pad, pad_mode) == 1)
             with _record(plan), (_span('dgrad_resblock') if rb else contextlib.nullcontext()):
                 L.conv2d_bwd_data_ex(_p(gd), _p(w), None, ACT_NONE, 0.0, _p(gxd), C0, _p(gx2), C1, Nd, H, W, K, OH, OW, R, S,
                                      stride, pad, pad_mode, _p(ws), wsb, hit, st,
                                      _extras(arena, gmax[n0:] if (gmax is not None and Nd != N) else gmax, gy_out=gpl,
-                                             addend=gskip if ride else None,
-                                             in_act=(x, in_act[0], in_act[1]) if act_rides else None))
+                                             addend=gskip if ride else None))
             if gskip is not None and gx is not None and not ride:
                 L.add2(_p(gx), _p(gskip), _p(gx), gx.numel(), st)       # (a route without a last pass to ride in: one more launch)
-            if in_act is not None and gx is not None and not act_rides:
-                L.act_bwd(_p(gx), _p(x), _p(gx), gx.numel(), in_act[0], in_act[1], st)      # (the producer deferred its derivative to this node)
             if gpl is not None and not L.last_gy_planes():
                 gpl = None
             if not need_x2:
@@ -770,7 +752,7 @@ class _Conv2d(Function):
             grad_ready(ctx.bias)
         if gx is None and getattr(ctx, 'gskip', None) is not None:
             gx = ctx.gskip
-        return gx, gx2, None, None, None, None, None, None, None, None, None, None, None
+        return gx, gx2, None, None, None, None, None, None, None, None, None
 
 
 def _bias_grad(g, gb, N, C, HW, st):
@@ -778,32 +760,18 @@ def _bias_grad(g, gb, N, C, HW, st):
     L.bias_grad(_p(g), _p(gb), N, C, HW, _p(_workspace(wsb, g.device)), wsb, st)
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2, x2=None, wshape=None, defer_act_grad=False):
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2, x2=None, wshape=None):
     """act(conv2d(pad(cat(x, x2)), weight) + bias).  pad_mode PAD_REFLECT == nn.ReflectionPad2d(pad) + conv.
-    `weight` must be the leaf Parameter (its .grad is the accumulation target); `wshape` reinterprets it as 4-D.
-    defer_act_grad: the caller hands the result to conv2d_with_skip(..., input_act=(act, slope)) and to nothing else — that node's backward
-    pass multiplies by the derivative of this layer's fused ReLU / LeakyReLU, and this node launches no act_bwd (pairs_act_grad())."""
-    if defer_act_grad:
-        return _Conv2d.apply(x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape, False, True, None)
+    `weight` must be the leaf Parameter (its .grad is the accumulation target); `wshape` reinterprets it as 4-D."""
     return _Conv2d.apply(x, x2, weight, bias, stride, pad, pad_mode, act, slope, wshape)
 
 
-def pairs_act_grad(act):
-    """May a producer with the fused activation `act` defer its derivative to a conv2d_with_skip consumer?  (The pair exists only where
-    that consumer is an autograd node of its own: ops' own nodes on, autograd recording.)"""
-    return _own_nodes and torch.is_grad_enabled() and act in (ACT_RELU, ACT_LRELU)
-
-
-def conv2d_with_skip(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2, input_act=None):
+def conv2d_with_skip(x, weight, bias=None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2):
     """-> (conv2d(x, ...), a second handle of x for the caller's skip connection).  The skip's gradient returns to the convolution's node
-    and is added in the last pass of its data gradient (one launch less than a separate sum; ops.fork where autograd is off).
-    input_act = (act, slope): x is the output of conv2d(..., defer_act_grad=True) — this node's backward pass returns the gradient of that
-    layer's PRE-activation (times f'(x), in the same last pass where there is one)."""
+    and is added in the last pass of its data gradient (one launch less than a separate sum; ops.fork where autograd is off)."""
     if not (_own_nodes and torch.is_grad_enabled() and x.requires_grad):
-        if input_act is not None and torch.is_grad_enabled() and x.requires_grad:
-            raise RuntimeError("conv2d_with_skip: input_act without the library's own autograd nodes (ask ops.pairs_act_grad first)")
         return _Conv2d.apply(x, None, weight, bias, stride, pad, pad_mode, act, slope, None), x
-    y, skip = _Conv2d.apply(x, None, weight, bias, stride, pad, pad_mode, act, slope, None, True, False, input_act)
+    y, skip = _Conv2d.apply(x, None, weight, bias, stride, pad, pad_mode, act, slope, None, True)
     for name in _TAGS:
         v = getattr(x, name, None)
         if v is not None:

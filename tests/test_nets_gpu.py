@@ -295,39 +295,3 @@ def test_skip_gradients_riding_in_another_pass(size):
     a, r = run(True), run(False)
     assert torch.equal(a[0], r[0]), float((a[0] - r[0]).abs().max())
     assert torch.equal(a[1], r[1]) and torch.equal(a[2], r[2])
-
-
-@pytest.mark.parametrize("size", [4, 16, 64])
-def test_deferred_activation_gradient_rides_in_the_consumer(size):
-    """ops.conv2d(..., act=LeakyReLU, defer_act_grad=True) -> ops.conv2d_with_skip(..., input_act=...) (layers.Conv -> ResnetBlock in the
-    registration net): the producer launches no act_bwd, the consumer's last data-gradient pass computes (data gradient + skip gradient) *
-    f'(y) — against the plain composition with the producer's own act_bwd and autograd's sum: bit for bit (the same product)."""
-    import torch
-    from nemar_amd import ops
-    dev = torch.device('cuda:0')
-    C = 32 if size == 64 else 64
-    gen = lambda s: torch.Generator(device=dev).manual_seed(s)
-    w0 = torch.randn(C, 6, 3, 3, device=dev, generator=gen(1)) * 0.2
-    b0 = torch.randn(C, device=dev, generator=gen(2)) * 0.1
-    w1 = torch.randn(C, C, 3, 3, device=dev, generator=gen(3)) * 0.05
-    b1 = torch.randn(C, device=dev, generator=gen(4)) * 0.1
-    x0 = torch.randn(8, 6, size, size, device=dev, generator=gen(5))
-    g0 = torch.randn(8, C, size, size, device=dev, generator=gen(6))
-
-    def run(own):
-        x = x0.clone().requires_grad_()
-        ps = [torch.nn.Parameter(t.clone()) for t in (w0, b0, w1, b1)]
-        if own:
-            assert ops.pairs_act_grad(ops.ACT_LRELU)
-            h = ops.conv2d(x, ps[0], ps[1], 1, 1, ops.PAD_ZERO, act=ops.ACT_LRELU, slope=0.2, defer_act_grad=True)
-            y, skip = ops.conv2d_with_skip(h, ps[2], ps[3], 1, 1, ops.PAD_REFLECT, input_act=(ops.ACT_LRELU, 0.2))
-        else:
-            h = ops.conv2d(x, ps[0], ps[1], 1, 1, ops.PAD_ZERO, act=ops.ACT_LRELU, slope=0.2)
-            y, skip = ops.conv2d(h, ps[2], ps[3], 1, 1, ops.PAD_REFLECT), h
-        torch.autograd.backward([y, skip], [g0, g0 * 0.5])
-        ops.join_side()
-        return [x.grad.clone()] + [p.grad.clone() for p in ps]
-
-    a, r = run(True), run(False)
-    for i, (p, q) in enumerate(zip(a, r)):
-        assert torch.equal(p, q), (i, float((p - q).abs().max()))
